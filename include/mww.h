@@ -1,0 +1,188 @@
+/* mww.h — C ABI of libmww_hip.so: the MI355X-native (gfx950) train-step engine for
+ * microWakeWord's MixedNet classifier.
+ *
+ * The reference (kahrendt/microWakeWord) has no FFI layer: its hot path is duck-typed Python
+ * (microwakeword/train.py:249-299) calling numpy batch assembly (microwakeword/data.py:497-597)
+ * and Keras `train_on_batch` on the graph built by microwakeword/mixednet.py:278-386.  This
+ * header is the boundary a maintainer would bind (ctypes / cffi / pybind — see INTEGRATION.md):
+ * plain pointers and sizes, no torch / Python types.  Each entry point names the reference
+ * interface it replaces.
+ *
+ * Conventions: every call returns MWW_OK (0) or a negative error code; the message is available
+ * from mww_last_error() (thread-local).  The caller owns every host pointer; the library owns
+ * all device memory.  A context is bound to one device and one HIP stream and is NOT thread
+ * safe (one context per rank, one host thread).  Calls enqueue work on the context's stream;
+ * only the mww_read_* / mww_get_* / mww_synchronize calls wait for the device.
+ */
+#ifndef MWW_H
+#define MWW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MWW_OK 0
+#define MWW_ERR_INVALID -1      /* bad argument / unsupported configuration */
+#define MWW_ERR_HIP -2          /* a HIP runtime call failed */
+#define MWW_ERR_UNSUPPORTED -3  /* model shape has no compiled kernel instantiation */
+#define MWW_ERR_STATE -4        /* call sequence error (e.g. train step before a batch) */
+
+#define MWW_MAX_BLOCKS 8
+#define MWW_MAX_STORES 64
+#define MWW_FEATURE_BINS 40
+
+typedef struct mww_ctx mww_ctx;
+
+/* ---- model: replaces mixednet.model(flags, shape, batch_size) (mixednet.py:278-386).
+ * `block_kernel[i]` is the aligned depthwise length of block i (= the LAST listed MixConv kernel
+ * size, mixednet.py:227); smaller MixConv groups are expressed by the host as zero leading taps
+ * plus a gradient mask (mww_set_grad_mask), SURVEY §A.2.
+ * Flat trainable-parameter order ("native order" == Keras get_weights() order without the BN
+ * moving statistics):
+ *   conv1.kernel[K1*40*C1] ; per block: dw.kernel[K*Cin] dw.bias[Cin] pw.kernel[Cin*Cout]
+ *   bn.gamma[Cout] bn.beta[Cout] ; dense.kernel[T_last*C_last] dense.bias[1]
+ * BN state order: per block moving_mean[Cout] moving_variance[Cout]. */
+typedef struct {
+  int32_t frames;               /* T: spectrogram_length (model_train_eval.py:82-88) */
+  int32_t conv1_filters;        /* --first_conv_filters  (mixednet.py:76-81) */
+  int32_t conv1_kernel;         /* --first_conv_kernel_size */
+  int32_t conv1_stride;         /* --stride (only 1 is implemented) */
+  int32_t n_blocks;
+  int32_t block_filters[MWW_MAX_BLOCKS];  /* --pointwise_filters */
+  int32_t block_kernel[MWW_MAX_BLOCKS];   /* max/last of --mixconv_kernel_sizes per block */
+  int32_t max_batch;            /* largest batch any call will use */
+} mww_mixednet_desc;
+
+const char* mww_version(void);
+const char* mww_last_error(void);
+int mww_device_count(void);
+
+/* stream: a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a
+ * private non-blocking stream. */
+int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx** out);
+void mww_destroy(mww_ctx* ctx);
+int mww_synchronize(mww_ctx* ctx);
+
+int64_t mww_num_params(const mww_ctx* ctx);    /* trainable scalars (22177 for default mixednet) */
+int64_t mww_num_bn_state(const mww_ctx* ctx);  /* moving mean/variance scalars (384) */
+
+/* ---- weights: replace model.get_weights()/set_weights()/save_weights()/load_weights()
+ * (train.py:336-338,391-399,448-450; model_train_eval.py:420-426) at the array level. */
+int mww_set_params(mww_ctx* ctx, const float* host, int64_t n);
+int mww_get_params(mww_ctx* ctx, float* host, int64_t n);
+int mww_set_bn_state(mww_ctx* ctx, const float* host, int64_t n);
+int mww_get_bn_state(mww_ctx* ctx, float* host, int64_t n);
+int mww_set_grad_mask(mww_ctx* ctx, const float* host_mask01, int64_t n);
+/* optimizer slots of tf.keras.optimizers.Adam (train.py:207): m, v and the iteration count;
+ * replaces the tf.train.Checkpoint(optimizer=...) payload of train.py:229-233 */
+int mww_set_opt_state(mww_ctx* ctx, const float* m, const float* v, int64_t n, int64_t step);
+int mww_get_opt_state(mww_ctx* ctx, float* m, float* v, int64_t n, int64_t* step);
+int mww_get_grads(mww_ctx* ctx, float* host, int64_t n);  /* flat gradient of the last step */
+
+/* ---- feature stores: replace the RaggedMmap page-cache reads of data.py:255-258.  A store is the
+ * flat concatenation of its samples ([T_i][40], uint16 raw micro-frontend values or float32
+ * already scaled), uploaded once and kept resident in HBM. */
+#define MWW_DTYPE_U16 0
+#define MWW_DTYPE_F32 1
+int mww_upload_store(mww_ctx* ctx, int store_id, const void* host_data, int64_t n_elems, int dtype);
+
+/* ---- batch assembly: replaces FeatureHandler.get_data("training") materialisation
+ * (data.py:555-597: fixed_length_spectrogram :74-118, uint16->f32 * 0.0390625 :268-269,
+ * spec_augment :32-71, final shuffle :591-597).  All random choices are made on the host
+ * (mww_sample_training_batch) and arrive here as integers. */
+typedef struct {
+  int32_t store;      /* store id */
+  int32_t pad_rows;   /* zero frames in front (left pad, data.py:107-113) */
+  int32_t copy_rows;  /* frames copied */
+  int32_t reserved;
+  int64_t src_elem;   /* element offset of the first copied frame inside the store */
+} mww_window;
+/* masks: [B][n_time_masks + n_freq_masks][2] = (start, width); time masks first.
+ * Writes x[B][T][40] float32 into the context's batch buffer. */
+int mww_assemble_batch(mww_ctx* ctx, const mww_window* windows, const int32_t* masks, int B, int n_time_masks,
+                       int n_freq_masks);
+/* ready-made batch: the `x` argument of Keras train_on_batch / evaluate (train.py:295-299,50-58) */
+int mww_set_batch(mww_ctx* ctx, const float* host_x, int B);
+int mww_get_batch(mww_ctx* ctx, float* host_x, int B);
+/* labels and per-sample weights (penalty_weight * class weight, train.py:288-293) */
+int mww_set_targets(mww_ctx* ctx, const float* host_y, const float* host_w, int B);
+
+/* ---- the train step: replaces model.train_on_batch (train.py:295-299): forward(training=True),
+ * weighted Keras BCE, backward, Adam(lr), BN moving statistics, metric update.
+ * flags: MWW_STEP_NO_APPLY stops after the flat gradient is assembled (data-parallel: all-reduce
+ * mww_device_ptr(MWW_BUF_GRADS), then mww_apply_gradients). */
+#define MWW_STEP_NO_APPLY 1
+#define MWW_STEP_NO_METRICS 2
+int mww_train_step(mww_ctx* ctx, int B, float learning_rate, int flags);
+int mww_apply_gradients(mww_ctx* ctx, float learning_rate, float grad_scale);
+
+/* ---- inference forward on the current batch: replaces model(x, training=...) /
+ * model.evaluate's per-batch forward (train.py:50-58). training=1 uses batch statistics without
+ * touching the moving averages. update_metrics=1 also accumulates the compiled metrics. */
+int mww_forward(mww_ctx* ctx, int B, int training, int update_metrics);
+
+/* outputs of the last train step / forward (waits for the stream). Any pointer may be NULL. */
+int mww_read_outputs(mww_ctx* ctx, int B, float* probs, float* logits, float* loss);
+
+/* ---- metrics: the nine compiled Keras metrics of train.py:209-221 as raw cumulative counters;
+ * the host derives accuracy/recall/precision/tp..fn@101/auc@200/loss from them. */
+typedef struct {
+  uint64_t hist101[2][101]; /* [label][bucket], bucket = ceil(p*100)-1 (Keras evenly spaced thresholds) */
+  uint64_t hist200[2][200]; /* AUC buckets, ceil(p*199)-1 clamped at 0 */
+  uint64_t n, correct, tp5, fp5, fn5, pos, neg;
+  double bce_sum;           /* unweighted Keras BCE summed over samples */
+} mww_metrics;
+int mww_metrics_read(mww_ctx* ctx, mww_metrics* out);
+int mww_metrics_reset(mww_ctx* ctx);
+
+/* ---- device buffers for the host's collectives (torch.distributed over RCCL) */
+#define MWW_BUF_PARAMS 0
+#define MWW_BUF_GRADS 1
+#define MWW_BUF_BN_STATE 2
+#define MWW_BUF_X 3
+void* mww_device_ptr(mww_ctx* ctx, int which);
+
+/* named internal tensors for parity tests ("p1".."p8" pre-BN block outputs, "g1".. gradients at
+ * the BN outputs, "bn_mean<k>", "bn_rstd<k>"); returns the element count or a negative error */
+int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64_t capacity);
+
+/* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head" */
+int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);
+
+/* per-kernel timing of the last N steps measured with HIP events on the context's stream:
+ * enable with mww_set_option("profile", 1); names/ms are returned in launch order. */
+int mww_profile_read(mww_ctx* ctx, char* names, int names_capacity, float* ms, int capacity);
+
+/* ---- host sampler: replaces the RNG-consuming part of FeatureHandler.get_data("training")
+ * (data.py:540-569,591-595) bit-exactly; see csrc/sampler.cpp. */
+#define MWW_STRATEGY_RANDOM 0
+#define MWW_STRATEGY_TRUNCATE_START 1
+#define MWW_STRATEGY_TRUNCATE_END 2
+#define MWW_STRATEGY_FIXED_RIGHT_CUTOFF 3
+#define MWW_STRATEGY_NONE 4
+typedef struct {
+  int32_t n_providers;            /* providers that have training samples, reference order */
+  const double* sampling_weight;  /* [n_providers] */
+  const int32_t* strategy;        /* [n_providers] MWW_STRATEGY_* */
+  const int64_t* set_offsets;     /* [n_providers+1] into the set_* arrays */
+  const int32_t* set_store;       /* store id of each entry of feature_sets["training"] (shuffled order) */
+  const int64_t* set_src_elem;    /* element offset of the sample inside its store */
+  const int32_t* set_len;         /* frames of the sample */
+  const int32_t* cutoff_offsets;  /* [n_providers+1] */
+  const int32_t* cutoffs;         /* fixed_right_cutoffs, concatenated */
+} mww_sampler_desc;
+/* py_state / np_state: 624 MT19937 words + position (625 uint32), advanced in place.
+ * Outputs are in DRAW order; out_order is the final np.random.shuffle permutation: output slot j
+ * of the batch is draw out_order[j].  default_strategy < 0 means "default" (per provider). */
+int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py_state, uint32_t* np_state, int B, int T, int tmax,
+                              int tcount, int fmax, int fcount, int32_t default_strategy, mww_window* out_windows,
+                              int32_t* out_masks, int32_t* out_provider, int32_t* out_sample, int32_t* out_order);
+int mww_rng_selftest(uint32_t* state, int which, int n, double* out_real, uint32_t* out_int, uint32_t bound);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MWW_H */

@@ -1,0 +1,61 @@
+// Shared definitions for the gfx950 kernels of the microWakeWord train step.
+//
+// Geometry used by every conv kernel:
+//   * one workgroup = 256 threads = 4 wave64; it owns whole samples (grid-stride over the batch)
+//     and walks each sample in time tiles of TT = 64 output frames, so the only cross-tile state
+//     (the depthwise halo) stays inside the workgroup's LDS / L1.
+//   * VALU phases (BN+ReLU, depthwise, masks, stats) map thread -> (channel c, time chunk):
+//     lanes of a wave cover consecutive channels of one frame => 128/192-byte coalesced rows in
+//     HBM and conflict-free LDS rows.
+//   * GEMM-shaped phases (3x1 first conv as im2col, 1x1 pointwise, their transposes and weight
+//     gradients) run on v_mfma_f32_16x16x4_f32 (exact fp32 fma chain): lane l supplies
+//     A[i=l&15][k=l>>4], B[k=l>>4][j=l&15] and owns C/D[row=(l>>4)*4+r][col=l&15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mww {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int TT = 64;        // output frames per time tile (4 waves x one 16-row MFMA tile)
+constexpr int FBINS = 40;     // mel bins of the micro-frontend features
+constexpr float kBnEps = 1e-3f;
+constexpr float kBnMomentum = 0.99f;
+constexpr float kKerasEps = 1e-7f;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+
+// LDS row pitch: +4 floats keeps 16-byte alignment of float4 rows and breaks 2^n strides.
+__host__ __device__ constexpr int pitch(int c) { return c + 4; }
+
+// number of time chunks / chunk length of the (channel, chunk) VALU mapping
+__host__ __device__ constexpr int nchunks(int c) { return kThreads / c; }
+__host__ __device__ constexpr int chunk_len(int c) { return (TT + nchunks(c) - 1) / nchunks(c); }
+
+// sum over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float sum_over_groups(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+}  // namespace mww

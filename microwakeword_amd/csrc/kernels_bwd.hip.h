@@ -1,0 +1,619 @@
+// Backward kernels of the MixedNet train step.  The reference gets these from TF autodiff of
+// the graph in microwakeword/mixednet.py:307-386 (Keras train_on_batch, train.py:295-299); here
+// each block's backward is one fused kernel that RECOMPUTES the block's activations from the
+// stored pre-BN tensor p_{k-1} (SURVEY §8d "minimal materialisation"):
+//
+//   inputs  : p_{k-1} (raw), p_k (raw), g_k = dL/d(BN_k output) already ReLU-masked
+//             (block L: rebuilt from the per-sample scalar dL/dz and the dense weights)
+//   BN_k bwd: dp_k = gamma*rstd * (g_k - mean(g_k) - xhat_k * mean(g_k*xhat_k))
+//   1x1 bwd : dW_pw += u^T dp_k           (MFMA, accumulated in registers over the whole grid-stride loop)
+//             du     = dp_k W_pw^T        (MFMA)
+//   dw  bwd : dW_dw[i,c] += sum_t du[t,c] a[t+i,c] ; db[c] += sum_t du[t,c]
+//             da[s,c]    = sum_i du[s-i,c] w[i,c]    (K-1 rows of du carried across time tiles in LDS)
+//   output  : g_{k-1} = da * relu'(.)  -> HBM, plus per-workgroup partials of sum g_{k-1}, sum g_{k-1} xhat_{k-1}
+//
+// Weight-gradient partials are written once per workgroup ([grid][params of the block]) and
+// summed in a fixed order by grad_reduce_kernel => bit-reproducible gradients.
+#pragma once
+#include "kernels_fwd.hip.h"
+
+namespace mww {
+
+struct BwdBlockArgs {
+  const float* in;        // p_{k-1} [B][Tin][CIN] raw
+  const float* in_scale;  // BN_{k-1} folded scale/shift (activation recompute)
+  const float* in_shift;
+  const float* in_mean;   // BN_{k-1} batch mean / rstd (xhat for the stats of g_{k-1})
+  const float* in_rstd;
+  const float* pk;        // p_k [B][Tout][COUT] raw
+  const float* gk;        // g_k [B][Tout][COUT]            (unused when LAST)
+  const float* k_mean;    // BN_k: batch mean, rstd
+  const float* k_rstd;
+  const float* k_c1;      // gamma_k * rstd_k
+  const float* k_mg;      // mean(g_k)
+  const float* k_mgx;     // mean(g_k * xhat_k)
+  const float* k_scale;   // LAST only: BN_k folded (ReLU mask of the head input)
+  const float* k_shift;
+  const float* wd;        // LAST only: dense kernel [Tout*COUT]
+  const float* dz;        // LAST only: dL/dz [B]
+  const float* dw_w;      // [K][CIN]
+  const float* dw_b;      // [CIN]
+  const float* pw_w;      // [CIN][COUT]
+  float* g_out;           // g_{k-1} [B][Tin][CIN]
+  float* gstat_part;      // [gridDim.x][2][CIN]
+  float* grad_part;       // [gridDim.x][K*CIN + CIN + CIN*COUT]  (dW_dw, db, dW_pw)
+  int B, Tin, Tout;
+};
+
+// dp tile: BN_k backward applied while staging rows [t0, t0+TT) of (g_k, p_k) into LDS
+template <int COUT, bool LAST>
+__device__ __forceinline__ void stage_dp_tile(const BwdBlockArgs& a, int b, int t0, float* sDP, const float* sKp, int tid) {
+  constexpr int CPO = pitch(COUT), QO = COUT / 4;
+  const float dzb = LAST ? a.dz[b] : 0.f;
+  for (int i = tid; i < TT * QO; i += kThreads) {
+    const int r = i / QO, q = i - r * QO;
+    const int t = t0 + r;
+    float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < a.Tout) {
+      const size_t off = ((size_t)b * a.Tout + t) * COUT + q * 4;
+      const float4 pk = *reinterpret_cast<const float4*>(a.pk + off);
+      const float4 mean = *reinterpret_cast<const float4*>(sKp + 0 * COUT + q * 4);
+      const float4 rstd = *reinterpret_cast<const float4*>(sKp + 1 * COUT + q * 4);
+      const float4 c1 = *reinterpret_cast<const float4*>(sKp + 2 * COUT + q * 4);
+      const float4 mg = *reinterpret_cast<const float4*>(sKp + 3 * COUT + q * 4);
+      const float4 mgx = *reinterpret_cast<const float4*>(sKp + 4 * COUT + q * 4);
+      float4 g;
+      if (LAST) {
+        const float4 sc = *reinterpret_cast<const float4*>(sKp + 5 * COUT + q * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(sKp + 6 * COUT + q * 4);
+        const float4 w = *reinterpret_cast<const float4*>(a.wd + (size_t)t * COUT + q * 4);
+        g.x = fmaf(pk.x, sc.x, sh.x) > 0.f ? dzb * w.x : 0.f;
+        g.y = fmaf(pk.y, sc.y, sh.y) > 0.f ? dzb * w.y : 0.f;
+        g.z = fmaf(pk.z, sc.z, sh.z) > 0.f ? dzb * w.z : 0.f;
+        g.w = fmaf(pk.w, sc.w, sh.w) > 0.f ? dzb * w.w : 0.f;
+      } else {
+        g = *reinterpret_cast<const float4*>(a.gk + off);
+      }
+      dp.x = c1.x * (g.x - mg.x - (pk.x - mean.x) * rstd.x * mgx.x);
+      dp.y = c1.y * (g.y - mg.y - (pk.y - mean.y) * rstd.y * mgx.y);
+      dp.z = c1.z * (g.z - mg.z - (pk.z - mean.z) * rstd.z * mgx.z);
+      dp.w = c1.w * (g.w - mg.w - (pk.w - mean.w) * rstd.w * mgx.w);
+    }
+    *reinterpret_cast<float4*>(sDP + r * CPO + q * 4) = dp;
+  }
+}
+
+// carry the last K-1 rows of du to the front of the ring (or clear them at the start of a sample)
+template <int K, int CPI>
+__device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
+  for (int i = tid; i < (K - 1) * CPI; i += kThreads) sDU[i] = first_tile ? 0.f : sDU[TT * CPI + i];
+}
+
+// MFMA part shared by both backward kernels:
+//   dwacc[mt][nt] += U^T DP over this wave's 16 rows;  du = DP W^T -> sDU rows [K-1+16*wave, ...)
+template <int CIN, int COUT, int K>
+__device__ __forceinline__ void pointwise_backward_tile(const float* sU, const float* sDP, float* sDU, int wave, int r16,
+                                                        int g, const float (&wtfrag)[COUT / 4][CIN / 16],
+                                                        f32x4 (&dwacc)[CIN / 16][COUT / 16]) {
+  constexpr int CPI = pitch(CIN), CPO = pitch(COUT), MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int row = wave * 16 + kk * 4 + g;
+    float av[MT], bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[mt] = sU[row * CPI + mt * 16 + r16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[row * CPO + nt * 16 + r16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma4(av[mt], bv[nt], dwacc[mt][nt]);
+  }
+  f32x4 du[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) du[mt] = zero4();
+#pragma unroll
+  for (int kk = 0; kk < KSO; ++kk) {
+    const float av = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, wtfrag[kk][mt], du[mt]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDU[(K - 1 + wave * 16 + g * 4 + r) * CPI + mt * 16 + r16] = du[mt][r];
+}
+
+// final per-workgroup write of dW_pw (cross-wave sum), dW_dw / db (cross-chunk sum)
+template <int CIN, int COUT, int K>
+__device__ __forceinline__ void write_block_grad_partials(float* scratch, float* dst, const f32x4 (&dwacc)[CIN / 16][COUT / 16],
+                                                          const float (&accw)[K], float accb, bool dw_active, int c,
+                                                          int chunk, int tid, int wave, int r16, int g) {
+  constexpr int MT = CIN / 16, NT = COUT / 16, NCH = nchunks(CIN);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        scratch[(wave * CIN + mt * 16 + g * 4 + r) * COUT + nt * 16 + r16] = dwacc[mt][nt][r];
+  __syncthreads();
+  for (int e = tid; e < CIN * COUT; e += kThreads)
+    dst[(K + 1) * CIN + e] = (scratch[e] + scratch[CIN * COUT + e]) + (scratch[2 * CIN * COUT + e] + scratch[3 * CIN * COUT + e]);
+  __syncthreads();
+  if (dw_active) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) scratch[(chunk * (K + 1) + i) * CIN + c] = accw[i];
+    scratch[(chunk * (K + 1) + K) * CIN + c] = accb;
+  }
+  __syncthreads();
+  for (int e = tid; e < (K + 1) * CIN; e += kThreads) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v += scratch[j * (K + 1) * CIN + e];
+    dst[e] = v;
+  }
+  __syncthreads();
+}
+
+// depthwise backward of one (channel, chunk) for one time tile:
+//   da[sl]      = sum_j w[K-1-j] * du_ring[sl + j]                     (sl local input row)
+//   dW_dw[i]   += sum_t du[t] * a[t+i] ;  db += sum_t du[t]            (t local output row)
+// `a_at(row)` returns the activation of local input row `row` for channel c.
+template <int K, int L, int CPI, typename ActFn>
+__device__ __forceinline__ void depthwise_backward_chunk(const float* sDU, int chunk, int c, const float (&dww)[K],
+                                                         float (&accw)[K], float& accb, float (&da)[L], ActFn a_at) {
+  float zero_bias = 0.f;
+  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, TT + K - 1, c, dww, zero_bias, da);
+  float win[L + K - 1];
+#pragma unroll
+  for (int j = 0; j < L + K - 1; ++j) win[j] = a_at(chunk * L + j);
+#pragma unroll
+  for (int t = 0; t < L; ++t) {
+    const int tl = chunk * L + t;
+    const float du = (tl < TT) ? sDU[(K - 1 + tl) * CPI + c] : 0.f;
+    accb += du;
+#pragma unroll
+    for (int i = 0; i < K; ++i) accw[i] = fmaf(du, win[t + i], accw[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int K, bool LAST>
+__global__ __launch_bounds__(kThreads) void bwd_block_kernel(BwdBlockArgs a) {
+  constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
+  constexpr int RA = TT + K - 1;
+  constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
+  constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
+  constexpr int QI = CIN / 4;
+  constexpr int OFF_P = 0, OFF_DP = OFF_P + RA * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TT * CPI;
+  constexpr int OFF_END = OFF_DU + RA * CPI;
+  static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN && OFF_END >= NCH * 2 * CIN, "scratch aliasing");
+  static_assert(TT >= K - 1, "carry rows must not overlap");
+
+  __shared__ float smem[OFF_END];
+  __shared__ float sKp[7 * COUT];
+  float* sP = smem + OFF_P;
+  float* sDP = smem + OFF_DP;
+  float* sU = smem + OFF_U;
+  float* sDU = smem + OFF_DU;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int c = tid % CIN, chunk = tid / CIN;
+  const bool dw_active = chunk < NCH;
+
+  for (int i = tid; i < COUT; i += kThreads) {
+    sKp[0 * COUT + i] = a.k_mean[i];
+    sKp[1 * COUT + i] = a.k_rstd[i];
+    sKp[2 * COUT + i] = a.k_c1[i];
+    sKp[3 * COUT + i] = a.k_mg[i];
+    sKp[4 * COUT + i] = a.k_mgx[i];
+    sKp[5 * COUT + i] = LAST ? a.k_scale[i] : 0.f;
+    sKp[6 * COUT + i] = LAST ? a.k_shift[i] : 0.f;
+  }
+  // W_pw^T fragments: B[k=co][n=ci] = W[ci][co]
+  float wtfrag[KSO][MT];
+#pragma unroll
+  for (int kk = 0; kk < KSO; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wtfrag[kk][mt] = a.pw_w[(mt * 16 + r16) * COUT + kk * 4 + g];
+  float dww[K], accw[K];
+  float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
+  float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    dww[i] = dw_active ? a.dw_w[i * CIN + c] : 0.f;
+    accw[i] = 0.f;
+  }
+  if (dw_active) {
+    dwb = a.dw_b[c];
+    sc_c = a.in_scale[c];
+    sh_c = a.in_shift[c];
+    mu_c = a.in_mean[c];
+    rs_c = a.in_rstd[c];
+  }
+  f32x4 dwacc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
+  __syncthreads();
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int t0 = 0; t0 < a.Tin; t0 += TT) {
+      const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
+      const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
+      // ---- P0: stage raw p_{k-1} rows [t0, t0+RA), dp rows [t0, t0+TT); roll the du ring
+      for (int i = tid; i < RA * QI; i += kThreads) {
+        const int r = i / QI, q = i - r * QI;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + r < a.Tin) v = *reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0 + r) * CIN + q * 4);
+        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = v;
+      }
+      stage_dp_tile<COUT, LAST>(a, b, t0, sDP, sKp, tid);
+      carry_du<K, CPI>(sDU, t0 == 0, tid);
+      __syncthreads();
+      // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
+      if (dw_active) {
+        float o[L];
+        dw_chunk<K, L, false, true>(sP, CPI, chunk * L, RA, c, dww, dwb, o, sc_c, sh_c);
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        }
+      }
+      __syncthreads();
+      // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
+      pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, wtfrag, dwacc);
+      __syncthreads();
+      // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
+      if (dw_active) {
+        float da[L];
+        depthwise_backward_chunk<K, L, CPI>(sDU, chunk, c, dww, accw, accb, da, [&](int row) {
+          return row < RA ? fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f) : 0.f;
+        });
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int sl = chunk * L + t;
+          if (sl < rows_da) {
+            const float raw = sP[sl * CPI + c];
+            const float gg = fmaf(raw, sc_c, sh_c) > 0.f ? da[t] : 0.f;
+            a.g_out[((size_t)b * a.Tin + t0 + sl) * CIN + c] = gg;
+            gs1 += gg;
+            gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
+  write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
+  if (dw_active) {
+    smem[(chunk * 2 + 0) * CIN + c] = gs1;
+    smem[(chunk * 2 + 1) * CIN + c] = gs2;
+  }
+  __syncthreads();
+  if (tid < 2 * CIN) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v += smem[j * 2 * CIN + tid];
+    a.gstat_part[(size_t)blockIdx.x * 2 * CIN + tid] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// First block: the block input is relu(conv1(x)) (no BN), recomputed from x; instead of an
+// input gradient tensor the kernel produces the first-conv weight gradient
+//   dW1[j*40+f][c1] += sum_s x[s+j][f] * g0[s][c1]      (im2col^T x g0 on MFMA)
+struct BwdFirstArgs {
+  const float* x;         // [B][T][40]
+  const float* w1;        // [K1*40][C1]
+  const float* pk;        // p_1 [B][Tout][COUT]
+  const float* gk;        // g_1 [B][Tout][COUT]
+  const float* k_mean;
+  const float* k_rstd;
+  const float* k_c1;
+  const float* k_mg;
+  const float* k_mgx;
+  const float* dw_w;      // [K][C1]
+  const float* dw_b;      // [C1]
+  const float* pw_w;      // [C1][COUT]
+  float* grad_part;       // [gridDim.x][K1*40*C1 + K*C1 + C1 + C1*COUT]
+  int B, T, Tout;         // Tout = T-(K1-1)-(K-1); a0 frames Ta = T-(K1-1)
+};
+
+template <int K1, int C1, int COUT, int K>
+__global__ __launch_bounds__(kThreads) void bwd_first_kernel(BwdFirstArgs a) {
+  constexpr int CIN = C1;
+  constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
+  constexpr int RA = TT + K - 1;
+  constexpr int RT1 = (RA + 15) / 16;
+  constexpr int XR = RT1 * 16 + K1 - 1;
+  constexpr int KS1 = K1 * FBINS / 4;
+  constexpr int NT1 = C1 / 16;
+  constexpr int M1 = K1 * FBINS;                 // rows of W1
+  constexpr int MT1 = (M1 + 15) / 16;            // m-tiles of dW1
+  constexpr int MPW = (MT1 + 3) / 4;             // m-tiles per wave
+  constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
+  constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
+  constexpr int OFF_A = 0, OFF_DP = OFF_A + RA * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TT * CPI;
+  constexpr int OFF_G0 = OFF_DU + RA * CPI, OFF_END = OFF_G0 + TT * CPI;
+  static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
+  static_assert(4 % NT1 == 0 && TT >= K - 1, "shape");
+
+  __shared__ float sX[XR * FBINS];
+  __shared__ float smem[OFF_END];
+  __shared__ float sKp[7 * COUT];
+  float* sA = smem + OFF_A;
+  float* sDP = smem + OFF_DP;
+  float* sU = smem + OFF_U;
+  float* sDU = smem + OFF_DU;
+  float* sG0 = smem + OFF_G0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int c = tid % CIN, chunk = tid / CIN;
+  const bool dw_active = chunk < NCH;
+  const int Ta = a.T - (K1 - 1);
+
+  for (int i = tid; i < COUT; i += kThreads) {
+    sKp[0 * COUT + i] = a.k_mean[i];
+    sKp[1 * COUT + i] = a.k_rstd[i];
+    sKp[2 * COUT + i] = a.k_c1[i];
+    sKp[3 * COUT + i] = a.k_mg[i];
+    sKp[4 * COUT + i] = a.k_mgx[i];
+    sKp[5 * COUT + i] = 0.f;
+    sKp[6 * COUT + i] = 0.f;
+  }
+  const int nt1 = wave % NT1;
+  float w1frag[KS1];
+#pragma unroll
+  for (int kk = 0; kk < KS1; ++kk) w1frag[kk] = a.w1[(kk * 4 + g) * C1 + nt1 * 16 + r16];
+  float wtfrag[KSO][MT];
+#pragma unroll
+  for (int kk = 0; kk < KSO; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wtfrag[kk][mt] = a.pw_w[(mt * 16 + r16) * COUT + kk * 4 + g];
+  float dww[K], accw[K];
+  float accb = 0.f, dwb = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    dww[i] = dw_active ? a.dw_w[i * CIN + c] : 0.f;
+    accw[i] = 0.f;
+  }
+  if (dw_active) dwb = a.dw_b[c];
+  f32x4 dwacc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
+  f32x4 w1acc[MPW][NT1];
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = zero4();
+  __syncthreads();
+
+  // the BwdBlockArgs view used by the shared dp staging helper
+  BwdBlockArgs ba;
+  ba.pk = a.pk;
+  ba.gk = a.gk;
+  ba.Tout = a.Tout;
+  ba.dz = nullptr;
+  ba.wd = nullptr;
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int t0 = 0; t0 < Ta; t0 += TT) {
+      const int nrows_new = max(0, min(TT, a.Tout - t0));
+      const int rows_da = min(TT, Ta - t0);
+      const int rows_a = min(RA, Ta - t0);          // a0 rows that exist in this tile
+      const int rows_x = rows_a + K1 - 1;
+      // ---- P0: stage x, dp; roll the du ring
+      {
+        const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+        float4* dst = reinterpret_cast<float4*>(sX);
+        const int nvalid = rows_x * FBINS / 4;
+        for (int i = tid; i < XR * FBINS / 4; i += kThreads) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < nvalid) v = src[i];
+          dst[i] = v;
+        }
+      }
+      stage_dp_tile<COUT, false>(ba, b, t0, sDP, sKp, tid);
+      carry_du<K, CPI>(sDU, t0 == 0, tid);
+      __syncthreads();
+      // ---- recompute a0 = relu(conv1(x)) for local rows [0, RA)
+      for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kk = 0; kk < KS1; ++kk) acc = mfma4(sX[(rt * 16 + r16) * FBINS + kk * 4 + g], w1frag[kk], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + g * 4 + r;
+          if (row < RA) sA[row * CPI + nt1 * 16 + r16] = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
+        }
+      }
+      __syncthreads();
+      // ---- P1: u = depthwise(a0) + bias
+      if (dw_active) {
+        float o[L];
+        dw_chunk<K, L>(sA, CPI, chunk * L, RA, c, dww, dwb, o);
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        }
+      }
+      __syncthreads();
+      pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, wtfrag, dwacc);
+      __syncthreads();
+      // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
+      if (dw_active) {
+        float da[L];
+        depthwise_backward_chunk<K, L, CPI>(sDU, chunk, c, dww, accw, accb, da,
+                                            [&](int row) { return row < RA ? sA[row * CPI + c] : 0.f; });
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int sl = chunk * L + t;
+          if (sl < TT) sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
+        }
+      }
+      __syncthreads();
+      // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = sX[s*40 + m], B[k=s][n] = sG0[s][n]
+#pragma unroll
+      for (int kk = 0; kk < TT / 4; ++kk) {
+        const int s = kk * 4 + g;
+        float bv[NT1];
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) bv[nt] = sG0[s * CPI + nt * 16 + r16];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+          const int m = (wave * MPW + mi) * 16 + r16;
+          const float av = (m < M1) ? sX[s * FBINS + m] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av, bv[nt], w1acc[mi][nt]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* gdst = a.grad_part + (size_t)blockIdx.x * (M1 * C1 + (K + 1) * CIN + CIN * COUT);
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (wave * MPW + mi) * 16 + g * 4 + r;
+        if (m < M1) gdst[m * C1 + nt * 16 + r16] = w1acc[mi][nt][r];
+      }
+  write_block_grad_partials<CIN, COUT, K>(smem, gdst + M1 * C1, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
+}
+
+// ------------------------------------------------------------------------------------------
+// BN backward coefficients from the (sum g, sum g*xhat) partials; also emits dgamma / dbeta.
+struct BnBwdFinalizeArgs {
+  const float* gstat_part;  // [G][2][C]
+  int G, C;
+  float inv_n;              // 1/(B*T)
+  const float* gamma;
+  const float* rstd;
+  float* c1;                // gamma*rstd
+  float* mg;                // mean g
+  float* mgx;               // mean g*xhat
+  float* dgamma;            // -> flat gradient
+  float* dbeta;
+};
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+  __shared__ double sAcc[8 * 128];
+  const int tid = threadIdx.x, slot = tid & 127, grp = tid >> 7;
+  double acc = 0.0;
+  if (slot < 2 * a.C)
+    for (int j = grp; j < a.G; j += 8) acc += (double)a.gstat_part[(size_t)j * 2 * a.C + slot];
+  sAcc[grp * 128 + slot] = acc;
+  __syncthreads();
+  if (tid < a.C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < 8; ++j) {
+      s1 += sAcc[j * 128 + tid];
+      s2 += sAcc[j * 128 + a.C + tid];
+    }
+    a.dbeta[tid] = (float)s1;
+    a.dgamma[tid] = (float)s2;
+    a.c1[tid] = a.gamma[tid] * a.rstd[tid];
+    a.mg[tid] = (float)(s1 * (double)a.inv_n);
+    a.mgx[tid] = (float)(s2 * (double)a.inv_n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient assembly: sum the per-workgroup partials of every segment in a fixed order.
+struct GradSegment {
+  const float* part;   // [G][stride]
+  int G;
+  int stride;          // floats between consecutive workgroups' partials
+  int n;               // parameters in this segment
+  int dst;             // offset in the flat gradient
+};
+constexpr int kMaxSegments = 16;
+constexpr int kGradSplit = 8;    // second-level split of the partial index
+struct GradReduceArgs {
+  GradSegment seg[kMaxSegments];
+  int nseg;
+  float* stage;        // [kGradSplit][P]
+  int P;
+};
+
+// grid = (ceil(maxn/256), nseg, kGradSplit)
+__global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a) {
+  const GradSegment s = a.seg[blockIdx.y];
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= s.n) return;
+  const int js = blockIdx.z;
+  const int per = (s.G + kGradSplit - 1) / kGradSplit;
+  const int j0 = js * per, j1 = min(s.G, j0 + per);
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int j = j0;
+  for (; j + 3 < j1; j += 4) {
+    v0 += s.part[(size_t)(j + 0) * s.stride + e];
+    v1 += s.part[(size_t)(j + 1) * s.stride + e];
+    v2 += s.part[(size_t)(j + 2) * s.stride + e];
+    v3 += s.part[(size_t)(j + 3) * s.stride + e];
+  }
+  for (; j < j1; ++j) v0 += s.part[(size_t)j * s.stride + e];
+  a.stage[(size_t)js * a.P + s.dst + e] = (v0 + v1) + (v2 + v3);
+}
+
+// flat gradient = mask * sum of the staged slices (BN gamma/beta slots are written by
+// bn_bwd_finalize_kernel and flagged by direct[p] != 0)
+struct GradFinishArgs {
+  const float* stage;      // [kGradSplit][P]
+  const float* mask;       // [P] 1 = trainable tap, 0 = structural zero (MixConv padding)
+  const unsigned char* direct;  // [P] 1 = already final in grad[]
+  float* grad;             // [P]
+  int P;
+  float scale;             // 1/world_size folded here when gradients are averaged after all-reduce (1 otherwise)
+};
+
+__global__ __launch_bounds__(kThreads) void grad_finish_kernel(GradFinishArgs a) {
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= a.P) return;
+  float v;
+  if (a.direct[p]) {
+    v = a.grad[p];
+  } else {
+    v = 0.f;
+#pragma unroll
+    for (int j = 0; j < kGradSplit; ++j) v += a.stage[(size_t)j * a.P + p];
+  }
+  a.grad[p] = v * a.mask[p] * a.scale;
+}
+
+// Keras Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host per step.
+struct AdamArgs {
+  float* param;
+  const float* grad;
+  float* m;
+  float* v;
+  const float* hyper;   // device: [0] = alpha, [1] = grad scale (1/world for averaged all-reduce)
+  int P;
+  float beta1, beta2, eps;
+};
+
+__global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs a) {
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= a.P) return;
+  const float alpha = a.hyper[0];
+  const float gg = a.grad[p] * a.hyper[1];
+  float m = a.m[p], v = a.v[p];
+  m += (gg - m) * (1.0f - a.beta1);
+  v += (gg * gg - v) * (1.0f - a.beta2);
+  a.m[p] = m;
+  a.v[p] = v;
+  a.param[p] -= alpha * m / (sqrtf(v) + a.eps);
+}
+
+}  // namespace mww

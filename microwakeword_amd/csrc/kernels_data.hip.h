@@ -1,0 +1,73 @@
+// Batch assembly kernel: ragged gather + left pad / truncate + uint16->f32 scale + SpecAugment
+// zeroing, one workgroup per output window.  Replaces the per-sample Python loop of reference
+// microwakeword/data.py:555-569 (fixed_length_spectrogram :74-118, scaling :268-269,
+// spec_augment :32-71) and the shuffle copy :591-597 (the host hands the windows over already
+// in shuffled order).  Pure data movement: 4 elements per lane, rows of 40 bins are contiguous.
+#pragma once
+#include "common.hip.h"
+#include "../../include/mww.h"
+
+namespace mww {
+
+struct AssembleArgs {
+  const void* store[MWW_MAX_STORES];
+  int dtype[MWW_MAX_STORES];
+  const mww_window* win;   // [B] in output order
+  const int* masks;        // [B][ntm+nfm][2]
+  float* x;                // [B][T][40]
+  int B, T, ntm, nfm;
+};
+
+constexpr int kMaxMasks = 16;
+
+__global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
+  __shared__ int sMask[kMaxMasks * 2];
+  const int j = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nm = a.ntm + a.nfm;
+  if (tid < nm * 2) sMask[tid] = a.masks[(size_t)j * nm * 2 + tid];
+  __syncthreads();
+  const mww_window w = a.win[j];
+  const int dtype = a.dtype[w.store];
+  const unsigned short* s16 = reinterpret_cast<const unsigned short*>(a.store[w.store]);
+  const float* s32 = reinterpret_cast<const float*>(a.store[w.store]);
+  float* dst = a.x + (size_t)j * a.T * FBINS;
+  constexpr int Q = FBINS / 4;
+  for (int i = tid; i < a.T * Q; i += kThreads) {
+    const int t = i / Q, q = i - t * Q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r = t - w.pad_rows;
+    if (r >= 0 && r < w.copy_rows) {
+      const size_t e = (size_t)w.src_elem + (size_t)r * FBINS + q * 4;
+      if (dtype == MWW_DTYPE_U16) {
+        const ushort4 u = *reinterpret_cast<const ushort4*>(s16 + e);
+        v.x = (float)u.x * 0.0390625f;   // data.py:268-269
+        v.y = (float)u.y * 0.0390625f;
+        v.z = (float)u.z * 0.0390625f;
+        v.w = (float)u.w * 0.0390625f;
+      } else {
+        v = *reinterpret_cast<const float4*>(s32 + e);
+      }
+    }
+    bool row_masked = false;
+    for (int m = 0; m < a.ntm; ++m) {
+      const int t0 = sMask[2 * m], tw = sMask[2 * m + 1];
+      row_masked = row_masked || (t >= t0 && t < t0 + tw);
+    }
+    if (row_masked) {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int m = a.ntm; m < nm; ++m) {
+        const int f0 = sMask[2 * m], fw = sMask[2 * m + 1];
+        const int f = q * 4;
+        if (f + 0 >= f0 && f + 0 < f0 + fw) v.x = 0.f;
+        if (f + 1 >= f0 && f + 1 < f0 + fw) v.y = 0.f;
+        if (f + 2 >= f0 && f + 2 < f0 + fw) v.z = 0.f;
+        if (f + 3 >= f0 && f + 3 < f0 + fw) v.w = 0.f;
+      }
+    }
+    *reinterpret_cast<float4*>(dst + (size_t)t * FBINS + q * 4) = v;
+  }
+}
+
+}  // namespace mww

@@ -1,0 +1,883 @@
+// libmww_hip.so — context, device memory, launch sequencing and the C ABI of include/mww.h.
+// One context = one device + one HIP stream + one model; every call enqueues on that stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mww.h"
+#include "kernels_bwd.hip.h"
+#include "kernels_data.hip.h"
+#include "kernels_fwd.hip.h"
+
+using namespace mww;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(MWW_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+struct Layer {
+  int cin, cout, k, tin, tout;
+  // offsets into the flat parameter / state vectors
+  int64_t o_dw_w, o_dw_b, o_pw_w, o_gamma, o_beta, o_mm, o_mv;
+  // device buffers
+  float* p = nullptr;          // pre-BN output [maxB][tout][cout]
+  float* g = nullptr;          // gradient at the BN output (masked by ReLU) [maxB][tout][cout]
+  float* stat_part = nullptr;  // [grid_fwd][2][cout]
+  float* gstat_part = nullptr; // [grid_bwd or grid_head][2][cout]
+  float* grad_part = nullptr;  // [grid_bwd][params of the block (+ conv1 for block 0)]
+  int grad_part_stride = 0;
+  float* bn = nullptr;         // 9 x cout: scale, shift, mean, rstd, c1, mg, mgx, (spare x2)
+};
+
+struct ProfileEntry {
+  std::string name;
+  hipEvent_t a, b;
+};
+
+constexpr int kRing = 8;
+
+}  // namespace
+
+struct mww_ctx {
+  mww_mixednet_desc d;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  int grid_fwd = 0, grid_bwd = 0, grid_head = 0;
+  int64_t P = 0, S = 0;
+  int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
+  int t_last = 0, c_last = 0, dwd_stride = 0;
+  std::vector<Layer> L;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr, *stage = nullptr;
+  unsigned char* direct = nullptr;
+  float* bn_state = nullptr;
+  float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
+  float* dwd_part = nullptr;
+  MetricState* metrics = nullptr;
+  float* hyper = nullptr;  // device [2]
+  // pinned staging rings
+  float* hyper_pin[kRing] = {};
+  hipEvent_t hyper_ev[kRing] = {};
+  int hyper_slot = 0;
+  void* desc_pin[kRing] = {};
+  hipEvent_t desc_ev[kRing] = {};
+  size_t desc_pin_bytes = 0;
+  int desc_slot = 0;
+  mww_window* win_dev = nullptr;
+  int* mask_dev = nullptr;
+  void* store[MWW_MAX_STORES] = {};
+  int store_dtype[MWW_MAX_STORES] = {};
+  int64_t store_elems[MWW_MAX_STORES] = {};
+  int64_t step = 0;
+  int have_batch = 0, have_targets = 0;
+  bool use_graphs = false, profile = false;
+  std::vector<ProfileEntry> prof;
+  // cached graphs keyed by (B, flags)
+  struct GraphEntry { int B, flags; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+};
+
+namespace {
+
+struct Launcher {
+  mww_ctx* c;
+  hipEvent_t ea = nullptr;
+  const char* name = nullptr;
+  void begin(const char* n) {
+    if (!c->profile) return;
+    name = n;
+    ProfileEntry e;
+    e.name = n;
+    hipEventCreate(&e.a);
+    hipEventCreate(&e.b);
+    hipEventRecord(e.a, c->stream);
+    c->prof.push_back(e);
+  }
+  void end() {
+    if (!c->profile) return;
+    hipEventRecord(c->prof.back().b, c->stream);
+  }
+};
+
+// ---------------------------------------------------------------------------------- dispatch
+#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5)
+#define MWW_BLOCK_SHAPES(X)                                                                               \
+  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21)
+
+int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, const FwdFirstArgs& a, int grid) {
+#define X(K1, C1, CO, K)                                                                                       \
+  if (k1 == K1 && c1 == C1 && cout == CO && k == K) {                                                          \
+    hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);        \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_FIRST_SHAPES(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "no first-block kernel for this (conv1 kernel, filters, pointwise, depthwise) shape");
+}
+
+int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, const BwdFirstArgs& a, int grid) {
+#define X(K1, C1, CO, K)                                                                                       \
+  if (k1 == K1 && c1 == C1 && cout == CO && k == K) {                                                          \
+    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);        \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_FIRST_SHAPES(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "no first-block backward kernel for this shape");
+}
+
+int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a, int grid) {
+#define X(CI, CO, K)                                                                                           \
+  if (cin == CI && cout == CO && k == K) {                                                                     \
+    hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);            \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_BLOCK_SHAPES(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "no block kernel for this (cin, cout, depthwise) shape");
+}
+
+int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
+#define X(CI, CO, K)                                                                                           \
+  if (cin == CI && cout == CO && k == K) {                                                                     \
+    if (last)                                                                                                  \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_BLOCK_SHAPES(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "no block backward kernel for this shape");
+}
+
+int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
+#define X(C, J)                                                                                                \
+  if (ch == C && jmax <= J) {                                                                                  \
+    hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                      \
+    return MWW_OK;                                                                                             \
+  }
+  X(48, 2) X(48, 4) X(48, 8) X(48, 12)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
+}
+
+bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
+  bool ok = false;
+#define X(K1, C1, CO, K) ok = ok || (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.block_filters[0] == CO && d.block_kernel[0] == K);
+  MWW_FIRST_SHAPES(X)
+#undef X
+  if (!ok) { *why = "first block (conv1 kernel/filters, pointwise filters, depthwise kernel) not instantiated"; return false; }
+  for (int i = 1; i < d.n_blocks; ++i) {
+    ok = false;
+#define X(CI, CO, K) ok = ok || (d.block_filters[i - 1] == CI && d.block_filters[i] == CO && d.block_kernel[i] == K);
+    MWW_BLOCK_SHAPES(X)
+#undef X
+    if (!ok) { *why = "block " + std::to_string(i) + " (cin, cout, depthwise kernel) not instantiated"; return false; }
+  }
+  const int cl = d.block_filters[d.n_blocks - 1];
+  if (cl != 48) { *why = "head kernel needs 48 channels"; return false; }
+  return true;
+}
+
+float* bn_slot(Layer& l, int i) { return l.bn + (size_t)i * l.cout; }
+enum { BN_SCALE = 0, BN_SHIFT, BN_MEAN, BN_RSTD, BN_C1, BN_MG, BN_MGX };
+
+// ---------------------------------------------------------------------------------- sequences
+int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
+  Launcher lp{c};
+  const mww_mixednet_desc& d = c->d;
+  const int nb = d.n_blocks;
+  if (!training) {
+    for (int i = 0; i < nb; ++i) {
+      Layer& l = c->L[i];
+      BnEvalPrepareArgs a{c->params + l.o_gamma, c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv,
+                          bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), l.cout};
+      lp.begin("bn_eval_prepare");
+      hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(64), 0, c->stream, a);
+      lp.end();
+    }
+  }
+  for (int i = 0; i < nb; ++i) {
+    Layer& l = c->L[i];
+    const int grid = std::min(B, c->grid_fwd);
+    if (i == 0) {
+      FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
+                     l.p, l.stat_part, B, d.frames, l.tout};
+      lp.begin("fwd_first");
+      int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, grid);
+      lp.end();
+      if (rc) return rc;
+    } else {
+      Layer& pl = c->L[i - 1];
+      FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
+                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout};
+      lp.begin("fwd_block");
+      int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
+      lp.end();
+      if (rc) return rc;
+    }
+    if (training) {
+      BnFwdFinalizeArgs f{l.stat_part, grid, l.cout, 1.0f / ((float)B * (float)l.tout), c->params + l.o_gamma,
+                          c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv, bn_slot(l, BN_SCALE),
+                          bn_slot(l, BN_SHIFT), bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), update_moving ? 1 : 0};
+      lp.begin("bn_fwd_finalize");
+      hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+      lp.end();
+    }
+  }
+  Layer& ll = c->L[nb - 1];
+  const int ghead = std::min(B, c->grid_head);
+  HeadArgs h;
+  h.p = ll.p;
+  h.scale = bn_slot(ll, BN_SCALE);
+  h.shift = bn_slot(ll, BN_SHIFT);
+  h.mean = bn_slot(ll, BN_MEAN);
+  h.rstd = bn_slot(ll, BN_RSTD);
+  h.wd = c->params + c->o_dense_w;
+  h.bd = c->params + c->o_dense_b;
+  h.y = (loss || metrics) ? c->y : nullptr;
+  h.sw = c->sw;
+  h.z = c->z;
+  h.prob = c->prob;
+  h.dz = c->dz;
+  h.loss_part = c->loss_part;
+  h.dwd_part = c->dwd_part;
+  h.gstat_part = ll.gstat_part;
+  h.metrics = metrics ? c->metrics : nullptr;
+  h.B = B;
+  h.T = ll.tout;
+  h.dwd_stride = c->dwd_stride;
+  h.inv_b = 1.0f / (float)B;
+  h.training = loss ? 1 : 0;
+  const int q = ll.cout / 4, nrg = kThreads / q;
+  lp.begin("head");
+  int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
+  lp.end();
+  return rc;
+}
+
+int enqueue_backward(mww_ctx* c, int B) {
+  Launcher lp{c};
+  const mww_mixednet_desc& d = c->d;
+  const int nb = d.n_blocks;
+  const int gbwd = std::min(B, c->grid_bwd);
+  const int ghead = std::min(B, c->grid_head);
+  for (int i = nb - 1; i >= 0; --i) {
+    Layer& l = c->L[i];
+    const bool last = (i == nb - 1);
+    BnBwdFinalizeArgs f{l.gstat_part, last ? ghead : gbwd, l.cout, 1.0f / ((float)B * (float)l.tout),
+                        c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
+                        bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta};
+    lp.begin("bn_bwd_finalize");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+    lp.end();
+    if (i > 0) {
+      Layer& pl = c->L[i - 1];
+      BwdBlockArgs a;
+      a.in = pl.p;
+      a.in_scale = bn_slot(pl, BN_SCALE);
+      a.in_shift = bn_slot(pl, BN_SHIFT);
+      a.in_mean = bn_slot(pl, BN_MEAN);
+      a.in_rstd = bn_slot(pl, BN_RSTD);
+      a.pk = l.p;
+      a.gk = l.g;
+      a.k_mean = bn_slot(l, BN_MEAN);
+      a.k_rstd = bn_slot(l, BN_RSTD);
+      a.k_c1 = bn_slot(l, BN_C1);
+      a.k_mg = bn_slot(l, BN_MG);
+      a.k_mgx = bn_slot(l, BN_MGX);
+      a.k_scale = bn_slot(l, BN_SCALE);
+      a.k_shift = bn_slot(l, BN_SHIFT);
+      a.wd = c->params + c->o_dense_w;
+      a.dz = c->dz;
+      a.dw_w = c->params + l.o_dw_w;
+      a.dw_b = c->params + l.o_dw_b;
+      a.pw_w = c->params + l.o_pw_w;
+      a.g_out = pl.g;
+      a.gstat_part = pl.gstat_part;
+      a.grad_part = l.grad_part;
+      a.B = B;
+      a.Tin = l.tin;
+      a.Tout = l.tout;
+      lp.begin(last ? "bwd_block_last" : "bwd_block");
+      int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
+      lp.end();
+      if (rc) return rc;
+    } else {
+      if (last) return fail(MWW_ERR_UNSUPPORTED, "single-block models are not supported");
+      BwdFirstArgs a{c->x, c->params + c->o_conv1, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
+                     bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
+                     c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout};
+      lp.begin("bwd_first");
+      int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, gbwd);
+      lp.end();
+      if (rc) return rc;
+    }
+  }
+  // gradient assembly
+  GradReduceArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  int ns = 0, maxn = 0;
+  for (int i = 0; i < nb; ++i) {
+    Layer& l = c->L[i];
+    GradSegment s;
+    s.part = l.grad_part;
+    s.G = gbwd;
+    s.stride = l.grad_part_stride;
+    s.n = l.grad_part_stride;
+    s.dst = (int)(i == 0 ? c->o_conv1 : l.o_dw_w);
+    ga.seg[ns++] = s;
+    maxn = std::max(maxn, s.n);
+  }
+  {
+    GradSegment s;
+    s.part = c->dwd_part;
+    s.G = ghead;
+    s.stride = c->dwd_stride;
+    s.n = c->t_last * c->c_last + 1;
+    s.dst = (int)c->o_dense_w;
+    ga.seg[ns++] = s;
+    maxn = std::max(maxn, s.n);
+  }
+  ga.nseg = ns;
+  ga.stage = c->stage;
+  ga.P = (int)c->P;
+  lp.begin("grad_reduce");
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ns, kGradSplit), dim3(kThreads), 0,
+                     c->stream, ga);
+  lp.end();
+  GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
+  lp.begin("grad_finish");
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
+  lp.end();
+  return MWW_OK;
+}
+
+int enqueue_adam(mww_ctx* c) {
+  Launcher lp{c};
+  AdamArgs a{c->params, c->grads, c->adam_m, c->adam_v, c->hyper, (int)c->P, 0.9f, 0.999f, 1e-7f};
+  lp.begin("adam");
+  hipLaunchKernelGGL(adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, a);
+  lp.end();
+  return MWW_OK;
+}
+
+int push_hyper(mww_ctx* c, float alpha, float gscale) {
+  const int s = c->hyper_slot;
+  c->hyper_slot = (s + 1) % kRing;
+  HIPCHK(hipEventSynchronize(c->hyper_ev[s]));
+  c->hyper_pin[s][0] = alpha;
+  c->hyper_pin[s][1] = gscale;
+  HIPCHK(hipMemcpyAsync(c->hyper, c->hyper_pin[s], 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->hyper_ev[s], c->stream));
+  return MWW_OK;
+}
+
+float adam_alpha(float lr, int64_t t) {
+  // Keras: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in float32 like the variables
+  const float b1p = powf(0.9f, (float)t), b2p = powf(0.999f, (float)t);
+  return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+}
+
+int step_sequence(mww_ctx* c, int B, int flags) {
+  int rc = enqueue_forward(c, B, true, true, true, !(flags & MWW_STEP_NO_METRICS));
+  if (rc) return rc;
+  rc = enqueue_backward(c, B);
+  if (rc) return rc;
+  if (!(flags & MWW_STEP_NO_APPLY)) rc = enqueue_adam(c);
+  return rc;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  return MWW_OK;
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" {
+
+const char* mww_version(void) { return "mww-hip 0.1 (gfx950)"; }
+const char* mww_last_error(void) { return g_err.c_str(); }
+
+int mww_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx** out) {
+  if (!desc || !out) return fail(MWW_ERR_INVALID, "null argument");
+  const mww_mixednet_desc& d = *desc;
+  if (d.n_blocks < 2 || d.n_blocks > MWW_MAX_BLOCKS) return fail(MWW_ERR_INVALID, "n_blocks must be in [2, 8]");
+  if (d.conv1_stride != 1) return fail(MWW_ERR_UNSUPPORTED, "first-conv stride != 1 is not implemented");
+  if (d.conv1_filters <= 0) return fail(MWW_ERR_UNSUPPORTED, "first_conv_filters == 0 is not implemented");
+  if (d.max_batch <= 0 || d.frames <= 0) return fail(MWW_ERR_INVALID, "frames and max_batch must be positive");
+  std::string why;
+  if (!shape_supported(d, &why)) return fail(MWW_ERR_UNSUPPORTED, why);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MWW_ERR_HIP, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MWW_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  mww_ctx* c = new mww_ctx();
+  c->d = d;
+  c->device = device;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  c->grid_fwd = c->n_cu * 4;
+  c->grid_bwd = c->n_cu * 2;
+  c->grid_head = c->n_cu;
+  // ---- parameter layout
+  int64_t off = 0, soff = 0;
+  c->o_conv1 = off;
+  off += (int64_t)d.conv1_kernel * MWW_FEATURE_BINS * d.conv1_filters;
+  int t = d.frames - (d.conv1_kernel - 1), ch = d.conv1_filters;
+  c->L.resize(d.n_blocks);
+  for (int i = 0; i < d.n_blocks; ++i) {
+    Layer& l = c->L[i];
+    l.cin = ch;
+    l.cout = d.block_filters[i];
+    l.k = d.block_kernel[i];
+    l.tin = t;
+    l.tout = t - (l.k - 1);
+    if (l.tout <= 0) { delete c; return fail(MWW_ERR_INVALID, "spectrogram too short for the kernel sizes"); }
+    l.o_dw_w = off; off += (int64_t)l.k * l.cin;
+    l.o_dw_b = off; off += l.cin;
+    l.o_pw_w = off; off += (int64_t)l.cin * l.cout;
+    l.o_gamma = off; off += l.cout;
+    l.o_beta = off; off += l.cout;
+    l.o_mm = soff; soff += l.cout;
+    l.o_mv = soff; soff += l.cout;
+    t = l.tout;
+    ch = l.cout;
+  }
+  c->t_last = t;
+  c->c_last = ch;
+  c->o_dense_w = off; off += (int64_t)t * ch;
+  c->o_dense_b = off; off += 1;
+  c->P = off;
+  c->S = soff;
+  c->dwd_stride = t * ch + 4;
+  const size_t mb = (size_t)d.max_batch;
+  const int gmax_f = c->grid_fwd, gmax_b = c->grid_bwd, gmax_h = c->grid_head;
+  int rc = 0;
+#define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
+  A(dev_alloc(&c->params, c->P));
+  A(dev_alloc(&c->grads, c->P));
+  A(dev_alloc(&c->adam_m, c->P));
+  A(dev_alloc(&c->adam_v, c->P));
+  A(dev_alloc(&c->mask, c->P));
+  A(dev_alloc(&c->direct, c->P));
+  A(dev_alloc(&c->stage, (size_t)kGradSplit * c->P));
+  A(dev_alloc(&c->bn_state, c->S));
+  A(dev_alloc(&c->x, mb * d.frames * MWW_FEATURE_BINS));
+  A(dev_alloc(&c->y, mb));
+  A(dev_alloc(&c->sw, mb));
+  A(dev_alloc(&c->z, mb));
+  A(dev_alloc(&c->prob, mb));
+  A(dev_alloc(&c->dz, mb));
+  A(dev_alloc(&c->loss_part, mb));
+  A(dev_alloc(&c->dwd_part, (size_t)gmax_h * c->dwd_stride));
+  A(dev_alloc(&c->metrics, 1));
+  A(dev_alloc(&c->hyper, 2));
+  A(dev_alloc(&c->win_dev, mb));
+  A(dev_alloc(&c->mask_dev, mb * kMaxMasks * 2));
+  for (int i = 0; i < d.n_blocks; ++i) {
+    Layer& l = c->L[i];
+    A(dev_alloc(&l.p, mb * l.tout * l.cout));
+    A(dev_alloc(&l.g, mb * l.tout * l.cout));
+    A(dev_alloc(&l.stat_part, (size_t)gmax_f * 2 * l.cout));
+    A(dev_alloc(&l.gstat_part, (size_t)std::max(gmax_b, gmax_h) * 2 * l.cout));
+    l.grad_part_stride = (l.k + 1) * l.cin + l.cin * l.cout;
+    if (i == 0) l.grad_part_stride += d.conv1_kernel * MWW_FEATURE_BINS * d.conv1_filters;
+    A(dev_alloc(&l.grad_part, (size_t)gmax_b * l.grad_part_stride));
+    A(dev_alloc(&l.bn, (size_t)9 * l.cout));
+  }
+  // mask = 1 everywhere, direct flags on the BN gamma/beta slots; moving variance starts at 1
+  {
+    std::vector<float> ones((size_t)c->P, 1.0f);
+    std::vector<unsigned char> dir((size_t)c->P, 0);
+    std::vector<float> st((size_t)c->S, 0.0f);
+    for (int i = 0; i < d.n_blocks; ++i) {
+      Layer& l = c->L[i];
+      for (int j = 0; j < l.cout; ++j) {
+        dir[(size_t)l.o_gamma + j] = 1;
+        dir[(size_t)l.o_beta + j] = 1;
+        st[(size_t)l.o_mv + j] = 1.0f;
+      }
+    }
+    hipMemcpy(c->mask, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice);
+    hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice);
+    hipMemcpy(c->bn_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+  c->desc_pin_bytes = mb * (sizeof(mww_window) + kMaxMasks * 2 * sizeof(int) + 2 * sizeof(float));
+  for (int i = 0; i < kRing; ++i) {
+    A(hipHostMalloc((void**)&c->hyper_pin[i], 2 * sizeof(float), hipHostMallocDefault) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc"));
+    A(hipEventCreateWithFlags(&c->hyper_ev[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
+    A(hipHostMalloc(&c->desc_pin[i], c->desc_pin_bytes, hipHostMallocDefault) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc"));
+    A(hipEventCreateWithFlags(&c->desc_ev[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
+  }
+#undef A
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return MWW_OK;
+}
+
+void mww_destroy(mww_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+  for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
+                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->hyper, c->win_dev, c->mask_dev};
+  for (void* p : flat) if (p) hipFree(p);
+  for (auto& l : c->L) {
+    void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
+    for (void* p : lp) if (p) hipFree(p);
+  }
+  for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
+  for (int i = 0; i < kRing; ++i) {
+    if (c->hyper_pin[i]) hipHostFree(c->hyper_pin[i]);
+    if (c->desc_pin[i]) hipHostFree(c->desc_pin[i]);
+    if (c->hyper_ev[i]) hipEventDestroy(c->hyper_ev[i]);
+    if (c->desc_ev[i]) hipEventDestroy(c->desc_ev[i]);
+  }
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mww_synchronize(mww_ctx* c) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MWW_OK;
+}
+
+int64_t mww_num_params(const mww_ctx* c) { return c ? c->P : 0; }
+int64_t mww_num_bn_state(const mww_ctx* c) { return c ? c->S : 0; }
+
+static int copy_in(mww_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MWW_OK;
+}
+static int copy_out(mww_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return MWW_OK;
+}
+
+int mww_set_params(mww_ctx* c, const float* h, int64_t n) {
+  if (!c || !h || n != c->P) return fail(MWW_ERR_INVALID, "parameter vector size mismatch");
+  return copy_in(c, c->params, h, (size_t)n * sizeof(float));
+}
+int mww_get_params(mww_ctx* c, float* h, int64_t n) {
+  if (!c || !h || n != c->P) return fail(MWW_ERR_INVALID, "parameter vector size mismatch");
+  return copy_out(c, h, c->params, (size_t)n * sizeof(float));
+}
+int mww_set_bn_state(mww_ctx* c, const float* h, int64_t n) {
+  if (!c || !h || n != c->S) return fail(MWW_ERR_INVALID, "BN state size mismatch");
+  return copy_in(c, c->bn_state, h, (size_t)n * sizeof(float));
+}
+int mww_get_bn_state(mww_ctx* c, float* h, int64_t n) {
+  if (!c || !h || n != c->S) return fail(MWW_ERR_INVALID, "BN state size mismatch");
+  return copy_out(c, h, c->bn_state, (size_t)n * sizeof(float));
+}
+int mww_set_grad_mask(mww_ctx* c, const float* h, int64_t n) {
+  if (!c || !h || n != c->P) return fail(MWW_ERR_INVALID, "mask size mismatch");
+  return copy_in(c, c->mask, h, (size_t)n * sizeof(float));
+}
+int mww_set_opt_state(mww_ctx* c, const float* m, const float* v, int64_t n, int64_t step) {
+  if (!c || !m || !v || n != c->P || step < 0) return fail(MWW_ERR_INVALID, "optimizer state size mismatch");
+  int rc = copy_in(c, c->adam_m, m, (size_t)n * sizeof(float));
+  if (rc) return rc;
+  rc = copy_in(c, c->adam_v, v, (size_t)n * sizeof(float));
+  c->step = step;
+  return rc;
+}
+int mww_get_opt_state(mww_ctx* c, float* m, float* v, int64_t n, int64_t* step) {
+  if (!c || n != c->P) return fail(MWW_ERR_INVALID, "optimizer state size mismatch");
+  int rc = 0;
+  if (m) rc = copy_out(c, m, c->adam_m, (size_t)n * sizeof(float));
+  if (!rc && v) rc = copy_out(c, v, c->adam_v, (size_t)n * sizeof(float));
+  if (step) *step = c->step;
+  return rc;
+}
+int mww_get_grads(mww_ctx* c, float* h, int64_t n) {
+  if (!c || !h || n != c->P) return fail(MWW_ERR_INVALID, "gradient vector size mismatch");
+  return copy_out(c, h, c->grads, (size_t)n * sizeof(float));
+}
+
+int mww_upload_store(mww_ctx* c, int id, const void* data, int64_t n, int dtype) {
+  if (!c || !data || id < 0 || id >= MWW_MAX_STORES || n <= 0) return fail(MWW_ERR_INVALID, "bad store arguments");
+  if (dtype != MWW_DTYPE_U16 && dtype != MWW_DTYPE_F32) return fail(MWW_ERR_INVALID, "store dtype must be uint16 or float32");
+  if (n % MWW_FEATURE_BINS) return fail(MWW_ERR_INVALID, "store length is not a multiple of 40 bins");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->store[id]) { HIPCHK(hipFree(c->store[id])); c->store[id] = nullptr; }
+  const size_t bytes = (size_t)n * (dtype == MWW_DTYPE_U16 ? 2 : 4);
+  HIPCHK(hipMalloc(&c->store[id], bytes + 16));
+  c->store_dtype[id] = dtype;
+  c->store_elems[id] = n;
+  return copy_in(c, c->store[id], data, bytes);
+}
+
+int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, int B, int ntm, int nfm) {
+  if (!c || !win || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  const int nm = ntm + nfm;
+  if (ntm < 0 || nfm < 0 || nm > kMaxMasks || (nm > 0 && !masks)) return fail(MWW_ERR_INVALID, "too many masks");
+  const int T = c->d.frames;
+  for (int j = 0; j < B; ++j) {
+    const mww_window& w = win[j];
+    if (w.store < 0 || w.store >= MWW_MAX_STORES || !c->store[w.store]) return fail(MWW_ERR_INVALID, "window refers to a store that was not uploaded");
+    if (w.pad_rows < 0 || w.copy_rows < 0 || w.pad_rows + w.copy_rows != T) return fail(MWW_ERR_INVALID, "window rows do not add up to the spectrogram length");
+    if (w.src_elem < 0 || w.src_elem + (int64_t)w.copy_rows * MWW_FEATURE_BINS > c->store_elems[w.store]) return fail(MWW_ERR_INVALID, "window reads past the end of its store");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const int s = c->desc_slot;
+  c->desc_slot = (s + 1) % kRing;
+  HIPCHK(hipEventSynchronize(c->desc_ev[s]));
+  char* pin = (char*)c->desc_pin[s];
+  memcpy(pin, win, (size_t)B * sizeof(mww_window));
+  int* pm = (int*)(pin + (size_t)c->d.max_batch * sizeof(mww_window));
+  if (nm) memcpy(pm, masks, (size_t)B * nm * 2 * sizeof(int));
+  HIPCHK(hipMemcpyAsync(c->win_dev, pin, (size_t)B * sizeof(mww_window), hipMemcpyHostToDevice, c->stream));
+  if (nm) HIPCHK(hipMemcpyAsync(c->mask_dev, pm, (size_t)B * nm * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->desc_ev[s], c->stream));
+  AssembleArgs a;
+  for (int i = 0; i < MWW_MAX_STORES; ++i) { a.store[i] = c->store[i]; a.dtype[i] = c->store_dtype[i]; }
+  a.win = c->win_dev;
+  a.masks = c->mask_dev;
+  a.x = c->x;
+  a.B = B;
+  a.T = T;
+  a.ntm = ntm;
+  a.nfm = nfm;
+  Launcher lp{c};
+  lp.begin("assemble");
+  hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->stream, a);
+  lp.end();
+  HIPCHK(hipGetLastError());
+  c->have_batch = B;
+  return MWW_OK;
+}
+
+int mww_set_batch(mww_ctx* c, const float* hx, int B) {
+  if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = copy_in(c, c->x, hx, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
+  if (!rc) c->have_batch = B;
+  return rc;
+}
+int mww_get_batch(mww_ctx* c, float* hx, int B) {
+  if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  return copy_out(c, hx, c->x, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
+}
+
+int mww_set_targets(mww_ctx* c, const float* hy, const float* hw, int B) {
+  if (!c || !hy || !hw || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  HIPCHK(hipSetDevice(c->device));
+  const int s = c->desc_slot;
+  c->desc_slot = (s + 1) % kRing;
+  HIPCHK(hipEventSynchronize(c->desc_ev[s]));
+  float* pin = (float*)((char*)c->desc_pin[s] + (size_t)c->d.max_batch * (sizeof(mww_window) + kMaxMasks * 2 * sizeof(int)));
+  memcpy(pin, hy, (size_t)B * sizeof(float));
+  memcpy(pin + c->d.max_batch, hw, (size_t)B * sizeof(float));
+  HIPCHK(hipMemcpyAsync(c->y, pin, (size_t)B * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->sw, pin + c->d.max_batch, (size_t)B * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->desc_ev[s], c->stream));
+  c->have_targets = B;
+  return MWW_OK;
+}
+
+int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
+  if (!c || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  if (c->have_batch < B || c->have_targets < B) return fail(MWW_ERR_STATE, "train step needs a batch and targets of at least B rows");
+  HIPCHK(hipSetDevice(c->device));
+  const bool apply = !(flags & MWW_STEP_NO_APPLY);
+  if (apply) {
+    c->step += 1;
+    int rc = push_hyper(c, adam_alpha(lr, c->step), 1.0f);
+    if (rc) return rc;
+  }
+  if (c->use_graphs && !c->profile) {
+    for (auto& g : c->graphs)
+      if (g.B == B && g.flags == flags) {
+        HIPCHK(hipGraphLaunch(g.exec, c->stream));
+        return MWW_OK;
+      }
+    hipGraph_t graph;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = step_sequence(c, B, flags);
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(MWW_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    hipGraphExec_t exec;
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+    c->graphs.push_back({B, flags, exec});
+    HIPCHK(hipGraphLaunch(exec, c->stream));
+    return MWW_OK;
+  }
+  int rc = step_sequence(c, B, flags);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return MWW_OK;
+}
+
+int mww_apply_gradients(mww_ctx* c, float lr, float gscale) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(c->device));
+  c->step += 1;
+  int rc = push_hyper(c, adam_alpha(lr, c->step), gscale);
+  if (rc) return rc;
+  rc = enqueue_adam(c);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return MWW_OK;
+}
+
+int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
+  if (!c || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  if (c->have_batch < B) return fail(MWW_ERR_STATE, "forward needs a batch of at least B rows");
+  if (update_metrics && c->have_targets < B) return fail(MWW_ERR_STATE, "metric update needs targets");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = enqueue_forward(c, B, training != 0, false, false, update_metrics != 0);
+  if (rc) return rc;
+  HIPCHK(hipGetLastError());
+  return MWW_OK;
+}
+
+int mww_read_outputs(mww_ctx* c, int B, float* probs, float* logits, float* loss) {
+  if (!c || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  if (probs) HIPCHK(hipMemcpyAsync(probs, c->prob, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (logits) HIPCHK(hipMemcpyAsync(logits, c->z, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> lp;
+  if (loss) {
+    lp.resize(B);
+    HIPCHK(hipMemcpyAsync(lp.data(), c->loss_part, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (loss) {
+    double s = 0.0;
+    for (int i = 0; i < B; ++i) s += lp[i];
+    *loss = (float)s;
+  }
+  return MWW_OK;
+}
+
+int mww_metrics_read(mww_ctx* c, mww_metrics* out) {
+  if (!c || !out) return fail(MWW_ERR_INVALID, "null argument");
+  static_assert(sizeof(mww_metrics) == sizeof(MetricState), "metric layouts must match");
+  return copy_out(c, out, c->metrics, sizeof(MetricState));
+}
+int mww_metrics_reset(mww_ctx* c) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  HIPCHK(hipMemsetAsync(c->metrics, 0, sizeof(MetricState), c->stream));
+  return MWW_OK;
+}
+
+void* mww_device_ptr(mww_ctx* c, int which) {
+  if (!c) return nullptr;
+  switch (which) {
+    case MWW_BUF_PARAMS: return c->params;
+    case MWW_BUF_GRADS: return c->grads;
+    case MWW_BUF_BN_STATE: return c->bn_state;
+    case MWW_BUF_X: return c->x;
+    default: return nullptr;
+  }
+}
+
+int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t cap) {
+  if (!c || !name || !host || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad debug_read arguments");
+  const float* src = nullptr;
+  int64_t n = 0;
+  const int nb = c->d.n_blocks;
+  auto idx = [&](const char* prefix) -> int {
+    const size_t pl = strlen(prefix);
+    if (strncmp(name, prefix, pl) != 0) return -1;
+    const int k = atoi(name + pl);
+    return (k >= 1 && k <= nb && name[pl] >= '0' && name[pl] <= '9') ? k - 1 : -1;
+  };
+  int k;
+  if ((k = idx("p")) >= 0) { src = c->L[k].p; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
+  else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
+  else if ((k = idx("bn")) >= 0) { src = c->L[k].bn; n = (int64_t)9 * c->L[k].cout; }
+  else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
+  else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
+  else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
+  if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");
+  int rc = copy_out(c, host, src, (size_t)n * sizeof(float));
+  return rc ? rc : n;
+}
+
+int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
+  if (!c || !name) return fail(MWW_ERR_INVALID, "null argument");
+  if (!strcmp(name, "graphs")) c->use_graphs = v != 0;
+  else if (!strcmp(name, "profile")) {
+    c->profile = v != 0;
+    for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    c->prof.clear();
+  }
+  else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
+  else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
+  else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
+  else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+  c->graphs.clear();
+  return MWW_OK;
+}
+
+int mww_profile_read(mww_ctx* c, char* names, int names_cap, float* ms, int cap) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int n = 0, pos = 0;
+  for (auto& e : c->prof) {
+    if (n >= cap) break;
+    float t = 0.f;
+    hipEventElapsedTime(&t, e.a, e.b);
+    ms[n] = t;
+    const int len = (int)e.name.size();
+    if (names && pos + len + 1 < names_cap) {
+      memcpy(names + pos, e.name.c_str(), len);
+      names[pos + len] = '\n';
+      pos += len + 1;
+    }
+    ++n;
+  }
+  if (names && names_cap > 0) names[pos < names_cap ? pos : names_cap - 1] = 0;
+  for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  c->prof.clear();
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// Host-side batch sampler: draws one training batch's window descriptors from the SAME two
+// Mersenne-Twister streams the reference consumes, in the same order, so that the
+// SpecAugment mask indices and the chosen windows are bit-identical to
+// reference microwakeword/data.py:531-597 under identical seeds:
+//
+//   1. random.choices(providers, sampling_weights, k=B)                    data.py:541-553
+//   2. per slot: [random.choice(fixed_right_cutoffs)]                      data.py:252-253
+//               random.choice(feature_sets["training"])                    data.py:255
+//               [np.random.randint(0, L-T)]  (strategy "random", L > T)    data.py:100
+//               per time mask: np.random.uniform(0,tmax) ; random.randint  data.py:61-64
+//               per freq mask: np.random.uniform(0,fmax) ; random.randint  data.py:66-69
+//   3. np.random.shuffle(indices)                                          data.py:591-595
+//
+// The Python host hands over the raw MT19937 states (random.getstate() / np.random.get_state()),
+// this code advances them, and the host installs them back, so Python code that keeps using the
+// global RNGs afterwards sees exactly the stream positions the reference would have left.
+//
+// Algorithms restated from CPython 3.10 Lib/random.py + Modules/_randommodule.c and numpy
+// (legacy RandomState over MT19937: random_standard_uniform, masked-rejection bounded ints).
+#include <stdint.h>
+#include <string.h>
+
+#include <cmath>
+
+#include "../../include/mww.h"
+
+namespace {
+
+struct MT {
+  uint32_t* s;   // 624 words
+  uint32_t* pos; // index
+  inline uint32_t next() {
+    if (*pos >= 624) regen();
+    uint32_t y = s[(*pos)++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  void regen() {
+    const uint32_t N = 624, M = 397;
+    uint32_t kk;
+    for (kk = 0; kk < N - M; kk++) {
+      uint32_t y = (s[kk] & 0x80000000u) | (s[kk + 1] & 0x7fffffffu);
+      s[kk] = s[kk + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; kk < N - 1; kk++) {
+      uint32_t y = (s[kk] & 0x80000000u) | (s[kk + 1] & 0x7fffffffu);
+      s[kk] = s[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (s[N - 1] & 0x80000000u) | (s[0] & 0x7fffffffu);
+    s[N - 1] = s[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    *pos = 0;
+  }
+  // 53-bit double in [0,1): identical in CPython random.random() and numpy legacy random_sample()
+  inline double real53() {
+    uint32_t a = next() >> 5, b = next() >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+  }
+};
+
+inline int bit_length(uint32_t n) {
+  int k = 0;
+  while (n) { ++k; n >>= 1; }
+  return k;
+}
+
+// CPython Random._randbelow_with_getrandbits (n < 2^32 here)
+inline uint32_t py_randbelow(MT& r, uint32_t n) {
+  if (n == 0) return 0;
+  const int k = bit_length(n);
+  uint32_t v = r.next() >> (32 - k);
+  while (v >= n) v = r.next() >> (32 - k);
+  return v;
+}
+
+// numpy legacy bounded integer in [0, rng] (inclusive), masked rejection, one 32-bit draw per try
+inline uint32_t np_interval(MT& r, uint32_t rng) {
+  if (rng == 0) return 0;
+  uint32_t mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v;
+  while ((v = (r.next() & mask)) > rng) {}
+  return v;
+}
+
+}  // namespace
+
+extern "C" int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py_state, uint32_t* np_state, int B, int T,
+                                         int tmax, int tcount, int fmax, int fcount, int32_t default_strategy,
+                                         mww_window* out_windows, int32_t* out_masks, int32_t* out_provider,
+                                         int32_t* out_sample, int32_t* out_order) {
+  if (!d || !py_state || !np_state || B < 0 || d->n_providers <= 0) return MWW_ERR_INVALID;
+  MT py{py_state, py_state + 624}, np{np_state, np_state + 624};
+  const int n = d->n_providers;
+  const int nm = tcount + fcount;
+  // 1. random.choices: bisect_right(cum_weights, random()*total, 0, n-1)
+  double total = 0.0;
+  double cum[64];
+  if (n > 64) return MWW_ERR_INVALID;
+  for (int i = 0; i < n; ++i) { total += d->sampling_weight[i]; cum[i] = total; }
+  total = cum[n - 1] + 0.0;
+  for (int j = 0; j < B; ++j) {
+    const double x = py.real53() * total;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (x < cum[mid]) hi = mid; else lo = mid + 1;
+    }
+    out_provider[j] = lo;
+  }
+  // 2. per-slot draws, in draw order (slot j) — the final permutation is applied afterwards
+  for (int j = 0; j < B; ++j) {
+    const int p = out_provider[j];
+    const int strat = default_strategy >= 0 ? default_strategy : d->strategy[p];
+    int cutoff = 0;
+    if (strat == MWW_STRATEGY_FIXED_RIGHT_CUTOFF) {
+      const int nc = d->cutoff_offsets[p + 1] - d->cutoff_offsets[p];
+      cutoff = d->cutoffs[d->cutoff_offsets[p] + (int)py_randbelow(py, (uint32_t)nc)];
+    }
+    const int64_t s0 = d->set_offsets[p], s1 = d->set_offsets[p + 1];
+    const int64_t pick = s0 + (int64_t)py_randbelow(py, (uint32_t)(s1 - s0));
+    const int len = d->set_len[pick];
+    int off = 0, copy = T, pad = 0;
+    if (len > T) {
+      switch (strat) {
+        case MWW_STRATEGY_RANDOM: off = (int)np_interval(np, (uint32_t)(len - T - 1)); break;  // randint(0, L-T): high exclusive
+        case MWW_STRATEGY_TRUNCATE_START: off = len - T; break;
+        case MWW_STRATEGY_TRUNCATE_END: off = 0; break;
+        case MWW_STRATEGY_FIXED_RIGHT_CUTOFF:
+          off = len - T - cutoff;
+          if (off < 0) return MWW_ERR_INVALID;  // the reference would produce a short window here
+          break;
+        default: return MWW_ERR_INVALID;        // "none" cannot form a fixed-length batch
+      }
+    } else {
+      copy = len;
+      pad = T - len;
+    }
+    mww_window w;
+    w.store = d->set_store[pick];
+    w.pad_rows = pad;
+    w.copy_rows = copy;
+    w.reserved = 0;
+    w.src_elem = d->set_src_elem[pick] + (int64_t)off * 40;
+    out_windows[j] = w;
+    out_sample[j] = (int32_t)(pick - s0);
+    int32_t* m = out_masks + (size_t)j * nm * 2;
+    for (int i = 0; i < tcount; ++i) {
+      const int t = (int)(0.0 + (double)tmax * np.real53());   // int(np.random.uniform(0, tmax))
+      const int t0 = (int)py_randbelow(py, (uint32_t)(T - t + 1));  // random.randint(0, T - t)
+      m[2 * i] = t0;
+      m[2 * i + 1] = t;
+    }
+    for (int i = 0; i < fcount; ++i) {
+      const int f = (int)(0.0 + (double)fmax * np.real53());
+      const int f0 = (int)py_randbelow(py, (uint32_t)(40 - f + 1));
+      m[2 * (tcount + i)] = f0;
+      m[2 * (tcount + i) + 1] = f;
+    }
+  }
+  // 3. np.random.shuffle(arange(B)): Fisher-Yates from the top with random_interval(i)
+  for (int j = 0; j < B; ++j) out_order[j] = j;
+  for (int i = B - 1; i >= 1; --i) {
+    const int jx = (int)np_interval(np, (uint32_t)i);
+    const int32_t tmp = out_order[i];
+    out_order[i] = out_order[jx];
+    out_order[jx] = tmp;
+  }
+  return MWW_OK;
+}
+
+// exposes the two primitive streams so the tests can compare them with CPython / numpy directly
+extern "C" int mww_rng_selftest(uint32_t* state, int which, int n, double* out_real, uint32_t* out_int, uint32_t bound) {
+  MT r{state, state + 624};
+  for (int i = 0; i < n; ++i) {
+    if (which == 0) out_real[i] = r.real53();
+    else if (which == 1) out_int[i] = py_randbelow(r, bound);
+    else out_int[i] = np_interval(r, bound);
+  }
+  return MWW_OK;
+}

@@ -1,0 +1,335 @@
+"""ctypes binding of ``libmww_hip.so`` (C ABI: ``include/mww.h``).
+
+There is deliberately **no CPU fallback**: if the HIP library is missing, fails to load, or no
+MI355X is visible, every entry point raises.  (The test-suite can point :class:`NativeLib` at the
+host-side kernel emulator built under ``tests/hipemu`` by passing an explicit path; product code
+never does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libmww_hip.so")
+
+MWW_MAX_BLOCKS = 8
+MWW_MAX_STORES = 64
+MAX_MASKS = 16
+STEP_NO_APPLY = 1
+STEP_NO_METRICS = 2
+BUF_PARAMS, BUF_GRADS, BUF_BN_STATE, BUF_X = 0, 1, 2, 3
+DTYPE_U16, DTYPE_F32 = 0, 1
+STRATEGIES = {"random": 0, "truncate_start": 1, "truncate_end": 2, "fixed_right_cutoff": 3, "none": 4}
+
+
+class MixedNetDesc(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("conv1_filters", C.c_int32), ("conv1_kernel", C.c_int32),
+                ("conv1_stride", C.c_int32), ("n_blocks", C.c_int32), ("block_filters", C.c_int32 * MWW_MAX_BLOCKS),
+                ("block_kernel", C.c_int32 * MWW_MAX_BLOCKS), ("max_batch", C.c_int32)]
+
+
+class Window(C.Structure):
+    _fields_ = [("store", C.c_int32), ("pad_rows", C.c_int32), ("copy_rows", C.c_int32), ("reserved", C.c_int32),
+                ("src_elem", C.c_int64)]
+
+
+WINDOW_DTYPE = np.dtype([("store", np.int32), ("pad_rows", np.int32), ("copy_rows", np.int32), ("reserved", np.int32),
+                         ("src_elem", np.int64)])
+assert WINDOW_DTYPE.itemsize == C.sizeof(Window)
+
+
+class MetricsRaw(C.Structure):
+    _fields_ = [("hist101", C.c_uint64 * 101 * 2), ("hist200", C.c_uint64 * 200 * 2), ("n", C.c_uint64),
+                ("correct", C.c_uint64), ("tp5", C.c_uint64), ("fp5", C.c_uint64), ("fn5", C.c_uint64),
+                ("pos", C.c_uint64), ("neg", C.c_uint64), ("bce_sum", C.c_double)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("n_providers", C.c_int32), ("sampling_weight", C.POINTER(C.c_double)), ("strategy", C.POINTER(C.c_int32)),
+                ("set_offsets", C.POINTER(C.c_int64)), ("set_store", C.POINTER(C.c_int32)),
+                ("set_src_elem", C.POINTER(C.c_int64)), ("set_len", C.POINTER(C.c_int32)),
+                ("cutoff_offsets", C.POINTER(C.c_int32)), ("cutoffs", C.POINTER(C.c_int32))]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+EXPORTS = [
+    "mww_version", "mww_last_error", "mww_device_count", "mww_create", "mww_destroy", "mww_synchronize",
+    "mww_num_params", "mww_num_bn_state", "mww_set_params", "mww_get_params", "mww_set_bn_state", "mww_get_bn_state",
+    "mww_set_grad_mask", "mww_set_opt_state", "mww_get_opt_state", "mww_get_grads", "mww_upload_store",
+    "mww_assemble_batch", "mww_set_batch", "mww_get_batch", "mww_set_targets", "mww_train_step", "mww_apply_gradients",
+    "mww_forward", "mww_read_outputs", "mww_metrics_read", "mww_metrics_reset", "mww_device_ptr", "mww_debug_read",
+    "mww_set_option", "mww_profile_read", "mww_sample_training_batch", "mww_rng_selftest",
+]
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class NativeLib:
+    """Loads the shared library and declares the prototypes."""
+
+    _instances = {}
+
+    def __init__(self, path: Optional[str] = None):
+        self.path = path or os.environ.get("MWW_HIP_LIB") or DEFAULT_LIB
+        if not os.path.isfile(self.path):
+            raise NativeError(
+                "HIP library %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % self.path)
+        try:
+            self.lib = C.CDLL(self.path)
+        except OSError as e:
+            raise NativeError("cannot load %s: %s" % (self.path, e)) from None
+        L = self.lib
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise NativeError("%s does not export %s (stale build?)" % (self.path, name))
+        L.mww_version.restype = C.c_char_p
+        L.mww_last_error.restype = C.c_char_p
+        L.mww_create.argtypes = [C.POINTER(MixedNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mww_destroy.argtypes = [C.c_void_p]
+        L.mww_destroy.restype = None
+        L.mww_synchronize.argtypes = [C.c_void_p]
+        L.mww_num_params.argtypes = [C.c_void_p]
+        L.mww_num_params.restype = C.c_int64
+        L.mww_num_bn_state.argtypes = [C.c_void_p]
+        L.mww_num_bn_state.restype = C.c_int64
+        for f in (L.mww_set_params, L.mww_get_params, L.mww_set_bn_state, L.mww_get_bn_state, L.mww_set_grad_mask,
+                  L.mww_get_grads):
+            f.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64]
+        L.mww_set_opt_state.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64, C.c_int64]
+        L.mww_get_opt_state.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64,
+                                        C.POINTER(C.c_int64)]
+        L.mww_upload_store.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]
+        L.mww_assemble_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mww_set_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.mww_get_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.mww_set_targets.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        L.mww_train_step.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+        L.mww_apply_gradients.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.mww_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.mww_read_outputs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float)]
+        L.mww_metrics_read.argtypes = [C.c_void_p, C.POINTER(MetricsRaw)]
+        L.mww_metrics_reset.argtypes = [C.c_void_p]
+        L.mww_device_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.mww_device_ptr.restype = C.c_void_p
+        L.mww_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int64]
+        L.mww_debug_read.restype = C.c_int64
+        L.mww_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.mww_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
+        L.mww_sample_training_batch.argtypes = [C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p]
+        L.mww_rng_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+
+    @classmethod
+    def get(cls, path: Optional[str] = None) -> "NativeLib":
+        key = path or os.environ.get("MWW_HIP_LIB") or DEFAULT_LIB
+        if key not in cls._instances:
+            cls._instances[key] = NativeLib(key)
+        return cls._instances[key]
+
+    def check(self, rc: int):
+        if rc < 0:
+            raise NativeError("libmww error %d: %s" % (rc, self.lib.mww_last_error().decode()))
+        return rc
+
+    def version(self) -> str:
+        return self.lib.mww_version().decode()
+
+    def device_count(self) -> int:
+        return int(self.lib.mww_device_count())
+
+
+class Engine:
+    """One device context (``mww_ctx``): model weights, HBM-resident feature stores, the train step."""
+
+    def __init__(self, frames, conv1_filters, conv1_kernel, conv1_stride, block_filters, block_kernel, max_batch,
+                 device=0, stream=None, lib: Optional[NativeLib] = None):
+        self.nl = lib or NativeLib.get()
+        d = MixedNetDesc()
+        d.frames, d.conv1_filters, d.conv1_kernel, d.conv1_stride = frames, conv1_filters, conv1_kernel, conv1_stride
+        d.n_blocks = len(block_filters)
+        if len(block_filters) != len(block_kernel) or len(block_filters) > MWW_MAX_BLOCKS:
+            raise ValueError("bad block lists")
+        for i, (f, k) in enumerate(zip(block_filters, block_kernel)):
+            d.block_filters[i], d.block_kernel[i] = int(f), int(k)
+        d.max_batch = int(max_batch)
+        self.desc = d
+        self.max_batch = int(max_batch)
+        self.frames = int(frames)
+        h = C.c_void_p()
+        self.nl.check(self.nl.lib.mww_create(C.byref(d), int(device), C.c_void_p(stream or 0), C.byref(h)))
+        self.h = h
+        self.n_params = int(self.nl.lib.mww_num_params(h))
+        self.n_state = int(self.nl.lib.mww_num_bn_state(h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.nl.lib.mww_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- vectors
+    def _vec_in(self, fn, a, n):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1)
+        if a.size != n:
+            raise ValueError("expected %d values, got %d" % (n, a.size))
+        self.nl.check(fn(self.h, _fptr(a), n))
+
+    def _vec_out(self, fn, n):
+        a = np.empty(n, np.float32)
+        self.nl.check(fn(self.h, _fptr(a), n))
+        return a
+
+    def set_params(self, a):
+        self._vec_in(self.nl.lib.mww_set_params, a, self.n_params)
+
+    def get_params(self):
+        return self._vec_out(self.nl.lib.mww_get_params, self.n_params)
+
+    def set_bn_state(self, a):
+        self._vec_in(self.nl.lib.mww_set_bn_state, a, self.n_state)
+
+    def get_bn_state(self):
+        return self._vec_out(self.nl.lib.mww_get_bn_state, self.n_state)
+
+    def set_grad_mask(self, a):
+        self._vec_in(self.nl.lib.mww_set_grad_mask, a, self.n_params)
+
+    def get_grads(self):
+        return self._vec_out(self.nl.lib.mww_get_grads, self.n_params)
+
+    def set_opt_state(self, m, v, step):
+        m = np.ascontiguousarray(m, np.float32).reshape(-1)
+        v = np.ascontiguousarray(v, np.float32).reshape(-1)
+        self.nl.check(self.nl.lib.mww_set_opt_state(self.h, _fptr(m), _fptr(v), self.n_params, int(step)))
+
+    def get_opt_state(self):
+        m, v = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32)
+        step = C.c_int64()
+        self.nl.check(self.nl.lib.mww_get_opt_state(self.h, _fptr(m), _fptr(v), self.n_params, C.byref(step)))
+        return m, v, int(step.value)
+
+    # ---- data
+    def upload_store(self, store_id, flat: np.ndarray):
+        flat = np.ascontiguousarray(flat).reshape(-1)
+        if flat.dtype == np.uint16:
+            dt = DTYPE_U16
+        elif flat.dtype == np.float32:
+            dt = DTYPE_F32
+        else:
+            raise ValueError("feature stores must be uint16 or float32")
+        self.nl.check(self.nl.lib.mww_upload_store(self.h, int(store_id), flat.ctypes.data_as(C.c_void_p), flat.size, dt))
+
+    def assemble(self, windows: np.ndarray, masks: Optional[np.ndarray], n_time, n_freq):
+        windows = np.ascontiguousarray(windows, WINDOW_DTYPE)
+        B = windows.shape[0]
+        mp = None
+        if n_time + n_freq:
+            masks = np.ascontiguousarray(masks, np.int32)
+            if masks.size != B * (n_time + n_freq) * 2:
+                raise ValueError("mask array has the wrong size")
+            mp = masks.ctypes.data_as(C.c_void_p)
+        self.nl.check(self.nl.lib.mww_assemble_batch(self.h, windows.ctypes.data_as(C.c_void_p), mp, B, n_time, n_freq))
+        return B
+
+    def set_batch(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 3 or x.shape[1] != self.frames or x.shape[2] != 40:
+            raise ValueError("batch must be [B,%d,40], got %s" % (self.frames, x.shape))
+        self.nl.check(self.nl.lib.mww_set_batch(self.h, _fptr(x), x.shape[0]))
+        return x.shape[0]
+
+    def get_batch(self, B):
+        x = np.empty((B, self.frames, 40), np.float32)
+        self.nl.check(self.nl.lib.mww_get_batch(self.h, _fptr(x), B))
+        return x
+
+    def set_targets(self, y, w):
+        y = np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1))
+        w = np.ascontiguousarray(np.asarray(w, np.float32).reshape(-1))
+        if y.size != w.size:
+            raise ValueError("labels and weights differ in length")
+        self.nl.check(self.nl.lib.mww_set_targets(self.h, _fptr(y), _fptr(w), y.size))
+
+    # ---- compute
+    def train_step(self, B, lr, flags=0):
+        self.nl.check(self.nl.lib.mww_train_step(self.h, int(B), float(lr), int(flags)))
+
+    def apply_gradients(self, lr, grad_scale=1.0):
+        self.nl.check(self.nl.lib.mww_apply_gradients(self.h, float(lr), float(grad_scale)))
+
+    def forward(self, B, training=False, update_metrics=False):
+        self.nl.check(self.nl.lib.mww_forward(self.h, int(B), int(bool(training)), int(bool(update_metrics))))
+
+    def read_outputs(self, B, want_loss=True):
+        p, z = np.empty(B, np.float32), np.empty(B, np.float32)
+        loss = C.c_float()
+        self.nl.check(self.nl.lib.mww_read_outputs(self.h, int(B), _fptr(p), _fptr(z), C.byref(loss) if want_loss else None))
+        return p, z, float(loss.value)
+
+    def synchronize(self):
+        self.nl.check(self.nl.lib.mww_synchronize(self.h))
+
+    def metrics_raw(self) -> MetricsRaw:
+        m = MetricsRaw()
+        self.nl.check(self.nl.lib.mww_metrics_read(self.h, C.byref(m)))
+        return m
+
+    def metrics_reset(self):
+        self.nl.check(self.nl.lib.mww_metrics_reset(self.h))
+
+    def device_ptr(self, which) -> int:
+        return int(self.nl.lib.mww_device_ptr(self.h, which) or 0)
+
+    def debug_read(self, name, B, capacity):
+        a = np.empty(capacity, np.float32)
+        n = self.nl.check(self.nl.lib.mww_debug_read(self.h, name.encode(), int(B), _fptr(a), capacity))
+        return a[:n]
+
+    def set_option(self, name, value):
+        self.nl.check(self.nl.lib.mww_set_option(self.h, name.encode(), int(value)))
+
+    def profile_read(self, capacity=4096):
+        names = C.create_string_buffer(capacity * 24)
+        ms = np.empty(capacity, np.float32)
+        n = self.nl.check(self.nl.lib.mww_profile_read(self.h, names, len(names), _fptr(ms), capacity))
+        nm = names.value.decode().split("\n")[:n]
+        return list(zip(nm, ms[:n].tolist()))
+
+
+def metrics_from_raw(m: MetricsRaw) -> dict:
+    """Derives the reference's nine compiled metrics (train.py:209-221) from the raw counters."""
+    h101 = np.array([[m.hist101[l][i] for i in range(101)] for l in range(2)], np.float64)
+    h200 = np.array([[m.hist200[l][i] for i in range(200)] for l in range(2)], np.float64)
+
+    def div(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.where(b != 0, a / np.where(b != 0, b, 1), 0.0)
+
+    pos, neg = float(m.pos), float(m.neg)
+    tp = np.cumsum(h101[1][::-1])[::-1]
+    fp = np.cumsum(h101[0][::-1])[::-1]
+    tp2 = np.cumsum(h200[1][::-1])[::-1]
+    fp2 = np.cumsum(h200[0][::-1])[::-1]
+    rec = div(tp2, tp2 + (pos - tp2))
+    fpr = div(fp2, fp2 + (neg - fp2))
+    auc = float(np.sum((fpr[:-1] - fpr[1:]) * (rec[:-1] + rec[1:]) / 2.0))
+    return dict(accuracy=float(div(m.correct, m.n)), recall=float(div(m.tp5, m.tp5 + m.fn5)),
+                precision=float(div(m.tp5, m.tp5 + m.fp5)), tp=tp, fp=fp, tn=neg - fp, fn=pos - tp, auc=auc,
+                loss=float(div(m.bce_sum, m.n)), count=int(m.n))

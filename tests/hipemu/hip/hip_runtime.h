@@ -1,0 +1,174 @@
+// TEST INFRASTRUCTURE ONLY — a host-side stand-in for <hip/hip_runtime.h>.
+//
+// The build container has hipcc but no GPU.  To debug kernel index logic before spending GPU
+// minutes, tests/hipemu compiles the *unchanged* product HIP sources (microwakeword_amd/csrc)
+// as host C++ with this header shadowing the real one (-I tests/hipemu comes first).  Every
+// workgroup is run as a set of ucontext fibers on one OS thread:
+//   * __syncthreads()            -> fiber yields until every live thread of the block arrived
+//   * __shfl*/mfma (wave ops)    -> fiber yields until all 64 lanes of its wave arrived
+//   * fibers are scheduled in a selectable order (HIPEMU_ORDER=0 forward, 1 reverse,
+//     2 waves reversed) so a missing barrier shows up as a deterministic mismatch
+//   * device memory = host memory with an inaccessible guard page right after each allocation
+//   * v_mfma_f32_16x16x4_f32 follows the lane maps of cdna_hip_programming.md §3
+// The product never links this: microwakeword_amd loads only libmww_hip.so (real HIP).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include <algorithm>
+using std::min;
+using std::max;
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct ushort4 { unsigned short x, y, z, w; };
+struct ushort2 { unsigned short x, y; };
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+static inline int2 make_int2(int a, int b) { return {a, b}; }
+
+namespace hipemu {
+extern uint3_emu g_threadIdx, g_blockIdx;
+extern dim3 g_blockDim, g_gridDim;
+void sync_block();
+unsigned wave_exchange(unsigned v, int src_lane);                 // 32-bit shuffle primitive
+void wave_exchange2(float a, float b, const float** A, const float** B);  // publish 2 floats, get arrays
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+int lane_id();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_threadIdx)
+#define blockIdx (hipemu::g_blockIdx)
+#define blockDim (hipemu::g_blockDim)
+#define gridDim (hipemu::g_gridDim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::sync_block(); }
+static inline float __shfl_xor(float v, int mask, int = 64) {
+  unsigned u; std::memcpy(&u, &v, 4);
+  u = hipemu::wave_exchange(u, hipemu::lane_id() ^ mask);
+  std::memcpy(&v, &u, 4); return v;
+}
+static inline int __shfl_xor(int v, int mask, int = 64) { return (int)hipemu::wave_exchange((unsigned)v, hipemu::lane_id() ^ mask); }
+static inline float __shfl(float v, int src, int = 64) {
+  unsigned u; std::memcpy(&u, &v, 4);
+  u = hipemu::wave_exchange(u, src & 63);
+  std::memcpy(&v, &u, 4); return v;
+}
+static inline int __shfl(int v, int src, int = 64) { return (int)hipemu::wave_exchange((unsigned)v, src & 63); }
+static inline float __shfl_down(float v, unsigned d, int = 64) {
+  int l = hipemu::lane_id(); int s = l + (int)d; if (s > 63) s = l;
+  unsigned u; std::memcpy(&u, &v, 4);
+  u = hipemu::wave_exchange(u, s);
+  std::memcpy(&v, &u, 4); return v;
+}
+
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+// D = A(16x4) * B(4x16) + C ; lane l: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; C/D[row=(l>>4)*4+r][col=l&15]
+static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  const float *A, *B;
+  hipemu::wave_exchange2(a, b, &A, &B);
+  int l = hipemu::lane_id();
+  int col = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = std::fmaf(A[k * 16 + row], B[k * 16 + col], acc);  // k-ordered fma chain
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline float __ldg(const float* p) { return *p; }
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float fmaxf_emu(float a, float b) { return a > b ? a : b; }
+
+// ------------------------------------------------------------------ runtime API subset
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotSupported = 801 };
+struct hipemu_stream { bool capturing = false; struct hipemu_graph* g = nullptr; };
+typedef hipemu_stream* hipStream_t;
+struct hipemu_event { double t = 0; };
+typedef hipemu_event* hipEvent_t;
+struct hipemu_graph { std::vector<std::function<void()>> nodes; };
+typedef hipemu_graph* hipGraph_t;
+typedef hipemu_graph* hipGraphExec_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0 };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; size_t totalGlobalMem; };
+
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemset(void* d, int v, size_t n);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipGetLastError();
+hipError_t hipPeekAtLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t);
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
+hipError_t hipGraphDestroy(hipGraph_t g);
+hipError_t hipGraphExecDestroy(hipGraphExec_t e);
+
+namespace hipemu {
+void enqueue(hipStream_t st, std::function<void()> fn);  // runs now, or records when capturing
+}
+
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                  \
+  do {                                                                                               \
+    dim3 hipemu_g = (grid), hipemu_b = (block);                                                      \
+    hipemu::enqueue((stream), [=]() { hipemu::launch(hipemu_g, hipemu_b, (shmem), [=]() { kernel(__VA_ARGS__); }); }); \
+  } while (0)

@@ -1,0 +1,244 @@
+// TEST INFRASTRUCTURE ONLY — runtime of the host-side HIP stand-in (see hip/hip_runtime.h here).
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+#include <time.h>
+#include <ucontext.h>
+#include <unistd.h>
+
+#include <map>
+#include <stdexcept>
+
+namespace hipemu {
+
+uint3_emu g_threadIdx, g_blockIdx;
+dim3 g_blockDim, g_gridDim;
+
+namespace {
+enum State { RUN, WAIT_BLOCK, WAIT_WAVE, DONE };
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  State st = RUN;
+  uint3_emu tid;
+};
+constexpr size_t kStack = 256 * 1024;
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1;
+const std::function<void()>* cur_body = nullptr;
+struct WaveBuf {
+  unsigned v[2][64];
+  float a[2][64], b[2][64];
+  int gen = 0;
+};
+std::vector<WaveBuf> waves;
+std::vector<char*> stack_pool;
+
+void fiber_main() {
+  (*cur_body)();
+  fibers[cur].st = DONE;
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+void yield(State s) {
+  fibers[cur].st = s;
+  swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+}  // namespace
+
+int lane_id() { return cur & 63; }
+
+void sync_block() { yield(WAIT_BLOCK); }
+
+unsigned wave_exchange(unsigned v, int src_lane) {
+  WaveBuf& w = waves[cur >> 6];
+  int g = w.gen & 1;
+  w.v[g][cur & 63] = v;
+  yield(WAIT_WAVE);
+  // after release the scheduler bumped w.gen; our data sits in buffer g
+  return w.v[g][src_lane & 63];
+}
+
+void wave_exchange2(float a, float b, const float** A, const float** B) {
+  WaveBuf& w = waves[cur >> 6];
+  int g = w.gen & 1;
+  w.a[g][cur & 63] = a;
+  w.b[g][cur & 63] = b;
+  yield(WAIT_WAVE);
+  *A = w.a[g];
+  *B = w.b[g];
+}
+
+static int sched_order() {
+  const char* e = getenv("HIPEMU_ORDER");
+  return e ? atoi(e) : 0;
+}
+
+static void run_block(dim3 block, const std::function<void()>& body) {
+  const int n = block.x * block.y * block.z;
+  const int nw = (n + 63) / 64;
+  fibers.resize(n);
+  waves.assign(nw, WaveBuf());
+  while ((int)stack_pool.size() < n) stack_pool.push_back((char*)malloc(kStack));
+  cur_body = &body;
+  for (int i = 0; i < n; ++i) {
+    Fiber& f = fibers[i];
+    f.st = RUN;
+    f.stack = stack_pool[i];
+    f.tid.x = i % block.x;
+    f.tid.y = (i / block.x) % block.y;
+    f.tid.z = i / (block.x * block.y);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, fiber_main, 0);
+  }
+  const int order = sched_order();
+  std::vector<int> seq(n);
+  for (int i = 0; i < n; ++i) {
+    if (order == 1) seq[i] = n - 1 - i;
+    else if (order == 2) seq[i] = ((nw - 1 - (i >> 6)) << 6 | (i & 63)) < n ? ((nw - 1 - (i >> 6)) << 6 | (i & 63)) : i;
+    else seq[i] = i;
+  }
+  for (;;) {
+    bool progressed = false;
+    int done = 0;
+    for (int k = 0; k < n; ++k) {
+      int i = seq[k];
+      if (fibers[i].st == DONE) { ++done; continue; }
+      if (fibers[i].st != RUN) continue;
+      cur = i;
+      g_threadIdx = fibers[i].tid;
+      swapcontext(&sched_ctx, &fibers[i].ctx);
+      progressed = true;
+      if (fibers[i].st == DONE) ++done;
+    }
+    if (done == n) break;
+    // release waves whose live lanes all wait at a wave op
+    for (int w = 0; w < nw; ++w) {
+      int lo = w * 64, hi = std::min(n, lo + 64), waiting = 0, live = 0;
+      for (int i = lo; i < hi; ++i) {
+        if (fibers[i].st != DONE) ++live;
+        if (fibers[i].st == WAIT_WAVE) ++waiting;
+      }
+      if (live && waiting == live) {
+        waves[w].gen++;
+        for (int i = lo; i < hi; ++i) if (fibers[i].st == WAIT_WAVE) fibers[i].st = RUN;
+        progressed = true;
+      }
+    }
+    // release the block barrier when every live thread waits on it
+    int live = 0, atbar = 0;
+    for (int i = 0; i < n; ++i) {
+      if (fibers[i].st != DONE) ++live;
+      if (fibers[i].st == WAIT_BLOCK) ++atbar;
+    }
+    if (live && atbar == live) {
+      for (int i = 0; i < n; ++i) if (fibers[i].st == WAIT_BLOCK) fibers[i].st = RUN;
+      progressed = true;
+    }
+    if (!progressed) {
+      fprintf(stderr, "hipemu: deadlock (divergent barrier / partial-wave shuffle) in block (%u,%u,%u)\n", g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
+      abort();
+    }
+  }
+}
+
+void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+  g_gridDim = grid;
+  g_blockDim = block;
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        g_blockIdx = {x, y, z};
+        run_block(block, body);
+      }
+}
+
+void enqueue(hipStream_t st, std::function<void()> fn) {
+  if (st && st->capturing) st->g->nodes.push_back(std::move(fn));
+  else fn();
+}
+
+}  // namespace hipemu
+
+// ---------------------------------------------------------------------------------- runtime API
+namespace {
+std::map<void*, std::pair<void*, size_t>> g_allocs;  // user ptr -> (mapping base, mapping size)
+hipemu_stream g_null_stream;
+}
+
+hipError_t hipMalloc(void** p, size_t n) {
+  const size_t page = 4096;
+  size_t body = (n + 15) / 16 * 16;
+  size_t pages = (body + page - 1) / page * page;
+  char* base = (char*)mmap(nullptr, pages + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (base == MAP_FAILED) return hipErrorOutOfMemory;
+  mprotect(base + pages, page, PROT_NONE);  // reads/writes past the end fault immediately
+  char* user = base + pages - body;
+  memset(base, 0xFF, pages);  // poison: uninitialised floats read as NaN
+  g_allocs[user] = {base, pages + page};
+  *p = user;
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  if (!p) return hipSuccess;
+  auto it = g_allocs.find(p);
+  if (it == g_allocs.end()) return hipErrorInvalidValue;
+  munmap(it->second.first, it->second.second);
+  g_allocs.erase(it);
+  return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) {
+  hipemu::enqueue(st, [=]() { memcpy(d, s, n); });
+  return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
+  hipemu::enqueue(st, [=]() { memset(d, v, n); });
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipemu_stream(); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemu_stream(); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  memset(p, 0, sizeof(*p));
+  strcpy(p->name, "hipemu (host fibers)");
+  strcpy(p->gcnArchName, "hipemu");
+  p->multiProcessorCount = 4;
+  return hipSuccess;
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipPeekAtLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) {
+  if (st && st->capturing) return hipSuccess;
+  e->t = now_ms();
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  if (!s) return hipErrorInvalidValue;
+  s->capturing = true;
+  s->g = new hipemu_graph();
+  return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) { s->capturing = false; *g = s->g; s->g = nullptr; return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new hipemu_graph(*g); return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto& f : e->nodes) f(); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
