@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — spectrogram-windows/sec of the MixedNet train step on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic ragged spectrograms already
+resident in HBM: exact-RNG window/mask draw (host C++, continuing the reference's MT19937 streams)
+-> HIP batch assembly (gather + pad/truncate + uint16->f32 + SpecAugment) -> forward (batch-stat BN)
+-> weighted Keras BCE -> backward -> gradient assembly [-> RCCL all-reduce] -> Adam, + metric update.
+Workload = BASELINE configs[1]: default mixednet (argparse defaults + residual_connection "0,0,0,0"),
+T=194, batch 1024 per GPU, fp32; weak scaling (per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed in this process)
+and, at N=1, `cpu_baseline` (the oracle port timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+T_FRAMES = 194
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+BYTES_PER_WINDOW_STEP = 793216  # fp32 algorithmic bytes per window for the whole train step
+
+# per-kernel share of the §8(d) element accounting (elements per window, fp32 => x4 bytes); DESIGN.md §5
+P_ELEMS = {1: 188 * 48, 2: 180 * 48, 3: 168 * 48, 4: 148 * 48}
+X_ELEMS = 194 * 40
+KERNEL_ELEMS = {
+    "assemble": X_ELEMS // 2 + X_ELEMS,  # uint16 source read (2 B/elem) + fp32 write, in 4-byte units
+    "fwd_block1": X_ELEMS + P_ELEMS[1],
+    "fwd_block2": P_ELEMS[1] + P_ELEMS[2],
+    "fwd_block3": P_ELEMS[2] + P_ELEMS[3],
+    "fwd_block4": P_ELEMS[3] + P_ELEMS[4],
+    "head": P_ELEMS[4],
+    "bwd_block4": P_ELEMS[3] + P_ELEMS[4] + P_ELEMS[3],              # R p3, R p4, W g3
+    "bwd_block3": P_ELEMS[2] + P_ELEMS[3] + P_ELEMS[3] + P_ELEMS[2],  # R p2, R p3, R g3, W g2
+    "bwd_block2": P_ELEMS[1] + P_ELEMS[2] + P_ELEMS[2] + P_ELEMS[1],
+    "bwd_block1": X_ELEMS + P_ELEMS[1] + P_ELEMS[1],                  # R x, R p1, R g1
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
+    ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--store-samples", type=int, default=4096)
+    ap.add_argument("--profile-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, budget_s=20.0):
+    """CPU port of the same step (oracle loader + torch-CPU fp32 train step, all host cores), on a
+    bounded sample; rank 0 / N=1 only.  kind="port": TensorFlow is not installable here, so the
+    reference's own train.py cannot run."""
+    import torch
+
+    from oracle import data_oracle as do
+    from oracle import model_oracle as mo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    flags = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0,0,0")
+    random.seed(0)
+    np.random.seed(0)
+    provs = do.synthetic_providers(512, 1234)
+    om = mo.OracleModel("mixednet", flags, T_FRAMES, seed=42, dtype=torch.float32)
+    pol = dict(time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)
+    # one untimed step (allocator / thread-pool warm-up), then timed steps until the budget is used
+    x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
+    om.train_step(x, y, w, 1e-3)
+    t_load = t_model = 0.0
+    n = 0
+    t_start = time.perf_counter()
+    while n < 1 or (time.perf_counter() - t_start) < budget_s * 0.6:
+        t0 = time.perf_counter()
+        x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
+        t1 = time.perf_counter()
+        om.train_step(x, y, w, 1e-3)
+        t2 = time.perf_counter()
+        t_load += t1 - t0
+        t_model += t2 - t1
+        n += 1
+        if n >= 8:
+            break
+    total = t_load + t_model
+    return {"value": round(n * batch / total, 1), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of batch %d (oracle loader %.2fs + torch-CPU fp32 fwd/bwd/Adam %.2fs)" % (n, batch, t_load, t_model),
+            "loader_windows_per_s": round(n * batch / t_load, 1), "model_windows_per_s": round(n * batch / t_model, 1)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
+
+    from microwakeword_amd import native, synthetic
+    from microwakeword_amd.data import FeatureHandler
+    from microwakeword_amd.model import Model
+    from microwakeword_amd.parallel import DataParallel, shard_feature_handler
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    stream = torch.cuda.Stream(device=device)
+    B = args.batch
+
+    with torch.cuda.stream(stream):
+        model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
+                      seed=42, max_batch=B)
+        eng = model.engine
+        cfg, _ = synthetic.benchmark_config(args.store_samples, 1234)
+        random.seed(0)
+        np.random.seed(0)
+        fh = FeatureHandler(cfg, engine=eng)
+        if world > 1:
+            shard_feature_handler(fh, rank, world, seed=0)
+        else:
+            fh.use_private_rng()
+        dp = DataParallel.for_engine(eng, device)
+        dp.broadcast_parameters(0)
+        if not args.no_graphs:
+            eng.set_option("graphs", 1)
+        policy = synthetic.SPEC_AUGMENT_POLICY
+        lr = 1e-3
+
+        def one_step():
+            y, w = fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
+            eng.set_targets(y, w)  # class weights 1/1 (train.py:176-187 defaults)
+            if world > 1:
+                dp.train_step(B, lr)
+            else:
+                eng.train_step(B, lr)
+
+        def fence():
+            eng.synchronize()
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize(device)
+
+        for _ in range(args.warmup):
+            one_step()
+        fence()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        ev1.record(stream)
+        fence()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        _, _, last_loss = eng.read_outputs(B)
+
+        # ---- per-kernel durations with HIP events on the engine's stream (eager launches, separate pass)
+        prof = {}
+        if rank == 0:
+            eng.set_option("graphs", 0)
+            eng.set_option("profile", 1)
+            for _ in range(args.profile_steps):
+                y, w = fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
+                eng.set_targets(y, w)
+                eng.train_step(B, lr, native.STEP_NO_APPLY if world > 1 else 0)
+                if world > 1:
+                    eng.apply_gradients(lr, 1.0)
+            for name, ms in eng.profile_read():
+                prof.setdefault(name, []).append(ms)
+            eng.set_option("profile", 0)
+        if world > 1:
+            dist.barrier()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    windows = B * world * args.steps
+    value = windows / elapsed
+    kern = {k: float(np.mean(v)) for k, v in prof.items()}
+    ksum = sum(kern.values())
+    dominant = max((k for k in kern if k in KERNEL_ELEMS), key=lambda k: kern[k])
+    dom_bytes = KERNEL_ELEMS[dominant] * 4 * B
+    achieved = dom_bytes / (kern[dominant] * 1e-3)
+    out = {
+        "metric": "spectrogram-windows/sec (train step) on default mixednet",
+        "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "default mixednet (argparse defaults + residual_connection 0,0,0,0), T=194, batch %d/GPU, fp32, "
+                               "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM" % (B, args.store_samples),
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graphs,
+                   "bn": "local" if world > 1 else "batch"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
+                     "step_frac": round(value / world * BYTES_PER_WINDOW_STEP / HBM_PEAK, 4),
+                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
+        "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "final_loss": round(float(last_loss), 5),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,11 +175,13 @@ typedef struct {
   const int32_t* cutoffs;         /* fixed_right_cutoffs, concatenated */
 } mww_sampler_desc;
 /* py_state / np_state: 624 MT19937 words + position (625 uint32), advanced in place.
- * Outputs are in DRAW order; out_order is the final np.random.shuffle permutation: output slot j
- * of the batch is draw out_order[j].  default_strategy < 0 means "default" (per provider). */
+ * out_order is the final np.random.shuffle permutation: output slot j of the batch is draw
+ * out_order[j].  apply_order = 0 leaves windows/masks/provider/sample in DRAW order, 1 permutes them
+ * into the final batch order.  default_strategy < 0 means "default" (per provider). */
 int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py_state, uint32_t* np_state, int B, int T, int tmax,
-                              int tcount, int fmax, int fcount, int32_t default_strategy, mww_window* out_windows,
-                              int32_t* out_masks, int32_t* out_provider, int32_t* out_sample, int32_t* out_order);
+                              int tcount, int fmax, int fcount, int32_t default_strategy, int32_t apply_order,
+                              mww_window* out_windows, int32_t* out_masks, int32_t* out_provider, int32_t* out_sample,
+                              int32_t* out_order);
 int mww_rng_selftest(uint32_t* state, int which, int n, double* out_real, uint32_t* out_int, uint32_t bound);
 
 #ifdef __cplusplus

@@ -100,11 +100,12 @@ struct Launcher {
   mww_ctx* c;
   hipEvent_t ea = nullptr;
   const char* name = nullptr;
-  void begin(const char* n) {
+  void begin(const char* n, int layer = -1) {
     if (!c->profile) return;
     name = n;
     ProfileEntry e;
     e.name = n;
+    if (layer >= 0) e.name += std::to_string(layer + 1);
     hipEventCreate(&e.a);
     hipEventCreate(&e.b);
     hipEventRecord(e.a, c->stream);
@@ -210,7 +211,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       Layer& l = c->L[i];
       BnEvalPrepareArgs a{c->params + l.o_gamma, c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv,
                           bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), l.cout};
-      lp.begin("bn_eval_prepare");
+      lp.begin("bn_eval_prepare", i);
       hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(64), 0, c->stream, a);
       lp.end();
     }
@@ -221,7 +222,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
                      l.p, l.stat_part, B, d.frames, l.tout};
-      lp.begin("fwd_first");
+      lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, grid);
       lp.end();
       if (rc) return rc;
@@ -229,7 +230,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       Layer& pl = c->L[i - 1];
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout};
-      lp.begin("fwd_block");
+      lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
       if (rc) return rc;
@@ -238,7 +239,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       BnFwdFinalizeArgs f{l.stat_part, grid, l.cout, 1.0f / ((float)B * (float)l.tout), c->params + l.o_gamma,
                           c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv, bn_slot(l, BN_SCALE),
                           bn_slot(l, BN_SHIFT), bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), update_moving ? 1 : 0};
-      lp.begin("bn_fwd_finalize");
+      lp.begin("bn_fwd_finalize", i);
       hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
       lp.end();
     }
@@ -286,7 +287,7 @@ int enqueue_backward(mww_ctx* c, int B) {
     BnBwdFinalizeArgs f{l.gstat_part, last ? ghead : gbwd, l.cout, 1.0f / ((float)B * (float)l.tout),
                         c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
                         bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta};
-    lp.begin("bn_bwd_finalize");
+    lp.begin("bn_bwd_finalize", i);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
     lp.end();
     if (i > 0) {
@@ -317,7 +318,7 @@ int enqueue_backward(mww_ctx* c, int B) {
       a.B = B;
       a.Tin = l.tin;
       a.Tout = l.tout;
-      lp.begin(last ? "bwd_block_last" : "bwd_block");
+      lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
       if (rc) return rc;
@@ -326,7 +327,7 @@ int enqueue_backward(mww_ctx* c, int B) {
       BwdFirstArgs a{c->x, c->params + c->o_conv1, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout};
-      lp.begin("bwd_first");
+      lp.begin("bwd_block", i);
       int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, gbwd);
       lp.end();
       if (rc) return rc;

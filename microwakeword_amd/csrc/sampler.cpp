@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <vector>
 
 #include "../../include/mww.h"
 
@@ -89,8 +90,8 @@ inline uint32_t np_interval(MT& r, uint32_t rng) {
 
 extern "C" int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py_state, uint32_t* np_state, int B, int T,
                                          int tmax, int tcount, int fmax, int fcount, int32_t default_strategy,
-                                         mww_window* out_windows, int32_t* out_masks, int32_t* out_provider,
-                                         int32_t* out_sample, int32_t* out_order) {
+                                         int32_t apply_order, mww_window* out_windows, int32_t* out_masks,
+                                         int32_t* out_provider, int32_t* out_sample, int32_t* out_order) {
   if (!d || !py_state || !np_state || B < 0 || d->n_providers <= 0) return MWW_ERR_INVALID;
   MT py{py_state, py_state + 624}, np{np_state, np_state + 624};
   const int n = d->n_providers;
@@ -167,6 +168,19 @@ extern "C" int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py
     const int32_t tmp = out_order[i];
     out_order[i] = out_order[jx];
     out_order[jx] = tmp;
+  }
+  if (apply_order) {
+    // hand the batch over in its final order: output slot j = draw out_order[j]
+    std::vector<mww_window> w(out_windows, out_windows + B);
+    std::vector<int32_t> m(out_masks, out_masks + (size_t)B * nm * 2), pr(out_provider, out_provider + B),
+        sm(out_sample, out_sample + B);
+    for (int j = 0; j < B; ++j) {
+      const int src = out_order[j];
+      out_windows[j] = w[src];
+      out_provider[j] = pr[src];
+      out_sample[j] = sm[src];
+      for (int k = 0; k < nm * 2; ++k) out_masks[(size_t)j * nm * 2 + k] = m[(size_t)src * nm * 2 + k];
+    }
   }
   return MWW_OK;
 }

@@ -1,0 +1,346 @@
+"""Host-side mirror of the reference loader API with the feature stores resident in HBM.
+
+Same names, arguments and error behaviour as the reference for the mmap-provider path:
+  * ``FeatureHandler(config)``                          microwakeword/data.py:405-466
+  * ``FeatureHandler.get_data(mode, batch_size, features_length, truncation_strategy,
+    augmentation_policy)``                               microwakeword/data.py:497-597
+  * ``get_mode_size`` / ``get_mode_duration``            microwakeword/data.py:468-495
+  * provider dict keys ``type, features_dir, truth, sampling_weight, penalty_weight,
+    truncation_strategy, fixed_right_cutoffs``           microwakeword/data.py:420-433
+  * directory convention ``<features_dir>/<mode>/**/*_mmap/``   microwakeword/data.py:171-187
+
+What differs is *where* the work happens: the per-sample Python loop (data.py:555-569) is
+replaced by (1) ``mww_sample_training_batch`` — a C++ sampler that continues the very same two
+Mersenne-Twister streams (Python ``random`` and ``numpy.random``) in the reference's call order,
+so windows and SpecAugment masks are bit-identical under identical seeds — and (2) the HIP
+``assemble`` kernel that gathers, pads, scales and masks straight from the HBM-resident store.
+
+``"clips"`` providers (online audio augmentation, data.py:324-402) are out of scope and raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import native
+from .ragged import FEATURE_BINS, RaggedStoreReader, find_store_dirs
+
+MODES = ("testing", "training", "validation", "testing_ambient", "validation_ambient")  # data.py:171-177
+DEFAULT_POLICY = {"freq_mix_prob": 0.0, "time_mask_max_size": 0, "time_mask_count": 0, "freq_mask_max_size": 0,
+                  "freq_mask_count": 0}
+
+
+class MmapFeatureProvider:
+    """Index of one provider's ragged stores (the state of the reference's ``MmapFeatureGenerator``,
+    data.py:148-211): per mode a shuffled list of (store, sample) plus lengths."""
+
+    def __init__(self, path, label, sampling_weight, penalty_weight, truncation_strategy, stride, step,
+                 fixed_right_cutoffs=(0,), stores=None):
+        self.label = float(label)
+        self.sampling_weight = sampling_weight
+        self.penalty_weight = penalty_weight
+        self.truncation_strategy = truncation_strategy
+        self.fixed_right_cutoffs = list(fixed_right_cutoffs)
+        self.stride = stride
+        self.step = step
+        self.stats: Dict[str, Dict[str, float]] = {}
+        self.feature_sets: Dict[str, List[Tuple[int, int]]] = {m: [] for m in MODES}
+        self.loaded_features: List[Sequence[np.ndarray]] = []
+        for mode in MODES:
+            duration, count = 0.0, 0
+            if stores is not None:
+                mode_stores = list(stores.get(mode, []))
+            else:
+                mode_stores = [RaggedStoreReader(p) for p in find_store_dirs(path, mode)]
+            for st in mode_stores:
+                self.loaded_features.append(st)
+                fi = len(self.loaded_features) - 1
+                for i in range(len(st)):
+                    self.feature_sets[mode].append((fi, i))
+                    duration += step * st[i].shape[0]
+                    count += 1
+            random.shuffle(self.feature_sets[mode])  # data.py:206 — consumes the global RNG like the reference
+            self.stats[mode] = {"spectrogram_count": count, "total_duration": duration}
+        # flat HBM image: one store per dtype
+        self.flat: Dict[str, np.ndarray] = {}
+        self.sample_start: List[List[int]] = []   # [loaded_feature][sub] -> element offset in its flat store
+        self.sample_len: List[List[int]] = []
+        self.feature_dtype: List[str] = []
+        chunks: Dict[str, List[np.ndarray]] = {}
+        cursor: Dict[str, int] = {}
+        for st in self.loaded_features:
+            starts, lens = [], []
+            dt = None
+            for i in range(len(st)):
+                a = np.asarray(st[i])
+                if a.ndim != 2 or a.shape[1] != FEATURE_BINS:
+                    raise ValueError("spectrogram %d has shape %s, expected [T,%d]" % (i, a.shape, FEATURE_BINS))
+                key = "u16" if a.dtype == np.uint16 else "f32"
+                if a.dtype not in (np.uint16, np.float32):
+                    a = a.astype(np.float32)
+                if dt is None:
+                    dt = key
+                elif dt != key:
+                    raise ValueError("mixed dtypes inside one ragged store")
+                chunks.setdefault(key, []).append(np.ascontiguousarray(a).reshape(-1))
+                starts.append(cursor.get(key, 0))
+                lens.append(a.shape[0])
+                cursor[key] = cursor.get(key, 0) + a.size
+            self.sample_start.append(starts)
+            self.sample_len.append(lens)
+            self.feature_dtype.append(dt or "u16")
+        for key, parts in chunks.items():
+            self.flat[key] = np.concatenate(parts)
+        self.store_id: Dict[str, int] = {}
+
+    def get_mode_duration(self, mode):
+        return self.stats[mode]["total_duration"]
+
+    def get_mode_size(self, mode):
+        return self.stats[mode]["spectrogram_count"]
+
+    def strategy(self, requested):
+        return self.truncation_strategy if requested == "default" else requested
+
+
+class FeatureHandler:
+    """Drop-in for ``microwakeword.data.FeatureHandler`` (mmap providers)."""
+
+    def __init__(self, config: dict, engine: Optional[native.Engine] = None):
+        self.feature_providers: List[MmapFeatureProvider] = []
+        for feature_set in config["features"]:
+            if feature_set["type"] == "mmap":
+                self.feature_providers.append(MmapFeatureProvider(
+                    feature_set.get("features_dir"), feature_set["truth"], feature_set["sampling_weight"],
+                    feature_set["penalty_weight"], feature_set["truncation_strategy"], stride=config["stride"],
+                    step=config["window_step_ms"] / 1000.0,
+                    fixed_right_cutoffs=feature_set.get("fixed_right_cutoffs", [0]), stores=feature_set.get("stores")))
+            elif feature_set["type"] == "clips":
+                raise NotImplementedError("'clips' providers (online audio augmentation, reference data.py:324-402) are "
+                                          "outside the MI355X hot path; generate RaggedMmap features offline")
+            else:
+                continue  # the reference silently ignores unknown provider types (data.py:419-452)
+        self.engine: Optional[native.Engine] = None
+        self._sampler = None
+        self._private_rng = None
+        if engine is not None:
+            self.attach(engine)
+
+    # ---- reference API
+    def get_mode_duration(self, mode: str):
+        return sum(p.get_mode_duration(mode) for p in self.feature_providers)
+
+    def get_mode_size(self, mode: str):
+        return sum(p.get_mode_size(mode) for p in self.feature_providers)
+
+    # ---- device residency
+    def attach(self, engine: native.Engine):
+        """Uploads every provider's flat store into the engine's HBM (once)."""
+        self.engine = engine
+        next_id = 0
+        for p in self.feature_providers:
+            for key, flat in p.flat.items():
+                if next_id >= native.MWW_MAX_STORES:
+                    raise ValueError("too many feature stores")
+                engine.upload_store(next_id, flat)
+                p.store_id[key] = next_id
+                next_id += 1
+        self._sampler = None
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("FeatureHandler is not attached to an MI355X engine (FeatureHandler.attach); "
+                               "there is no CPU batch-assembly path")
+
+    def _build_sampler(self):
+        live = [p for p in self.feature_providers if p.get_mode_size("training")]
+        if not live:
+            raise ValueError("no provider has training spectrograms")
+        sw = np.array([p.sampling_weight for p in live], np.float64)
+        strat = np.array([native.STRATEGIES.get(p.truncation_strategy, -1) for p in live], np.int32)
+        offs, st, src, ln, coffs, cuts = [0], [], [], [], [0], []
+        for p in live:
+            for fi, sub in p.feature_sets["training"]:
+                st.append(p.store_id[p.feature_dtype[fi]])
+                src.append(p.sample_start[fi][sub])
+                ln.append(p.sample_len[fi][sub])
+            offs.append(len(st))
+            cuts += [int(c) for c in p.fixed_right_cutoffs]
+            coffs.append(len(cuts))
+        arrs = dict(labels=np.array([p.label for p in live], np.float64),
+                    penalty=np.array([float(p.penalty_weight) for p in live], np.float64), sw=sw, strat=strat, offs=np.array(offs, np.int64), st=np.array(st, np.int32),
+                    src=np.array(src, np.int64), ln=np.array(ln, np.int32), coffs=np.array(coffs, np.int32),
+                    cuts=np.array(cuts if cuts else [0], np.int32))
+        d = native.SamplerDesc()
+        d.n_providers = len(live)
+        d.sampling_weight = arrs["sw"].ctypes.data_as(C.POINTER(C.c_double))
+        d.strategy = arrs["strat"].ctypes.data_as(C.POINTER(C.c_int32))
+        d.set_offsets = arrs["offs"].ctypes.data_as(C.POINTER(C.c_int64))
+        d.set_store = arrs["st"].ctypes.data_as(C.POINTER(C.c_int32))
+        d.set_src_elem = arrs["src"].ctypes.data_as(C.POINTER(C.c_int64))
+        d.set_len = arrs["ln"].ctypes.data_as(C.POINTER(C.c_int32))
+        d.cutoff_offsets = arrs["coffs"].ctypes.data_as(C.POINTER(C.c_int32))
+        d.cutoffs = arrs["cuts"].ctypes.data_as(C.POINTER(C.c_int32))
+        self._sampler = (d, arrs, live)
+
+    # ---- RNG plumbing: the sampler continues Python's and numpy's global MT19937 streams
+    @staticmethod
+    def _export_global_rng():
+        ps = random.getstate()
+        ns = np.random.get_state()
+        py = np.array(ps[1], dtype=np.uint32)
+        npst = np.empty(625, np.uint32)
+        npst[:624] = ns[1]
+        npst[624] = ns[2]
+        return py, npst, ps, ns
+
+    @staticmethod
+    def _import_global_rng(py, npst, ps, ns):
+        random.setstate((ps[0], tuple(int(v) for v in py), ps[2]))
+        np.random.set_state((ns[0], npst[:624].copy(), int(npst[624]), ns[3], ns[4]))
+
+    def use_private_rng(self):
+        """Snapshot the global RNG states now and keep advancing private copies from here on
+        (same streams, no per-batch get/setstate cost).  The global generators are left untouched."""
+        py, npst, _, _ = self._export_global_rng()
+        self._private_rng = (py, npst)
+
+    def _policy(self, augmentation_policy, truncation_strategy):
+        pol = dict(DEFAULT_POLICY)
+        pol.update(augmentation_policy or {})
+        tmax, tc = int(pol["time_mask_max_size"]), int(pol["time_mask_count"])
+        fmax, fc = int(pol["freq_mask_max_size"]), int(pol["freq_mask_count"])
+        if tc + fc > native.MAX_MASKS:
+            raise ValueError("at most %d SpecAugment masks per window" % native.MAX_MASKS)
+        if truncation_strategy == "default":
+            dstrat = -1
+            if any(s < 0 or s == native.STRATEGIES["none"] for s in self._sampler[1]["strat"]):
+                raise ValueError("a provider's truncation strategy cannot form a fixed-length training batch")
+        else:
+            if truncation_strategy not in native.STRATEGIES or truncation_strategy == "none":
+                raise ValueError("truncation strategy %r cannot form a fixed-length training batch" % truncation_strategy)
+            dstrat = native.STRATEGIES[truncation_strategy]
+        return tmax, tc, fmax, fc, dstrat
+
+    def _sample(self, B, features_length, truncation_strategy, augmentation_policy, apply_order):
+        self._need_engine()
+        if self._sampler is None:
+            self._build_sampler()
+        d, arrs, live = self._sampler
+        tmax, tc, fmax, fc, dstrat = self._policy(augmentation_policy, truncation_strategy)
+        nm = tc + fc
+        buf = self._bufs.get((B, nm)) if hasattr(self, "_bufs") else None
+        if buf is None:
+            if not hasattr(self, "_bufs"):
+                self._bufs = {}
+            buf = dict(win=np.zeros(B, native.WINDOW_DTYPE), masks=np.zeros((B, max(nm, 1), 2), np.int32),
+                       prov=np.zeros(B, np.int32), samp=np.zeros(B, np.int32), order=np.zeros(B, np.int32))
+            buf["ptrs"] = [buf[k].ctypes.data_as(C.c_void_p) for k in ("win", "masks", "prov", "samp", "order")]
+            self._bufs[(B, nm)] = buf
+        if self._private_rng is not None:
+            py, npst = self._private_rng
+            saved = None
+        else:
+            py, npst, ps, ns = self._export_global_rng()
+            saved = (ps, ns)
+        lib = self.engine.nl
+        lib.check(lib.lib.mww_sample_training_batch(
+            C.byref(d), py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p), B, int(features_length), tmax, tc,
+            fmax, fc, dstrat, int(apply_order), *buf["ptrs"]))
+        if saved is not None:
+            self._import_global_rng(py, npst, *saved)
+        return buf, tc, fc, arrs
+
+    def draw_training_batch(self, batch_size, features_length, truncation_strategy="default", augmentation_policy=None):
+        """RNG half of ``get_data("training")``: returns (windows, masks, labels, weights) in the
+        final (shuffled) order plus the draw-order details for tests."""
+        buf, tc, fc, arrs = self._sample(int(batch_size), features_length, truncation_strategy, augmentation_policy, 0)
+        nm = tc + fc
+        order = buf["order"].copy()
+        prov = buf["prov"].copy()
+        labels = arrs["labels"][prov]
+        weights = arrs["penalty"][prov]
+        return dict(windows=buf["win"][order], masks=buf["masks"][order][:, :nm], labels=labels[order], weights=weights[order],
+                    n_time=tc, n_freq=fc, order=order, provider=prov, sample=buf["samp"].copy(),
+                    draw_windows=buf["win"].copy(), draw_masks=buf["masks"].copy())
+
+    def next_training_batch_on_device(self, batch_size, features_length, truncation_strategy="default",
+                                      augmentation_policy=None):
+        """Fast path of the train loop: leaves x in the engine's batch buffer (no host copy of the
+        spectrograms) and returns ``(labels float64 [B], penalty_weights float64 [B])``."""
+        buf, tc, fc, arrs = self._sample(int(batch_size), features_length, truncation_strategy, augmentation_policy, 1)
+        self.engine.assemble(buf["win"], buf["masks"], tc, fc)
+        return arrs["labels"][buf["prov"]], arrs["penalty"][buf["prov"]]
+
+    def _eval_windows(self, mode, features_length, truncation_strategy):
+        win, labels, weights = [], [], []
+        for p in self.feature_providers:
+            strat = p.strategy(truncation_strategy)
+            for fi, sub in p.feature_sets[mode]:
+                length = p.sample_len[fi][sub]
+                base = p.sample_start[fi][sub]
+                sid = p.store_id[p.feature_dtype[fi]]
+                if strat == "split":  # data.py:301-311
+                    hop = int(1000 * p.step * p.stride)
+                    for s0 in range(0, length - features_length, hop):
+                        win.append((sid, 0, features_length, 0, base + s0 * FEATURE_BINS))
+                        labels.append(p.label)
+                        weights.append(p.penalty_weight)
+                    continue
+                for cutoff in p.fixed_right_cutoffs:  # data.py:312-321
+                    if length > features_length:
+                        if strat == "truncate_start":
+                            off = length - features_length
+                        elif strat == "truncate_end":
+                            off = 0
+                        elif strat == "fixed_right_cutoff":
+                            off = length - features_length - cutoff
+                            if off < 0:
+                                raise ValueError("fixed_right_cutoff larger than the spare frames")
+                        elif strat == "random":
+                            off = int(np.random.randint(0, length - features_length))
+                        else:
+                            raise ValueError("truncation strategy %r does not give fixed-length windows" % strat)
+                        win.append((sid, 0, features_length, 0, base + off * FEATURE_BINS))
+                    else:
+                        win.append((sid, features_length - length, length, 0, base))
+                    labels.append(p.label)
+                    weights.append(p.penalty_weight)
+        return np.array(win, native.WINDOW_DTYPE) if win else np.zeros(0, native.WINDOW_DTYPE), \
+            np.array(labels), np.array(weights)
+
+    def get_data(self, mode: str, batch_size: int, features_length: int, truncation_strategy: str = "default",
+                 augmentation_policy: dict = DEFAULT_POLICY):
+        """Same contract as the reference (data.py:497-597): returns host arrays
+        ``(x float32 [N,T,40], labels float64 [N], weights float64 [N])``."""
+        self._need_engine()
+        eng = self.engine
+        if mode == "training":
+            b = self.draw_training_batch(batch_size, features_length, truncation_strategy, augmentation_policy)
+            chunks = []
+            for s in range(0, batch_size, eng.max_batch):
+                e = min(batch_size, s + eng.max_batch)
+                eng.assemble(b["windows"][s:e], b["masks"][s:e], b["n_time"], b["n_freq"])
+                chunks.append(eng.get_batch(e - s))
+            x = np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
+            return x, b["labels"], b["weights"]
+        if truncation_strategy == "none":
+            raise NotImplementedError("variable-length ('none') evaluation batches are produced by the reference "
+                                      "loader only for streaming TFLite tests, outside the MI355X path")
+        win, labels, weights = self._eval_windows(mode, features_length, truncation_strategy)
+        n = win.shape[0]
+        indices = np.arange(n)
+        np.random.shuffle(indices)  # data.py:593-595 (the guard there is always true)
+        win = win[indices]
+        if n == 0:
+            return np.zeros((0,), np.float64), labels, weights  # np.array([]) in the reference
+        chunks = []
+        for s in range(0, n, eng.max_batch):
+            e = min(n, s + eng.max_batch)
+            eng.assemble(win[s:e], None, 0, 0)
+            chunks.append(eng.get_batch(e - s))
+        x = np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
+        return x, labels[indices], weights[indices]

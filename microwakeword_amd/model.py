@@ -1,0 +1,252 @@
+"""The subset of ``tf.keras.Model`` that the reference train loop touches, backed by the MI355X
+engine (C ABI in ``include/mww.h``).  Call sites in the reference:
+
+  compile / make_train_function / train_function      microwakeword/train.py:223-227
+  optimizer.learning_rate.assign(lr)                   microwakeword/train.py:265
+  train_on_batch(x, y, sample_weight=) -> list         microwakeword/train.py:295-299 (indices 1,2,3,8,9 used)
+  evaluate(x, y, batch_size=1024, return_dict=True)    microwakeword/train.py:50-58,89-96
+  reset_metrics (swappable attribute)                  microwakeword/train.py:48,89,343
+  save_weights / load_weights                          microwakeword/train.py:336-338,393-399,448-450,462;
+                                                       microwakeword/model_train_eval.py:424-426
+  summary(print_fn=)                                   microwakeword/utils.py:131-145
+  get_weights / set_weights                            Keras order, SURVEY §A.4
+
+Weights files: the reference writes Keras ``.weights.h5`` (needs h5py/Keras, absent here); this
+class writes the same arrays in the same order as ``<path>`` + ``.npz`` twin (documented in
+INTEGRATION.md) and reads either the twin or — if h5py is importable — a real ``.weights.h5``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import native
+from .layout import FEATURE_BINS, MixedNetLayout
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def initial_weights(layout: MixedNetLayout, seed: Optional[int] = None) -> List[np.ndarray]:
+    """Keras default initialisers (glorot_uniform kernels with Keras' fan computation, zero biases,
+    BN gamma=1 beta=0 mean=0 var=1) — SURVEY §A.1."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for name, shape, _ in layout.keras_vars:
+        if name.endswith(".kernel"):
+            if len(shape) == 4:
+                rf = shape[0] * shape[1]
+                out.append(glorot_uniform(rng, shape, shape[2] * rf, shape[3] * rf))
+            else:
+                out.append(glorot_uniform(rng, shape, shape[0], shape[1]))
+        elif name.endswith(("gamma", "moving_variance")):
+            out.append(np.ones(shape, np.float32))
+        else:
+            out.append(np.zeros(shape, np.float32))
+    return out
+
+
+class _Assignable:
+    def __init__(self, value):
+        self.value = float(value)
+
+    def assign(self, v):
+        self.value = float(v)
+
+    def numpy(self):
+        return np.float32(self.value)
+
+
+class _Optimizer:
+    def __init__(self, lr=1e-3):
+        self.learning_rate = _Assignable(lr)
+
+
+class _Counts:
+    """tp/fp/tn/fn results expose ``.numpy()`` in the reference (train.py:72,103-105)."""
+
+    def __init__(self, a):
+        self._a = np.asarray(a, np.float32)
+
+    def numpy(self):
+        return self._a
+
+
+class Model:
+    def __init__(self, flags, shape, batch_size, device=0, stream=None, lib=None, seed=None, max_batch=None):
+        if tuple(shape)[1] != FEATURE_BINS:
+            raise ValueError("input shape must be (spectrogram_length, 40)")
+        self.flags = flags
+        self.layout = MixedNetLayout(flags, int(shape[0]))
+        self.input_shape = (batch_size, int(shape[0]), FEATURE_BINS)
+        self.batch_size = batch_size
+        mb = int(max_batch or max(int(batch_size or 1), 1024))
+        self.engine = native.Engine(lib=lib, device=device, stream=stream, **self.layout.engine_args(mb))
+        self.engine.set_grad_mask(self.layout.grad_mask())
+        self.set_weights(initial_weights(self.layout, seed))
+        self.optimizer = _Optimizer()
+        self.loss = None
+        self.train_function = None
+        self._compiled = False
+
+    # ---- Keras surface
+    def compile(self, optimizer=None, loss=None, metrics=None):
+        """The loss (BinaryCrossentropy, from_logits=False), optimizer (Adam defaults) and the nine
+        metrics of train.py:206-221 are built into the engine; the arguments are accepted for
+        signature compatibility and checked for the two things that would change the arithmetic."""
+        if optimizer is not None and hasattr(optimizer, "learning_rate"):
+            lr = optimizer.learning_rate
+            self.optimizer.learning_rate.assign(float(lr.numpy()) if hasattr(lr, "numpy") else float(getattr(lr, "value", lr)))
+        if getattr(loss, "from_logits", False):
+            raise ValueError("the engine implements BinaryCrossentropy(from_logits=False) as the reference uses")
+        self._compiled = True
+
+    def make_train_function(self):
+        self.train_function = self._train_function
+        return self.train_function
+
+    def _train_function(self, *a, **k):
+        raise RuntimeError("train_function is internal to the engine; call train_on_batch")
+
+    def count_params(self):
+        return self.layout.keras_param_counts()[0]
+
+    def get_weights(self):
+        return self.layout.unpack(self.engine.get_params(), self.engine.get_bn_state())
+
+    def set_weights(self, weights: Sequence[np.ndarray]):
+        p, s = self.layout.pack(weights)
+        self.engine.set_params(p)
+        self.engine.set_bn_state(s)
+
+    def reset_metrics(self):
+        self.engine.metrics_reset()
+        self._loss_sum, self._loss_n = 0.0, 0
+
+    def _metric_results(self):
+        return native.metrics_from_raw(self.engine.metrics_raw())
+
+    @staticmethod
+    def _per_sample_weights(sample_weight, n):
+        if sample_weight is None:
+            return np.ones(n, np.float32)
+        sw = np.asarray(sample_weight, np.float64)
+        if sw.ndim == 2 and sw.shape == (n, n):
+            # train.py:291-293 broadcasts penalty[B] * class_weight(y)[B,1] to [B,B] with
+            # W[i,j] = penalty_j * cw(y_i).  The intended per-sample weight is the diagonal
+            # (identical to every reading of Keras' behaviour when either factor is uniform).
+            sw = np.diagonal(sw)
+        sw = sw.reshape(-1)
+        if sw.size != n:
+            raise ValueError("sample_weight does not match the batch")
+        return sw.astype(np.float32)
+
+    def train_on_batch(self, x, y, sample_weight=None, return_dict=False):
+        """Returns ``[loss, accuracy, recall, precision, tp[101], fp[101], tn[101], fn[101], auc, loss_metric]``
+        (the compiled metric order of train.py:209-221; cumulative since the last reset_metrics)."""
+        x = np.asarray(x, np.float32)
+        n = x.shape[0]
+        self.engine.set_batch(x)
+        return self._step_on_device(n, y, sample_weight, return_dict)
+
+    def train_on_device_batch(self, n, y, sample_weight=None, return_dict=False):
+        """Same as train_on_batch for a batch that ``FeatureHandler.next_training_batch_on_device``
+        already left in HBM (no host round trip of x)."""
+        return self._step_on_device(n, y, sample_weight, return_dict)
+
+    def _step_on_device(self, n, y, sample_weight, return_dict):
+        y = np.asarray(y, np.float32).reshape(-1)
+        self.engine.set_targets(y, self._per_sample_weights(sample_weight, n))
+        self.engine.train_step(n, self.optimizer.learning_rate.value)
+        _, _, loss = self.engine.read_outputs(n)
+        m = self._metric_results()
+        # Keras' first entry is the loss tracker: a running mean since the last reset_metrics()
+        self._loss_sum = getattr(self, "_loss_sum", 0.0) + loss * n
+        self._loss_n = getattr(self, "_loss_n", 0) + n
+        self.last_batch_loss = loss
+        run = self._loss_sum / self._loss_n
+        if return_dict:
+            return dict(m, loss=run)
+        return [run, m["accuracy"], m["recall"], m["precision"], m["tp"], m["fp"], m["tn"], m["fn"], m["auc"], m["loss"]]
+
+    def predict_on_batch(self, x):
+        x = np.asarray(x, np.float32)
+        out = []
+        for s in range(0, x.shape[0], self.engine.max_batch):
+            e = min(x.shape[0], s + self.engine.max_batch)
+            self.engine.set_batch(x[s:e])
+            self.engine.forward(e - s, training=False)
+            out.append(self.engine.read_outputs(e - s, want_loss=False)[0])
+        return np.concatenate(out).reshape(-1, 1)
+
+    __call__ = predict_on_batch
+
+    def evaluate(self, x, y, batch_size=1024, return_dict=True, verbose=0):
+        """Forward-only pass in inference mode (BN moving statistics) that accumulates the compiled
+        metrics; like Keras it resets them first (the reference swaps ``reset_metrics`` for a no-op
+        to keep accumulating across two calls, train.py:88-96 — honoured because the attribute is
+        looked up at call time)."""
+        self.reset_metrics()
+        x = np.asarray(x, np.float32)
+        y = np.asarray(y, np.float32).reshape(-1)
+        bs = min(int(batch_size), self.engine.max_batch)
+        for s in range(0, x.shape[0], bs):
+            e = min(x.shape[0], s + bs)
+            self.engine.set_batch(x[s:e])
+            self.engine.set_targets(y[s:e], np.ones(e - s, np.float32))
+            self.engine.forward(e - s, training=False, update_metrics=True)
+        m = self._metric_results()
+        res = dict(accuracy=m["accuracy"], recall=m["recall"], precision=m["precision"], auc=m["auc"], loss=m["loss"],
+                   tp=_Counts(m["tp"]), fp=_Counts(m["fp"]), tn=_Counts(m["tn"]), fn=_Counts(m["fn"]))
+        if return_dict:
+            return res
+        return [res["loss"], res["accuracy"], res["recall"], res["precision"], res["tp"], res["fp"], res["tn"], res["fn"],
+                res["auc"], res["loss"]]
+
+    # ---- persistence
+    def save_weights(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        ws = self.get_weights()
+        np.savez(path + ".npz", **{"%03d:%s" % (i, n): w for i, ((n, _, _), w) in enumerate(zip(self.layout.keras_vars, ws))})
+
+    def load_weights(self, path):
+        twin = path + ".npz" if not path.endswith(".npz") else path
+        if os.path.isfile(twin):
+            z = np.load(twin)
+            keys = sorted(z.files)
+            self.set_weights([z[k] for k in keys])
+            return
+        if os.path.isfile(path):
+            try:
+                import h5py  # noqa: F401
+            except ImportError:
+                raise RuntimeError("%s is a Keras .weights.h5 file and h5py is not installed; convert it with "
+                                   "tools/keras_weights_to_npz.py on a machine that has it" % path) from None
+            raise NotImplementedError("reading Keras .weights.h5 directly is not implemented yet")
+        raise FileNotFoundError(path)
+
+    def save_optimizer_state(self, path):
+        m, v, step = self.engine.get_opt_state()
+        np.savez(path, m=m, v=v, step=np.int64(step), lr=np.float64(self.optimizer.learning_rate.value))
+
+    def load_optimizer_state(self, path):
+        z = np.load(path)
+        self.engine.set_opt_state(z["m"], z["v"], int(z["step"]))
+
+    def summary(self, print_fn=print):
+        total, trainable = self.layout.keras_param_counts()
+        lay = self.layout
+        print_fn("Model: mixednet on MI355X engine (%s)" % self.engine.nl.version())
+        print_fn("input                      [B, %d, %d]" % (lay.frames, FEATURE_BINS))
+        print_fn("conv1 %dx1 -> %d, relu       [B, %d, %d]" % (lay.conv1_kernel, lay.conv1_filters, lay.blocks[0].tin, lay.conv1_filters))
+        for i, b in enumerate(lay.blocks):
+            print_fn("block %d: mixconv %s + 1x1 %d->%d + BN + relu   [B, %d, %d]" % (i, list(b.kernel_sizes), b.cin, b.cout, b.tout, b.cout))
+        print_fn("flatten + dense(1, sigmoid)  [B, 1]")
+        print_fn("Total params: %d" % total)
+        print_fn("Trainable params: %d" % trainable)
+        print_fn("Non-trainable params: %d" % (total - trainable))

@@ -127,8 +127,8 @@ class NativeLib:
         L.mww_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.mww_profile_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
         L.mww_sample_training_batch.argtypes = [C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_void_p]
+                                                C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
         L.mww_rng_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
 
     @classmethod

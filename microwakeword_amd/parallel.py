@@ -1,0 +1,81 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, ``torch.distributed``
+(backend "nccl" == RCCL over xGMI) for the single exchange step of the path — an all-reduce(sum)
+of the flat 22 177-float gradient (88.7 KB: latency-bound, one collective, no bucketing).
+
+The reference has no distributed code at all (SURVEY §2 "Parallelism strategies: none"); this is
+new work defined by SURVEY §8(e):
+  * each rank draws its own B/W windows per step from its shard of every provider
+    (sample i -> rank i mod W) with a rank-distinct RNG stream (seed*W + rank);
+  * local forward/backward -> flat gradient of the LOCAL mean loss;
+  * all-reduce(sum), then Adam consumes grad/W (== gradient of the global-batch mean loss);
+  * weights, Adam slots and the step counter stay bit-identical across ranks because every rank
+    applies the same reduced gradient; BN moving statistics are rank-local batch statistics
+    ("local-BN" throughput mode; sync-BN is not implemented yet and is stated as such in DESIGN.md).
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import native
+
+
+class _DeviceArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_floats(ptr: int, n: int, device) -> torch.Tensor:
+    """A torch view of ``n`` floats of engine-owned HBM (no copy) so RCCL can reduce it in place."""
+    return torch.as_tensor(_DeviceArray(ptr, n), device=device)
+
+
+def shard_feature_handler(handler, rank: int, world: int, seed: int):
+    """Per provider keep training samples ``rank, rank+W, ...`` of the (identically shuffled) list and
+    give the rank its own RNG streams."""
+    for p in handler.feature_providers:
+        p.feature_sets["training"] = p.feature_sets["training"][rank::world]
+        if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:
+            raise ValueError("provider has fewer training samples than ranks")
+    handler._sampler = None
+    random.seed(seed * world + rank)
+    np.random.seed(seed * world + rank)
+    handler.use_private_rng()
+
+
+class DataParallel:
+    """Wraps one engine per rank.  ``grad_view`` / ``param_view`` are torch tensors aliasing the
+    engine's flat gradient / parameter vectors (device memory on the GPU path)."""
+
+    def __init__(self, engine, grad_view: torch.Tensor, param_view: torch.Tensor, state_view: Optional[torch.Tensor] = None,
+                 group=None):
+        self.engine = engine
+        self.grad_view, self.param_view, self.state_view = grad_view, param_view, state_view
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    @classmethod
+    def for_engine(cls, engine: native.Engine, device, group=None):
+        g = wrap_device_floats(engine.device_ptr(native.BUF_GRADS), engine.n_params, device)
+        p = wrap_device_floats(engine.device_ptr(native.BUF_PARAMS), engine.n_params, device)
+        s = wrap_device_floats(engine.device_ptr(native.BUF_BN_STATE), engine.n_state, device)
+        return cls(engine, g, p, s, group)
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            self.engine.synchronize()
+            dist.broadcast(self.param_view, src=src, group=self.group)
+            if self.state_view is not None:
+                dist.broadcast(self.state_view, src=src, group=self.group)
+
+    def train_step(self, B, lr, flags=0):
+        """Local forward/backward, gradient all-reduce, Adam on the averaged gradient."""
+        self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
+        if self.world > 1:
+            dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group)
+        self.engine.apply_gradients(lr, 1.0 / self.world)

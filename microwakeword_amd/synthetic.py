@@ -1,0 +1,34 @@
+"""Synthetic feature stores of the benchmark configuration: two providers
+(label 1 / 0, sampling_weight 2 / 10, penalty 1 / 1, ``truncate_start`` / ``random``), 4096 ragged
+samples each, lengths U{150..400} frames, raw micro-frontend uint16 values U{0..666}
+(or an already-scaled float32 variant), ``numpy.random.default_rng(1234)``."""
+import numpy as np
+
+
+def synthetic_stores(n_samples=4096, seed=1234, dtype=np.uint16, min_len=150, max_len=400):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(2):
+        lens = rng.integers(min_len, max_len + 1, size=n_samples)
+        if dtype == np.uint16:
+            st = [rng.integers(0, 667, size=(int(l), 40), dtype=np.uint16) for l in lens]
+        else:
+            st = [(rng.random((int(l), 40), dtype=np.float32) * np.float32(26.0)) for l in lens]
+        out.append(st)
+    return out
+
+
+def benchmark_config(n_samples=4096, seed=1234, dtype=np.uint16):
+    """A ``config`` dict for :class:`microwakeword_amd.data.FeatureHandler` holding the stores in RAM."""
+    pos, neg = synthetic_stores(n_samples, seed, dtype)
+    return {"stride": 1, "window_step_ms": 10, "features": [
+        dict(type="mmap", stores={"training": [pos]}, truth=True, sampling_weight=2.0, penalty_weight=1.0,
+             truncation_strategy="truncate_start"),
+        dict(type="mmap", stores={"training": [neg]}, truth=False, sampling_weight=10.0, penalty_weight=1.0,
+             truncation_strategy="random")]}, (pos, neg)
+
+
+DEFAULT_MIXEDNET_FLAGS = dict(pointwise_filters="48, 48, 48, 48", residual_connection="0,0,0,0", repeat_in_block="1,1,1,1",
+                              mixconv_kernel_sizes="[5], [9], [13], [21]", max_pool=0, first_conv_filters=32,
+                              first_conv_kernel_size=3, spatial_attention=0, pooled=0, stride=1)
+SPEC_AUGMENT_POLICY = dict(freq_mix_prob=0.0, time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)

@@ -1,0 +1,62 @@
+"""Runs the product HIP sources on the CPU under tests/hipemu (fibers + emulated wave ops) and
+checks them against oracle/.  This is a *debugging aid for the kernels' index logic* — it is not a
+product path and proves nothing about the GPU build; the real parity tests are tests/test_engine_gpu.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import engine_checks as ec
+from microwakeword_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hipemu", "libmww_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    srcs = [os.path.join(ROOT, "microwakeword_amd", "csrc", f) for f in ("mww_lib.hip", "sampler.cpp")] + [os.path.join(ROOT, "tests", "hipemu", "hipemu.cpp")]
+    deps = srcs + [os.path.join(ROOT, "microwakeword_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "microwakeword_amd", "csrc"))]
+    deps += [os.path.join(ROOT, "include", "mww.h"), os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")]
+    if not os.path.isfile(CLANG):
+        pytest.skip("clang++ not available for the host-side emulator build")
+    if not os.path.isfile(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "hipemu"),
+               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value"] + srcs + ["-o", EMU]
+        subprocess.run(cmd, check=True)
+    return native.NativeLib(EMU)
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "data_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", ["u16", "f32"])
+def test_get_data_reference_golden(emu_lib, gold, tag):
+    ec.check_get_data_against_reference_golden(emu_lib, gold, tag)
+
+
+def test_sampler_descriptors(emu_lib):
+    ec.check_sampler_matches_oracle_descriptors(emu_lib, B=48, n_samples=40)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_forward(emu_lib, training):
+    ec.check_forward_parity(emu_lib, B=3, T=194, training=training, grid=2)
+
+
+def test_forward_short_and_ragged_tiles(emu_lib):
+    ec.check_forward_parity(emu_lib, B=2, T=111, training=True, grid=1)
+    ec.check_forward_parity(emu_lib, B=1, T=60, training=False)
+
+
+def test_train_steps(emu_lib):
+    ec.check_train_steps(emu_lib, B=5, T=194, steps=2, grid=2)
+
+
+def test_train_steps_other_lengths(emu_lib):
+    ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4)
+    ec.check_train_steps(emu_lib, B=2, T=60, steps=1, grid=1, graphs=True)
