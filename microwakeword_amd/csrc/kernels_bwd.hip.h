@@ -192,8 +192,8 @@ __global__ __launch_bounds__(kThreads) void bwd_block_kernel(BwdBlockArgs a) {
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN && OFF_END >= NCH * 2 * CIN, "scratch aliasing");
   static_assert(TT >= K - 1, "carry rows must not overlap");
 
-  __shared__ float smem[OFF_END];
-  __shared__ float sKp[7 * COUT];
+  __shared__ __attribute__((aligned(16))) float smem[OFF_END];
+  __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   float* sP = smem + OFF_P;
   float* sDP = smem + OFF_DP;
   float* sU = smem + OFF_U;
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(kThreads) void bwd_first_kernel(BwdFirstArgs a) {
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
   static_assert(4 % NT1 == 0 && TT >= K - 1, "shape");
 
-  __shared__ float sX[XR * FBINS];
-  __shared__ float smem[OFF_END];
-  __shared__ float sKp[7 * COUT];
+  __shared__ __attribute__((aligned(16))) float sX[XR * FBINS];
+  __shared__ __attribute__((aligned(16))) float smem[OFF_END];
+  __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   float* sA = smem + OFF_A;
   float* sDP = smem + OFF_DP;
   float* sU = smem + OFF_U;
@@ -508,7 +508,7 @@ struct BnBwdFinalizeArgs {
 };
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
-  __shared__ double sAcc[8 * 128];
+  __shared__ __attribute__((aligned(16))) double sAcc[8 * 128];
   const int tid = threadIdx.x, slot = tid & 127, grp = tid >> 7;
   double acc = 0.0;
   if (slot < 2 * a.C)

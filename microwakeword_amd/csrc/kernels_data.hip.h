@@ -21,7 +21,7 @@ struct AssembleArgs {
 constexpr int kMaxMasks = 16;
 
 __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
-  __shared__ int sMask[kMaxMasks * 2];
+  __shared__ __attribute__((aligned(16))) int sMask[kMaxMasks * 2];
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
   const int nm = a.ntm + a.nfm;

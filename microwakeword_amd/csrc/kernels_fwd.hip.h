@@ -132,10 +132,10 @@ __global__ __launch_bounds__(kThreads) void fwd_first_kernel(FwdFirstArgs a) {
   static_assert(4 % NT1 == 0, "first-conv filters must be 16, 32 or 64");
   static_assert((K1 * FBINS) % 4 == 0 && C1 % 16 == 0 && COUT % 16 == 0, "shape");
 
-  __shared__ float sX[XR * FBINS];
-  __shared__ float sA[RA * CP1];
-  __shared__ float sU[TT * CP1];
-  __shared__ float sRed[4 * 2 * COUT];
+  __shared__ __attribute__((aligned(16))) float sX[XR * FBINS];
+  __shared__ __attribute__((aligned(16))) float sA[RA * CP1];
+  __shared__ __attribute__((aligned(16))) float sU[TT * CP1];
+  __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % C1, chunk = tid / C1;
@@ -223,11 +223,11 @@ __global__ __launch_bounds__(kThreads) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int Q = CIN / 4;
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
 
-  __shared__ float sA[RA * CPI];
-  __shared__ float sU[TT * CPI];
-  __shared__ float sRed[4 * 2 * COUT];
-  __shared__ float sScale[CIN];
-  __shared__ float sShift[CIN];
+  __shared__ __attribute__((aligned(16))) float sA[RA * CPI];
+  __shared__ __attribute__((aligned(16))) float sU[TT * CPI];
+  __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
+  __shared__ __attribute__((aligned(16))) float sScale[CIN];
+  __shared__ __attribute__((aligned(16))) float sShift[CIN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % CIN, chunk = tid / CIN;
@@ -311,7 +311,7 @@ struct BnFwdFinalizeArgs {
 };
 
 __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(BnFwdFinalizeArgs a) {
-  __shared__ double sAcc[8 * 128];
+  __shared__ __attribute__((aligned(16))) double sAcc[8 * 128];
   const int tid = threadIdx.x, slot = tid & 127, grp = tid >> 7;
   double acc = 0.0;
   if (slot < 2 * a.C)
@@ -397,9 +397,9 @@ template <int C, int JMAX>
 __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs a) {
   constexpr int Q = C / 4;                 // float4 per frame
   constexpr int NRG = kThreads / Q;        // frame groups
-  __shared__ float sRed[8];
-  __shared__ float sBcast[2];
-  __shared__ float sStat[NRG * 2 * C];
+  __shared__ __attribute__((aligned(16))) float sRed[8];
+  __shared__ __attribute__((aligned(16))) float sBcast[2];
+  __shared__ __attribute__((aligned(16))) float sStat[NRG * 2 * C];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = tid % Q, rg = tid / Q;
