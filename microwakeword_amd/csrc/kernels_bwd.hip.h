@@ -181,7 +181,7 @@ __device__ __forceinline__ void depthwise_backward_chunk(const float* sDU, int c
 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K, bool LAST>
-__global__ __launch_bounds__(kThreads) void bwd_block_kernel(BwdBlockArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
   constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
@@ -326,7 +326,7 @@ struct BwdFirstArgs {
 };
 
 template <int K1, int C1, int COUT, int K>
-__global__ __launch_bounds__(kThreads) void bwd_first_kernel(BwdFirstArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) {
   constexpr int CIN = C1;
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
@@ -507,25 +507,20 @@ struct BnBwdFinalizeArgs {
   float* dbeta;
 };
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
-  __shared__ __attribute__((aligned(16))) double sAcc[8 * 128];
-  const int tid = threadIdx.x, slot = tid & 127, grp = tid >> 7;
-  double acc = 0.0;
-  if (slot < 2 * a.C)
-    for (int j = grp; j < a.G; j += 8) acc += (double)a.gstat_part[(size_t)j * 2 * a.C + slot];
-  sAcc[grp * 128 + slot] = acc;
+__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
+  __shared__ double sOut[2];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  const double r = reduce_partials_256(a.gstat_part, a.G, a.C, c, sAcc, tid);
+  if ((tid & 127) == 0) sOut[tid >> 7] = r;
   __syncthreads();
-  if (tid < a.C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < 8; ++j) {
-      s1 += sAcc[j * 128 + tid];
-      s2 += sAcc[j * 128 + a.C + tid];
-    }
-    a.dbeta[tid] = (float)s1;
-    a.dgamma[tid] = (float)s2;
-    a.c1[tid] = a.gamma[tid] * a.rstd[tid];
-    a.mg[tid] = (float)(s1 * (double)a.inv_n);
-    a.mgx[tid] = (float)(s2 * (double)a.inv_n);
+  if (tid == 0) {
+    const double s1 = sOut[0], s2 = sOut[1];
+    a.dbeta[c] = (float)s1;
+    a.dgamma[c] = (float)s2;
+    a.c1[c] = a.gamma[c] * a.rstd[c];
+    a.mg[c] = (float)(s1 * (double)a.inv_n);
+    a.mgx[c] = (float)(s2 * (double)a.inv_n);
   }
 }
 

@@ -8,9 +8,7 @@
 //   bn_fwd_finalize_kernel : partials -> batch mean / biased variance -> folded scale/shift,
 //                      saved mean/rstd for backward, Keras moving-average update
 //   bn_eval_prepare_kernel : moving stats -> folded scale/shift (inference)
-//   head_kernel      : p_L -> BN_L + ReLU -> Flatten -> Dense(1) -> sigmoid, Keras BCE (clipped
-//                      probability form, train.py:206), dL/dz, dense-weight gradient partials,
-//                      BN_L backward partials, metric histograms (train.py:209-221)
+//   (classifier head and loss: kernels_head.hip.h)
 #pragma once
 #include "common.hip.h"
 
@@ -120,7 +118,7 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 
 // ------------------------------------------------------------------------------------------
 template <int K1, int C1, int COUT, int K>
-__global__ __launch_bounds__(kThreads) void fwd_first_kernel(FwdFirstArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) {
   constexpr int CP1 = pitch(C1);
   constexpr int RA = TT + K - 1;               // a0 rows per tile
   constexpr int RT1 = (RA + 15) / 16;          // MFMA row tiles of the first conv
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void fwd_first_kernel(FwdFirstArgs a) {
 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K>
-__global__ __launch_bounds__(kThreads) void fwd_block_kernel(FwdBlockArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int CPI = pitch(CIN);
   constexpr int RA = TT + K - 1;
   constexpr int KS = CIN / 4, NT = COUT / 16;
@@ -294,7 +292,8 @@ __global__ __launch_bounds__(kThreads) void fwd_block_kernel(FwdBlockArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// One workgroup of 1024 threads: 8 partial-groups x 128 (stat,channel) slots, fp64 combine.
+// Per-channel reduction of the per-workgroup partials: one workgroup per channel, 2 x 128 threads
+// stride over the G partials (fp64, fixed order => bit-reproducible), then thread 0 folds the result.
 struct BnFwdFinalizeArgs {
   const float* stat_part;  // [G][2][C]
   int G, C;
@@ -310,33 +309,54 @@ struct BnFwdFinalizeArgs {
   int update_moving;
 };
 
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(BnFwdFinalizeArgs a) {
-  __shared__ __attribute__((aligned(16))) double sAcc[8 * 128];
-  const int tid = threadIdx.x, slot = tid & 127, grp = tid >> 7;
-  double acc = 0.0;
-  if (slot < 2 * a.C)
-    for (int j = grp; j < a.G; j += 8) acc += (double)a.stat_part[(size_t)j * 2 * a.C + slot];
-  sAcc[grp * 128 + slot] = acc;
+// sum of part[j][stat][c] over j for stat = tid>>7, returned to threads 0 (stat 0) and 128 (stat 1)
+__device__ __forceinline__ double reduce_partials_256(const float* part, int G, int C, int c, double* sAcc, int tid) {
+  const int stat = tid >> 7, jp = tid & 127;
+  double a0 = 0.0, a1 = 0.0;
+  int j = jp;
+  for (; j + 128 < G; j += 256) {
+    a0 += (double)part[(size_t)j * 2 * C + stat * C + c];
+    a1 += (double)part[(size_t)(j + 128) * 2 * C + stat * C + c];
+  }
+  if (j < G) a0 += (double)part[(size_t)j * 2 * C + stat * C + c];
+  sAcc[tid] = a0 + a1;
   __syncthreads();
-  if (tid < a.C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < 8; ++j) {
-      s1 += sAcc[j * 128 + tid];
-      s2 += sAcc[j * 128 + a.C + tid];
-    }
-    const double m = s1 * (double)a.inv_n;
-    double var = s2 * (double)a.inv_n - m * m;  // biased batch variance (Keras BN)
+  if (jp < 8) {
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += sAcc[stat * 128 + jp * 16 + i];
+    sAcc[256 + stat * 8 + jp] = v;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (jp == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += sAcc[256 + stat * 8 + i];
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
+  __shared__ double sOut[2];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  const double r = reduce_partials_256(a.stat_part, a.G, a.C, c, sAcc, tid);
+  if ((tid & 127) == 0) sOut[tid >> 7] = r;
+  __syncthreads();
+  if (tid == 0) {
+    const double m = sOut[0] * (double)a.inv_n;
+    double var = sOut[1] * (double)a.inv_n - m * m;  // biased batch variance (Keras BN)
     if (var < 0.0) var = 0.0;
     const float meanf = (float)m, varf = (float)var;
     const float rstd = 1.0f / sqrtf(varf + kBnEps);
-    const float sc = a.gamma[tid] * rstd;
-    a.scale[tid] = sc;
-    a.shift[tid] = a.beta[tid] - meanf * sc;
-    a.mean[tid] = meanf;
-    a.rstd[tid] = rstd;
+    const float sc = a.gamma[c] * rstd;
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[c] - meanf * sc;
+    a.mean[c] = meanf;
+    a.rstd[c] = rstd;
     if (a.update_moving) {
-      a.moving_mean[tid] = a.moving_mean[tid] * kBnMomentum + meanf * (1.0f - kBnMomentum);
-      a.moving_var[tid] = a.moving_var[tid] * kBnMomentum + varf * (1.0f - kBnMomentum);
+      a.moving_mean[c] = a.moving_mean[c] * kBnMomentum + meanf * (1.0f - kBnMomentum);
+      a.moving_var[c] = a.moving_var[c] * kBnMomentum + varf * (1.0f - kBnMomentum);
     }
   }
 }
@@ -359,175 +379,6 @@ __global__ void bn_eval_prepare_kernel(BnEvalPrepareArgs a) {
     const float sc = a.gamma[c] * rstd;
     a.scale[c] = sc;
     a.shift[c] = a.beta[c] - a.moving_mean[c] * sc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-struct MetricState {            // device-resident cumulative metric counters (train.py:209-221)
-  unsigned long long hist101[2][101];
-  unsigned long long hist200[2][200];
-  unsigned long long n, correct, tp5, fp5, fn5, pos, neg;
-  double bce_sum;
-};
-
-struct HeadArgs {
-  const float* p;          // p_L [B][T][C]
-  const float* scale;      // BN_L folded
-  const float* shift;
-  const float* mean;       // BN_L batch mean / rstd (training only)
-  const float* rstd;
-  const float* wd;         // [T*C]
-  const float* bd;         // [1]
-  const float* y;          // [B] labels (training / metrics)
-  const float* sw;         // [B] per-sample weight (penalty * class weight)
-  float* z;                // [B] logits
-  float* prob;             // [B]
-  float* dz;               // [B] dL/dz (training)
-  float* loss_part;        // [B] weighted loss / B per sample (training)
-  float* dwd_part;         // [gridDim.x][dwd_stride], dwd_stride = T*C + 4 (element T*C = dense bias gradient)
-  float* gstat_part;       // [gridDim.x][2][C]   sum g, sum g*xhat of the BN_L input gradient
-  MetricState* metrics;    // may be null
-  int B, T;
-  int dwd_stride;
-  float inv_b;
-  int training;
-};
-
-template <int C, int JMAX>
-__global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs a) {
-  constexpr int Q = C / 4;                 // float4 per frame
-  constexpr int NRG = kThreads / Q;        // frame groups
-  __shared__ __attribute__((aligned(16))) float sRed[8];
-  __shared__ __attribute__((aligned(16))) float sBcast[2];
-  __shared__ __attribute__((aligned(16))) float sStat[NRG * 2 * C];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = tid % Q, rg = tid / Q;
-  const bool active = rg < NRG;
-  float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, rs = sc;
-  if (active) {
-    sc = *reinterpret_cast<const float4*>(a.scale + q * 4);
-    sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
-    if (a.training) {
-      mu = *reinterpret_cast<const float4*>(a.mean + q * 4);
-      rs = *reinterpret_cast<const float4*>(a.rstd + q * 4);
-    }
-  }
-  float4 wdv[JMAX], dwd[JMAX];
-#pragma unroll
-  for (int j = 0; j < JMAX; ++j) {
-    const int t = rg + NRG * j;
-    wdv[j] = (active && t < a.T) ? *reinterpret_cast<const float4*>(a.wd + (size_t)t * C + q * 4) : make_float4(0, 0, 0, 0);
-    dwd[j] = make_float4(0, 0, 0, 0);
-  }
-  const float bias = a.bd[0];
-  float4 g1 = make_float4(0, 0, 0, 0), g2 = g1;
-  float dbias = 0.f;
-
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    float4 raw[JMAX], act[JMAX];
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      const int t = rg + NRG * j;
-      raw[j] = make_float4(0, 0, 0, 0);
-      act[j] = raw[j];
-      if (active && t < a.T) {
-        raw[j] = *reinterpret_cast<const float4*>(a.p + ((size_t)b * a.T + t) * C + q * 4);
-        act[j].x = fmaxf(fmaf(raw[j].x, sc.x, sh.x), 0.f);
-        act[j].y = fmaxf(fmaf(raw[j].y, sc.y, sh.y), 0.f);
-        act[j].z = fmaxf(fmaf(raw[j].z, sc.z, sh.z), 0.f);
-        act[j].w = fmaxf(fmaf(raw[j].w, sc.w, sh.w), 0.f);
-        dot = fmaf(act[j].x, wdv[j].x, dot);
-        dot = fmaf(act[j].y, wdv[j].y, dot);
-        dot = fmaf(act[j].z, wdv[j].z, dot);
-        dot = fmaf(act[j].w, wdv[j].w, dot);
-      }
-    }
-    dot = wave_sum(dot);
-    if (lane == 0) sRed[wave] = dot;
-    __syncthreads();
-    if (tid == 0) {
-      const float zz = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + bias;
-      const float pr = 1.0f / (1.0f + expf(-zz));
-      a.z[b] = zz;
-      a.prob[b] = pr;
-      float dzz = 0.f;
-      if (a.y != nullptr) {
-        const float yy = a.y[b];
-        // Keras binary_crossentropy(from_logits=False): clip to [eps, 1-eps], probability form
-        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
-        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
-        if (a.training) {
-          const float w = a.sw[b];
-          a.loss_part[b] = w * bce * a.inv_b;
-          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
-          dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
-          a.dz[b] = dzz;
-        }
-        if (a.metrics != nullptr) {
-          MetricState* m = a.metrics;
-          const int lab = yy > 0.5f ? 1 : 0;
-          const float p01 = fminf(fmaxf(pr, 0.f), 1.f);
-          const int b101 = (int)ceilf(p01 * 100.0f) - 1;                 // Keras evenly-spaced bucketing
-          int b200 = (int)ceilf(p01 * 199.0f) - 1;
-          if (b200 < 0) b200 = 0;                                         // AUC thresholds carry epsilon ends
-          if (b101 >= 0) atomicAdd(&m->hist101[lab][b101], 1ull);
-          atomicAdd(&m->hist200[lab][b200], 1ull);
-          const bool ppos = pr > 0.5f;
-          atomicAdd(&m->n, 1ull);
-          if (ppos == (lab == 1)) atomicAdd(&m->correct, 1ull);
-          if (ppos && lab) atomicAdd(&m->tp5, 1ull);
-          if (ppos && !lab) atomicAdd(&m->fp5, 1ull);
-          if (!ppos && lab) atomicAdd(&m->fn5, 1ull);
-          atomicAdd(lab ? &m->pos : &m->neg, 1ull);
-          atomicAdd(&m->bce_sum, (double)bce);
-        }
-      }
-      sBcast[0] = dzz;
-    }
-    __syncthreads();
-    if (a.training) {
-      const float dzz = sBcast[0];
-      if (tid == 0) dbias += dzz;
-#pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        dwd[j].x = fmaf(dzz, act[j].x, dwd[j].x);
-        dwd[j].y = fmaf(dzz, act[j].y, dwd[j].y);
-        dwd[j].z = fmaf(dzz, act[j].z, dwd[j].z);
-        dwd[j].w = fmaf(dzz, act[j].w, dwd[j].w);
-        // gradient entering BN_L: g = dz * wd * relu'(.) ; partial sums of g and g*xhat
-        const float gx = act[j].x > 0.f ? dzz * wdv[j].x : 0.f;
-        const float gy = act[j].y > 0.f ? dzz * wdv[j].y : 0.f;
-        const float gz = act[j].z > 0.f ? dzz * wdv[j].z : 0.f;
-        const float gw = act[j].w > 0.f ? dzz * wdv[j].w : 0.f;
-        g1.x += gx; g1.y += gy; g1.z += gz; g1.w += gw;
-        g2.x = fmaf(gx, (raw[j].x - mu.x) * rs.x, g2.x);
-        g2.y = fmaf(gy, (raw[j].y - mu.y) * rs.y, g2.y);
-        g2.z = fmaf(gz, (raw[j].z - mu.z) * rs.z, g2.z);
-        g2.w = fmaf(gw, (raw[j].w - mu.w) * rs.w, g2.w);
-      }
-    }
-    // sRed / sBcast are rewritten only after the next sample's first barrier
-  }
-  if (a.training) {
-    float* dst = a.dwd_part + (size_t)blockIdx.x * (size_t)a.dwd_stride;
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      const int t = rg + NRG * j;
-      if (active && t < a.T) *reinterpret_cast<float4*>(dst + (size_t)t * C + q * 4) = dwd[j];
-    }
-    if (tid == 0) dst[(size_t)a.T * C] = dbias;
-    if (active) {
-      *reinterpret_cast<float4*>(sStat + (rg * 2 + 0) * C + q * 4) = g1;
-      *reinterpret_cast<float4*>(sStat + (rg * 2 + 1) * C + q * 4) = g2;
-    }
-    __syncthreads();
-    if (tid < 2 * C) {
-      float v = 0.f;
-      for (int r = 0; r < NRG; ++r) v += sStat[r * 2 * C + tid];
-      a.gstat_part[(size_t)blockIdx.x * 2 * C + tid] = v;
-    }
   }
 }
 

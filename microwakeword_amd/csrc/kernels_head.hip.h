@@ -1,0 +1,196 @@
+// Classifier head of MixedNet (reference microwakeword/mixednet.py:383-384 after :352,:360 of the
+// last block) and the loss of train.py:206,295-299:
+//
+//   head_kernel       : one workgroup per window.  p_L -> BN_L + ReLU -> Flatten -> Dense(1) -> sigmoid,
+//                       Keras BCE (probabilities clipped to [1e-7, 1-1e-7]) times the per-sample
+//                       weight, dL/dz, the (sum g, sum g*xhat) partials of BN_L's backward (g rebuilt
+//                       from the per-sample scalar dL/dz) and the metric histograms of
+//                       train.py:209-221.  The window's 7104 activations stay in registers between
+//                       the dot product and the backward partials: p_L is read from HBM once.
+//   dense_grad_kernel : dW_dense[t,c] = sum_b dL/dz_b * relu(bn(p_L[b,t,c])) as a batch-chunked
+//                       reduction (fixed order) + the dense bias gradient.
+#pragma once
+#include "common.hip.h"
+
+namespace mww {
+
+struct MetricState {            // device-resident cumulative metric counters (train.py:209-221)
+  unsigned long long hist101[2][101];
+  unsigned long long hist200[2][200];
+  unsigned long long n, correct, tp5, fp5, fn5, pos, neg;
+  double bce_sum;
+};
+
+struct HeadArgs {
+  const float* p;          // p_L [B][T][C]
+  const float* scale;      // BN_L folded
+  const float* shift;
+  const float* mean;       // BN_L batch mean / rstd (training only)
+  const float* rstd;
+  const float* wd;         // [T*C]
+  const float* bd;         // [1]
+  const float* y;          // [B] labels (training / metrics) or null
+  const float* sw;         // [B] per-sample weight (penalty * class weight)
+  float* z;                // [B] logits
+  float* prob;             // [B]
+  float* dz;               // [B] dL/dz (training)
+  float* loss_part;        // [B] weighted loss / B per sample (training)
+  float* gstat_part;       // [gridDim.x][2][C]   sum g, sum g*xhat of the BN_L input gradient
+  MetricState* metrics;    // may be null
+  int B, T;
+  float inv_b;
+  int training;
+};
+
+template <int C, int JMAX>
+__global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
+  constexpr int Q = C / 4;                 // float4 per frame
+  constexpr int NRG = kThreads / Q;        // frame groups
+  __shared__ __attribute__((aligned(16))) float sRed[8];
+  __shared__ __attribute__((aligned(16))) float sBcast[2];
+  __shared__ __attribute__((aligned(16))) float sStat[NRG * 2 * C];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = tid % Q, rg = tid / Q;
+  const bool active = rg < NRG;
+  float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, rs = sc;
+  if (active) {
+    sc = *reinterpret_cast<const float4*>(a.scale + q * 4);
+    sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
+    if (a.training) {
+      mu = *reinterpret_cast<const float4*>(a.mean + q * 4);
+      rs = *reinterpret_cast<const float4*>(a.rstd + q * 4);
+    }
+  }
+  const float bias = a.bd[0];
+  float4 g1 = make_float4(0, 0, 0, 0), g2 = g1;
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    float4 raw[JMAX], wdv[JMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int t = rg + NRG * j;
+      raw[j] = make_float4(0, 0, 0, 0);
+      wdv[j] = raw[j];
+      if (active && t < a.T) {
+        raw[j] = *reinterpret_cast<const float4*>(a.p + ((size_t)b * a.T + t) * C + q * 4);
+        wdv[j] = *reinterpret_cast<const float4*>(a.wd + (size_t)t * C + q * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      // rows past T hold raw = 0 and wd = 0: relu(shift)*0 contributes nothing
+      dot = fmaf(fmaxf(fmaf(raw[j].x, sc.x, sh.x), 0.f), wdv[j].x, dot);
+      dot = fmaf(fmaxf(fmaf(raw[j].y, sc.y, sh.y), 0.f), wdv[j].y, dot);
+      dot = fmaf(fmaxf(fmaf(raw[j].z, sc.z, sh.z), 0.f), wdv[j].z, dot);
+      dot = fmaf(fmaxf(fmaf(raw[j].w, sc.w, sh.w), 0.f), wdv[j].w, dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) sRed[wave] = dot;
+    __syncthreads();
+    if (tid == 0) {
+      const float zz = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + bias;
+      const float pr = 1.0f / (1.0f + expf(-zz));
+      a.z[b] = zz;
+      a.prob[b] = pr;
+      float dzz = 0.f;
+      if (a.y != nullptr) {
+        const float yy = a.y[b];
+        // Keras binary_crossentropy(from_logits=False): clip to [eps, 1-eps], probability form
+        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
+        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
+        if (a.training) {
+          const float w = a.sw[b];
+          a.loss_part[b] = w * bce * a.inv_b;
+          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
+          dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
+          a.dz[b] = dzz;
+        }
+        if (a.metrics != nullptr) {
+          MetricState* m = a.metrics;
+          const int lab = yy > 0.5f ? 1 : 0;
+          const float p01 = fminf(fmaxf(pr, 0.f), 1.f);
+          const int b101 = (int)ceilf(p01 * 100.0f) - 1;                 // Keras evenly-spaced bucketing
+          int b200 = (int)ceilf(p01 * 199.0f) - 1;
+          if (b200 < 0) b200 = 0;                                         // AUC thresholds carry epsilon ends
+          if (b101 >= 0) atomicAdd(&m->hist101[lab][b101], 1ull);
+          atomicAdd(&m->hist200[lab][b200], 1ull);
+          const bool ppos = pr > 0.5f;
+          atomicAdd(&m->n, 1ull);
+          if (ppos == (lab == 1)) atomicAdd(&m->correct, 1ull);
+          if (ppos && lab) atomicAdd(&m->tp5, 1ull);
+          if (ppos && !lab) atomicAdd(&m->fp5, 1ull);
+          if (!ppos && lab) atomicAdd(&m->fn5, 1ull);
+          atomicAdd(lab ? &m->pos : &m->neg, 1ull);
+          atomicAdd(&m->bce_sum, (double)bce);
+        }
+      }
+      sBcast[0] = dzz;
+    }
+    __syncthreads();
+    if (a.training) {
+      const float dzz = sBcast[0];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        // gradient entering BN_L: g = dz * wd * relu'(.) ; partial sums of g and g*xhat
+        const float gx = fmaf(raw[j].x, sc.x, sh.x) > 0.f ? dzz * wdv[j].x : 0.f;
+        const float gy = fmaf(raw[j].y, sc.y, sh.y) > 0.f ? dzz * wdv[j].y : 0.f;
+        const float gz = fmaf(raw[j].z, sc.z, sh.z) > 0.f ? dzz * wdv[j].z : 0.f;
+        const float gw = fmaf(raw[j].w, sc.w, sh.w) > 0.f ? dzz * wdv[j].w : 0.f;
+        g1.x += gx; g1.y += gy; g1.z += gz; g1.w += gw;
+        g2.x = fmaf(gx, (raw[j].x - mu.x) * rs.x, g2.x);
+        g2.y = fmaf(gy, (raw[j].y - mu.y) * rs.y, g2.y);
+        g2.z = fmaf(gz, (raw[j].z - mu.z) * rs.z, g2.z);
+        g2.w = fmaf(gw, (raw[j].w - mu.w) * rs.w, g2.w);
+      }
+    }
+    // sRed / sBcast are rewritten only after the next window's first barrier
+  }
+  if (a.training) {
+    if (active) {
+      *reinterpret_cast<float4*>(sStat + (rg * 2 + 0) * C + q * 4) = g1;
+      *reinterpret_cast<float4*>(sStat + (rg * 2 + 1) * C + q * 4) = g2;
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      float v = 0.f;
+      for (int r = 0; r < NRG; ++r) v += sStat[r * 2 * C + tid];
+      a.gstat_part[(size_t)blockIdx.x * 2 * C + tid] = v;
+    }
+  }
+}
+
+// grid = (ceil(T*C / 256), n_chunks): thread e owns dense weight e and sums one chunk of the batch.
+struct DenseGradArgs {
+  const float* p;       // p_L [B][T*C]
+  const float* scale;   // [C]
+  const float* shift;   // [C]
+  const float* dz;      // [B]
+  float* part;          // [n_chunks][stride]   (element n = dense bias gradient)
+  int B, n, C, stride, chunk;
+};
+
+__global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  const int b0 = blockIdx.y * a.chunk, b1 = min(a.B, b0 + a.chunk);
+  if (e < a.n) {
+    const int c = e % a.C;
+    const float sc = a.scale[c], sh = a.shift[c];
+    float acc0 = 0.f, acc1 = 0.f;
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
+      const float v0 = a.p[(size_t)b * a.n + e], v1 = a.p[(size_t)(b + 1) * a.n + e];
+      acc0 = fmaf(a.dz[b], fmaxf(fmaf(v0, sc, sh), 0.f), acc0);
+      acc1 = fmaf(a.dz[b + 1], fmaxf(fmaf(v1, sc, sh), 0.f), acc1);
+    }
+    if (b < b1) acc0 = fmaf(a.dz[b], fmaxf(fmaf(a.p[(size_t)b * a.n + e], sc, sh), 0.f), acc0);
+    a.part[(size_t)blockIdx.y * a.stride + e] = acc0 + acc1;
+  } else if (e == a.n) {
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += a.dz[b];
+    a.part[(size_t)blockIdx.y * a.stride + a.n] = s;
+  }
+}
+
+}  // namespace mww

@@ -12,6 +12,7 @@
 #include "kernels_bwd.hip.h"
 #include "kernels_data.hip.h"
 #include "kernels_fwd.hip.h"
+#include "kernels_head.hip.h"
 
 using namespace mww;
 
@@ -51,6 +52,7 @@ struct ProfileEntry {
 };
 
 constexpr int kRing = 8;
+constexpr int kDenseChunks = 32;  // batch chunks of the dense-weight gradient reduction
 
 }  // namespace
 
@@ -240,7 +242,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
                           c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv, bn_slot(l, BN_SCALE),
                           bn_slot(l, BN_SHIFT), bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), update_moving ? 1 : 0};
       lp.begin("bn_fwd_finalize", i);
-      hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+      hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(l.cout), dim3(kThreads), 0, c->stream, f);
       lp.end();
     }
   }
@@ -260,12 +262,10 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.prob = c->prob;
   h.dz = c->dz;
   h.loss_part = c->loss_part;
-  h.dwd_part = c->dwd_part;
   h.gstat_part = ll.gstat_part;
   h.metrics = metrics ? c->metrics : nullptr;
   h.B = B;
   h.T = ll.tout;
-  h.dwd_stride = c->dwd_stride;
   h.inv_b = 1.0f / (float)B;
   h.training = loss ? 1 : 0;
   const int q = ll.cout / 4, nrg = kThreads / q;
@@ -281,6 +281,16 @@ int enqueue_backward(mww_ctx* c, int B) {
   const int nb = d.n_blocks;
   const int gbwd = std::min(B, c->grid_bwd);
   const int ghead = std::min(B, c->grid_head);
+  const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
+  const int ndchunks = (B + dchunk - 1) / dchunk;
+  {
+    Layer& ll = c->L[nb - 1];
+    DenseGradArgs dg{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
+                     c->c_last, c->dwd_stride, dchunk};
+    lp.begin("dense_grad");
+    hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, c->stream, dg);
+    lp.end();
+  }
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -288,7 +298,7 @@ int enqueue_backward(mww_ctx* c, int B) {
                         c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
                         bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta};
     lp.begin("bn_bwd_finalize", i);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, c->stream, f);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(l.cout), dim3(kThreads), 0, c->stream, f);
     lp.end();
     if (i > 0) {
       Layer& pl = c->L[i - 1];
@@ -351,7 +361,7 @@ int enqueue_backward(mww_ctx* c, int B) {
   {
     GradSegment s;
     s.part = c->dwd_part;
-    s.G = ghead;
+    s.G = ndchunks;
     s.stride = c->dwd_stride;
     s.n = c->t_last * c->c_last + 1;
     s.dst = (int)c->o_dense_w;
@@ -456,7 +466,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   }
   c->grid_fwd = c->n_cu * 4;
   c->grid_bwd = c->n_cu * 2;
-  c->grid_head = c->n_cu;
+  c->grid_head = c->n_cu * 4;
   // ---- parameter layout
   int64_t off = 0, soff = 0;
   c->o_conv1 = off;
@@ -507,7 +517,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   A(dev_alloc(&c->prob, mb));
   A(dev_alloc(&c->dz, mb));
   A(dev_alloc(&c->loss_part, mb));
-  A(dev_alloc(&c->dwd_part, (size_t)gmax_h * c->dwd_stride));
+  A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
   A(dev_alloc(&c->hyper, 2));
   A(dev_alloc(&c->win_dev, mb));
@@ -851,7 +861,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   }
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
-  else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
+  else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
   else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   c->graphs.clear();

@@ -208,6 +208,15 @@ class MixedNetLayout:
         out.append(p(1).copy())
         return out
 
+    def segments(self):
+        """(name, size) of every contiguous piece of the native parameter vector, in order."""
+        seg = [("conv1.kernel", self.conv1_kernel * FEATURE_BINS * self.conv1_filters)]
+        for i, b in enumerate(self.blocks):
+            seg += [("b%d.dw.kernel" % i, b.k * b.cin), ("b%d.dw.bias" % i, b.cin), ("b%d.pw.kernel" % i, b.cin * b.cout),
+                    ("b%d.bn.gamma" % i, b.cout), ("b%d.bn.beta" % i, b.cout)]
+        seg += [("dense.kernel", self.t_last * self.c_last), ("dense.bias", 1)]
+        return seg
+
     def grad_mask(self) -> np.ndarray:
         parts = [np.ones(self.conv1_kernel * FEATURE_BINS * self.conv1_filters, np.float32)]
         for b in self.blocks:

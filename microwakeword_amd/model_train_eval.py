@@ -1,0 +1,116 @@
+"""CLI / config surface of the reference kept for the training path:
+``python -m microwakeword_amd.model_train_eval --training_config cfg.yaml mixednet --residual_connection "0,0,0,0"``
+
+Mirrors microwakeword/model_train_eval.py:
+  * ``load_config(flags, model_module)``     :45-96   (YAML keys + derived ``summaries_dir, stride,
+    spectrogram_length_final_layer, spectrogram_length, flags, training_input_shape``)
+  * ``train_model(config, model, data_processor, restore_checkpoint)``   :99-128
+  * argparse surface                          :277-389 (the ``--test_*`` export flags are accepted; TFLite
+    export / streaming evaluation stay with the reference and raise here if requested)
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+
+import yaml
+
+from . import mixednet
+from .data import FeatureHandler
+from . import train as train_mod
+
+
+def get_input_data_shape(config):
+    """layers/modes.py:40-64 for the TRAINING / NON_STREAM_INFERENCE modes."""
+    return (config["spectrogram_length"], 40)
+
+
+def load_config(flags, model_module):
+    config = yaml.load(open(flags.training_config, "r").read(), yaml.Loader)
+    config["summaries_dir"] = os.path.join(config["train_dir"], "logs/")
+    config["stride"] = flags.__dict__.get("stride", 1)
+    config["window_step_ms"] = config.get("window_step_ms", 20)
+    sample_rate, window_size_ms = 16000, 30
+    desired_samples = int(sample_rate * config["clip_duration_ms"] / 1000)
+    window_size_samples = int(sample_rate * window_size_ms / 1000)
+    window_step_samples = int(config["stride"] * sample_rate * config["window_step_ms"] / 1000)
+    length_minus_window = desired_samples - window_size_samples
+    if length_minus_window < 0:
+        config["spectrogram_length_final_layer"] = 0
+    else:
+        config["spectrogram_length_final_layer"] = 1 + int(length_minus_window / window_step_samples)
+    config["spectrogram_length"] = config["spectrogram_length_final_layer"] + model_module.spectrogram_slices_dropped(flags)
+    config["flags"] = flags.__dict__
+    config["training_input_shape"] = get_input_data_shape(config)
+    return config
+
+
+def save_model_summary(model, path, file_name="model_summary.txt"):
+    """utils.py:131-145."""
+    with open(os.path.join(path, file_name), "wt") as fd:
+        model.summary(print_fn=lambda x: fd.write(x + "\n"))
+
+
+def train_model(config, model, data_processor, restore_checkpoint):
+    try:
+        os.makedirs(config["train_dir"])
+        os.mkdir(config["summaries_dir"])
+    except OSError:
+        if not restore_checkpoint:
+            raise ValueError("model already exists in folder %s" % config["train_dir"]) from None
+    with open(os.path.join(config["train_dir"], "training_config.yaml"), "w") as outfile:
+        yaml.dump({k: v for k, v in config.items() if k != "features" or all("stores" not in f for f in v)}, outfile,
+                  default_flow_style=False)
+    save_model_summary(model, config["train_dir"])
+    return train_mod.train(model, config, data_processor)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--training_config", type=str, default="trained_models/model/training_parameters.yaml")
+    parser.add_argument("--train", type=int, default=1)
+    parser.add_argument("--test_tf_nonstreaming", type=int, default=0)
+    parser.add_argument("--test_tflite_nonstreaming", type=int, default=0)
+    parser.add_argument("--test_tflite_nonstreaming_quantized", type=int, default=0)
+    parser.add_argument("--test_tflite_streaming", type=int, default=0)
+    parser.add_argument("--test_tflite_streaming_quantized", type=int, default=0)
+    parser.add_argument("--restore_checkpoint", type=int, default=0)
+    parser.add_argument("--use_weights", type=str, default="best_weights")
+    parser.add_argument("--verbosity", type=str, default="INFO")
+    parser.add_argument("--device", type=int, default=0, help="HIP device index (one process per GPU)")
+    subparsers = parser.add_subparsers(dest="model_name", help="NN model name")
+    subparsers.add_parser("inception")
+    mixednet.model_parameters(subparsers.add_parser("mixednet"))
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    flags, unparsed = parser.parse_known_args(argv)
+    if unparsed:
+        raise ValueError("Unknown argument: {}".format(unparsed))
+    if flags.model_name == "mixednet":
+        model_module = mixednet
+    elif flags.model_name == "inception":
+        raise NotImplementedError("the inception topology is not implemented by the MI355X engine yet (DESIGN.md §8)")
+    else:
+        raise ValueError("Unknown model type: {}".format(flags.model_name))
+    logging.basicConfig(level=getattr(logging, flags.verbosity.upper(), logging.INFO))
+    if any((flags.test_tf_nonstreaming, flags.test_tflite_nonstreaming, flags.test_tflite_nonstreaming_quantized,
+            flags.test_tflite_streaming, flags.test_tflite_streaming_quantized)):
+        raise NotImplementedError("model export / TFLite evaluation stays with the reference (microwakeword.utils / .test); "
+                                  "train here, then load the saved weights there (INTEGRATION.md)")
+    config = load_config(flags, model_module)
+    if flags.train:
+        model = model_module.model(flags, config["training_input_shape"], config["batch_size"], device=flags.device)
+        data_processor = FeatureHandler(config, engine=model.engine)
+        model.summary(print_fn=logging.getLogger("microwakeword_amd").info)
+        return train_model(config, model, data_processor, flags.restore_checkpoint)
+    if not os.path.isdir(config["train_dir"]):
+        raise ValueError('model is not trained set "--train 1" and retrain it')
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

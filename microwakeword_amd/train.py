@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference train loop (microwakeword/train.py) driving the MI355X engine.
+
+``train(model, config, data_processor)`` keeps the reference's per-step behaviour:
+  * phase schedule: lists padded with their last entry, piecewise constant by cumulative
+    ``training_steps``                                             train.py:168-204,249-263
+  * ``model.optimizer.learning_rate.assign(lr)`` every step        train.py:265
+  * ``get_data("training", batch_size, spectrogram_length, "default", policy)``   train.py:276-286
+  * class weight x penalty weight                                   train.py:288-293 (per-sample form)
+  * ``train_on_batch``                                              train.py:295-299
+  * every ``eval_step_interval`` steps: save last weights, ``validate_nonstreaming``, reset metrics,
+    best-weights rule, checkpoint                                   train.py:315-451
+and ``validate_nonstreaming`` reproduces train.py:41-163 (validation set + 100 ms-stride split of
+the ambient set accumulated into the same counters, FAPH / recall-at-cutoff / average viable recall).
+
+When both objects come from this package the spectrogram batch never leaves HBM
+(``FeatureHandler.next_training_batch_on_device`` + ``Model.train_on_device_batch``); with any other
+duck-typed pair it falls back to the reference's host-array calls.  TensorBoard summaries
+(train.py:236-241,328-334,361-389) are written as JSON lines under ``<summaries_dir>``.
+"""
+from __future__ import annotations
+
+import contextlib
+import json
+import logging
+import os
+
+import numpy as np
+
+log = logging.getLogger("microwakeword_amd.train")
+
+
+@contextlib.contextmanager
+def swap_attribute(obj, attr, temp_value):
+    original_value = getattr(obj, attr)
+    setattr(obj, attr, temp_value)
+    try:
+        yield
+    finally:
+        setattr(obj, attr, original_value)
+
+
+def _trapezoid(y, x):
+    fn = getattr(np, "trapezoid", None) or getattr(np, "trapz")
+    return fn(y, x)
+
+
+def validate_nonstreaming(config, data_processor, model, test_set):
+    fingerprints, ground_truth, _ = data_processor.get_data(
+        test_set, batch_size=config["batch_size"], features_length=config["spectrogram_length"],
+        truncation_strategy="truncate_start")
+    ground_truth = ground_truth.reshape(-1, 1)
+    model.reset_metrics()
+    result = model.evaluate(fingerprints, ground_truth, batch_size=1024, return_dict=True, verbose=0)
+    metrics = {k: result[k] for k in ("accuracy", "recall", "precision", "auc", "loss")}
+    metrics.update(recall_at_no_faph=0, cutoff_for_no_faph=0, ambient_false_positives=0,
+                   ambient_false_positives_per_hour=0, average_viable_recall=0)
+    test_set_fp = result["fp"].numpy()
+
+    if data_processor.get_mode_size("validation_ambient") > 0:
+        amb_x, amb_y, _ = data_processor.get_data(
+            test_set + "_ambient", batch_size=config["batch_size"], features_length=config["spectrogram_length"],
+            truncation_strategy="split")
+        amb_y = amb_y.reshape(-1, 1)
+        # keep accumulating into the same counters (the reference swaps reset_metrics for a no-op)
+        with swap_attribute(model, "reset_metrics", lambda: None):
+            amb = model.evaluate(amb_x, amb_y, batch_size=1024, return_dict=True, verbose=0)
+        hours = data_processor.get_mode_duration("validation_ambient") / 3600.0
+        all_tp = amb["tp"].numpy()
+        ambient_fp = amb["fp"].numpy() - test_set_fp
+        all_fn = amb["fn"].numpy()
+        metrics["auc"] = amb["auc"]
+        metrics["loss"] = amb["loss"]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            recall_at_cutoffs = all_tp / (all_tp + all_fn)
+        faph_at_cutoffs = ambient_fp / hours
+
+        target_cutoff = 1.0
+        recall_at_no_faph = 0
+        for index, cutoff in enumerate(np.linspace(0.0, 1.0, 101)):
+            if faph_at_cutoffs[index] == 0:
+                target_cutoff = cutoff
+                recall_at_no_faph = recall_at_cutoffs[index]
+                break
+
+        if faph_at_cutoffs[0] > 2:
+            first = 1
+            while faph_at_cutoffs[first] > 2:
+                first += 1
+            x0, y0 = faph_at_cutoffs[first - 1], recall_at_cutoffs[first - 1]
+            x1, y1 = faph_at_cutoffs[first], recall_at_cutoffs[first]
+            recall_at_2faph = (y0 * (x1 - 2.0) + y1 * (2.0 - x0)) / (x1 - x0)
+        else:
+            first = 0
+            recall_at_2faph = recall_at_cutoffs[0]
+        xs, ys = [2.0], [recall_at_2faph]
+        for index in range(first, len(recall_at_cutoffs)):
+            if faph_at_cutoffs[index] != xs[-1]:
+                xs.append(faph_at_cutoffs[index])
+                ys.append(recall_at_cutoffs[index])
+        metrics["recall_at_no_faph"] = recall_at_no_faph
+        metrics["cutoff_for_no_faph"] = target_cutoff
+        metrics["ambient_false_positives"] = ambient_fp[50]
+        metrics["ambient_false_positives_per_hour"] = faph_at_cutoffs[50]
+        metrics["average_viable_recall"] = _trapezoid(np.flip(ys), np.flip(xs)) / 2.0
+    return metrics
+
+
+def _phase_lists(config):
+    def get(key, default):
+        v = config.get(key)
+        return list(v) if v else list(default)
+
+    lists = dict(
+        training_steps=get("training_steps", [20000]), learning_rates=get("learning_rates", [0.001]),
+        mix_up_prob=get("mix_up_augmentation_prob", [0.0]), freq_mix_prob=get("freq_mix_augmentation_prob", [0.0]),
+        time_mask_max_size=get("time_mask_max_size", [5]), time_mask_count=get("time_mask_count", [2]),
+        freq_mask_max_size=get("freq_mask_max_size", [5]), freq_mask_count=get("freq_mask_count", [2]),
+        positive_class_weight=get("positive_class_weight", [1.0]), negative_class_weight=get("negative_class_weight", [1.0]))
+    n = len(lists["training_steps"])
+    for k, v in lists.items():
+        while len(v) < n:
+            v.append(v[-1])
+    return lists
+
+
+def _is_better(cur_min, cur_max, best_min, best_max, target):
+    return ((cur_min <= target and (cur_max > best_max or best_min > target))
+            or (cur_min > target and cur_min < best_min)
+            or (cur_min == best_min and cur_max > best_max))
+
+
+class _JsonSummary:
+    def __init__(self, directory, name):
+        os.makedirs(directory, exist_ok=True)
+        self.f = open(os.path.join(directory, name + ".jsonl"), "a")
+
+    def scalars(self, step, **kv):
+        self.f.write(json.dumps(dict(step=int(step), **{k: float(v) for k, v in kv.items()})) + "\n")
+        self.f.flush()
+
+
+def train(model, config, data_processor, verbose=True):
+    ph = _phase_lists(config)
+    model.compile()
+    model.make_train_function()
+    ckpt_dir = os.path.join(config["train_dir"], "restore")
+    ckpt = os.path.join(ckpt_dir, "ckpt")
+    if os.path.isfile(ckpt + ".weights.npz") and hasattr(model, "load_optimizer_state"):
+        # restore is unconditional in the reference (train.py:232-233)
+        model.load_weights(ckpt + ".weights")
+        model.load_optimizer_state(ckpt + ".opt.npz")
+    train_writer = _JsonSummary(os.path.join(config["summaries_dir"], "train"), "scalars")
+    val_writer = _JsonSummary(os.path.join(config["summaries_dir"], "validation"), "scalars")
+
+    steps_max = int(np.sum(ph["training_steps"]))
+    best_min, best_max, best_cutoff = 10000, 0.0, 1.0
+    fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
+        and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
+
+    def save_ckpt():
+        os.makedirs(ckpt_dir, exist_ok=True)
+        model.save_weights(ckpt + ".weights")
+        if hasattr(model, "save_optimizer_state"):
+            model.save_optimizer_state(ckpt + ".opt.npz")
+
+    for step in range(1, steps_max + 1):
+        acc = 0
+        for i, n in enumerate(ph["training_steps"]):
+            acc += n
+            if step <= acc:
+                break
+        lr = ph["learning_rates"][i]
+        model.optimizer.learning_rate.assign(lr)
+        policy = {"mix_up_prob": ph["mix_up_prob"][i], "freq_mix_prob": ph["freq_mix_prob"][i],
+                  "time_mask_max_size": ph["time_mask_max_size"][i], "time_mask_count": ph["time_mask_count"][i],
+                  "freq_mask_max_size": ph["freq_mask_max_size"][i], "freq_mask_count": ph["freq_mask_count"][i]}
+        cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
+        if fast:
+            y, w = data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy)
+            combined = w * np.where(y > 0.5, cw_pos, cw_neg)
+            result = model.train_on_device_batch(config["batch_size"], y, sample_weight=combined)
+        else:
+            x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
+                                              features_length=config["spectrogram_length"], truncation_strategy="default",
+                                              augmentation_policy=policy)
+            combined = w * np.where(y > 0.5, cw_pos, cw_neg)
+            result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
+        if verbose:
+            print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(
+                (step // config["eval_step_interval"] + 1), result[1], result[2], result[3], result[9],
+                (step % config["eval_step_interval"])), end="\r")
+
+        is_last = step == steps_max
+        if (step % config["eval_step_interval"]) == 0 or is_last:
+            log.info("Step #%d: rate %f, accuracy %.2f%%, recall %.2f%%, precision %.2f%%, cross entropy %f",
+                     step, lr, result[1] * 100, result[2] * 100, result[3] * 100, result[9])
+            train_writer.scalars(step, loss=result[9], accuracy=result[1], recall=result[2], precision=result[3], auc=result[8])
+            model.save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+            nm = validate_nonstreaming(config, data_processor, model, "validation")
+            model.reset_metrics()
+            log.info("Step %d (nonstreaming): Validation: recall at no faph = %.3f with cutoff %.2f, accuracy = %.2f%%, recall = %.2f%%, "
+                     "precision = %.2f%%, ambient false positives = %d, estimated false positives per hour = %.5f, loss = %.5f, "
+                     "auc = %.5f, average viable recall = %.9f", step, nm["recall_at_no_faph"] * 100, nm["cutoff_for_no_faph"],
+                     nm["accuracy"] * 100, nm["recall"] * 100, nm["precision"] * 100, nm["ambient_false_positives"],
+                     nm["ambient_false_positives_per_hour"], nm["loss"], nm["auc"], nm["average_viable_recall"])
+            val_writer.scalars(step, loss=nm["loss"], accuracy=nm["accuracy"], recall=nm["recall"], precision=nm["precision"],
+                               recall_at_no_faph=nm["recall_at_no_faph"], auc=nm["auc"], average_viable_recall=nm["average_viable_recall"])
+            os.makedirs(os.path.join(config["train_dir"], "train"), exist_ok=True)
+            model.save_weights(os.path.join(config["train_dir"], "train", f"{int(best_min * 10000)}_weights_{step}.weights.h5"))
+            cur_min = 0.0 if config["minimization_metric"] is None else nm[config["minimization_metric"]]
+            cur_max = nm[config["maximization_metric"]]
+            if _is_better(cur_min, cur_max, best_min, best_max, config["target_minimization"]):
+                best_min, best_max, best_cutoff = cur_min, cur_max, nm["cutoff_for_no_faph"]
+                model.save_weights(os.path.join(config["train_dir"], "best_weights.weights.h5"))
+                save_ckpt()
+            log.info("So far the best minimization quantity is %.3f with best maximization quantity of %.5f%%; no faph cutoff is %.2f",
+                     best_min, best_max * 100, best_cutoff)
+    save_ckpt()
+    model.save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+    return dict(best_minimization=best_min, best_maximization=best_max, best_no_faph_cutoff=best_cutoff)

@@ -191,7 +191,20 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False):
         worst["grad"] = max(worst.get("grad", 0), float(np.abs(g - gref).max() / scale))
         assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
         assert np.abs(pr - po).max() <= FWD_TOL
-        assert np.abs(g - gref).max() <= 2e-4 * scale, (s, np.abs(g - gref).max(), scale)
+        # per parameter tensor: error relative to that tensor's own gradient scale.  The depthwise
+        # biases are followed by a BatchNorm, so their true gradient is exactly zero: what any fp32
+        # implementation returns there is cancellation noise (sum of O(B*T) terms), bounded in
+        # absolute terms instead.
+        off = 0
+        for name, n in lay.segments():
+            a, r = g[off:off + n], gref[off:off + n]
+            off += n
+            if name.endswith("dw.bias"):
+                assert np.abs(a - r).max() <= 2e-3 * scale, (s, name, np.abs(a - r).max(), scale)
+            else:
+                seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
+                assert np.abs(a - r).max() <= 2e-4 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
+                worst["grad"] = max(worst.get("grad", 0), float(np.abs(a - r).max() / seg_scale))
         om.train_step(x, y, w, lr)
         p_ref, s_ref = lay.pack(om.get_weights())
         p_got, s_got = eng.get_params(), eng.get_bn_state()

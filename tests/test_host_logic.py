@@ -1,0 +1,185 @@
+"""Host-side logic that needs no GPU: flag parsing / shape derivation, Keras<->native weight
+mapping (incl. MixConv zero-tap fusion), config loading, the train-loop schedule and best-model
+rule, validate_nonstreaming arithmetic — against the oracle / reference semantics."""
+import argparse
+import os
+import types
+
+import numpy as np
+import pytest
+import yaml
+
+from microwakeword_amd import layout as lay
+from microwakeword_amd import mixednet, model_train_eval, synthetic, train as tr
+from microwakeword_amd.model import initial_weights
+from oracle import data_oracle as do
+from oracle import model_oracle as mo
+
+DEF = synthetic.DEFAULT_MIXEDNET_FLAGS
+
+
+def test_argparse_defaults_match_reference_and_do_not_construct():
+    p = argparse.ArgumentParser()
+    mixednet.model_parameters(p)
+    flags = p.parse_args([])
+    for k, v in mo.MIXEDNET_DEFAULTS.items():
+        assert str(getattr(flags, k)) == str(v), k
+    with pytest.raises(ValueError, match="same length"):
+        lay.MixedNetLayout(flags, 194)  # five residual entries vs four blocks (mixednet.py:52-57,298-305)
+    flags.residual_connection = "0,0,0,0"
+    L = lay.MixedNetLayout(flags, 194)
+    assert L.keras_param_counts() == (22561, 22177) and L.n_params == 22177 and L.n_state == 384
+    assert mixednet.spectrogram_slices_dropped(flags) == 46
+
+
+def test_unsupported_options_raise_loudly():
+    for k, v in (("stride", 3), ("residual_connection", "0,1,0,0"), ("repeat_in_block", "1,2,1,1"), ("spatial_attention", 1), ("pooled", 1), ("first_conv_filters", 0)):
+        with pytest.raises(NotImplementedError):
+            lay.MixedNetLayout(dict(DEF, **{k: v}), 194)
+
+
+def test_pack_unpack_roundtrip_and_oracle_order():
+    L = lay.MixedNetLayout(DEF, 194)
+    om = mo.OracleModel("mixednet", DEF, 194, seed=1)
+    ws = [w + 0.01 * (i + 1) for i, w in enumerate(om.get_weights())]
+    assert [tuple(s) for _, s, _ in L.keras_vars] == [w.shape for w in ws]
+    p, s = L.pack(ws)
+    back = L.unpack(p, s)
+    for a, b in zip(ws, back):
+        np.testing.assert_array_equal(a.astype(np.float32), b)
+    assert L.grad_mask().min() == 1.0
+
+
+def test_mixconv_fusion_matches_oracle_right_alignment():
+    """Multi-kernel MixConv groups fused into one [K_last, C] depthwise with zero leading taps give the
+    same block output as the reference's split / StridedDrop / concat (checked through the oracle)."""
+    flags = dict(DEF, mixconv_kernel_sizes="[5],[7,11],[9,15],[23]", pointwise_filters="48,48,48,48")
+    T = 110
+    L = lay.MixedNetLayout(flags, T)
+    assert [b.k for b in L.blocks] == [5, 11, 15, 23] and L.blocks[1].group_channels == (24, 24)
+    om = mo.OracleModel("mixednet", flags, T, seed=2)
+    assert [tuple(s) for _, s, _ in L.keras_vars] == [w.shape for w in om.get_weights()]
+    ws = om.get_weights()
+    p, s = L.pack(ws)
+    m = L.grad_mask()
+    assert m.sum() == L.keras_param_counts()[1]
+    # fused single-kernel model with the packed weights == multi-kernel oracle
+    fused_flags = dict(flags, mixconv_kernel_sizes="[5],[11],[15],[23]")
+    Lf = lay.MixedNetLayout(fused_flags, T)
+    omf = mo.OracleModel("mixednet", fused_flags, T, seed=0)
+    omf.set_weights(Lf.unpack(p, s))
+    x = np.random.default_rng(0).random((2, T, 40)) * 5
+    np.testing.assert_allclose(omf.predict(x, True), om.predict(x, True), rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        lay.MixedNetLayout(dict(DEF, mixconv_kernel_sizes="[5],[11,7],[13],[21]"), 194)
+
+
+def test_initial_weights_follow_keras_defaults():
+    L = lay.MixedNetLayout(DEF, 194)
+    ws = initial_weights(L, seed=0)
+    for (name, shape, _), w in zip(L.keras_vars, ws):
+        assert w.shape == tuple(shape)
+        if name.endswith(("gamma", "moving_variance")):
+            assert (w == 1).all()
+        elif name.endswith(("bias", "beta", "moving_mean")):
+            assert (w == 0).all()
+    k = ws[0]
+    assert np.abs(k).max() <= np.sqrt(6.0 / (3 * 40 + 3 * 32)) + 1e-6
+
+
+def test_load_config_shape_derivation(tmp_path):
+    cfg = dict(window_step_ms=10, train_dir=str(tmp_path / "m"), features=[], training_steps=[10], batch_size=8, clip_duration_ms=1500,
+               eval_step_interval=5, target_minimization=0.9, minimization_metric=None, maximization_metric="average_viable_recall")
+    f = tmp_path / "c.yaml"
+    f.write_text(yaml.dump(cfg))
+    flags = model_train_eval.build_parser().parse_args(["--training_config", str(f), "mixednet", "--residual_connection", "0,0,0,0"])
+    c = model_train_eval.load_config(flags, mixednet)
+    assert (c["spectrogram_length_final_layer"], c["spectrogram_length"], c["stride"]) == (148, 194, 1)
+    assert c["training_input_shape"] == (194, 40) and c["summaries_dir"].endswith("logs/")
+    assert (c["spectrogram_length_final_layer"], c["spectrogram_length"]) == mo.spectrogram_length(1500, 10, 1, 46)
+
+
+class _FakeModel:
+    """Duck-typed model recording what the loop does."""
+
+    def __init__(self):
+        self.optimizer = types.SimpleNamespace(learning_rate=types.SimpleNamespace(assign=self._lr))
+        self.lrs, self.weights_seen, self.saved, self.resets, self.evals = [], [], [], 0, 0
+
+    def _lr(self, v):
+        self.lrs.append(v)
+
+    def compile(self, **k):
+        pass
+
+    def make_train_function(self):
+        pass
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        self.weights_seen.append(np.asarray(sample_weight).copy())
+        return [0.5, 0.9, 0.8, 0.7, None, None, None, None, 0.95, 0.4]
+
+    def reset_metrics(self):
+        self.resets += 1
+
+    def evaluate(self, x, y, **k):
+        self.evals += 1
+        c = types.SimpleNamespace
+        tp = np.linspace(10, 0, 101)
+        return dict(accuracy=0.9, recall=0.8, precision=0.7, auc=0.9, loss=0.3, tp=c(numpy=lambda: tp), fp=c(numpy=lambda: np.zeros(101)),
+                    tn=c(numpy=lambda: np.zeros(101)), fn=c(numpy=lambda: 10 - tp))
+
+    def save_weights(self, path):
+        self.saved.append(os.path.basename(path))
+
+
+class _FakeData:
+    def __init__(self):
+        self.policies = []
+
+    def get_data(self, mode, batch_size, features_length, truncation_strategy="default", augmentation_policy=None):
+        if mode == "training":
+            self.policies.append(dict(augmentation_policy))
+            y = np.array([1.0, 0.0, 1.0, 0.0])
+            return np.zeros((4, features_length, 40), np.float32), y, np.array([1.0, 2.0, 3.0, 4.0])
+        return np.zeros((3, features_length, 40), np.float32), np.array([1.0, 0.0, 1.0]), np.ones(3)
+
+    def get_mode_size(self, mode):
+        return 0
+
+    def get_mode_duration(self, mode):
+        return 0.0
+
+
+def test_train_loop_schedule_and_weights(tmp_path):
+    config = dict(train_dir=str(tmp_path / "run"), summaries_dir=str(tmp_path / "run" / "logs"), batch_size=4, spectrogram_length=50,
+                  training_steps=[2, 3], learning_rates=[0.01, 0.001], time_mask_max_size=[5, 0], time_mask_count=[2],
+                  positive_class_weight=[1.0, 2.0], negative_class_weight=[20.0], eval_step_interval=2, target_minimization=0.9,
+                  minimization_metric=None, maximization_metric="accuracy")
+    m, d = _FakeModel(), _FakeData()
+    out = tr.train(m, config, d, verbose=False)
+    assert m.lrs == [0.01, 0.01, 0.001, 0.001, 0.001]                       # piecewise constant by cumulative steps
+    assert [p["time_mask_max_size"] for p in d.policies] == [5, 5, 0, 0, 0]
+    assert [p["time_mask_count"] for p in d.policies] == [2] * 5             # padded with the last entry
+    np.testing.assert_array_equal(m.weights_seen[0], [1.0, 40.0, 3.0, 80.0])  # penalty * class weight per sample
+    np.testing.assert_array_equal(m.weights_seen[4], [2.0, 40.0, 6.0, 80.0])
+    assert m.evals == 3 and "best_weights.weights.h5" in m.saved and m.saved.count("last_weights.weights.h5") == 4
+    assert "100000000_weights_2.weights.h5" in m.saved                      # previous best (10000) embedded in the name
+    assert out["best_maximization"] == 0.9
+
+
+def test_best_model_rule():
+    f = tr._is_better
+    assert f(0.5, 0.1, 10000, 0.0, 0.9)        # first time under target
+    assert f(0.5, 0.3, 0.5, 0.2, 0.9)          # under target, accuracy improved
+    assert not f(0.5, 0.1, 0.5, 0.2, 0.9)
+    assert f(1.5, 0.0, 2.0, 0.5, 0.9)          # above target but decreased
+    assert not f(2.5, 0.9, 2.0, 0.5, 0.9)
+
+
+def test_synthetic_generators_agree_with_oracle_copy():
+    a = synthetic.synthetic_stores(16, 1234)
+    b = do.synthetic_stores(16, 1234)
+    for sa, sb in zip(a, b):
+        for x, y in zip(sa, sb):
+            np.testing.assert_array_equal(x, y)

@@ -1,0 +1,140 @@
+"""world_size-2 gloo tests of the data-parallel host logic (sharding, RNG streams, gradient
+all-reduce + averaged Adam, parameter broadcast).  The compute engine is stubbed with the CPU
+oracle here (tests may use the oracle); the collectives and bookkeeping are the product code of
+microwakeword_amd/parallel.py that runs unchanged over RCCL on the GPUs."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from microwakeword_amd import synthetic
+from microwakeword_amd.parallel import DataParallel, shard_feature_handler
+from oracle import model_oracle as mo
+
+DEF = synthetic.DEFAULT_MIXEDNET_FLAGS
+T = 60
+
+
+class OracleEngine:
+    """Minimal engine stand-in: flat gradient / parameter views + NO_APPLY step + apply."""
+
+    def __init__(self, seed):
+        self.om = mo.OracleModel("mixednet", DEF, T, seed=seed, dtype=torch.float64)
+        self.tr = [v for v in self.om.vars if v.trainable]
+        n = sum(v.value.size for v in self.tr)
+        self.grad_view = torch.zeros(n, dtype=torch.float64)
+        self.param_view = torch.zeros(n, dtype=torch.float64)
+        self._pull()
+        self.adam = mo.KerasAdam([(n,)], torch.float64)
+        self.batch = None
+
+    def _pull(self):
+        self.param_view.copy_(torch.cat([torch.tensor(v.value, dtype=torch.float64).reshape(-1) for v in self.tr]))
+
+    def _push(self):
+        o = 0
+        for v in self.tr:
+            v.value = self.param_view[o:o + v.value.size].reshape(v.value.shape).numpy().astype(np.float32)
+            o += v.value.size
+
+    def synchronize(self):
+        pass
+
+    def train_step(self, B, lr, flags):
+        assert flags & 1, "DP must request NO_APPLY"
+        self._push()
+        x, y, w = self.batch
+        _, _, grads, _ = self.om.loss_and_grads(x, y, w)
+        self.grad_view.copy_(torch.cat([grads[v.name].reshape(-1) for v in self.tr]))
+
+    def apply_gradients(self, lr, scale):
+        new = self.adam.apply([self.param_view.clone()], [self.grad_view * scale], lr)
+        self.param_view.copy_(new[0])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    eng = OracleEngine(seed=100 + rank)               # ranks start from DIFFERENT weights
+    dp = DataParallel(eng, eng.grad_view, eng.param_view)
+    dp.broadcast_parameters(0)                        # ... and must agree after the broadcast
+    rng = np.random.default_rng(7)
+    xs = rng.random((2, 4, T, 40)) * 5
+    ys = (rng.random((2, 4)) < 0.5).astype(np.float64)
+    for step in range(2):
+        eng.batch = (xs[rank] + step, ys[rank], np.ones(4))
+        dp.train_step(4, 1e-3)
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), eng.param_view.numpy())
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), eng.grad_view.numpy())
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_allreduce_and_apply(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    np.testing.assert_array_equal(p0, p1)             # identical weights on every rank
+    np.testing.assert_array_equal(np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy"))
+    # single-process restatement: average of the two local gradients, Keras Adam, two steps
+    ref = OracleEngine(seed=100)
+    rng = np.random.default_rng(7)
+    xs = rng.random((2, 4, T, 40)) * 5
+    ys = (rng.random((2, 4)) < 0.5).astype(np.float64)
+    for step in range(2):
+        gs = []
+        for r in range(2):
+            ref.batch = (xs[r] + step, ys[r], np.ones(4))
+            ref.train_step(4, 1e-3, 1)
+            gs.append(ref.grad_view.clone())
+        ref.grad_view.copy_(gs[0] + gs[1])
+        ref.apply_gradients(1e-3, 0.5)
+    np.testing.assert_allclose(p0, ref.param_view.numpy(), rtol=0, atol=1e-12)
+
+
+class _Prov:
+    def __init__(self, n):
+        self.feature_sets = {"training": [(0, i) for i in range(n)]}
+        self.stats = {"training": {"spectrogram_count": n}}
+
+
+class _Handler:
+    def __init__(self):
+        self.feature_providers = [_Prov(10), _Prov(7)]
+        self._sampler = "stale"
+        self.private = None
+
+    def use_private_rng(self):
+        self.private = (random.random(), float(np.random.random()))
+
+
+def test_sharding_partitions_every_provider_and_splits_rng_streams():
+    seen, streams = [set(), set()], []
+    for rank in range(3):
+        h = _Handler()
+        shard_feature_handler(h, rank, 3, seed=5)
+        assert h._sampler is None
+        for i, p in enumerate(h.feature_providers):
+            mine = {s for _, s in p.feature_sets["training"]}
+            assert not (mine & seen[i])
+            seen[i] |= mine
+        streams.append(h.private)
+    assert seen[0] == set(range(10)) and seen[1] == set(range(7))
+    assert len(set(streams)) == 3
+    with pytest.raises(ValueError):
+        h = _Handler()
+        h.feature_providers = [_Prov(2)]
+        shard_feature_handler(h, 2, 3, seed=0)
