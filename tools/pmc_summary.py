@@ -1,0 +1,44 @@
+"""Summarise rocprofv3 CSV output: kernel stats and per-kernel PMC averages.
+usage: python tools/pmc_summary.py <dir-with-*_kernel_stats.csv or *_counter_collection.csv> ..."""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name).replace("void ", "").replace("mww::", "")
+    return name
+
+
+def main():
+    for d in sys.argv[1:]:
+        for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
+            print("## kernel stats", f)
+            for row in csv.DictReader(open(f)):
+                print("%-46s calls=%-5s avg_us=%9.2f total_us=%10.1f pct=%s" % (
+                    short(row["Name"]), row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3, row["Percentage"]))
+        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+            print("## counters", f)
+            acc = collections.defaultdict(lambda: collections.defaultdict(list))
+            dur = collections.defaultdict(list)
+            seen = set()
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                key = (row["Dispatch_Id"])
+                if key not in seen:
+                    seen.add(key)
+                    dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+            names = sorted({c for k in acc for c in acc[k]})
+            for k in sorted(acc, key=lambda k: -sum(dur[k])):
+                if k.startswith("__amd"):
+                    continue
+                vals = " ".join("%s=%.4g" % (c, sum(acc[k][c]) / len(acc[k][c])) for c in names if c in acc[k])
+                print("%-40s n=%-3d us=%8.2f %s" % (k, len(dur[k]), sum(dur[k]) / len(dur[k]), vals))
+
+
+if __name__ == "__main__":
+    main()
