@@ -45,43 +45,61 @@ struct BwdBlockArgs {
   int B, Tin, Tout;
 };
 
-// dp tile: BN_k backward applied while staging rows [t0, t0+TT) of (g_k, p_k) into LDS
+// dp tile: rows [t0, t0+TT) of (p_k, g_k) are fetched into registers early (issue) and turned into
+// dp = BN_k backward of g_k while being written to LDS late (commit).  A sample's rows are
+// contiguous, so float4 i of the tile sits at offset 4*i from the tile start.
 template <int COUT, bool LAST>
-__device__ __forceinline__ void stage_dp_tile(const BwdBlockArgs& a, int b, int t0, float* sDP, const float* sKp, int tid) {
-  constexpr int CPO = pitch(COUT), QO = COUT / 4;
-  const float dzb = LAST ? a.dz[b] : 0.f;
-  for (int i = tid; i < TT * QO; i += kThreads) {
-    const int r = i / QO, q = i - r * QO;
-    const int t = t0 + r;
-    float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < a.Tout) {
-      const size_t off = ((size_t)b * a.Tout + t) * COUT + q * 4;
-      const float4 pk = *reinterpret_cast<const float4*>(a.pk + off);
-      const float4 mean = *reinterpret_cast<const float4*>(sKp + 0 * COUT + q * 4);
-      const float4 rstd = *reinterpret_cast<const float4*>(sKp + 1 * COUT + q * 4);
-      const float4 c1 = *reinterpret_cast<const float4*>(sKp + 2 * COUT + q * 4);
-      const float4 mg = *reinterpret_cast<const float4*>(sKp + 3 * COUT + q * 4);
-      const float4 mgx = *reinterpret_cast<const float4*>(sKp + 4 * COUT + q * 4);
-      float4 g;
-      if (LAST) {
-        const float4 sc = *reinterpret_cast<const float4*>(sKp + 5 * COUT + q * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(sKp + 6 * COUT + q * 4);
-        const float4 w = *reinterpret_cast<const float4*>(a.wd + (size_t)t * COUT + q * 4);
-        g.x = fmaf(pk.x, sc.x, sh.x) > 0.f ? dzb * w.x : 0.f;
-        g.y = fmaf(pk.y, sc.y, sh.y) > 0.f ? dzb * w.y : 0.f;
-        g.z = fmaf(pk.z, sc.z, sh.z) > 0.f ? dzb * w.z : 0.f;
-        g.w = fmaf(pk.w, sc.w, sh.w) > 0.f ? dzb * w.w : 0.f;
-      } else {
-        g = *reinterpret_cast<const float4*>(a.gk + off);
+struct DpStage {
+  static constexpr int QO = COUT / 4, CPO = pitch(COUT), N = (TT * QO + kThreads - 1) / kThreads;
+  float4 pk[N], gg[N];
+
+  __device__ __forceinline__ void issue(const float* pk_base, const float* g_base, int nvalid, int tid) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int i = tid + j * kThreads;
+      pk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gg[j] = pk[j];
+      if (i < nvalid) {
+        pk[j] = reinterpret_cast<const float4*>(pk_base)[i];
+        gg[j] = reinterpret_cast<const float4*>(g_base)[i];
       }
-      dp.x = c1.x * (g.x - mg.x - (pk.x - mean.x) * rstd.x * mgx.x);
-      dp.y = c1.y * (g.y - mg.y - (pk.y - mean.y) * rstd.y * mgx.y);
-      dp.z = c1.z * (g.z - mg.z - (pk.z - mean.z) * rstd.z * mgx.z);
-      dp.w = c1.w * (g.w - mg.w - (pk.w - mean.w) * rstd.w * mgx.w);
     }
-    *reinterpret_cast<float4*>(sDP + r * CPO + q * 4) = dp;
   }
-}
+
+  // g_base rows are g_k (middle blocks) or the dense kernel rows (LAST: g = dz * wd * relu'(bn_k(p_k)))
+  __device__ __forceinline__ void commit(float* sDP, const float* sKp, float dzb, int nvalid, int tid) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < TT * QO) {
+        const int r = i / QO, q = i - r * QO;
+        float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvalid) {
+          const float4 p = pk[j];
+          const float4 mean = *reinterpret_cast<const float4*>(sKp + 0 * COUT + q * 4);
+          const float4 rstd = *reinterpret_cast<const float4*>(sKp + 1 * COUT + q * 4);
+          const float4 c1 = *reinterpret_cast<const float4*>(sKp + 2 * COUT + q * 4);
+          const float4 mg = *reinterpret_cast<const float4*>(sKp + 3 * COUT + q * 4);
+          const float4 mgx = *reinterpret_cast<const float4*>(sKp + 4 * COUT + q * 4);
+          float4 g = gg[j];
+          if (LAST) {
+            const float4 sc = *reinterpret_cast<const float4*>(sKp + 5 * COUT + q * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(sKp + 6 * COUT + q * 4);
+            g.x = fmaf(p.x, sc.x, sh.x) > 0.f ? dzb * g.x : 0.f;
+            g.y = fmaf(p.y, sc.y, sh.y) > 0.f ? dzb * g.y : 0.f;
+            g.z = fmaf(p.z, sc.z, sh.z) > 0.f ? dzb * g.z : 0.f;
+            g.w = fmaf(p.w, sc.w, sh.w) > 0.f ? dzb * g.w : 0.f;
+          }
+          dp.x = c1.x * (g.x - mg.x - (p.x - mean.x) * rstd.x * mgx.x);
+          dp.y = c1.y * (g.y - mg.y - (p.y - mean.y) * rstd.y * mgx.y);
+          dp.z = c1.z * (g.z - mg.z - (p.z - mean.z) * rstd.z * mgx.z);
+          dp.w = c1.w * (g.w - mg.w - (p.w - mean.w) * rstd.w * mgx.w);
+        }
+        *reinterpret_cast<float4*>(sDP + r * CPO + q * 4) = dp;
+      }
+    }
+  }
+};
 
 // carry the last K-1 rows of du to the front of the ring (or clear them at the start of a sample)
 template <int K, int CPI>
@@ -91,9 +109,10 @@ __device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
 
 // MFMA part shared by both backward kernels:
 //   dwacc[mt][nt] += U^T DP over this wave's 16 rows;  du = DP W^T -> sDU rows [K-1+16*wave, ...)
+//   sWt = W_pw^T staged in LDS as [COUT][pitch(CIN)] (B[k=co][n=ci] = W[ci][co])
 template <int CIN, int COUT, int K>
 __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const float* sDP, float* sDU, int wave, int r16,
-                                                        int g, const float (&wtfrag)[COUT / 4][CIN / 16],
+                                                        int g, const float* sWt,
                                                         f32x4 (&dwacc)[CIN / 16][COUT / 16]) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT), MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
 #pragma unroll
@@ -116,7 +135,7 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
   for (int kk = 0; kk < KSO; ++kk) {
     const float av = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, wtfrag[kk][mt], du[mt]);
+    for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, sWt[(kk * 4 + g) * CPI + mt * 16 + r16], du[mt]);
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -157,15 +176,20 @@ __device__ __forceinline__ void write_block_grad_partials(float* scratch, float*
   __syncthreads();
 }
 
-// depthwise backward of one (channel, chunk) for one time tile:
+// depthwise backward of one (channel, chunk) for one time tile, in two steps so that the input
+// gradient can be consumed (masked, stored) before the weight-gradient window is loaded:
 //   da[sl]      = sum_j w[K-1-j] * du_ring[sl + j]                     (sl local input row)
 //   dW_dw[i]   += sum_t du[t] * a[t+i] ;  db += sum_t du[t]            (t local output row)
 // `a_at(row)` returns the activation of local input row `row` for channel c.
+template <int K, int L, int CPI>
+__device__ __forceinline__ void depthwise_input_grad_chunk(const float* sDU, int chunk, int c, const float (&dww)[K],
+                                                           float (&da)[L]) {
+  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, TT + K - 1, c, dww, 0.f, da);
+}
+
 template <int K, int L, int CPI, typename ActFn>
-__device__ __forceinline__ void depthwise_backward_chunk(const float* sDU, int chunk, int c, const float (&dww)[K],
-                                                         float (&accw)[K], float& accb, float (&da)[L], ActFn a_at) {
-  float zero_bias = 0.f;
-  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, TT + K - 1, c, dww, zero_bias, da);
+__device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, int chunk, int c, float (&accw)[K],
+                                                            float& accb, ActFn a_at) {
   float win[L + K - 1];
 #pragma unroll
   for (int j = 0; j < L + K - 1; ++j) win[j] = a_at(chunk * L + j);
@@ -194,6 +218,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
 
   __shared__ __attribute__((aligned(16))) float smem[OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
+  __shared__ __attribute__((aligned(16))) float sDW[K * CIN];      // depthwise taps
   float* sP = smem + OFF_P;
   float* sDP = smem + OFF_DP;
   float* sU = smem + OFF_U;
@@ -212,20 +238,16 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     sKp[5 * COUT + i] = LAST ? a.k_scale[i] : 0.f;
     sKp[6 * COUT + i] = LAST ? a.k_shift[i] : 0.f;
   }
-  // W_pw^T fragments: B[k=co][n=ci] = W[ci][co]
-  float wtfrag[KSO][MT];
-#pragma unroll
-  for (int kk = 0; kk < KSO; ++kk)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wtfrag[kk][mt] = a.pw_w[(mt * 16 + r16) * COUT + kk * 4 + g];
-  float dww[K], accw[K];
+  for (int i = tid; i < CIN * COUT; i += kThreads) {
+    const int ci = i / COUT, co = i - ci * COUT;
+    sWt[co * CPI + ci] = a.pw_w[i];
+  }
+  for (int i = tid; i < K * CIN; i += kThreads) sDW[i] = a.dw_w[i];
+  float accw[K];
   float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
   float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
 #pragma unroll
-  for (int i = 0; i < K; ++i) {
-    dww[i] = dw_active ? a.dw_w[i * CIN + c] : 0.f;
-    accw[i] = 0.f;
-  }
+  for (int i = 0; i < K; ++i) accw[i] = 0.f;
   if (dw_active) {
     dwb = a.dw_b[c];
     sc_c = a.in_scale[c];
@@ -240,40 +262,71 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
   __syncthreads();
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    for (int t0 = 0; t0 < a.Tin; t0 += TT) {
-      const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
-      const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
-      // ---- P0: stage raw p_{k-1} rows [t0, t0+RA), dp rows [t0, t0+TT); roll the du ring
-      for (int i = tid; i < RA * QI; i += kThreads) {
-        const int r = i / QI, q = i - r * QI;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + r < a.Tin) v = *reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0 + r) * CIN + q * 4);
-        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = v;
-      }
-      stage_dp_tile<COUT, LAST>(a, b, t0, sDP, sKp, tid);
-      carry_du<K, CPI>(sDU, t0 == 0, tid);
-      __syncthreads();
-      // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
-      if (dw_active) {
-        float o[L];
-        dw_chunk<K, L, false, true>(sP, CPI, chunk * L, RA, c, dww, dwb, o, sc_c, sh_c);
+  // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
+  // current one is computed
+  const int ntiles = (a.Tin + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  constexpr int NP = (RA * QI + kThreads - 1) / kThreads;
+  float4 pre_p[NP];
+  DpStage<COUT, LAST> dps;
+  float pre_dz = 0.f;
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvp = min(RA, a.Tin - t0) * QI;
+    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
 #pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
-        }
+    for (int j = 0; j < NP; ++j) {
+      const int i = tid + j * kThreads;
+      pre_p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvp) pre_p[j] = src[i];
+    }
+    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
+    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
+    dps.issue(a.pk + koff, LAST ? a.wd + (size_t)t0 * COUT : a.gk + koff, nvk, tid);
+    if (LAST) pre_dz = a.dz[b];
+  };
+  if (nitems > 0) issue(0);
+  for (int it = 0; it < nitems; ++it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
+    const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
+    // ---- P0: commit raw p_{k-1} rows [t0, t0+RA) (zero past the sample), dp rows; roll the du ring
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < RA * QI) {
+        const int r = i / QI, q = i - r * QI;
+        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = pre_p[j];
       }
-      __syncthreads();
-      // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-      pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, wtfrag, dwacc);
-      __syncthreads();
-      // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
-      if (dw_active) {
-        float da[L];
-        depthwise_backward_chunk<K, L, CPI>(sDU, chunk, c, dww, accw, accb, da, [&](int row) {
-          return row < RA ? fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f) : 0.f;
-        });
+    }
+    dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
+    carry_du<K, CPI>(sDU, t0 == 0, tid);
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
+    if (dw_active) {
+      float o[L], dww[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
+      dw_chunk<K, L, false, true>(sP, CPI, chunk * L, RA, c, dww, dwb, o, sc_c, sh_c);
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int tl = chunk * L + t;
+        if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
+    pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    __syncthreads();
+    // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
+    if (dw_active) {
+      {
+        float da[L], dww[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
+        depthwise_input_grad_chunk<K, L, CPI>(sDU, chunk, c, dww, da);
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int sl = chunk * L + t;
@@ -286,8 +339,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           }
         }
       }
-      __syncthreads();
+      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) {
+        return row < RA ? fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f) : 0.f;
+      });
     }
+    __syncthreads();
   }
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
   write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
@@ -341,12 +397,15 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
   constexpr int OFF_A = 0, OFF_DP = OFF_A + RA * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TT * CPI;
   constexpr int OFF_G0 = OFF_DU + RA * CPI, OFF_END = OFF_G0 + TT * CPI;
+  constexpr int PX = FBINS + 1;                  // odd pitch of the staged x rows (see fwd_first_kernel)
+  constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
   static_assert(4 % NT1 == 0 && TT >= K - 1, "shape");
 
-  __shared__ __attribute__((aligned(16))) float sX[XR * FBINS];
+  __shared__ __attribute__((aligned(16))) float sX[XR * PX];
   __shared__ __attribute__((aligned(16))) float smem[OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
   float* sA = smem + OFF_A;
   float* sDP = smem + OFF_DP;
   float* sU = smem + OFF_U;
@@ -371,11 +430,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   float w1frag[KS1];
 #pragma unroll
   for (int kk = 0; kk < KS1; ++kk) w1frag[kk] = a.w1[(kk * 4 + g) * C1 + nt1 * 16 + r16];
-  float wtfrag[KSO][MT];
-#pragma unroll
-  for (int kk = 0; kk < KSO; ++kk)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wtfrag[kk][mt] = a.pw_w[(mt * 16 + r16) * COUT + kk * 4 + g];
+  for (int i = tid; i < CIN * COUT; i += kThreads) {
+    const int ci = i / COUT, co = i - ci * COUT;
+    sWt[co * CPI + ci] = a.pw_w[i];
+  }
   float dww[K], accw[K];
   float accb = 0.f, dwb = 0.f;
 #pragma unroll
@@ -396,88 +454,109 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = zero4();
   __syncthreads();
 
-  // the BwdBlockArgs view used by the shared dp staging helper
-  BwdBlockArgs ba;
-  ba.pk = a.pk;
-  ba.gk = a.gk;
-  ba.Tout = a.Tout;
-  ba.dz = nullptr;
-  ba.wd = nullptr;
-
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    for (int t0 = 0; t0 < Ta; t0 += TT) {
-      const int nrows_new = max(0, min(TT, a.Tout - t0));
-      const int rows_da = min(TT, Ta - t0);
-      const int rows_a = min(RA, Ta - t0);          // a0 rows that exist in this tile
-      const int rows_x = rows_a + K1 - 1;
-      // ---- P0: stage x, dp; roll the du ring
+  const int ntiles = (Ta + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  float4 pre_x[NLDX];
+  DpStage<COUT, false> dps;
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvx = (min(RA, Ta - t0) + K1 - 1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+#pragma unroll
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      pre_x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvx) pre_x[j] = src[i];
+    }
+    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
+    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
+    dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
+  };
+  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s+j][f]
+  int offm[MPW];
+  bool okm[MPW];
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi) {
+    const int m = (wave * MPW + mi) * 16 + r16;
+    okm[mi] = m < M1;
+    offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
+  }
+  if (nitems > 0) issue(0);
+  for (int it = 0; it < nitems; ++it) {
+    const int t0 = (it % ntiles) * TT;
+    const int nrows_new = max(0, min(TT, a.Tout - t0));
+    const int rows_da = min(TT, Ta - t0);
+    const int rows_a = min(RA, Ta - t0);          // a0 rows that exist in this tile
+    // ---- P0: commit x (odd pitch), dp; roll the du ring
+#pragma unroll
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < XR * FBINS / 4) {
+        const int r = i / (FBINS / 4), f0 = (i - r * (FBINS / 4)) * 4;
+        float* d = sX + r * PX + f0;
+        d[0] = pre_x[j].x; d[1] = pre_x[j].y; d[2] = pre_x[j].z; d[3] = pre_x[j].w;
+      }
+    }
+    dps.commit(sDP, sKp, 0.f, nrows_new * (COUT / 4), tid);
+    carry_du<K, CPI>(sDU, t0 == 0, tid);
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    // ---- recompute a0 = relu(conv1(x)) for local rows [0, RA)
+    for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
+      f32x4 acc = zero4();
+      const float* xr = sX + (rt * 16 + r16) * PX + g;
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + g * 4 + r;
+        if (row < RA) sA[row * CPI + nt1 * 16 + r16] = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- P1: u = depthwise(a0) + bias
+    if (dw_active) {
+      float o[L];
+      dw_chunk<K, L>(sA, CPI, chunk * L, RA, c, dww, dwb, o);
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int tl = chunk * L + t;
+        if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    __syncthreads();
+    // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
+    if (dw_active) {
       {
-        const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
-        float4* dst = reinterpret_cast<float4*>(sX);
-        const int nvalid = rows_x * FBINS / 4;
-        for (int i = tid; i < XR * FBINS / 4; i += kThreads) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i < nvalid) v = src[i];
-          dst[i] = v;
-        }
-      }
-      stage_dp_tile<COUT, false>(ba, b, t0, sDP, sKp, tid);
-      carry_du<K, CPI>(sDU, t0 == 0, tid);
-      __syncthreads();
-      // ---- recompute a0 = relu(conv1(x)) for local rows [0, RA)
-      for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
-        f32x4 acc = zero4();
-#pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) acc = mfma4(sX[(rt * 16 + r16) * FBINS + kk * 4 + g], w1frag[kk], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + g * 4 + r;
-          if (row < RA) sA[row * CPI + nt1 * 16 + r16] = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
-        }
-      }
-      __syncthreads();
-      // ---- P1: u = depthwise(a0) + bias
-      if (dw_active) {
-        float o[L];
-        dw_chunk<K, L>(sA, CPI, chunk * L, RA, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
-        }
-      }
-      __syncthreads();
-      pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, wtfrag, dwacc);
-      __syncthreads();
-      // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
-      if (dw_active) {
         float da[L];
-        depthwise_backward_chunk<K, L, CPI>(sDU, chunk, c, dww, accw, accb, da,
-                                            [&](int row) { return row < RA ? sA[row * CPI + c] : 0.f; });
+        depthwise_input_grad_chunk<K, L, CPI>(sDU, chunk, c, dww, da);
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int sl = chunk * L + t;
           if (sl < TT) sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
         }
       }
-      __syncthreads();
-      // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = sX[s*40 + m], B[k=s][n] = sG0[s][n]
-#pragma unroll
-      for (int kk = 0; kk < TT / 4; ++kk) {
-        const int s = kk * 4 + g;
-        float bv[NT1];
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) bv[nt] = sG0[s * CPI + nt * 16 + r16];
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) {
-          const int m = (wave * MPW + mi) * 16 + r16;
-          const float av = (m < M1) ? sX[s * FBINS + m] : 0.f;
-#pragma unroll
-          for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av, bv[nt], w1acc[mi][nt]);
-        }
-      }
-      __syncthreads();
+      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return row < RA ? sA[row * CPI + c] : 0.f; });
     }
+    __syncthreads();
+    // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s + m/40][m%40], B[k=s][n] = g0[s][n]
+#pragma unroll
+    for (int kk = 0; kk < TT / 4; ++kk) {
+      const int s = kk * 4 + g;
+      float bv[NT1];
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) bv[nt] = sG0[s * CPI + nt * 16 + r16];
+#pragma unroll
+      for (int mi = 0; mi < MPW; ++mi) {
+        const float av = okm[mi] ? sX[s * PX + offm[mi]] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av, bv[nt], w1acc[mi][nt]);
+      }
+    }
+    __syncthreads();
   }
   float* gdst = a.grad_part + (size_t)blockIdx.x * (M1 * C1 + (K + 1) * CIN + CIN * COUT);
 #pragma unroll
@@ -534,7 +613,7 @@ struct GradSegment {
   int dst;             // offset in the flat gradient
 };
 constexpr int kMaxSegments = 16;
-constexpr int kGradSplit = 8;    // second-level split of the partial index
+constexpr int kGradSplit = 32;   // second-level split of the partial index
 struct GradReduceArgs {
   GradSegment seg[kMaxSegments];
   int nseg;
@@ -550,16 +629,16 @@ __global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a)
   const int js = blockIdx.z;
   const int per = (s.G + kGradSplit - 1) / kGradSplit;
   const int j0 = js * per, j1 = min(s.G, j0 + per);
-  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int j = j0;
-  for (; j + 3 < j1; j += 4) {
-    v0 += s.part[(size_t)(j + 0) * s.stride + e];
-    v1 += s.part[(size_t)(j + 1) * s.stride + e];
-    v2 += s.part[(size_t)(j + 2) * s.stride + e];
-    v3 += s.part[(size_t)(j + 3) * s.stride + e];
+  // issue every load of a 16-partial group before the first add: one memory round trip per group
+  float acc = 0.f;
+  for (int jb = j0; jb < j1; jb += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (jb + u < j1) ? s.part[(size_t)(jb + u) * s.stride + e] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
   }
-  for (; j < j1; ++j) v0 += s.part[(size_t)j * s.stride + e];
-  a.stage[(size_t)js * a.P + s.dst + e] = (v0 + v1) + (v2 + v3);
+  a.stage[(size_t)js * a.P + s.dst + e] = acc;
 }
 
 // flat gradient = mask * sum of the staged slices (BN gamma/beta slots are written by
@@ -580,9 +659,12 @@ __global__ __launch_bounds__(kThreads) void grad_finish_kernel(GradFinishArgs a)
   if (a.direct[p]) {
     v = a.grad[p];
   } else {
+    float t[kGradSplit];
+#pragma unroll
+    for (int j = 0; j < kGradSplit; ++j) t[j] = a.stage[(size_t)j * a.P + p];
     v = 0.f;
 #pragma unroll
-    for (int j = 0; j < kGradSplit; ++j) v += a.stage[(size_t)j * a.P + p];
+    for (int j = 0; j < kGradSplit; ++j) v += t[j];
   }
   a.grad[p] = v * a.mask[p] * a.scale;
 }

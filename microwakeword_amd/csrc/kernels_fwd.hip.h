@@ -127,10 +127,12 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
   constexpr int NT1 = C1 / 16;
   constexpr int KS = C1 / 4, NT = COUT / 16;
   constexpr int NCH = nchunks(C1), L = chunk_len(C1);
+  constexpr int PX = FBINS + 1;                // odd LDS pitch of the staged x rows: conflict-free MFMA operand reads
+  constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(4 % NT1 == 0, "first-conv filters must be 16, 32 or 64");
   static_assert((K1 * FBINS) % 4 == 0 && C1 % 16 == 0 && COUT % 16 == 0, "shape");
 
-  __shared__ __attribute__((aligned(16))) float sX[XR * FBINS];
+  __shared__ __attribute__((aligned(16))) float sX[XR * PX];
   __shared__ __attribute__((aligned(16))) float sA[RA * CP1];
   __shared__ __attribute__((aligned(16))) float sU[TT * CP1];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
@@ -163,57 +165,76 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    for (int t0 = 0; t0 < a.Tout; t0 += TT) {
-      const int rows_out = min(TT, a.Tout - t0);
-      const int rows_a = rows_out + K - 1;
-      const int rows_x = rows_a + K1 - 1;
-      // stage x rows [t0, t0+rows_x) (contiguous in HBM), zero fill the rest
-      const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
-      float4* dst = reinterpret_cast<float4*>(sX);
-      const int nvalid = rows_x * FBINS / 4;
-      for (int i = tid; i < XR * FBINS / 4; i += kThreads) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nvalid) v = src[i];
-        dst[i] = v;
-      }
-      __syncthreads();
-      // first conv as im2col GEMM: A[row][k] = sX[row*40 + k], k = j*40 + f
-      for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
-        f32x4 acc = zero4();
+  // work items = (sample, time tile); the next item's rows are fetched into registers while the
+  // current one is computed (global->register early, register->LDS late)
+  const int ntiles = (a.Tout + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  float4 pre[NLDX];
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvalid = (min(TT, a.Tout - t0) + K - 1 + K1 - 1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
 #pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) acc = mfma4(sX[(rt * 16 + r16) * FBINS + kk * 4 + g], w1frag[kk], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + g * 4 + r;
-          if (row < RA) sA[row * CP1 + nt1 * 16 + r16] = fmaxf(acc[r], 0.f);
-        }
-      }
-      __syncthreads();
-      // depthwise
-      if (dw_active) {
-        float o[L];
-        dw_chunk<K, L>(sA, CP1, chunk * L, rows_a, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          if (tl < TT) sU[tl * CP1 + c] = (tl < rows_out) ? o[t] : 0.f;
-        }
-      }
-      __syncthreads();
-      // pointwise
-      f32x4 acc[NT];
-      pw_rowtile<KS, NT>(sU, CP1, wave * 16, r16, g, bfrag, acc);
-      store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
-      __syncthreads();
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvalid) pre[j] = src[i];
     }
+  };
+  if (nitems > 0) issue(0);
+  for (int it = 0; it < nitems; ++it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int rows_out = min(TT, a.Tout - t0);
+    const int rows_a = rows_out + K - 1;
+    // commit the staged x rows (zero filled past the valid ones) with an odd row pitch
+#pragma unroll
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < XR * FBINS / 4) {
+        const int r = i / (FBINS / 4), f0 = (i - r * (FBINS / 4)) * 4;
+        float* d = sX + r * PX + f0;
+        d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
+      }
+    }
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    // first conv as im2col GEMM: A[row][k] = x[row + k/40][k%40]
+    for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
+      f32x4 acc = zero4();
+      const float* xr = sX + (rt * 16 + r16) * PX + g;
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + g * 4 + r;
+        if (row < RA) sA[row * CP1 + nt1 * 16 + r16] = fmaxf(acc[r], 0.f);
+      }
+    }
+    __syncthreads();
+    // depthwise
+    if (dw_active) {
+      float o[L];
+      dw_chunk<K, L>(sA, CP1, chunk * L, rows_a, c, dww, dwb, o);
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int tl = chunk * L + t;
+        if (tl < TT) sU[tl * CP1 + c] = (tl < rows_out) ? o[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    // pointwise
+    f32x4 acc[NT];
+    pw_rowtile<KS, NT>(sU, CP1, wave * 16, r16, g, bfrag, acc);
+    store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
+    __syncthreads();
   }
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
 }
 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K>
-__global__ __launch_bounds__(kThreads, 4) void fwd_block_kernel(FwdBlockArgs a) {
+__global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int CPI = pitch(CIN);
   constexpr int RA = TT + K - 1;
   constexpr int KS = CIN / 4, NT = COUT / 16;
@@ -255,14 +276,34 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_block_kernel(FwdBlockArgs a) 
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
   __syncthreads();
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    for (int t0 = 0; t0 < a.Tout; t0 += TT) {
-      const int rows_out = min(TT, a.Tout - t0);
-      const int rows_in = rows_out + K - 1;
-      const float* src = a.in + ((size_t)b * a.Tin + t0) * CIN;
-      for (int i = tid; i < rows_in * Q; i += kThreads) {
+  const int ntiles = (a.Tout + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  constexpr int NLD = (RA * Q + kThreads - 1) / kThreads;
+  float4 pre[NLD];
+  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at offset 4*i
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
+    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + j * kThreads;
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvalid) pre[j] = src[i];
+    }
+  };
+  if (nitems > 0) issue(0);
+  for (int it = 0; it < nitems; ++it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int rows_out = min(TT, a.Tout - t0);
+    const int rows_in = rows_out + K - 1;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < rows_in * Q) {
         const int r = i / Q, q = i - r * Q;
-        float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * CIN + q * 4);
+        float4 v = pre[j];
         const float4 sc = *reinterpret_cast<const float4*>(sScale + q * 4);
         const float4 sh = *reinterpret_cast<const float4*>(sShift + q * 4);
         v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
@@ -271,22 +312,23 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_block_kernel(FwdBlockArgs a) 
         v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
         *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = v;
       }
-      __syncthreads();
-      if (dw_active) {
-        float o[L];
-        dw_chunk<K, L>(sA, CPI, chunk * L, rows_in, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          if (tl < TT) sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
-        }
-      }
-      __syncthreads();
-      f32x4 acc[NT];
-      pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
-      store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
-      __syncthreads();
     }
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    if (dw_active) {
+      float o[L];
+      dw_chunk<K, L>(sA, CPI, chunk * L, rows_in, c, dww, dwb, o);
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int tl = chunk * L + t;
+        if (tl < TT) sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    f32x4 acc[NT];
+    pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
+    store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
+    __syncthreads();
   }
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
 }
@@ -312,14 +354,19 @@ struct BnFwdFinalizeArgs {
 // sum of part[j][stat][c] over j for stat = tid>>7, returned to threads 0 (stat 0) and 128 (stat 1)
 __device__ __forceinline__ double reduce_partials_256(const float* part, int G, int C, int c, double* sAcc, int tid) {
   const int stat = tid >> 7, jp = tid & 127;
-  double a0 = 0.0, a1 = 0.0;
-  int j = jp;
-  for (; j + 128 < G; j += 256) {
-    a0 += (double)part[(size_t)j * 2 * C + stat * C + c];
-    a1 += (double)part[(size_t)(j + 128) * 2 * C + stat * C + c];
+  // all loads of a thread are issued before the first use (one memory round trip for G <= 1024)
+  double total = 0.0;
+  for (int j0 = jp; j0 < G; j0 += 128 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + 128 * u;
+      v[u] = (j < G) ? part[(size_t)j * 2 * C + stat * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) total += (double)v[u];
   }
-  if (j < G) a0 += (double)part[(size_t)j * 2 * C + stat * C + c];
-  sAcc[tid] = a0 + a1;
+  sAcc[tid] = total;
   __syncthreads();
   if (jp < 8) {
     double v = 0.0;

@@ -4,8 +4,7 @@
 //   head_kernel       : one workgroup per window.  p_L -> BN_L + ReLU -> Flatten -> Dense(1) -> sigmoid,
 //                       Keras BCE (probabilities clipped to [1e-7, 1-1e-7]) times the per-sample
 //                       weight, dL/dz, the (sum g, sum g*xhat) partials of BN_L's backward (g rebuilt
-//                       from the per-sample scalar dL/dz) and the metric histograms of
-//                       train.py:209-221.  The window's 7104 activations stay in registers between
+//                       from the per-sample scalar dL/dz).  The window's 7104 activations stay in registers between
 //                       the dot product and the backward partials: p_L is read from HBM once.
 //   dense_grad_kernel : dW_dense[t,c] = sum_b dL/dz_b * relu(bn(p_L[b,t,c])) as a batch-chunked
 //                       reduction (fixed order) + the dense bias gradient.
@@ -36,7 +35,6 @@ struct HeadArgs {
   float* dz;               // [B] dL/dz (training)
   float* loss_part;        // [B] weighted loss / B per sample (training)
   float* gstat_part;       // [gridDim.x][2][C]   sum g, sum g*xhat of the BN_L input gradient
-  MetricState* metrics;    // may be null
   int B, T;
   float inv_b;
   int training;
@@ -107,24 +105,6 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
           dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
           a.dz[b] = dzz;
         }
-        if (a.metrics != nullptr) {
-          MetricState* m = a.metrics;
-          const int lab = yy > 0.5f ? 1 : 0;
-          const float p01 = fminf(fmaxf(pr, 0.f), 1.f);
-          const int b101 = (int)ceilf(p01 * 100.0f) - 1;                 // Keras evenly-spaced bucketing
-          int b200 = (int)ceilf(p01 * 199.0f) - 1;
-          if (b200 < 0) b200 = 0;                                         // AUC thresholds carry epsilon ends
-          if (b101 >= 0) atomicAdd(&m->hist101[lab][b101], 1ull);
-          atomicAdd(&m->hist200[lab][b200], 1ull);
-          const bool ppos = pr > 0.5f;
-          atomicAdd(&m->n, 1ull);
-          if (ppos == (lab == 1)) atomicAdd(&m->correct, 1ull);
-          if (ppos && lab) atomicAdd(&m->tp5, 1ull);
-          if (ppos && !lab) atomicAdd(&m->fp5, 1ull);
-          if (!ppos && lab) atomicAdd(&m->fn5, 1ull);
-          atomicAdd(lab ? &m->pos : &m->neg, 1ull);
-          atomicAdd(&m->bce_sum, (double)bce);
-        }
       }
       sBcast[0] = dzz;
     }
@@ -161,6 +141,63 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   }
 }
 
+// Metric update of train.py:209-221 as one workgroup: LDS histograms of the Keras threshold buckets
+// (evenly spaced thresholds => bucket = ceil(p*(n-1)) - 1), then one global add per non-empty bin.
+struct MetricsArgs {
+  const float* prob;   // [B]
+  const float* y;      // [B]
+  MetricState* m;
+  int B;
+};
+
+__global__ __launch_bounds__(1024) void metrics_kernel(MetricsArgs a) {
+  __shared__ unsigned sH101[2][101];
+  __shared__ unsigned sH200[2][200];
+  __shared__ unsigned sCnt[8];       // n, correct, tp5, fp5, fn5, pos, neg
+  __shared__ double sBce[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 202; i += 1024) (&sH101[0][0])[i] = 0u;
+  for (int i = tid; i < 400; i += 1024) (&sH200[0][0])[i] = 0u;
+  if (tid < 8) sCnt[tid] = 0u;
+  __syncthreads();
+  double bce = 0.0;
+  for (int b = tid; b < a.B; b += 1024) {
+    const float pr = a.prob[b], yy = a.y[b];
+    const int lab = yy > 0.5f ? 1 : 0;
+    const float p01 = fminf(fmaxf(pr, 0.f), 1.f);
+    const int b101 = (int)ceilf(p01 * 100.0f) - 1;
+    int b200 = (int)ceilf(p01 * 199.0f) - 1;
+    if (b200 < 0) b200 = 0;                       // AUC thresholds carry epsilon ends
+    if (b101 >= 0) atomicAdd(&sH101[lab][b101], 1u);
+    atomicAdd(&sH200[lab][b200], 1u);
+    const bool ppos = pr > 0.5f;
+    atomicAdd(&sCnt[0], 1u);
+    if (ppos == (lab == 1)) atomicAdd(&sCnt[1], 1u);
+    if (ppos && lab) atomicAdd(&sCnt[2], 1u);
+    if (ppos && !lab) atomicAdd(&sCnt[3], 1u);
+    if (!ppos && lab) atomicAdd(&sCnt[4], 1u);
+    atomicAdd(&sCnt[lab ? 5 : 6], 1u);
+    const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
+    bce += (double)(-(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc)));
+  }
+  sBce[tid] = bce;
+  __syncthreads();
+  for (int i = tid; i < 202; i += 1024) {
+    const unsigned v = (&sH101[0][0])[i];
+    if (v) atomicAdd(&a.m->hist101[0][0] + i, (unsigned long long)v);
+  }
+  for (int i = tid; i < 400; i += 1024) {
+    const unsigned v = (&sH200[0][0])[i];
+    if (v) atomicAdd(&a.m->hist200[0][0] + i, (unsigned long long)v);
+  }
+  if (tid < 7 && sCnt[tid]) atomicAdd(&a.m->n + tid, (unsigned long long)sCnt[tid]);
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 1024; ++i) s += sBce[i];
+    a.m->bce_sum += s;   // single workgroup, single writer
+  }
+}
+
 // grid = (ceil(T*C / 256), n_chunks): thread e owns dense weight e and sums one chunk of the batch.
 struct DenseGradArgs {
   const float* p;       // p_L [B][T*C]
@@ -177,15 +214,19 @@ __global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
   if (e < a.n) {
     const int c = e % a.C;
     const float sc = a.scale[c], sh = a.shift[c];
-    float acc0 = 0.f, acc1 = 0.f;
-    int b = b0;
-    for (; b + 1 < b1; b += 2) {
-      const float v0 = a.p[(size_t)b * a.n + e], v1 = a.p[(size_t)(b + 1) * a.n + e];
-      acc0 = fmaf(a.dz[b], fmaxf(fmaf(v0, sc, sh), 0.f), acc0);
-      acc1 = fmaf(a.dz[b + 1], fmaxf(fmaf(v1, sc, sh), 0.f), acc1);
+    float acc = 0.f;
+    for (int bb = b0; bb < b1; bb += 8) {
+      float v[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = bb + u < b1;
+        v[u] = ok ? a.p[(size_t)(bb + u) * a.n + e] : 0.f;
+        d[u] = ok ? a.dz[bb + u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh), 0.f), acc);
     }
-    if (b < b1) acc0 = fmaf(a.dz[b], fmaxf(fmaf(a.p[(size_t)b * a.n + e], sc, sh), 0.f), acc0);
-    a.part[(size_t)blockIdx.y * a.stride + e] = acc0 + acc1;
+    a.part[(size_t)blockIdx.y * a.stride + e] = acc;
   } else if (e == a.n) {
     float s = 0.f;
     for (int b = b0; b < b1; ++b) s += a.dz[b];

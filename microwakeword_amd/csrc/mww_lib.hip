@@ -263,7 +263,6 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.dz = c->dz;
   h.loss_part = c->loss_part;
   h.gstat_part = ll.gstat_part;
-  h.metrics = metrics ? c->metrics : nullptr;
   h.B = B;
   h.T = ll.tout;
   h.inv_b = 1.0f / (float)B;
@@ -272,7 +271,14 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   lp.begin("head");
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
   lp.end();
-  return rc;
+  if (rc) return rc;
+  if (metrics) {
+    MetricsArgs ma{c->prob, c->y, c->metrics, B};
+    lp.begin("metrics");
+    hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, c->stream, ma);
+    lp.end();
+  }
+  return MWW_OK;
 }
 
 int enqueue_backward(mww_ctx* c, int B) {
