@@ -40,6 +40,15 @@ __host__ __device__ constexpr int pitch(int c) { return c + 4; }
 // number of time chunks / chunk length of the (channel, chunk) VALU mapping
 __host__ __device__ constexpr int nchunks(int c) { return kThreads / c; }
 __host__ __device__ constexpr int chunk_len(int c) { return (TT + nchunks(c) - 1) / nchunks(c); }
+// rows the (channel, chunk) mapping may touch: tile rows rounded up to whole chunks (+ halo).  LDS
+// tiles are allocated with this many rows and kept zero past the valid ones, so the register
+// windows are loaded without per-element bounds checks (those compile to exec-mask branches).
+__host__ __device__ constexpr int tile_rows_padded(int c) { return nchunks(c) * chunk_len(c); }
+__host__ __device__ constexpr int halo_rows_padded(int c, int k) { return tile_rows_padded(c) + k - 1; }
+
+// keep a value (and the loads that produce it) from sinking below this point: used to retire the
+// prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
 // sum over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48)
 __device__ __forceinline__ float sum_over_groups(float v) {

@@ -184,7 +184,7 @@ __device__ __forceinline__ void write_block_grad_partials(float* scratch, float*
 template <int K, int L, int CPI>
 __device__ __forceinline__ void depthwise_input_grad_chunk(const float* sDU, int chunk, int c, const float (&dww)[K],
                                                            float (&da)[L]) {
-  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, TT + K - 1, c, dww, 0.f, da);
+  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, c, dww, 0.f, da);
 }
 
 template <int K, int L, int CPI, typename ActFn>
@@ -196,7 +196,7 @@ __device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, in
 #pragma unroll
   for (int t = 0; t < L; ++t) {
     const int tl = chunk * L + t;
-    const float du = (tl < TT) ? sDU[(K - 1 + tl) * CPI + c] : 0.f;
+    const float du = sDU[(K - 1 + tl) * CPI + c];   // ring rows past the tile are allocated and zero
     accb += du;
 #pragma unroll
     for (int i = 0; i < K; ++i) accw[i] = fmaf(du, win[t + i], accw[i]);
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
   constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
   constexpr int QI = CIN / 4;
-  constexpr int OFF_P = 0, OFF_DP = OFF_P + RA * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TT * CPI;
-  constexpr int OFF_END = OFF_DU + RA * CPI;
+  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
+  constexpr int OFF_P = 0, OFF_DP = OFF_P + RAP * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TTP * CPI;
+  constexpr int OFF_END = OFF_DU + RAP * CPI;
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN && OFF_END >= NCH * 2 * CIN, "scratch aliasing");
   static_assert(TT >= K - 1, "carry rows must not overlap");
 
@@ -243,6 +244,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     sWt[co * CPI + ci] = a.pw_w[i];
   }
   for (int i = tid; i < K * CIN; i += kThreads) sDW[i] = a.dw_w[i];
+  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {   // rows only the padded windows touch
+    sP[i] = 0.f;
+    sDU[i] = 0.f;
+  }
   float accw[K];
   float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
   float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
+  pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
   // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
@@ -309,11 +315,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       float o[L], dww[K];
 #pragma unroll
       for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-      dw_chunk<K, L, false, true>(sP, CPI, chunk * L, RA, c, dww, dwb, o, sc_c, sh_c);
+      dw_chunk<K, L, false, true>(sP, CPI, chunk * L, c, dww, dwb, o, sc_c, sh_c);
 #pragma unroll
       for (int t = 0; t < L; ++t) {
         const int tl = chunk * L + t;
-        if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
       }
     }
     __syncthreads();
@@ -339,9 +345,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           }
         }
       }
-      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) {
-        return row < RA ? fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f) : 0.f;
-      });
+      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb,
+                                             [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
     }
     __syncthreads();
   }
@@ -395,8 +400,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   constexpr int MPW = (MT1 + 3) / 4;             // m-tiles per wave
   constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
   constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
-  constexpr int OFF_A = 0, OFF_DP = OFF_A + RA * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TT * CPI;
-  constexpr int OFF_G0 = OFF_DU + RA * CPI, OFF_END = OFF_G0 + TT * CPI;
+  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
+  constexpr int OFF_A = 0, OFF_DP = OFF_A + RAP * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TTP * CPI;
+  constexpr int OFF_G0 = OFF_DU + RAP * CPI, OFF_END = OFF_G0 + TTP * CPI;
   constexpr int PX = FBINS + 1;                  // odd pitch of the staged x rows (see fwd_first_kernel)
   constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
@@ -434,6 +440,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     const int ci = i / COUT, co = i - ci * COUT;
     sWt[co * CPI + ci] = a.pw_w[i];
   }
+  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {
+    sA[i] = 0.f;
+    sDU[i] = 0.f;
+  }
   float dww[K], accw[K];
   float accb = 0.f, dwb = 0.f;
 #pragma unroll
@@ -442,6 +452,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     accw[i] = 0.f;
   }
   if (dw_active) dwb = a.dw_b[c];
+#pragma unroll
+  for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
+#pragma unroll
+  for (int i = 0; i < K; ++i) pin(dww[i]);
+  pin(dwb);
   f32x4 dwacc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -518,11 +533,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     // ---- P1: u = depthwise(a0) + bias
     if (dw_active) {
       float o[L];
-      dw_chunk<K, L>(sA, CPI, chunk * L, RA, c, dww, dwb, o);
+      dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
       for (int t = 0; t < L; ++t) {
         const int tl = chunk * L + t;
-        if (tl < TT) sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
       }
     }
     __syncthreads();
@@ -536,10 +551,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int sl = chunk * L + t;
-          if (sl < TT) sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
+          sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
         }
       }
-      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return row < RA ? sA[row * CPI + c] : 0.f; });
+      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return sA[row * CPI + c]; });
     }
     __syncthreads();
     // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s + m/40][m%40], B[k=s][n] = g0[s][n]

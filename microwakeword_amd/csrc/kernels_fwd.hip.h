@@ -42,15 +42,13 @@ struct FwdBlockArgs {
 //   REV : use the taps reversed (w[K-1-i]) — the transposed (input-gradient) depthwise
 //   ACT : apply y = relu(src*sc + sh) while loading (LDS holds the raw pre-BN tensor)
 template <int K, int L, bool REV = false, bool ACT = false>
-__device__ __forceinline__ void dw_chunk(const float* src, int src_pitch, int row0, int row_limit, int c,
-                                         const float (&w)[K], float bias, float (&out)[L], float sc = 1.f,
-                                         float sh = 0.f) {
+__device__ __forceinline__ void dw_chunk(const float* src, int src_pitch, int row0, int c, const float (&w)[K],
+                                         float bias, float (&out)[L], float sc = 1.f, float sh = 0.f) {
   float win[L + K - 1];
 #pragma unroll
   for (int j = 0; j < L + K - 1; ++j) {
-    const int r = row0 + j;
-    float v = (r < row_limit) ? src[r * src_pitch + c] : 0.f;
-    if (ACT) v = (r < row_limit) ? fmaxf(fmaf(v, sc, sh), 0.f) : 0.f;
+    float v = src[(row0 + j) * src_pitch + c];   // rows past the valid ones are allocated and zero
+    if (ACT) v = fmaxf(fmaf(v, sc, sh), 0.f);
     win[j] = v;
   }
 #pragma unroll
@@ -80,18 +78,29 @@ __device__ __forceinline__ void pw_rowtile(const float* sU, int cpi, int row0, i
 template <int NT, int COUT>
 __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* out_rows, int row0, int rows_valid,
                                                  int r16, int g, float (&s1)[NT], float (&s2)[NT]) {
+  if (rows_valid >= row0 + 16) {   // wave-uniform: the whole 16-row tile is inside the sample
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + g * 4 + r;
-      const float v = acc[nt][r];
-      if (row < rows_valid) {
-        out_rows[(size_t)row * COUT + nt * 16 + r16] = v;
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[nt][r];
+        out_rows[(size_t)(row0 + g * 4 + r) * COUT + nt * 16 + r16] = v;
         s1[nt] += v;
         s2[nt] = fmaf(v, v, s2[nt]);
       }
-    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + g * 4 + r;
+        const float v = acc[nt][r];
+        if (row < rows_valid) {
+          out_rows[(size_t)row * COUT + nt * 16 + r16] = v;
+          s1[nt] += v;
+          s2[nt] = fmaf(v, v, s2[nt]);
+        }
+      }
   }
 }
 
@@ -127,19 +136,21 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
   constexpr int NT1 = C1 / 16;
   constexpr int KS = C1 / 4, NT = COUT / 16;
   constexpr int NCH = nchunks(C1), L = chunk_len(C1);
+  constexpr int RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
   constexpr int PX = FBINS + 1;                // odd LDS pitch of the staged x rows: conflict-free MFMA operand reads
   constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(4 % NT1 == 0, "first-conv filters must be 16, 32 or 64");
   static_assert((K1 * FBINS) % 4 == 0 && C1 % 16 == 0 && COUT % 16 == 0, "shape");
 
   __shared__ __attribute__((aligned(16))) float sX[XR * PX];
-  __shared__ __attribute__((aligned(16))) float sA[RA * CP1];
-  __shared__ __attribute__((aligned(16))) float sU[TT * CP1];
+  __shared__ __attribute__((aligned(16))) float sA[RAP * CP1];
+  __shared__ __attribute__((aligned(16))) float sU[TTP * CP1];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % C1, chunk = tid / C1;
   const bool dw_active = chunk < NCH;
+  for (int i = RA * CP1 + tid; i < RAP * CP1; i += kThreads) sA[i] = 0.f;
 
   // register-resident weights
   const int nt1 = wave % NT1;
@@ -165,6 +176,15 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
 
+#pragma unroll
+  for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) pin(bfrag[kk][nt]);
+#pragma unroll
+  for (int i = 0; i < K; ++i) pin(dww[i]);
+  pin(dwb);
   // work items = (sample, time tile); the next item's rows are fetched into registers while the
   // current one is computed (global->register early, register->LDS late)
   const int ntiles = (a.Tout + TT - 1) / TT;
@@ -186,7 +206,6 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
-    const int rows_a = rows_out + K - 1;
     // commit the staged x rows (zero filled past the valid ones) with an odd row pitch
 #pragma unroll
     for (int j = 0; j < NLDX; ++j) {
@@ -215,11 +234,11 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
     // depthwise
     if (dw_active) {
       float o[L];
-      dw_chunk<K, L>(sA, CP1, chunk * L, rows_a, c, dww, dwb, o);
+      dw_chunk<K, L>(sA, CP1, chunk * L, c, dww, dwb, o);
 #pragma unroll
       for (int t = 0; t < L; ++t) {
         const int tl = chunk * L + t;
-        if (tl < TT) sU[tl * CP1 + c] = (tl < rows_out) ? o[t] : 0.f;
+        sU[tl * CP1 + c] = (tl < rows_out) ? o[t] : 0.f;
       }
     }
     __syncthreads();
@@ -240,10 +259,11 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
   constexpr int KS = CIN / 4, NT = COUT / 16;
   constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
   constexpr int Q = CIN / 4;
+  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
   static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
 
-  __shared__ __attribute__((aligned(16))) float sA[RA * CPI];
-  __shared__ __attribute__((aligned(16))) float sU[TT * CPI];
+  __shared__ __attribute__((aligned(16))) float sA[RAP * CPI];
+  __shared__ __attribute__((aligned(16))) float sU[TTP * CPI];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ __attribute__((aligned(16))) float sScale[CIN];
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     sScale[tid] = a.in_scale[tid];
     sShift[tid] = a.in_shift[tid];
   }
+  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) sA[i] = 0.f;
   float bfrag[KS][NT];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
@@ -274,6 +295,13 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) pin(bfrag[kk][nt]);
+#pragma unroll
+  for (int i = 0; i < K; ++i) pin(dww[i]);
+  pin(dwb);
   __syncthreads();
 
   const int ntiles = (a.Tout + TT - 1) / TT;
@@ -301,15 +329,16 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int i = tid + j * kThreads;
-      if (i < rows_in * Q) {
+      if (i < RA * Q) {   // rows past the sample are written as zeros
         const int r = i / Q, q = i - r * Q;
         float4 v = pre[j];
         const float4 sc = *reinterpret_cast<const float4*>(sScale + q * 4);
         const float4 sh = *reinterpret_cast<const float4*>(sShift + q * 4);
-        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        const bool ok = i < rows_in * Q;
+        v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
+        v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
+        v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
+        v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
         *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = v;
       }
     }
@@ -317,11 +346,11 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     if (it + 1 < nitems) issue(it + 1);
     if (dw_active) {
       float o[L];
-      dw_chunk<K, L>(sA, CPI, chunk * L, rows_in, c, dww, dwb, o);
+      dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
       for (int t = 0; t < L; ++t) {
         const int tl = chunk * L + t;
-        if (tl < TT) sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
+        sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
       }
     }
     __syncthreads();
