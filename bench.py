@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--grid-fwd", type=int, default=0)
     ap.add_argument("--grid-bwd", type=int, default=0)
     ap.add_argument("--grid-head", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0, help="profiling only: skip kernel phases (results invalid)")
     return ap.parse_args()
 
 
@@ -150,6 +151,8 @@ def main():
         for opt, v in (("grid_fwd", args.grid_fwd), ("grid_bwd", args.grid_bwd), ("grid_head", args.grid_head)):
             if v:
                 eng.set_option(opt, v)
+        if args.ablate:
+            eng.set_option("ablate", args.ablate)
         if not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY

@@ -43,6 +43,7 @@ struct BwdBlockArgs {
   float* gstat_part;      // [gridDim.x][2][CIN]
   float* grad_part;       // [gridDim.x][K*CIN + CIN + CIN*COUT]  (dW_dw, db, dW_pw)
   int B, Tin, Tout;
+  int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid)
 };
 
 // dp tile: rows [t0, t0+TT) of (p_k, g_k) are fetched into registers early (issue) and turned into
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     __syncthreads();
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
-    if (dw_active) {
+    if (dw_active && !(a.ablate & 1)) {
       float o[L], dww[K];
 #pragma unroll
       for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     }
     __syncthreads();
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-    pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
     __syncthreads();
     // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
-    if (dw_active) {
+    if (dw_active && !(a.ablate & 4)) {
       {
         float da[L], dww[K];
 #pragma unroll

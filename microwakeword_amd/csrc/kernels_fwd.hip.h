@@ -23,6 +23,7 @@ struct FwdFirstArgs {
   float* out;            // p_1 [B][Tout][COUT]
   float* stat_part;      // [gridDim.x][2][COUT]
   int B, T, Tout;        // Tout = T - (K1-1) - (K-1)
+  int ablate;            // profiling only: bit0 skip depthwise, bit1 skip MFMA, bit2 skip stores (results invalid)
 };
 
 struct FwdBlockArgs {
@@ -35,6 +36,7 @@ struct FwdBlockArgs {
   float* out;            // p_k [B][Tout][COUT]
   float* stat_part;      // [gridDim.x][2][COUT]
   int B, Tin, Tout;      // Tout = Tin - (K-1)
+  int ablate;            // profiling only (see FwdFirstArgs)
 };
 
 // depthwise conv over one (channel, chunk): out[t] = bias + sum_i w[i]*src[t+i], t in [0,L)
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     }
     __syncthreads();
     if (it + 1 < nitems) issue(it + 1);
-    if (dw_active) {
+    if (dw_active && !(a.ablate & 1)) {
       float o[L];
       dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     }
     __syncthreads();
     f32x4 acc[NT];
-    pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
-    store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
+    if (!(a.ablate & 2)) pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
+    else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+    if (!(a.ablate & 4)) store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
     __syncthreads();
   }
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);

@@ -90,6 +90,7 @@ struct mww_ctx {
   int64_t step = 0;
   int have_batch = 0, have_targets = 0;
   bool use_graphs = false, profile = false;
+  int ablate = 0;
   std::vector<ProfileEntry> prof;
   // cached graphs keyed by (B, flags)
   struct GraphEntry { int B, flags; hipGraphExec_t exec; };
@@ -223,7 +224,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     const int grid = std::min(B, c->grid_fwd);
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
-                     l.p, l.stat_part, B, d.frames, l.tout};
+                     l.p, l.stat_part, B, d.frames, l.tout, 0};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, grid);
       lp.end();
@@ -231,7 +232,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     } else {
       Layer& pl = c->L[i - 1];
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout};
+                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
@@ -334,6 +335,7 @@ int enqueue_backward(mww_ctx* c, int B) {
       a.B = B;
       a.Tin = l.tin;
       a.Tout = l.tout;
+      a.ablate = c->ablate;
       lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
@@ -865,6 +867,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
     for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     c->prof.clear();
   }
+  else if (!strcmp(name, "ablate")) c->ablate = (int)v;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }

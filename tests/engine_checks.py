@@ -208,9 +208,11 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False):
                 # relative L2 error of the tensor and a looser one on any single element.
                 seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
                 l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
-                assert l2 <= 2e-4, (s, name, l2)
-                assert np.abs(a - r).max() <= 3e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
+                # measured: 1e-6 typical; 2e-4..4e-4 on the rare step where one activation flips (B=6)
+                assert l2 <= 1e-3, (s, name, l2)
+                assert np.abs(a - r).max() <= 5e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
                 worst["grad"] = max(worst.get("grad", 0), l2)
+                worst.setdefault("l2s", []).append(l2)
         om.train_step(x, y, w, lr)
         p_ref, s_ref = lay.pack(om.get_weights())
         p_got, s_got = eng.get_params(), eng.get_bn_state()
@@ -233,6 +235,7 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False):
     assert abs(m["loss"] - r["loss"]) < 1e-5
     for k in ("tp", "fp", "tn", "fn"):
         np.testing.assert_array_equal(m[k], r[k])
+    assert np.median(worst.pop("l2s")) <= 2e-5   # the typical tensor agrees to fp32 rounding
     mm, vv, step = eng.get_opt_state()
     assert step == steps
     eng.close()
