@@ -42,7 +42,6 @@ KERNEL_ELEMS = {
     "fwd_block3": P_ELEMS[2] + P_ELEMS[3],
     "fwd_block4": P_ELEMS[3] + P_ELEMS[4],
     "head": P_ELEMS[4],
-    "dense_grad": P_ELEMS[4],
     "bwd_block4": P_ELEMS[3] + P_ELEMS[4] + P_ELEMS[3],              # R p3, R p4, W g3
     "bwd_block3": P_ELEMS[2] + P_ELEMS[3] + P_ELEMS[3] + P_ELEMS[2],  # R p2, R p3, R g3, W g2
     "bwd_block2": P_ELEMS[1] + P_ELEMS[2] + P_ELEMS[2] + P_ELEMS[1],
@@ -159,8 +158,7 @@ def main():
         lr = 1e-3
 
         def one_step():
-            y, w = fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
-            eng.set_targets(y, w)  # class weights 1/1 (train.py:176-187 defaults)
+            fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)  # class weights 1/1 (train.py:176-187 defaults)
             if world > 1:
                 dp.train_step(B, lr)
             else:
@@ -198,8 +196,7 @@ def main():
             eng.set_option("graphs", 0)
             eng.set_option("profile", 1)
             for _ in range(args.profile_steps):
-                y, w = fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
-                eng.set_targets(y, w)
+                fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
                 eng.train_step(B, lr, native.STEP_NO_APPLY if world > 1 else 0)
                 if world > 1:
                     eng.apply_gradients(lr, 1.0)

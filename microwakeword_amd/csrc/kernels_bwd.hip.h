@@ -691,7 +691,7 @@ struct AdamArgs {
   const float* grad;
   float* m;
   float* v;
-  const float* hyper;   // device: [0] = alpha, [1] = grad scale (1/world for averaged all-reduce)
+  const float* hyper;   // mailbox (mapped host memory): [0] = alpha, [1] = grad scale (1/world for averaged all-reduce)
   int P;
   float beta1, beta2, eps;
 };
@@ -701,6 +701,34 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs a) {
   if (p >= a.P) return;
   const float alpha = a.hyper[0];
   const float gg = a.grad[p] * a.hyper[1];
+  float m = a.m[p], v = a.v[p];
+  m += (gg - m) * (1.0f - a.beta1);
+  v += (gg * gg - v) * (1.0f - a.beta2);
+  a.m[p] = m;
+  a.v[p] = v;
+  a.param[p] -= alpha * m / (sqrtf(v) + a.eps);
+}
+
+// single-GPU step: gradient finish and Adam in one pass (the flat gradient is still written for
+// mww_get_grads / tests)
+__global__ __launch_bounds__(kThreads) void grad_finish_adam_kernel(GradFinishArgs f, AdamArgs a) {
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= f.P) return;
+  float g;
+  if (f.direct[p]) {
+    g = f.grad[p];
+  } else {
+    float t[kGradSplit];
+#pragma unroll
+    for (int j = 0; j < kGradSplit; ++j) t[j] = f.stage[(size_t)j * f.P + p];
+    g = 0.f;
+#pragma unroll
+    for (int j = 0; j < kGradSplit; ++j) g += t[j];
+  }
+  g = g * f.mask[p] * f.scale;
+  f.grad[p] = g;
+  const float alpha = a.hyper[0];
+  const float gg = g * a.hyper[1];
   float m = a.m[p], v = a.v[p];
   m += (gg - m) * (1.0f - a.beta1);
   v += (gg * gg - v) * (1.0f - a.beta2);

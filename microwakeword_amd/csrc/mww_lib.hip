@@ -73,17 +73,21 @@ struct mww_ctx {
   float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
   float* dwd_part = nullptr;
   MetricState* metrics = nullptr;
-  float* hyper = nullptr;  // device [2]
-  // pinned staging rings
-  float* hyper_pin[kRing] = {};
-  hipEvent_t hyper_ev[kRing] = {};
-  int hyper_slot = 0;
-  void* desc_pin[kRing] = {};
-  hipEvent_t desc_ev[kRing] = {};
-  size_t desc_pin_bytes = 0;
-  int desc_slot = 0;
-  mww_window* win_dev = nullptr;
-  int* mask_dev = nullptr;
+  // "mailboxes": pinned host memory mapped into the device address space.  The host writes one
+  // step's descriptors (windows, masks, labels, weights, Adam step size) into mailbox m and the
+  // kernels read them in place over PCIe (56 KB/step) — no H2D copy kernels on the stream.  A
+  // mailbox is rewritten only after the event of its previous use has completed.
+  char* mail_host[kRing] = {};
+  char* mail_dev[kRing] = {};
+  hipEvent_t mail_ev[kRing] = {};
+  int mail_cur = 0;
+  bool mail_open = false;
+  size_t mail_off_masks = 0, mail_off_y = 0, mail_off_sw = 0, mail_off_hyper = 0, mail_bytes = 0;
+  int targets_in_mail = 0;   // rows of (y, sw) sitting in the current mailbox, not yet on the device
+  // side stream: work that is off the critical path of the step (metric update, dense-weight gradient)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_pending = false;
   void* store[MWW_MAX_STORES] = {};
   int store_dtype[MWW_MAX_STORES] = {};
   int64_t store_elems[MWW_MAX_STORES] = {};
@@ -93,7 +97,7 @@ struct mww_ctx {
   int ablate = 0;
   std::vector<ProfileEntry> prof;
   // cached graphs keyed by (B, flags)
-  struct GraphEntry { int B, flags; hipGraphExec_t exec; };
+  struct GraphEntry { int B, flags, mail; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
 };
 
@@ -205,6 +209,16 @@ float* bn_slot(Layer& l, int i) { return l.bn + (size_t)i * l.cout; }
 enum { BN_SCALE = 0, BN_SHIFT, BN_MEAN, BN_RSTD, BN_C1, BN_MG, BN_MGX };
 
 // ---------------------------------------------------------------------------------- sequences
+const float* mail_hyper(mww_ctx* c) { return reinterpret_cast<const float*>(c->mail_dev[c->mail_cur] + c->mail_off_hyper); }
+
+int join_side(mww_ctx* c) {
+  if (c->side_pending) {
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->side_pending = false;
+  }
+  return MWW_OK;
+}
+
 int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
   Launcher lp{c};
   const mww_mixednet_desc& d = c->d;
@@ -273,16 +287,38 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
   lp.end();
   if (rc) return rc;
-  if (metrics) {
-    MetricsArgs ma{c->prob, c->y, c->metrics, B};
-    lp.begin("metrics");
-    hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, c->stream, ma);
-    lp.end();
+  // off the critical path: metric update and (training) the dense-weight gradient run on the side
+  // stream while the backward chain proceeds; joined before the gradient assembly
+  if (metrics || loss) {
+    hipStream_t ss = c->profile ? c->stream : c->side;
+    if (!c->profile) {
+      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
+    if (metrics) {
+      MetricsArgs ma{c->prob, c->y, c->metrics, B};
+      lp.begin("metrics");
+      hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
+      lp.end();
+    }
+    if (loss) {
+      const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
+      const int ndchunks = (B + dchunk - 1) / dchunk;
+      DenseGradArgs dg{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
+                       c->c_last, c->dwd_stride, dchunk};
+      lp.begin("dense_grad");
+      hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
+      lp.end();
+    }
+    if (!c->profile) {
+      HIPCHK(hipEventRecord(c->ev_join, c->side));
+      c->side_pending = true;
+    }
   }
   return MWW_OK;
 }
 
-int enqueue_backward(mww_ctx* c, int B) {
+int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   Launcher lp{c};
   const mww_mixednet_desc& d = c->d;
   const int nb = d.n_blocks;
@@ -290,14 +326,6 @@ int enqueue_backward(mww_ctx* c, int B) {
   const int ghead = std::min(B, c->grid_head);
   const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
   const int ndchunks = (B + dchunk - 1) / dchunk;
-  {
-    Layer& ll = c->L[nb - 1];
-    DenseGradArgs dg{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
-                     c->c_last, c->dwd_stride, dchunk};
-    lp.begin("dense_grad");
-    hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, c->stream, dg);
-    lp.end();
-  }
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -351,7 +379,11 @@ int enqueue_backward(mww_ctx* c, int B) {
       if (rc) return rc;
     }
   }
-  // gradient assembly
+  // gradient assembly (needs the dense-weight partials from the side stream)
+  {
+    int rcj = join_side(c);
+    if (rcj) return rcj;
+  }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
   int ns = 0, maxn = 0;
@@ -384,6 +416,13 @@ int enqueue_backward(mww_ctx* c, int B) {
                      c->stream, ga);
   lp.end();
   GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
+  if (fuse_adam) {
+    AdamArgs aa{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
+    lp.begin("grad_finish_adam");
+    hipLaunchKernelGGL(grad_finish_adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf, aa);
+    lp.end();
+    return MWW_OK;
+  }
   lp.begin("grad_finish");
   hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
   lp.end();
@@ -392,21 +431,46 @@ int enqueue_backward(mww_ctx* c, int B) {
 
 int enqueue_adam(mww_ctx* c) {
   Launcher lp{c};
-  AdamArgs a{c->params, c->grads, c->adam_m, c->adam_v, c->hyper, (int)c->P, 0.9f, 0.999f, 1e-7f};
+  AdamArgs a{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
   lp.begin("adam");
   hipLaunchKernelGGL(adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, a);
   lp.end();
   return MWW_OK;
 }
 
+// the host may rewrite the current mailbox once the GPU work of its previous use has finished
+int mail_begin(mww_ctx* c) {
+  if (!c->mail_open) {
+    HIPCHK(hipEventSynchronize(c->mail_ev[c->mail_cur]));
+    c->mail_open = true;
+  }
+  return MWW_OK;
+}
+// everything enqueued so far may read the current mailbox: stamp it and move on to the next one
+int mail_commit(mww_ctx* c) {
+  HIPCHK(hipEventRecord(c->mail_ev[c->mail_cur], c->stream));
+  c->mail_cur = (c->mail_cur + 1) % kRing;
+  c->mail_open = false;
+  c->targets_in_mail = 0;
+  return MWW_OK;
+}
 int push_hyper(mww_ctx* c, float alpha, float gscale) {
-  const int s = c->hyper_slot;
-  c->hyper_slot = (s + 1) % kRing;
-  HIPCHK(hipEventSynchronize(c->hyper_ev[s]));
-  c->hyper_pin[s][0] = alpha;
-  c->hyper_pin[s][1] = gscale;
-  HIPCHK(hipMemcpyAsync(c->hyper, c->hyper_pin[s], 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(c->hyper_ev[s], c->stream));
+  int rc = mail_begin(c);
+  if (rc) return rc;
+  float* h = reinterpret_cast<float*>(c->mail_host[c->mail_cur] + c->mail_off_hyper);
+  h[0] = alpha;
+  h[1] = gscale;
+  return MWW_OK;
+}
+// labels / weights written by mww_set_targets that no assembly kernel carried to the device
+int flush_targets(mww_ctx* c) {
+  if (c->targets_in_mail > 0) {
+    const char* m = c->mail_host[c->mail_cur];
+    const size_t n = (size_t)c->targets_in_mail * sizeof(float);
+    HIPCHK(hipMemcpyAsync(c->y, m + c->mail_off_y, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->sw, m + c->mail_off_sw, n, hipMemcpyHostToDevice, c->stream));
+    c->targets_in_mail = 0;
+  }
   return MWW_OK;
 }
 
@@ -419,10 +483,7 @@ float adam_alpha(float lr, int64_t t) {
 int step_sequence(mww_ctx* c, int B, int flags) {
   int rc = enqueue_forward(c, B, true, true, true, !(flags & MWW_STEP_NO_METRICS));
   if (rc) return rc;
-  rc = enqueue_backward(c, B);
-  if (rc) return rc;
-  if (!(flags & MWW_STEP_NO_APPLY)) rc = enqueue_adam(c);
-  return rc;
+  return enqueue_backward(c, B, !(flags & MWW_STEP_NO_APPLY));
 }
 
 template <typename T>
@@ -527,9 +588,6 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   A(dev_alloc(&c->loss_part, mb));
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
-  A(dev_alloc(&c->hyper, 2));
-  A(dev_alloc(&c->win_dev, mb));
-  A(dev_alloc(&c->mask_dev, mb * kMaxMasks * 2));
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
@@ -558,13 +616,20 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice);
     hipMemcpy(c->bn_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice);
   }
-  c->desc_pin_bytes = mb * (sizeof(mww_window) + kMaxMasks * 2 * sizeof(int) + 2 * sizeof(float));
+  c->mail_off_masks = mb * sizeof(mww_window);
+  c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
+  c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
+  c->mail_off_hyper = c->mail_off_sw + mb * sizeof(float);
+  c->mail_bytes = c->mail_off_hyper + 16;
   for (int i = 0; i < kRing; ++i) {
-    A(hipHostMalloc((void**)&c->hyper_pin[i], 2 * sizeof(float), hipHostMallocDefault) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc"));
-    A(hipEventCreateWithFlags(&c->hyper_ev[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
-    A(hipHostMalloc(&c->desc_pin[i], c->desc_pin_bytes, hipHostMallocDefault) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc"));
-    A(hipEventCreateWithFlags(&c->desc_ev[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
+    A(hipHostMalloc((void**)&c->mail_host[i], c->mail_bytes, hipHostMallocMapped) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc(mapped)"));
+    memset(c->mail_host[i], 0, c->mail_bytes);
+    A(hipHostGetDevicePointer((void**)&c->mail_dev[i], c->mail_host[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostGetDevicePointer"));
+    A(hipEventCreateWithFlags(&c->mail_ev[i], hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
   }
+  A(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipStreamCreate"));
+  A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
+  A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
 #undef A
   HIPCHK(hipDeviceSynchronize());
   *out = c;
@@ -578,7 +643,7 @@ void mww_destroy(mww_ctx* c) {
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
-                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->hyper, c->win_dev, c->mask_dev};
+                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics};
   for (void* p : flat) if (p) hipFree(p);
   for (auto& l : c->L) {
     void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
@@ -586,11 +651,12 @@ void mww_destroy(mww_ctx* c) {
   }
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
   for (int i = 0; i < kRing; ++i) {
-    if (c->hyper_pin[i]) hipHostFree(c->hyper_pin[i]);
-    if (c->desc_pin[i]) hipHostFree(c->desc_pin[i]);
-    if (c->hyper_ev[i]) hipEventDestroy(c->hyper_ev[i]);
-    if (c->desc_ev[i]) hipEventDestroy(c->desc_ev[i]);
+    if (c->mail_host[i]) hipHostFree(c->mail_host[i]);
+    if (c->mail_ev[i]) hipEventDestroy(c->mail_ev[i]);
   }
+  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -682,20 +748,23 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
     if (w.src_elem < 0 || w.src_elem + (int64_t)w.copy_rows * MWW_FEATURE_BINS > c->store_elems[w.store]) return fail(MWW_ERR_INVALID, "window reads past the end of its store");
   }
   HIPCHK(hipSetDevice(c->device));
-  const int s = c->desc_slot;
-  c->desc_slot = (s + 1) % kRing;
-  HIPCHK(hipEventSynchronize(c->desc_ev[s]));
-  char* pin = (char*)c->desc_pin[s];
-  memcpy(pin, win, (size_t)B * sizeof(mww_window));
-  int* pm = (int*)(pin + (size_t)c->d.max_batch * sizeof(mww_window));
-  if (nm) memcpy(pm, masks, (size_t)B * nm * 2 * sizeof(int));
-  HIPCHK(hipMemcpyAsync(c->win_dev, pin, (size_t)B * sizeof(mww_window), hipMemcpyHostToDevice, c->stream));
-  if (nm) HIPCHK(hipMemcpyAsync(c->mask_dev, pm, (size_t)B * nm * 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(c->desc_ev[s], c->stream));
+  int rcm = mail_begin(c);
+  if (rcm) return rcm;
+  char* mh = c->mail_host[c->mail_cur];
+  char* md = c->mail_dev[c->mail_cur];
+  memcpy(mh, win, (size_t)B * sizeof(mww_window));
+  if (nm) memcpy(mh + c->mail_off_masks, masks, (size_t)B * nm * 2 * sizeof(int));
   AssembleArgs a;
   for (int i = 0; i < MWW_MAX_STORES; ++i) { a.store[i] = c->store[i]; a.dtype[i] = c->store_dtype[i]; }
-  a.win = c->win_dev;
-  a.masks = c->mask_dev;
+  a.win = reinterpret_cast<const mww_window*>(md);
+  a.masks = reinterpret_cast<const int*>(md + c->mail_off_masks);
+  // labels / weights already in this mailbox ride along: window j's workgroup moves row j to HBM
+  a.n_targets = c->targets_in_mail >= B ? B : 0;
+  a.y_src = reinterpret_cast<const float*>(md + c->mail_off_y);
+  a.sw_src = reinterpret_cast<const float*>(md + c->mail_off_sw);
+  a.y_dst = c->y;
+  a.sw_dst = c->sw;
+  if (a.n_targets) c->targets_in_mail = 0;
   a.x = c->x;
   a.B = B;
   a.T = T;
@@ -725,15 +794,12 @@ int mww_get_batch(mww_ctx* c, float* hx, int B) {
 int mww_set_targets(mww_ctx* c, const float* hy, const float* hw, int B) {
   if (!c || !hy || !hw || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   HIPCHK(hipSetDevice(c->device));
-  const int s = c->desc_slot;
-  c->desc_slot = (s + 1) % kRing;
-  HIPCHK(hipEventSynchronize(c->desc_ev[s]));
-  float* pin = (float*)((char*)c->desc_pin[s] + (size_t)c->d.max_batch * (sizeof(mww_window) + kMaxMasks * 2 * sizeof(int)));
-  memcpy(pin, hy, (size_t)B * sizeof(float));
-  memcpy(pin + c->d.max_batch, hw, (size_t)B * sizeof(float));
-  HIPCHK(hipMemcpyAsync(c->y, pin, (size_t)B * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->sw, pin + c->d.max_batch, (size_t)B * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(c->desc_ev[s], c->stream));
+  int rc = mail_begin(c);
+  if (rc) return rc;
+  char* mh = c->mail_host[c->mail_cur];
+  memcpy(mh + c->mail_off_y, hy, (size_t)B * sizeof(float));
+  memcpy(mh + c->mail_off_sw, hw, (size_t)B * sizeof(float));
+  c->targets_in_mail = B;   // picked up by the next mww_assemble_batch, or copied at the next step
   c->have_targets = B;
   return MWW_OK;
 }
@@ -742,35 +808,37 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
   if (!c || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   if (c->have_batch < B || c->have_targets < B) return fail(MWW_ERR_STATE, "train step needs a batch and targets of at least B rows");
   HIPCHK(hipSetDevice(c->device));
+  int rc = flush_targets(c);
+  if (rc) return rc;
   const bool apply = !(flags & MWW_STEP_NO_APPLY);
   if (apply) {
     c->step += 1;
-    int rc = push_hyper(c, adam_alpha(lr, c->step), 1.0f);
+    rc = push_hyper(c, adam_alpha(lr, c->step), 1.0f);
     if (rc) return rc;
   }
   if (c->use_graphs && !c->profile) {
+    const int mail = apply ? c->mail_cur : -1;   // only the Adam node reads the mailbox
+    hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
-      if (g.B == B && g.flags == flags) {
-        HIPCHK(hipGraphLaunch(g.exec, c->stream));
-        return MWW_OK;
-      }
-    hipGraph_t graph;
-    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int rc = step_sequence(c, B, flags);
-    hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(MWW_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    hipGraphExec_t exec;
-    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    HIPCHK(hipGraphDestroy(graph));
-    c->graphs.push_back({B, flags, exec});
+      if (g.B == B && g.flags == flags && g.mail == mail) exec = g.exec;
+    if (!exec) {
+      hipGraph_t graph;
+      HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      rc = step_sequence(c, B, flags);
+      hipError_t e = hipStreamEndCapture(c->stream, &graph);
+      if (rc) return rc;
+      if (e != hipSuccess) return fail(MWW_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphDestroy(graph));
+      c->graphs.push_back({B, flags, mail, exec});
+    }
     HIPCHK(hipGraphLaunch(exec, c->stream));
-    return MWW_OK;
+    return mail_commit(c);
   }
-  int rc = step_sequence(c, B, flags);
+  rc = step_sequence(c, B, flags);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  return MWW_OK;
+  return mail_commit(c);
 }
 
 int mww_apply_gradients(mww_ctx* c, float lr, float gscale) {
@@ -782,7 +850,7 @@ int mww_apply_gradients(mww_ctx* c, float lr, float gscale) {
   rc = enqueue_adam(c);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  return MWW_OK;
+  return mail_commit(c);
 }
 
 int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
@@ -790,10 +858,14 @@ int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
   if (c->have_batch < B) return fail(MWW_ERR_STATE, "forward needs a batch of at least B rows");
   if (update_metrics && c->have_targets < B) return fail(MWW_ERR_STATE, "metric update needs targets");
   HIPCHK(hipSetDevice(c->device));
-  int rc = enqueue_forward(c, B, training != 0, false, false, update_metrics != 0);
+  int rc = flush_targets(c);
+  if (rc) return rc;
+  rc = enqueue_forward(c, B, training != 0, false, false, update_metrics != 0);
+  if (rc) return rc;
+  rc = join_side(c);
   if (rc) return rc;
   HIPCHK(hipGetLastError());
-  return MWW_OK;
+  return mail_commit(c);
 }
 
 int mww_read_outputs(mww_ctx* c, int B, float* probs, float* logits, float* loss) {

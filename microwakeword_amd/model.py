@@ -154,14 +154,16 @@ class Model:
         self.engine.set_batch(x)
         return self._step_on_device(n, y, sample_weight, return_dict)
 
-    def train_on_device_batch(self, n, y, sample_weight=None, return_dict=False):
+    def train_on_device_batch(self, n, y=None, sample_weight=None, return_dict=False):
         """Same as train_on_batch for a batch that ``FeatureHandler.next_training_batch_on_device``
-        already left in HBM (no host round trip of x)."""
+        already left in HBM together with its labels and weights (no host round trip of x).  Passing
+        ``y`` replaces the targets that travelled with the batch."""
         return self._step_on_device(n, y, sample_weight, return_dict)
 
     def _step_on_device(self, n, y, sample_weight, return_dict):
-        y = np.asarray(y, np.float32).reshape(-1)
-        self.engine.set_targets(y, self._per_sample_weights(sample_weight, n))
+        if y is not None:
+            y = np.asarray(y, np.float32).reshape(-1)
+            self.engine.set_targets(y, self._per_sample_weights(sample_weight, n))
         self.engine.train_step(n, self.optimizer.learning_rate.value)
         _, _, loss = self.engine.read_outputs(n)
         m = self._metric_results()

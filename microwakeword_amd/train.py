@@ -176,9 +176,9 @@ def train(model, config, data_processor, verbose=True):
                   "freq_mask_max_size": ph["freq_mask_max_size"][i], "freq_mask_count": ph["freq_mask_count"][i]}
         cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
         if fast:
-            y, w = data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy)
-            combined = w * np.where(y > 0.5, cw_pos, cw_neg)
-            result = model.train_on_device_batch(config["batch_size"], y, sample_weight=combined)
+            data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy,
+                                                         class_weights=(cw_neg, cw_pos))
+            result = model.train_on_device_batch(config["batch_size"])
         else:
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",

@@ -119,14 +119,14 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotSupported = 801 };
 struct hipemu_stream { bool capturing = false; struct hipemu_graph* g = nullptr; };
 typedef hipemu_stream* hipStream_t;
-struct hipemu_event { double t = 0; };
+struct hipemu_event { double t = 0; struct hipemu_graph* g = nullptr; };
 typedef hipemu_event* hipEvent_t;
-struct hipemu_graph { std::vector<std::function<void()>> nodes; };
+struct hipemu_graph { std::vector<std::function<void()>> nodes; std::vector<hipemu_stream*> joined; };
 typedef hipemu_graph* hipGraph_t;
 typedef hipemu_graph* hipGraphExec_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipEventDefault = 0, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; size_t totalGlobalMem; };
 
 hipError_t hipMalloc(void** p, size_t n);
@@ -154,6 +154,8 @@ hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
+hipError_t hipHostGetDevicePointer(void** dptr, void* hptr, unsigned flags = 0);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);

@@ -225,11 +225,18 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSu
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) {
+  e->g = (st && st->capturing) ? st->g : nullptr;
   if (st && st->capturing) return hipSuccess;
   e->t = now_ms();
   return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  // cross-stream capture: waiting on an event recorded in a capturing stream joins that capture
+  if (s && e && e->g && !s->capturing) { s->capturing = true; s->g = e->g; e->g->joined.push_back(s); }
+  return hipSuccess;
+}
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
   if (!s) return hipErrorInvalidValue;
@@ -237,7 +244,11 @@ hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
   s->g = new hipemu_graph();
   return hipSuccess;
 }
-hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) { s->capturing = false; *g = s->g; s->g = nullptr; return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+  for (auto* j : s->g->joined) { j->capturing = false; j->g = nullptr; }
+  s->g->joined.clear();
+  s->capturing = false; *g = s->g; s->g = nullptr; return hipSuccess;
+}
 hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new hipemu_graph(*g); return hipSuccess; }
 hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto& f : e->nodes) f(); return hipSuccess; }
 hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
