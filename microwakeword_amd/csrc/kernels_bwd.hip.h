@@ -231,6 +231,32 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   const int c = tid % CIN, chunk = tid / CIN;
   const bool dw_active = chunk < NCH;
 
+  // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
+  // current one is computed
+  const int ntiles = (a.Tin + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  constexpr int NP = (RA * QI + kThreads - 1) / kThreads;
+  float4 pre_p[NP];
+  DpStage<COUT, LAST> dps;
+  float pre_dz = 0.f;
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvp = min(RA, a.Tin - t0) * QI;
+    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = tid + j * kThreads;
+      pre_p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvp) pre_p[j] = src[i];
+    }
+    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
+    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
+    dps.issue(a.pk + koff, LAST ? a.wd + (size_t)t0 * COUT : a.gk + koff, nvk, tid);
+    if (LAST) pre_dz = a.dz[b];
+  };
+  if (nitems > 0) issue(0);
+
   for (int i = tid; i < COUT; i += kThreads) {
     sKp[0 * COUT + i] = a.k_mean[i];
     sKp[1 * COUT + i] = a.k_rstd[i];
@@ -269,31 +295,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
-  // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
-  // current one is computed
-  const int ntiles = (a.Tin + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  constexpr int NP = (RA * QI + kThreads - 1) / kThreads;
-  float4 pre_p[NP];
-  DpStage<COUT, LAST> dps;
-  float pre_dz = 0.f;
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvp = min(RA, a.Tin - t0) * QI;
-    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int i = tid + j * kThreads;
-      pre_p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvp) pre_p[j] = src[i];
-    }
-    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
-    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(a.pk + koff, LAST ? a.wd + (size_t)t0 * COUT : a.gk + koff, nvk, tid);
-    if (LAST) pre_dz = a.dz[b];
-  };
-  if (nitems > 0) issue(0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
@@ -424,6 +425,36 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   const bool dw_active = chunk < NCH;
   const int Ta = a.T - (K1 - 1);
 
+  const int ntiles = (Ta + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  float4 pre_x[NLDX];
+  DpStage<COUT, false> dps;
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvx = (min(RA, Ta - t0) + K1 - 1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+#pragma unroll
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      pre_x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvx) pre_x[j] = src[i];
+    }
+    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
+    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
+    dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
+  };
+  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s+j][f]
+  int offm[MPW];
+  bool okm[MPW];
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi) {
+    const int m = (wave * MPW + mi) * 16 + r16;
+    okm[mi] = m < M1;
+    offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
+  }
+  if (nitems > 0) issue(0);
+
   for (int i = tid; i < COUT; i += kThreads) {
     sKp[0 * COUT + i] = a.k_mean[i];
     sKp[1 * COUT + i] = a.k_rstd[i];
@@ -470,35 +501,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = zero4();
   __syncthreads();
 
-  const int ntiles = (Ta + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  float4 pre_x[NLDX];
-  DpStage<COUT, false> dps;
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvx = (min(RA, Ta - t0) + K1 - 1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      pre_x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvx) pre_x[j] = src[i];
-    }
-    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
-    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
-  };
-  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s+j][f]
-  int offm[MPW];
-  bool okm[MPW];
-#pragma unroll
-  for (int mi = 0; mi < MPW; ++mi) {
-    const int m = (wave * MPW + mi) * 16 + r16;
-    okm[mi] = m < M1;
-    offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
-  }
-  if (nitems > 0) issue(0);
   for (int it = 0; it < nitems; ++it) {
     const int t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));
@@ -606,6 +608,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalize
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ double sOut[2];
   const int tid = threadIdx.x, c = blockIdx.x;
+  float gam = 0.f, rs = 0.f;
+  if (tid == 0) {
+    gam = a.gamma[c];
+    rs = a.rstd[c];
+  }
   const double r = reduce_partials_256(a.gstat_part, a.G, a.C, c, sAcc, tid);
   if ((tid & 127) == 0) sOut[tid >> 7] = r;
   __syncthreads();
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalize
     const double s1 = sOut[0], s2 = sOut[1];
     a.dbeta[c] = (float)s1;
     a.dgamma[c] = (float)s2;
-    a.c1[c] = a.gamma[c] * a.rstd[c];
+    a.c1[c] = gam * rs;
     a.mg[c] = (float)(s1 * (double)a.inv_n);
     a.mgx[c] = (float)(s2 * (double)a.inv_n);
   }

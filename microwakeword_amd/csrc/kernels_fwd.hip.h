@@ -154,6 +154,25 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
   const bool dw_active = chunk < NCH;
   for (int i = RA * CP1 + tid; i < RAP * CP1; i += kThreads) sA[i] = 0.f;
 
+  // work items = (sample, time tile); the next item's rows are fetched into registers while the
+  // current one is computed (global->register early, register->LDS late)
+  const int ntiles = (a.Tout + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  float4 pre[NLDX];
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvalid = (min(TT, a.Tout - t0) + K - 1 + K1 - 1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+#pragma unroll
+    for (int j = 0; j < NLDX; ++j) {
+      const int i = tid + j * kThreads;
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvalid) pre[j] = src[i];
+    }
+  };
+  if (nitems > 0) issue(0);
+
   // register-resident weights
   const int nt1 = wave % NT1;
   float w1frag[KS1];
@@ -187,24 +206,6 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
-  // work items = (sample, time tile); the next item's rows are fetched into registers while the
-  // current one is computed (global->register early, register->LDS late)
-  const int ntiles = (a.Tout + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  float4 pre[NLDX];
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvalid = (min(TT, a.Tout - t0) + K - 1 + K1 - 1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvalid) pre[j] = src[i];
-    }
-  };
-  if (nitems > 0) issue(0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
@@ -279,6 +280,25 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     sShift[tid] = a.in_shift[tid];
   }
   for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) sA[i] = 0.f;
+
+  const int ntiles = (a.Tout + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  constexpr int NLD = (RA * Q + kThreads - 1) / kThreads;
+  float4 pre[NLD];
+  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at offset 4*i
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
+    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + j * kThreads;
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nvalid) pre[j] = src[i];
+    }
+  };
+  if (nitems > 0) issue(0);
   float bfrag[KS][NT];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
@@ -306,24 +326,6 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
   pin(dwb);
   __syncthreads();
 
-  const int ntiles = (a.Tout + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  constexpr int NLD = (RA * Q + kThreads - 1) / kThreads;
-  float4 pre[NLD];
-  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at offset 4*i
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
-    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int i = tid + j * kThreads;
-      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvalid) pre[j] = src[i];
-    }
-  };
-  if (nitems > 0) issue(0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
@@ -419,6 +421,14 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalize
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ double sOut[2];
   const int tid = threadIdx.x, c = blockIdx.x;
+  // per-channel parameters are fetched together with the partials (one memory round trip, not two)
+  float gam = 0.f, bet = 0.f, mm = 0.f, mv = 0.f;
+  if (tid == 0) {
+    gam = a.gamma[c];
+    bet = a.beta[c];
+    mm = a.moving_mean[c];
+    mv = a.moving_var[c];
+  }
   const double r = reduce_partials_256(a.stat_part, a.G, a.C, c, sAcc, tid);
   if ((tid & 127) == 0) sOut[tid >> 7] = r;
   __syncthreads();
@@ -428,14 +438,14 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalize
     if (var < 0.0) var = 0.0;
     const float meanf = (float)m, varf = (float)var;
     const float rstd = 1.0f / sqrtf(varf + kBnEps);
-    const float sc = a.gamma[c] * rstd;
+    const float sc = gam * rstd;
     a.scale[c] = sc;
-    a.shift[c] = a.beta[c] - meanf * sc;
+    a.shift[c] = bet - meanf * sc;
     a.mean[c] = meanf;
     a.rstd[c] = rstd;
     if (a.update_moving) {
-      a.moving_mean[c] = a.moving_mean[c] * kBnMomentum + meanf * (1.0f - kBnMomentum);
-      a.moving_var[c] = a.moving_var[c] * kBnMomentum + varf * (1.0f - kBnMomentum);
+      a.moving_mean[c] = mm * kBnMomentum + meanf * (1.0f - kBnMomentum);
+      a.moving_var[c] = mv * kBnMomentum + varf * (1.0f - kBnMomentum);
     }
   }
 }

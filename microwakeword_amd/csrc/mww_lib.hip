@@ -85,6 +85,12 @@ struct mww_ctx {
   size_t mail_off_masks = 0, mail_off_y = 0, mail_off_sw = 0, mail_off_hyper = 0, mail_bytes = 0;
   int targets_in_mail = 0;   // rows of (y, sw) sitting in the current mailbox, not yet on the device
   // side stream: work that is off the critical path of the step (metric update, dense-weight gradient)
+  // descriptors reach HBM through a DMA copy on their own stream, issued as soon as the host has
+  // written the mailbox — it overlaps the previous step's kernels; only the Adam step size is read in
+  // place from the mapped mailbox
+  hipStream_t copy_stream = nullptr;
+  char* mail_hbm[kRing] = {};
+  hipEvent_t ev_copy[kRing] = {};
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
@@ -627,6 +633,11 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     A(hipHostGetDevicePointer((void**)&c->mail_dev[i], c->mail_host[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostGetDevicePointer"));
     A(hipEventCreateWithFlags(&c->mail_ev[i], hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
   }
+  A(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipStreamCreate"));
+  for (int i = 0; i < kRing; ++i) {
+    A(dev_alloc(&c->mail_hbm[i], c->mail_bytes));
+    A(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
+  }
   A(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipStreamCreate"));
   A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
   A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
@@ -650,9 +661,12 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : lp) if (p) hipFree(p);
   }
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
+  if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kRing; ++i) {
     if (c->mail_host[i]) hipHostFree(c->mail_host[i]);
     if (c->mail_ev[i]) hipEventDestroy(c->mail_ev[i]);
+    if (c->mail_hbm[i]) hipFree(c->mail_hbm[i]);
+    if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]);
   }
   if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -751,9 +765,12 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
   int rcm = mail_begin(c);
   if (rcm) return rcm;
   char* mh = c->mail_host[c->mail_cur];
-  char* md = c->mail_dev[c->mail_cur];
+  char* md = c->mail_hbm[c->mail_cur];
   memcpy(mh, win, (size_t)B * sizeof(mww_window));
   if (nm) memcpy(mh + c->mail_off_masks, masks, (size_t)B * nm * 2 * sizeof(int));
+  HIPCHK(hipMemcpyAsync(md, mh, c->mail_off_hyper, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(hipEventRecord(c->ev_copy[c->mail_cur], c->copy_stream));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copy[c->mail_cur], 0));
   AssembleArgs a;
   for (int i = 0; i < MWW_MAX_STORES; ++i) { a.store[i] = c->store[i]; a.dtype[i] = c->store_dtype[i]; }
   a.win = reinterpret_cast<const mww_window*>(md);
