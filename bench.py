@@ -127,8 +127,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("MWW_BENCH_FORCE_DP") == "1"   # exercise the collective path on a 1-GPU box
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     stream = torch.cuda.Stream(device=device)
     B = args.batch
@@ -141,7 +143,7 @@ def main():
         random.seed(0)
         np.random.seed(0)
         fh = FeatureHandler(cfg, engine=eng)
-        if world > 1:
+        if world > 1 or force_dp:
             shard_feature_handler(fh, rank, world, seed=0)
         else:
             fh.use_private_rng()
@@ -159,7 +161,7 @@ def main():
 
         def one_step():
             fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)  # class weights 1/1 (train.py:176-187 defaults)
-            if world > 1:
+            if world > 1 or force_dp:
                 dp.train_step(B, lr)
             else:
                 eng.train_step(B, lr)
@@ -197,8 +199,8 @@ def main():
             eng.set_option("profile", 1)
             for _ in range(args.profile_steps):
                 fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
-                eng.train_step(B, lr, native.STEP_NO_APPLY if world > 1 else 0)
-                if world > 1:
+                eng.train_step(B, lr, native.STEP_NO_APPLY if (world > 1 or force_dp) else 0)
+                if world > 1 or force_dp:
                     eng.apply_gradients(lr, 1.0)
             for name, ms in eng.profile_read():
                 prof.setdefault(name, []).append(ms)
@@ -207,8 +209,7 @@ def main():
             dist.barrier()
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     windows = B * world * args.steps
     value = windows / elapsed
@@ -241,7 +242,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

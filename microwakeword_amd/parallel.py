@@ -67,7 +67,7 @@ class DataParallel:
         return cls(engine, g, p, s, group)
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if dist.is_initialized():
             self.engine.synchronize()
             dist.broadcast(self.param_view, src=src, group=self.group)
             if self.state_view is not None:
@@ -76,6 +76,6 @@ class DataParallel:
     def train_step(self, B, lr, flags=0):
         """Local forward/backward, gradient all-reduce, Adam on the averaged gradient."""
         self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
-        if self.world > 1:
+        if dist.is_initialized():
             dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group)
         self.engine.apply_gradients(lr, 1.0 / self.world)
