@@ -128,6 +128,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_dp = os.environ.get("MWW_BENCH_FORCE_DP") == "1"   # exercise the collective path on a 1-GPU box
+    real_stdout = None
+    if world > 1 or force_dp:
+        # RCCL prints a version banner on the C stdout; keep the process' fd 1 for the ONE JSON line
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -241,7 +247,12 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
-    print(json.dumps(out), flush=True)
+    line = json.dumps(out) + "\n"
+    if real_stdout is not None:
+        os.write(real_stdout, line.encode())
+    else:
+        sys.stdout.write(line)
+        sys.stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
