@@ -50,6 +50,27 @@ __host__ __device__ constexpr int halo_rows_padded(int c, int k) { return tile_r
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
+// profiling only: per-phase shader-clock accounting of one thread (enabled by the "ablate" bit 16)
+struct PhaseClock {
+  unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool on = false;
+  __device__ __forceinline__ void start(bool enable) {
+    on = enable;
+    if (on) last = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int slot) {
+    if (on) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      acc[slot] += t - last;
+      last = t;
+    }
+  }
+  __device__ __forceinline__ void dump(unsigned long long* dst) const {
+    if (on)
+      for (int i = 0; i < 8; ++i) dst[i] = acc[i];
+  }
+};
+
 // sum over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48)
 __device__ __forceinline__ float sum_over_groups(float v) {
   v += __shfl_xor(v, 16);

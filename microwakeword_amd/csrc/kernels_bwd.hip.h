@@ -43,7 +43,8 @@ struct BwdBlockArgs {
   float* gstat_part;      // [gridDim.x][2][CIN]
   float* grad_part;       // [gridDim.x][K*CIN + CIN + CIN*COUT]  (dW_dw, db, dW_pw)
   int B, Tin, Tout;
-  int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid)
+  int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid); bit 16: phase clocks
+  unsigned long long* phase_clk;   // [gridDim.x][8]
 };
 
 // dp tile: rows [t0, t0+TT) of (p_k, g_k) are fetched into registers early (issue) and turned into
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (LAST) pre_dz = a.dz[b];
   };
   if (nitems > 0) issue(0);
+  PhaseClock pc;
 
   for (int i = tid; i < COUT; i += kThreads) {
     sKp[0 * COUT + i] = a.k_mean[i];
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
+  pc.start((a.ablate & 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
@@ -310,7 +313,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
     carry_du<K, CPI>(sDU, t0 == 0, tid);
-    __syncthreads();
+    pc.mark(0);   // commit (incl. wait for the prefetch)
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
     if (dw_active && !(a.ablate & 1)) {
@@ -324,10 +329,14 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
       }
     }
-    __syncthreads();
+    pc.mark(2);   // issue + P1 (u recompute)
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
     if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
-    __syncthreads();
+    pc.mark(4);   // MFMA (dW_pw, du)
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(5);   // barrier 3
     // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
     if (dw_active && !(a.ablate & 4)) {
       {
@@ -350,8 +359,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb,
                                              [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
     }
-    __syncthreads();
+    pc.mark(6);   // P4 (depthwise backward, stores)
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(7);   // barrier 4
   }
+  if (a.phase_clk) pc.dump(a.phase_clk + (size_t)blockIdx.x * 8);
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
   write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
   if (dw_active) {

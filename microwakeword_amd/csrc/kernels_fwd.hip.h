@@ -36,7 +36,8 @@ struct FwdBlockArgs {
   float* out;            // p_k [B][Tout][COUT]
   float* stat_part;      // [gridDim.x][2][COUT]
   int B, Tin, Tout;      // Tout = Tin - (K-1)
-  int ablate;            // profiling only (see FwdFirstArgs)
+  int ablate;            // profiling only (see FwdFirstArgs); bit 16: per-phase clocks of thread 0 -> phase_clk
+  unsigned long long* phase_clk;   // [gridDim.x][8]
 };
 
 // depthwise conv over one (channel, chunk): out[t] = bias + sum_i w[i]*src[t+i], t in [0,L)
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     }
   };
   if (nitems > 0) issue(0);
+  PhaseClock pc;
   float bfrag[KS][NT];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
   pin(dwb);
   __syncthreads();
 
+  pc.start((a.ablate & 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
@@ -346,8 +349,11 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
         *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = v;
       }
     }
-    __syncthreads();
+    pc.mark(0);   // commit (incl. wait for the prefetch)
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
+    pc.mark(2);   // prefetch issue
     if (dw_active && !(a.ablate & 1)) {
       float o[L];
       dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
@@ -357,13 +363,19 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
         sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
       }
     }
-    __syncthreads();
+    pc.mark(3);   // depthwise
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(4);   // barrier 2
     f32x4 acc[NT];
     if (!(a.ablate & 2)) pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
     else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+    pc.mark(5);   // pointwise MFMA
     if (!(a.ablate & 4)) store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
-    __syncthreads();
+    pc.mark(6);   // stores + stats
+    if (!(a.ablate & 8)) __syncthreads();
+    pc.mark(7);   // barrier 3
   }
+  if (a.phase_clk) pc.dump(a.phase_clk + (size_t)blockIdx.x * 8);
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
 }
 

@@ -101,6 +101,7 @@ struct mww_ctx {
   int have_batch = 0, have_targets = 0;
   bool use_graphs = false, profile = false;
   int ablate = 0;
+  unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
   // cached graphs keyed by (B, flags)
   struct GraphEntry { int B, flags, mail; hipGraphExec_t exec; };
@@ -252,7 +253,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     } else {
       Layer& pl = c->L[i - 1];
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate};
+                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * 8};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
@@ -370,6 +371,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.Tin = l.tin;
       a.Tout = l.tout;
       a.ablate = c->ablate;
+      a.phase_clk = c->phase_clk + (size_t)(2 * i + 1) * 2048 * 8;
       lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
@@ -594,6 +596,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   A(dev_alloc(&c->loss_part, mb));
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
+  A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * 8));
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
@@ -654,7 +657,7 @@ void mww_destroy(mww_ctx* c) {
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
-                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics};
+                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk};
   for (void* p : flat) if (p) hipFree(p);
   for (auto& l : c->L) {
     void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
@@ -941,6 +944,13 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
   else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
   else if ((k = idx("bn")) >= 0) { src = c->L[k].bn; n = (int64_t)9 * c->L[k].cout; }
   else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
+  else if (!strncmp(name, "clkf", 4) || !strncmp(name, "clkb", 4)) {
+    // phase clocks of layer k (1-based) as raw 64-bit counters viewed as floats: 2048 x 8 x 2 words
+    const int kk = atoi(name + 4);
+    if (kk < 1 || kk > nb) return fail(MWW_ERR_INVALID, "bad layer");
+    src = reinterpret_cast<const float*>(c->phase_clk + (size_t)(2 * (kk - 1) + (name[3] == 'b' ? 1 : 0)) * 2048 * 8);
+    n = 2048 * 8 * 2;
+  }
   else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
   else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
   if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");

@@ -103,6 +103,8 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+static inline unsigned long long hipemu_memtime() { return 0ull; }
+#define __builtin_amdgcn_s_memtime hipemu_memtime
 
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -1,0 +1,32 @@
+"""Profiling aid: per-phase shader-clock breakdown of the block kernels (thread 0 of every workgroup).
+Runs a few eager train steps at the benchmark configuration with mww_set_option("ablate", 16)."""
+import os, random, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from microwakeword_amd import synthetic
+from microwakeword_amd.data import FeatureHandler
+from microwakeword_amd.model import Model
+
+B, T = 1024, 194
+model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T, 40), B, seed=42, max_batch=B)
+eng = model.engine
+cfg, _ = synthetic.benchmark_config(1024, 1234)
+random.seed(0); np.random.seed(0)
+fh = FeatureHandler(cfg, engine=eng)
+fh.use_private_rng()
+extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+eng.set_option("ablate", 16 | extra)
+for _ in range(3):
+    fh.next_training_batch_on_device(B, T, "default", synthetic.SPEC_AUGMENT_POLICY)
+    eng.train_step(B, 1e-3)
+eng.synchronize()
+FWD = ["commit+wait", "barrier1", "issue", "depthwise", "barrier2", "mfma", "stores", "barrier3"]
+BWD = ["commit+wait", "barrier1", "issue+P1", "barrier2", "mfma", "barrier3", "P4", "barrier4"]
+for k in (2, 3, 4):
+    for tag, names, grid in (("f", FWD, 1024), ("b", BWD, 512)):
+        raw = eng.debug_read("clk%s%d" % (tag, k), 1, 2048 * 8 * 2)
+        clk = raw.view(np.uint64).reshape(2048, 8)[:grid].astype(np.float64)
+        tot = clk.sum(1)
+        print("layer %d %s: total cycles/WG mean %.0f (min %.0f max %.0f)" % (k, "fwd" if tag == "f" else "bwd", tot.mean(), tot.min(), tot.max()))
+        print("   " + "  ".join("%s=%.0f(%.0f%%)" % (n, v, 100 * v / tot.mean()) for n, v in zip(names, clk.mean(0))))
