@@ -49,7 +49,7 @@ typedef struct {
   int32_t frames;               /* T: spectrogram_length (model_train_eval.py:82-88) */
   int32_t conv1_filters;        /* --first_conv_filters  (mixednet.py:76-81) */
   int32_t conv1_kernel;         /* --first_conv_kernel_size */
-  int32_t conv1_stride;         /* --stride (only 1 is implemented) */
+  int32_t conv1_stride;         /* --stride: time stride of the first convolution */
   int32_t n_blocks;
   int32_t block_filters[MWW_MAX_BLOCKS];  /* --pointwise_filters */
   int32_t block_kernel[MWW_MAX_BLOCKS];   /* max/last of --mixconv_kernel_sizes per block */

@@ -50,7 +50,20 @@ __host__ __device__ constexpr int halo_rows_padded(int c, int k) { return tile_r
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
-// profiling only: per-phase shader-clock accounting of one thread (enabled by the "ablate" bit 16)
+// profiling only (build with -DMWW_PHASE_CLOCKS, see tools/phase_clocks.py): per-phase shader-clock
+// accounting of one thread, enabled at run time by the "ablate" bit 16.  Compiled out by default
+// because the counters cost ~17 VGPRs.
+#ifdef MWW_PHASE_CLOCKS
+#define MWW_PC_DECL PhaseClock pc;
+#define MWW_PC_START(en) pc.start(en)
+#define MWW_PC_MARK(i) pc.mark(i)
+#define MWW_PC_DUMP(p) do { if (p) pc.dump(p); } while (0)
+#else
+#define MWW_PC_DECL
+#define MWW_PC_START(en) ((void)0)
+#define MWW_PC_MARK(i) ((void)0)
+#define MWW_PC_DUMP(p) ((void)0)
+#endif
 struct PhaseClock {
   unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool on = false;

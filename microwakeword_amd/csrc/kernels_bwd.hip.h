@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (LAST) pre_dz = a.dz[b];
   };
   if (nitems > 0) issue(0);
-  PhaseClock pc;
+  MWW_PC_DECL
 
   for (int i = tid; i < COUT; i += kThreads) {
     sKp[0 * COUT + i] = a.k_mean[i];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
-  pc.start((a.ablate & 16) && tid == 0);
+  MWW_PC_START((a.ablate & 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
     carry_du<K, CPI>(sDU, t0 == 0, tid);
-    pc.mark(0);   // commit (incl. wait for the prefetch)
+    MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(1);   // barrier 1
+    MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
     if (dw_active && !(a.ablate & 1)) {
@@ -329,14 +329,14 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
       }
     }
-    pc.mark(2);   // issue + P1 (u recompute)
+    MWW_PC_MARK(2);   // issue + P1 (u recompute)
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(3);   // barrier 2
+    MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
     if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
-    pc.mark(4);   // MFMA (dW_pw, du)
+    MWW_PC_MARK(4);   // MFMA (dW_pw, du)
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(5);   // barrier 3
+    MWW_PC_MARK(5);   // barrier 3
     // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
     if (dw_active && !(a.ablate & 4)) {
       {
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb,
                                              [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
     }
-    pc.mark(6);   // P4 (depthwise backward, stores)
+    MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(7);   // barrier 4
+    MWW_PC_MARK(7);   // barrier 4
   }
-  if (a.phase_clk) pc.dump(a.phase_clk + (size_t)blockIdx.x * 8);
+  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
   write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
   if (dw_active) {
@@ -397,16 +397,16 @@ struct BwdFirstArgs {
   const float* dw_b;      // [C1]
   const float* pw_w;      // [C1][COUT]
   float* grad_part;       // [gridDim.x][K1*40*C1 + K*C1 + C1 + C1*COUT]
-  int B, T, Tout;         // Tout = T-(K1-1)-(K-1); a0 frames Ta = T-(K1-1)
+  int B, T, Tout;         // a0 frames Ta = (T-K1)/S+1 ; Tout = Ta-(K-1)
 };
 
-template <int K1, int C1, int COUT, int K>
+template <int K1, int C1, int COUT, int K, int S>
 __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) {
   constexpr int CIN = C1;
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
   constexpr int RT1 = (RA + 15) / 16;
-  constexpr int XR = RT1 * 16 + K1 - 1;
+  constexpr int XR = (RT1 * 16 - 1) * S + K1;
   constexpr int KS1 = K1 * FBINS / 4;
   constexpr int NT1 = C1 / 16;
   constexpr int M1 = K1 * FBINS;                 // rows of W1
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % CIN, chunk = tid / CIN;
   const bool dw_active = chunk < NCH;
-  const int Ta = a.T - (K1 - 1);
+  const int Ta = (a.T - K1) / S + 1;
 
   const int ntiles = (Ta + TT - 1) / TT;
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   DpStage<COUT, false> dps;
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvx = (min(RA, Ta - t0) + K1 - 1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+    const int nvx = ((min(RA, Ta - t0) - 1) * S + K1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + (size_t)t0 * S) * FBINS);
 #pragma unroll
     for (int j = 0; j < NLDX; ++j) {
       const int i = tid + j * kThreads;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     // ---- recompute a0 = relu(conv1(x)) for local rows [0, RA)
     for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
       f32x4 acc = zero4();
-      const float* xr = sX + (rt * 16 + r16) * PX + g;
+      const float* xr = sX + (rt * 16 + r16) * S * PX + g;
 #pragma unroll
       for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
       for (int nt = 0; nt < NT1; ++nt) bv[nt] = sG0[s * CPI + nt * 16 + r16];
 #pragma unroll
       for (int mi = 0; mi < MPW; ++mi) {
-        const float av = okm[mi] ? sX[s * PX + offm[mi]] : 0.f;
+        const float av = okm[mi] ? sX[s * S * PX + offm[mi]] : 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av, bv[nt], w1acc[mi][nt]);
       }

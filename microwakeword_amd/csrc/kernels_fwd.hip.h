@@ -22,7 +22,7 @@ struct FwdFirstArgs {
   const float* pw_w;     // [C1][COUT]
   float* out;            // p_1 [B][Tout][COUT]
   float* stat_part;      // [gridDim.x][2][COUT]
-  int B, T, Tout;        // Tout = T - (K1-1) - (K-1)
+  int B, T, Tout;        // Tout = (T - K1)/S + 1 - (K-1)
   int ablate;            // profiling only: bit0 skip depthwise, bit1 skip MFMA, bit2 skip stores (results invalid)
 };
 
@@ -129,12 +129,12 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 }
 
 // ------------------------------------------------------------------------------------------
-template <int K1, int C1, int COUT, int K>
-__global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) {
+template <int K1, int C1, int COUT, int K, int S>
+__global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
   constexpr int CP1 = pitch(C1);
   constexpr int RA = TT + K - 1;               // a0 rows per tile
   constexpr int RT1 = (RA + 15) / 16;          // MFMA row tiles of the first conv
-  constexpr int XR = RT1 * 16 + K1 - 1;        // x rows staged (zero filled past the valid ones)
+  constexpr int XR = (RT1 * 16 - 1) * S + K1;  // x rows staged (zero filled past the valid ones); S = first-conv time stride
   constexpr int KS1 = K1 * FBINS / 4;          // k-steps of the im2col GEMM
   constexpr int NT1 = C1 / 16;
   constexpr int KS = C1 / 4, NT = COUT / 16;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
   float4 pre[NLDX];
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvalid = (min(TT, a.Tout - t0) + K - 1 + K1 - 1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + t0) * FBINS);
+    const int nvalid = ((min(TT, a.Tout - t0) + K - 2) * S + K1) * FBINS / 4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + (size_t)t0 * S) * FBINS);
 #pragma unroll
     for (int j = 0; j < NLDX; ++j) {
       const int i = tid + j * kThreads;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
     // first conv as im2col GEMM: A[row][k] = x[row + k/40][k%40]
     for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
       f32x4 acc = zero4();
-      const float* xr = sX + (rt * 16 + r16) * PX + g;
+      const float* xr = sX + (rt * 16 + r16) * S * PX + g;
 #pragma unroll
       for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 4) void fwd_first_kernel(FwdFirstArgs a) 
 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K>
-__global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(FwdBlockArgs a) {
+__global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int CPI = pitch(CIN);
   constexpr int RA = TT + K - 1;
   constexpr int KS = CIN / 4, NT = COUT / 16;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
     }
   };
   if (nitems > 0) issue(0);
-  PhaseClock pc;
+  MWW_PC_DECL
   float bfrag[KS][NT];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
   pin(dwb);
   __syncthreads();
 
-  pc.start((a.ablate & 16) && tid == 0);
+  MWW_PC_START((a.ablate & 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
@@ -349,11 +349,11 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
         *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = v;
       }
     }
-    pc.mark(0);   // commit (incl. wait for the prefetch)
+    MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(1);   // barrier 1
+    MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
-    pc.mark(2);   // prefetch issue
+    MWW_PC_MARK(2);   // prefetch issue
     if (dw_active && !(a.ablate & 1)) {
       float o[L];
       dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
@@ -363,19 +363,19 @@ __global__ __launch_bounds__(kThreads, (K > 13 ? 3 : 4)) void fwd_block_kernel(F
         sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
       }
     }
-    pc.mark(3);   // depthwise
+    MWW_PC_MARK(3);   // depthwise
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(4);   // barrier 2
+    MWW_PC_MARK(4);   // barrier 2
     f32x4 acc[NT];
     if (!(a.ablate & 2)) pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
     else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
-    pc.mark(5);   // pointwise MFMA
+    MWW_PC_MARK(5);   // pointwise MFMA
     if (!(a.ablate & 4)) store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
-    pc.mark(6);   // stores + stats
+    MWW_PC_MARK(6);   // stores + stats
     if (!(a.ablate & 8)) __syncthreads();
-    pc.mark(7);   // barrier 3
+    MWW_PC_MARK(7);   // barrier 3
   }
-  if (a.phase_clk) pc.dump(a.phase_clk + (size_t)blockIdx.x * 8);
+  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
 }
 

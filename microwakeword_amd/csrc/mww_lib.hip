@@ -132,14 +132,15 @@ struct Launcher {
 };
 
 // ---------------------------------------------------------------------------------- dispatch
-#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5)
+// (conv1 kernel, conv1 filters, block-1 pointwise filters, block-1 depthwise kernel, conv1 stride)
+#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1) X(5, 32, 64, 5, 3) X(5, 32, 64, 5, 1)
 #define MWW_BLOCK_SHAPES(X)                                                                               \
-  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21)
+  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21) X(64, 64, 11) X(64, 64, 15) X(64, 64, 23)
 
-int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, const FwdFirstArgs& a, int grid) {
-#define X(K1, C1, CO, K)                                                                                       \
-  if (k1 == K1 && c1 == C1 && cout == CO && k == K) {                                                          \
-    hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);        \
+int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
+#define X(K1, C1, CO, K, S)                                                                                    \
+  if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
+    hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
     return MWW_OK;                                                                                             \
   }
   MWW_FIRST_SHAPES(X)
@@ -147,10 +148,10 @@ int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, const FwdFirst
   return fail(MWW_ERR_UNSUPPORTED, "no first-block kernel for this (conv1 kernel, filters, pointwise, depthwise) shape");
 }
 
-int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, const BwdFirstArgs& a, int grid) {
-#define X(K1, C1, CO, K)                                                                                       \
-  if (k1 == K1 && c1 == C1 && cout == CO && k == K) {                                                          \
-    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);        \
+int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
+#define X(K1, C1, CO, K, S)                                                                                    \
+  if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
+    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
     return MWW_OK;                                                                                             \
   }
   MWW_FIRST_SHAPES(X)
@@ -189,14 +190,14 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
     hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                      \
     return MWW_OK;                                                                                             \
   }
-  X(48, 2) X(48, 4) X(48, 8) X(48, 12)
+  X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(64, 2) X(64, 4) X(64, 8)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
 }
 
 bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
   bool ok = false;
-#define X(K1, C1, CO, K) ok = ok || (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.block_filters[0] == CO && d.block_kernel[0] == K);
+#define X(K1, C1, CO, K, S) ok = ok || (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.block_filters[0] == CO && d.block_kernel[0] == K && d.conv1_stride == S);
   MWW_FIRST_SHAPES(X)
 #undef X
   if (!ok) { *why = "first block (conv1 kernel/filters, pointwise filters, depthwise kernel) not instantiated"; return false; }
@@ -208,7 +209,7 @@ bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
     if (!ok) { *why = "block " + std::to_string(i) + " (cin, cout, depthwise kernel) not instantiated"; return false; }
   }
   const int cl = d.block_filters[d.n_blocks - 1];
-  if (cl != 48) { *why = "head kernel needs 48 channels"; return false; }
+  if (cl != 48 && cl != 64) { *why = "head kernel needs 48 or 64 channels"; return false; }
   return true;
 }
 
@@ -247,7 +248,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
                      l.p, l.stat_part, B, d.frames, l.tout, 0};
       lp.begin("fwd_block", i);
-      int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, grid);
+      int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
       if (rc) return rc;
     } else {
@@ -382,7 +383,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout};
       lp.begin("bwd_block", i);
-      int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, a, gbwd);
+      int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, gbwd);
       lp.end();
       if (rc) return rc;
     }
@@ -519,7 +520,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   if (!desc || !out) return fail(MWW_ERR_INVALID, "null argument");
   const mww_mixednet_desc& d = *desc;
   if (d.n_blocks < 2 || d.n_blocks > MWW_MAX_BLOCKS) return fail(MWW_ERR_INVALID, "n_blocks must be in [2, 8]");
-  if (d.conv1_stride != 1) return fail(MWW_ERR_UNSUPPORTED, "first-conv stride != 1 is not implemented");
+  if (d.conv1_stride < 1 || d.frames < d.conv1_kernel) return fail(MWW_ERR_INVALID, "bad first-conv stride / kernel");
   if (d.conv1_filters <= 0) return fail(MWW_ERR_UNSUPPORTED, "first_conv_filters == 0 is not implemented");
   if (d.max_batch <= 0 || d.frames <= 0) return fail(MWW_ERR_INVALID, "frames and max_batch must be positive");
   std::string why;
@@ -548,7 +549,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   int64_t off = 0, soff = 0;
   c->o_conv1 = off;
   off += (int64_t)d.conv1_kernel * MWW_FEATURE_BINS * d.conv1_filters;
-  int t = d.frames - (d.conv1_kernel - 1), ch = d.conv1_filters;
+  int t = (d.frames - d.conv1_kernel) / d.conv1_stride + 1, ch = d.conv1_filters;
   c->L.resize(d.n_blocks);
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];

@@ -81,8 +81,6 @@ class MixedNetLayout:
         self.conv1_kernel = int(_flag(flags, "first_conv_kernel_size"))
         self.stride = int(_flag(flags, "stride"))
         unsupported = []
-        if self.stride != 1:
-            unsupported.append("stride != 1")
         if self.conv1_filters <= 0:
             unsupported.append("first_conv_filters == 0")
         if any(res):
@@ -95,7 +93,7 @@ class MixedNetLayout:
             unsupported.append("pooled")
         if unsupported:
             raise NotImplementedError("MixedNet options not implemented by the MI355X engine yet: " + ", ".join(unsupported))
-        t = self.frames - (self.conv1_kernel - 1)
+        t = (self.frames - self.conv1_kernel) // self.stride + 1
         c = self.conv1_filters
         self.blocks: List[BlockSpec] = []
         for filters, ks in zip(pf, ksz):

@@ -36,6 +36,7 @@ def perturbed_oracle(T, seed=42, flags=DEF, dtype=torch.float64):
 def make_engine(lib, T, max_batch, om=None, flags=DEF):
     lay = MixedNetLayout(flags, T)
     eng = native.Engine(lib=lib, **lay.engine_args(max_batch))
+    eng.set_grad_mask(lay.grad_mask())
     if om is not None:
         p, s = lay.pack(om.get_weights())
         eng.set_params(p)
@@ -140,9 +141,15 @@ def check_sampler_matches_oracle_descriptors(lib, B=64, n_samples=48, seed=0):
 
 
 # ------------------------------------------------------------------------------------------ model
-def check_forward_parity(lib, B=5, T=194, training=False, grid=None):
-    om = perturbed_oracle(T)
-    lay, eng = make_engine(lib, T, max(B, 2), om)
+# the topology of the reference's training notebook (cell 10): first conv 5x1 stride 3, 64 pointwise
+# filters, multi-kernel MixConv groups; spectrogram_length 204
+NOTEBOOK = dict(DEF, first_conv_kernel_size=5, stride=3, first_conv_filters=32, pointwise_filters="64,64,64,64",
+                mixconv_kernel_sizes="[5],[7,11],[9,15],[23]")
+
+
+def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
+    om = perturbed_oracle(T, flags=flags)
+    lay, eng = make_engine(lib, T, max(B, 2), om, flags=flags)
     if grid:
         for k in ("grid_fwd", "grid_head"):
             eng.set_option(k, grid)
@@ -164,11 +171,11 @@ def check_forward_parity(lib, B=5, T=194, training=False, grid=None):
     return float(np.abs(pr - po).max())
 
 
-def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False):
+def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=DEF):
     """loss, probabilities, flat gradient, Adam-updated weights, BN moving statistics and the
     metric counters after `steps` train_on_batch calls."""
-    om = perturbed_oracle(T)
-    lay, eng = make_engine(lib, T, B, om)
+    om = perturbed_oracle(T, flags=flags)
+    lay, eng = make_engine(lib, T, B, om, flags=flags)
     if grid:
         for k in ("grid_fwd", "grid_bwd", "grid_head"):
             eng.set_option(k, grid)

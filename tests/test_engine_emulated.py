@@ -60,3 +60,9 @@ def test_train_steps(emu_lib):
 def test_train_steps_other_lengths(emu_lib):
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4)
     ec.check_train_steps(emu_lib, B=2, T=60, steps=1, grid=1, graphs=True)
+
+
+def test_notebook_topology_stride3_mixconv_groups(emu_lib):
+    """first conv 5x1 stride 3, 64 filters, MixConv [7,11] / [9,15] groups (fused with zero taps + gradient mask)."""
+    ec.check_forward_parity(emu_lib, B=2, T=204, training=True, grid=2, flags=ec.NOTEBOOK)
+    ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=ec.NOTEBOOK)

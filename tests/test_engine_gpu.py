@@ -87,3 +87,10 @@ def test_determinism(lib):
         outs.append(eng.get_grads())
         eng.close()
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_notebook_topology_stride3_mixconv_groups(lib):
+    """The topology the reference's notebook trains (first conv 5x1 stride 3, 64 filters, MixConv groups)."""
+    ec.check_forward_parity(lib, B=4, T=204, training=False, flags=ec.NOTEBOOK)
+    ec.check_forward_parity(lib, B=9, T=204, training=True, flags=ec.NOTEBOOK)
+    ec.check_train_steps(lib, B=8, T=204, steps=2, grid=0, flags=ec.NOTEBOOK)

@@ -33,7 +33,7 @@ def test_argparse_defaults_match_reference_and_do_not_construct():
 
 
 def test_unsupported_options_raise_loudly():
-    for k, v in (("stride", 3), ("residual_connection", "0,1,0,0"), ("repeat_in_block", "1,2,1,1"), ("spatial_attention", 1), ("pooled", 1), ("first_conv_filters", 0)):
+    for k, v in (("residual_connection", "0,1,0,0"), ("repeat_in_block", "1,2,1,1"), ("spatial_attention", 1), ("pooled", 1), ("first_conv_filters", 0)):
         with pytest.raises(NotImplementedError):
             lay.MixedNetLayout(dict(DEF, **{k: v}), 194)
 

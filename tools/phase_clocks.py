@@ -8,8 +8,14 @@ from microwakeword_amd import synthetic
 from microwakeword_amd.data import FeatureHandler
 from microwakeword_amd.model import Model
 
+import subprocess
+from microwakeword_amd import native
+LIB = "/tmp/libmww_hip_phaseclk.so"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PHASE_CLOCKS",
+                "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
+                os.path.join(ROOT, "microwakeword_amd", "csrc", "sampler.cpp"), "-o", LIB], check=True)
 B, T = 1024, 194
-model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T, 40), B, seed=42, max_batch=B)
+model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T, 40), B, seed=42, max_batch=B, lib=native.NativeLib(LIB))
 eng = model.engine
 cfg, _ = synthetic.benchmark_config(1024, 1234)
 random.seed(0); np.random.seed(0)
