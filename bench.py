@@ -49,12 +49,53 @@ KERNEL_ELEMS = {
 }
 
 
+def inception_kernel_elems(layout):
+    """Algorithmic fp32 elements per window each conv/BN graph kernel must move: every op
+    reads its (aligned) sources and writes its pre-BN output; the weight gradient re-reads the sources and
+    reads (g, p) of the output; the data gradient reads (g, p) of the output and, per source, reads p and
+    writes g (+ reads g when it accumulates after an earlier consumer)."""
+    ops = layout.ops
+    elems = {"assemble": X_ELEMS // 2 + X_ELEMS}
+    consumers = {}
+    for i, op in enumerate(ops):
+        for s in op["src"]:
+            if s >= 0:
+                consumers.setdefault(s, []).append(i)
+
+    def src_elems(op, full):
+        n = 0
+        for s, d in zip(op["src"], op["drop"]):
+            t, c = (layout.frames, 40) if s < 0 else (ops[s]["tout"], ops[s]["filters"])
+            n += (t if full else t - d) * c
+        return n
+
+    for i, op in enumerate(ops):
+        out = op["tout"] * op["filters"]
+        elems["conv_fwd%d" % (i + 1)] = src_elems(op, False) + out
+        elems["conv_wgrad%d" % (i + 1)] = src_elems(op, False) + 2 * out
+        if any(s >= 0 for s in op["src"]):
+            n = 2 * out
+            for s in op["src"]:
+                if s >= 0:
+                    e = ops[s]["tout"] * ops[s]["filters"]
+                    n += 2 * e + (e if i != max(consumers[s]) else 0)
+            elems["conv_dgrad%d" % (i + 1)] = n
+    last = ops[-1]["tout"] * ops[-1]["filters"]
+    elems["head"] = 2 * last + (last if layout.dropout > 0 else 0)          # read p, write g (+ keep mask)
+    elems["dense_grad"] = last + (last if layout.dropout > 0 else 0)
+    if layout.dropout > 0:
+        elems["dropout_mask"] = last
+    return elems
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
+    ap.add_argument("--model", choices=("mixednet", "inception"), default="mixednet",
+                    help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--store-samples", type=int, default=4096)
@@ -66,7 +107,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(batch, budget_s=20.0):
+def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
     """CPU port of the same step (oracle loader + torch-CPU fp32 train step, all host cores), on a
     bounded sample; rank 0 / N=1 only.  kind="port": TensorFlow is not installable here, so the
     reference's own train.py cannot run."""
@@ -83,11 +124,18 @@ def cpu_baseline(batch, budget_s=20.0):
     random.seed(0)
     np.random.seed(0)
     provs = do.synthetic_providers(512, 1234)
-    om = mo.OracleModel("mixednet", flags, T_FRAMES, seed=42, dtype=torch.float32)
+    if model == "inception":
+        flags = dict(mo.INCEPTION_DEFAULTS)
+    om = mo.OracleModel(model, flags, T_FRAMES, seed=42, dtype=torch.float32)
+    n_keep = (T_FRAMES - mo.inception_slices_dropped(flags)) * 16 if model == "inception" else 0
+
+    def keep_mask():
+        return (np.random.default_rng(0).random((batch, n_keep)) >= 0.2).astype(np.float32) if n_keep else None
+
     pol = dict(time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)
     # one untimed step (allocator / thread-pool warm-up), then timed steps until the budget is used
     x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
-    om.train_step(x, y, w, 1e-3)
+    om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask())
     t_load = t_model = 0.0
     n = 0
     t_start = time.perf_counter()
@@ -95,7 +143,7 @@ def cpu_baseline(batch, budget_s=20.0):
         t0 = time.perf_counter()
         x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
         t1 = time.perf_counter()
-        om.train_step(x, y, w, 1e-3)
+        om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask())
         t2 = time.perf_counter()
         t_load += t1 - t0
         t_model += t2 - t1
@@ -142,8 +190,17 @@ def main():
     B = args.batch
 
     with torch.cuda.stream(stream):
-        model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
-                      seed=42, max_batch=B)
+        if args.model == "inception":
+            from microwakeword_amd import inception
+            from oracle.model_oracle import INCEPTION_DEFAULTS   # flag defaults only (no compute)
+            model = inception.model(dict(INCEPTION_DEFAULTS), (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
+                                    seed=42, max_batch=B)
+            kernel_elems = inception_kernel_elems(model.layout)
+            step_bytes = 4 * sum(kernel_elems.values())
+        else:
+            model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
+                          seed=42, max_batch=B)
+            kernel_elems, step_bytes = KERNEL_ELEMS, BYTES_PER_WINDOW_STEP
         eng = model.engine
         cfg, _ = synthetic.benchmark_config(args.store_samples, 1234)
         random.seed(0)
@@ -221,32 +278,34 @@ def main():
     value = windows / elapsed
     kern = {k: float(np.mean(v)) for k, v in prof.items()}
     ksum = sum(kern.values())
-    cands = [k for k in kern if k in KERNEL_ELEMS]
+    cands = [k for k in kern if k in kernel_elems]
     if cands:
         dominant = max(cands, key=lambda k: kern[k])
-        dom_bytes = KERNEL_ELEMS[dominant] * 4 * B
+        dom_bytes = kernel_elems[dominant] * 4 * B
         achieved = dom_bytes / (kern[dominant] * 1e-3)
     else:  # --profile-steps 0 (e.g. under rocprofv3): whole-step figure only
-        dominant, dom_bytes, achieved = "train_step(all kernels)", BYTES_PER_WINDOW_STEP * B, value / world * BYTES_PER_WINDOW_STEP
+        dominant, dom_bytes, achieved = "train_step(all kernels)", step_bytes * B, value / world * step_bytes
         kern[dominant] = 1e3 * elapsed / args.steps
     out = {
-        "metric": "spectrogram-windows/sec (train step) on default mixednet",
+        "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "default mixednet (argparse defaults + residual_connection 0,0,0,0), T=194, batch %d/GPU, fp32, "
-                               "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM" % (B, args.store_samples),
+        "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, fp32, "
+                               "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM"
+                               % (args.model, " + residual_connection 0,0,0,0" if args.model == "mixednet" else ", dropout 0.2 from the built-in generator",
+                                  B, args.store_samples),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graphs,
                    "bn": "local" if world > 1 else "batch"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
-                     "step_frac": round(value / world * BYTES_PER_WINDOW_STEP / HBM_PEAK, 4),
+                     "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "final_loss": round(float(last_loss), 5),
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B)
+        out["cpu_baseline"] = cpu_baseline(B, model=args.model)
     line = json.dumps(out) + "\n"
     if real_stdout is not None:
         os.write(real_stdout, line.encode())

@@ -63,6 +63,38 @@ int mww_device_count(void);
 /* stream: a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a
  * private non-blocking stream. */
 int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx** out);
+
+/* ---- conv -> BN/SSN -> ReLU graphs: replaces inception.model(flags, shape, batch_size)
+ * (microwakeword/inception.py:232-340) and its building blocks conv2d_bn / conv2d_bn_delay (:46-141:
+ * Conv2D(k x 1, dilation, valid, use_bias=False) -> BatchNormalization or SubSpectralNormalization
+ * (layers/sub_spectral_normalization.py:49-61: channel c uses slot c % groups) -> ReLU) and the
+ * three-branch block's StridedDrop + Concatenate (:143-209; strided_drop.py:42 drops LEADING frames).
+ * The head is Flatten -> Dropout(rate) -> Dense(1, sigmoid) (:330-338) on the LAST op.
+ * Ops are listed in layer-creation order, so the flat parameter vector is Keras get_weights() order:
+ *   per op: kernel[k*Cin*filters] gamma[slots] beta[slots] ; dense.kernel[T_last*C_last] dense.bias[1]
+ *   (slots = bn_groups if bn_groups > 1 else filters); BN state: per op moving_mean[slots] moving_variance[slots].
+ * Every other entry point of this header works on such a context exactly as on a MixedNet one. */
+#define MWW_MAX_GRAPH_OPS 48
+#define MWW_MAX_OP_SOURCES 3
+typedef struct {
+  int32_t n_src;                        /* inputs concatenated along channels, in this order */
+  int32_t src[MWW_MAX_OP_SOURCES];      /* producing op (index < this op's) or -1 for the spectrogram */
+  int32_t src_drop[MWW_MAX_OP_SOURCES]; /* leading frames of that input dropped to align the branches */
+  int32_t kernel, dilation, filters;
+  int32_t bn_groups;                    /* 1 = BatchNormalization, g > 1 = SubSpectralNormalization(g) */
+} mww_conv_bn_op;
+typedef struct {
+  int32_t frames;
+  int32_t n_ops;
+  mww_conv_bn_op ops[MWW_MAX_GRAPH_OPS];
+  float dropout;                        /* --dropout (inception.py:330), active in the train step only */
+  int32_t max_batch;
+} mww_convnet_desc;
+int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, mww_ctx** out);
+/* Dropout keep decisions for the next train steps, [B][T_last*C_last] bytes (0 = dropped); NULL
+ * returns to the built-in counter-based generator (mww_set_option "dropout_seed").  Keras draws the
+ * mask from a generator that cannot be reproduced outside TensorFlow, so parity tests inject it. */
+int mww_set_dropout_mask(mww_ctx* ctx, const uint8_t* keep, int B);
 void mww_destroy(mww_ctx* ctx);
 int mww_synchronize(mww_ctx* ctx);
 

@@ -647,7 +647,7 @@ struct GradSegment {
   int n;               // parameters in this segment
   int dst;             // offset in the flat gradient
 };
-constexpr int kMaxSegments = 16;
+constexpr int kMaxSegments = 50;
 constexpr int kGradSplit = 32;   // second-level split of the partial index
 struct GradReduceArgs {
   GradSegment seg[kMaxSegments];

@@ -1,0 +1,496 @@
+// Conv -> (sub-spectral) BatchNorm -> ReLU graphs with time-aligned concatenation: the layer
+// vocabulary of the reference's Inception model (microwakeword/inception.py:46-141 conv2d_bn /
+// conv2d_bn_delay / the three-branch block with StridedDrop + Concatenate, :232-340 model) and of
+// SubSpectralNormalization (layers/sub_spectral_normalization.py:49-61).
+//
+// An op = valid k x 1 convolution (dilation d, no bias) over the channel-concatenation of up to
+// three sources, each aligned by dropping its leading frames, followed by BN (or SSN with g slots:
+// channel c uses slot c % g) and ReLU.  As in the MixedNet kernels only the pre-BN output p of
+// every op is materialised; consumers apply the producer's folded BN + ReLU on load, and the
+// backward pass recomputes activations from p.
+//
+// Mapping (all kernels: 256-thread workgroups that own whole windows, grid-stride over the batch):
+//   * staging / epilogues: thread -> (channel c = tid % C, frame group tid / C): a wave touches
+//     consecutive channels of consecutive frames => contiguous HBM segments;
+//   * convolution: lane <-> output frame, NC accumulators per lane, the activation tile of the whole
+//     window in LDS (odd row pitch => conflict-free column walks), weights through scalar loads
+//     (uniform addresses), so the inner loop is one ds_read + NC v_fma per input element;
+//   * the data gradient is the same convolution run on the BN-backward-transformed output gradient
+//     with reversed taps and transposed weights (gweights_transpose_kernel), its epilogue scatters
+//     into the sources' gradient tensors (first consumer stores, later ones accumulate, the last one
+//     also produces the BN statistics partials of that source);
+//   * the weight gradient maps thread -> (tap j, input channel ci, frame subset q) with NC
+//     accumulators held across the workgroup's windows; partials are summed by grad_reduce_kernel.
+// These channel counts (10..48) are far from MFMA tile shapes and the work is a few MFLOP per
+// window, so the kernels are VALU/LDS kernels by design.
+#pragma once
+#include "common.hip.h"
+
+namespace mww {
+
+constexpr int kGMaxSrc = 3;
+enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8 };
+
+struct GSrc {
+  const float* p;       // [B][T][C] pre-BN output of the producer (or the spectrogram)
+  const float* scale;   // producer's folded BN (unused with GSRC_IDENTITY)
+  const float* shift;
+  const float* mean;    // producer's batch statistics (backward only)
+  const float* rstd;
+  float* g;             // gradient at the producer's BN output, ReLU mask applied [B][T][C]
+  float* gstat_part;    // [grid][2][C]
+  int T, C, toff, flags;
+};
+
+struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - xhat * mgx)
+  const float* g;         // [B][Tout][C]
+  const float* p;
+  const float *mean, *rstd, *c1, *mg, *mgx;
+};
+
+// ---------------------------------------------------------------------------------------------
+// staging helpers
+__device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b, int rows, float* sIn, int PI, int tid) {
+  int c0 = 0;
+  for (int i = 0; i < n_src; ++i) {
+    const GSrc& s = src[i];
+    const int C = s.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
+    if (rg < nrg) {
+      const bool ident = (s.flags & GSRC_IDENTITY) != 0;
+      const float sc = ident ? 1.f : s.scale[c], sh = ident ? 0.f : s.shift[c];
+      const float* base = s.p + ((size_t)b * s.T + s.toff) * C + c;
+      for (int t = rg; t < rows; t += nrg) {
+        const float v = base[(size_t)t * C];
+        sIn[t * PI + c0 + c] = ident ? v : fmaxf(fmaf(v, sc, sh), 0.f);
+      }
+    }
+    c0 += C;
+  }
+}
+
+__device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid) {
+  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  if (rg < nrg) {
+    const float mu = y.mean[c], rs = y.rstd[c], c1 = y.c1[c], mg = y.mg[c], mgx = y.mgx[c];
+    const size_t base = (size_t)b * rows * C + c;
+    for (int t = rg; t < rows; t += nrg) {
+      const float g = y.g[base + (size_t)t * C], p = y.p[base + (size_t)t * C];
+      dst[t * ld + c] = c1 * (g - mg - (p - mu) * rs * mgx);
+    }
+  }
+}
+
+// per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][C] of this workgroup
+__device__ __forceinline__ void write_channel_partials(float s1, float s2, int C, float* sRed, float* part, int tid) {
+  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  __syncthreads();
+  if (rg < nrg) {
+    sRed[(rg * 2 + 0) * C + c] = s1;
+    sRed[(rg * 2 + 1) * C + c] = s2;
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    float v = 0.f;
+    for (int r = 0; r < nrg; ++r) v += sRed[r * 2 * C + tid];
+    part[tid] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MODE 0: forward convolution.  MODE 1: data gradient.
+struct GConvArgs {
+  GSrc src[kGMaxSrc];
+  int n_src;
+  const float* w;       // MODE 0: [k][cin][NC];  MODE 1: reversed taps, transposed: [k][cin = fwd cout][NC = fwd cin]
+  int k, dil, cin;      // cin = channels reduced over
+  int B;
+  int Tin;              // MODE 0: aligned input frames;   MODE 1: frames of the op's output (dp)
+  int Tout;             // MODE 0: Tin - (k-1)*dil;        MODE 1: Tin + (k-1)*dil (= aligned input frames)
+  float* out;           // MODE 0: pre-BN output [B][Tout][NC]
+  float* stat_part;     // MODE 0: [grid][2][NC]
+  GBnBwd y;             // MODE 1
+};
+
+template <int NC, int MODE>
+__global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
+  HIP_DYNAMIC_SHARED(float4, g_smem4)
+  float* g_smem = reinterpret_cast<float*>(g_smem4);
+  __shared__ float sRed[2 * kThreads];
+  const int tid = threadIdx.x;
+  const int PI = a.cin | 1, PO = NC | 1;
+  const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
+  const int rows_in = a.Tin + 2 * pad;
+  float* sIn = g_smem;
+  float* sOut = g_smem + rows_in * PI;
+  float s1[kGMaxSrc] = {0.f, 0.f, 0.f}, s2[kGMaxSrc] = {0.f, 0.f, 0.f};
+
+  if (MODE == 1) {
+    // the zero frames around dp are written once: staging only touches the middle
+    for (int i = tid; i < pad * PI; i += kThreads) {
+      sIn[i] = 0.f;
+      sIn[(pad + a.Tin) * PI + i] = 0.f;
+    }
+  }
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
+    if (MODE == 0) stage_sources(a.src, a.n_src, b, a.Tin, sIn, PI, tid);
+    else stage_dp(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid);
+    __syncthreads();
+    for (int t = tid; t < a.Tout; t += kThreads) {
+      float acc[NC];
+#pragma unroll
+      for (int co = 0; co < NC; ++co) acc[co] = 0.f;
+      for (int j = 0; j < a.k; ++j) {
+        const float* row = sIn + (t + j * a.dil) * PI;
+        const float* wj = a.w + (size_t)j * a.cin * NC;
+        for (int ci = 0; ci < a.cin; ++ci) {
+          const float v = row[ci];
+#pragma unroll
+          for (int co = 0; co < NC; ++co) acc[co] = fmaf(v, wj[ci * NC + co], acc[co]);
+        }
+      }
+#pragma unroll
+      for (int co = 0; co < NC; ++co) sOut[t * PO + co] = acc[co];
+    }
+    __syncthreads();
+    if (MODE == 0) {
+      const int nrg = kThreads / NC, c = tid % NC, rg = tid / NC;
+      if (rg < nrg) {
+        float* dst = a.out + (size_t)b * a.Tout * NC + c;
+        for (int t = rg; t < a.Tout; t += nrg) {
+          const float v = sOut[t * PO + c];
+          dst[(size_t)t * NC] = v;
+          s1[0] += v;
+          s2[0] = fmaf(v, v, s2[0]);
+        }
+      }
+    } else {
+      int c0 = 0;
+#pragma unroll
+      for (int i = 0; i < kGMaxSrc; ++i) {
+        if (i >= a.n_src) break;
+        const GSrc& s = a.src[i];
+        const int C = s.C;
+        if (s.flags & GSRC_GRAD) {
+          const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+          if (rg < nrg) {
+            const float sc = s.scale[c], sh = s.shift[c];
+            const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
+            const float mu = stats ? s.mean[c] : 0.f, rs = stats ? s.rstd[c] : 0.f;
+            const size_t base = (size_t)b * s.T * C + c;
+            float t1 = 0.f, t2 = 0.f;
+            for (int t = rg; t < s.T; t += nrg) {
+              const size_t idx = base + (size_t)t * C;
+              const float p = s.p[idx];
+              const int r = t - s.toff;
+              float gv = (r >= 0 && fmaf(p, sc, sh) > 0.f) ? sOut[r * PO + c0 + c] : 0.f;
+              if (accum) gv += s.g[idx];
+              s.g[idx] = gv;
+              t1 += gv;
+              t2 = fmaf(gv, (p - mu) * rs, t2);
+            }
+            s1[i] += t1;
+            s2[i] += t2;
+          }
+        }
+        c0 += C;
+      }
+    }
+  }
+  if (MODE == 0) {
+    write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kGMaxSrc; ++i) {
+      if (i >= a.n_src) break;
+      const GSrc& s = a.src[i];
+      if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
+        write_channel_partials(s1[i], s2[i], s.C, sRed, s.gstat_part + (size_t)blockIdx.x * 2 * s.C, tid);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dW[j][ci][co] = sum_{b,t} act[b][t + j*dil][ci] * dp[b][t][co]
+struct GWgradArgs {
+  GSrc src[kGMaxSrc];
+  int n_src;
+  GBnBwd y;
+  int k, dil, cin, B, Tin, Tout;
+  int nq;               // frame subsets per (tap, channel) task: nq * k * cin <= 256
+  float* grad_part;     // [grid * nq][k*cin*NC]
+};
+
+template <int NC>
+__global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
+  HIP_DYNAMIC_SHARED(float4, g_smem4)
+  float* g_smem = reinterpret_cast<float*>(g_smem4);
+  constexpr int PO = (NC + 3) / 4 * 4;
+  const int tid = threadIdx.x;
+  const int PI = a.cin | 1;
+  float* sA = g_smem;
+  float* sDP = g_smem + (a.Tin * PI + 3) / 4 * 4;
+  const int tasks = a.k * a.cin, nq = a.nq;
+  const int task = tid % tasks, q = tid / tasks;
+  const bool active = q < nq;
+  const int j = task / a.cin, ci = task % a.cin;
+  float acc[NC];
+#pragma unroll
+  for (int co = 0; co < NC; ++co) acc[co] = 0.f;
+  if (PO != NC) {
+    // columns NC..PO-1 of dp stay zero
+    for (int i = tid; i < a.Tout * PO; i += kThreads) sDP[i] = 0.f;
+  }
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    stage_sources(a.src, a.n_src, b, a.Tin, sA, PI, tid);
+    stage_dp(a.y, NC, b, a.Tout, sDP, PO, tid);
+    __syncthreads();
+    if (active) {
+      const float* col = sA + j * a.dil * PI + ci;
+      for (int t = q; t < a.Tout; t += nq) {
+        const float v = col[t * PI];
+        const float4* row = reinterpret_cast<const float4*>(sDP + t * PO);
+#pragma unroll
+        for (int c4 = 0; c4 < PO / 4; ++c4) {
+          const float4 d = row[c4];
+          if (c4 * 4 + 0 < NC) acc[c4 * 4 + 0] = fmaf(v, d.x, acc[c4 * 4 + 0]);
+          if (c4 * 4 + 1 < NC) acc[c4 * 4 + 1] = fmaf(v, d.y, acc[c4 * 4 + 1]);
+          if (c4 * 4 + 2 < NC) acc[c4 * 4 + 2] = fmaf(v, d.z, acc[c4 * 4 + 2]);
+          if (c4 * 4 + 3 < NC) acc[c4 * 4 + 3] = fmaf(v, d.w, acc[c4 * 4 + 3]);
+        }
+      }
+    }
+  }
+  if (active) {
+    float* dst = a.grad_part + ((size_t)blockIdx.x * nq + q) * ((size_t)tasks * NC) + (size_t)task * NC;
+#pragma unroll
+    for (int co = 0; co < NC; ++co) dst[co] = acc[co];
+  }
+}
+
+// W[k][cin][cout] -> WT[k][cout][cin] with reversed taps, for every op that needs a data gradient
+struct GTransposeItem { int src, dst, k, cin, cout; };
+constexpr int kGMaxOps = 48;
+struct GTransposeArgs {
+  GTransposeItem item[kGMaxOps];
+  const float* params;
+  float* wt;
+};
+// grid = (ceil(max n / 256), items)
+__global__ __launch_bounds__(kThreads) void gweights_transpose_kernel(GTransposeArgs a) {
+  const GTransposeItem it = a.item[blockIdx.y];
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= it.k * it.cin * it.cout) return;
+  const int ci = e % it.cin, co = (e / it.cin) % it.cout, j = e / (it.cin * it.cout);
+  a.wt[it.dst + e] = a.params[it.src + ((it.k - 1 - j) * it.cin + ci) * it.cout + co];
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN / SSN finalize: one workgroup per slot (slot s owns channels s, s+g, s+2g, ... when g > 1)
+__device__ __forceinline__ void block_sum2(double& t1, double& t2, double* sAcc, int tid) {
+  sAcc[tid] = t1;
+  sAcc[kThreads + tid] = t2;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (tid < w) {
+      sAcc[tid] += sAcc[tid + w];
+      sAcc[kThreads + tid] += sAcc[kThreads + tid + w];
+    }
+    __syncthreads();
+  }
+  t1 = sAcc[0];
+  t2 = sAcc[kThreads];
+}
+
+struct GBnFwdArgs {
+  const float* stat_part;   // [G][2][C]
+  int G, C, groups;
+  float inv_n;              // 1 / (B * T * channels per slot)
+  const float *gamma, *beta;   // [slots]
+  float *moving_mean, *moving_var;
+  float *scale, *shift, *mean, *rstd;   // [C] expanded per channel
+  int update_moving;
+};
+
+__global__ __launch_bounds__(kThreads) void gbn_fwd_finalize_kernel(GBnFwdArgs a) {
+  __shared__ double sAcc[2 * kThreads];
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  const int members = a.groups > 1 ? a.C / a.groups : 1, cstride = a.groups > 1 ? a.groups : 0;
+  double t1 = 0.0, t2 = 0.0;
+  for (int it = tid; it < a.G * members; it += kThreads) {
+    const int jj = it / members, c = slot + (it % members) * cstride;
+    t1 += (double)a.stat_part[(size_t)jj * 2 * a.C + c];
+    t2 += (double)a.stat_part[(size_t)jj * 2 * a.C + a.C + c];
+  }
+  block_sum2(t1, t2, sAcc, tid);
+  const double m = t1 * (double)a.inv_n;
+  double var = t2 * (double)a.inv_n - m * m;   // biased batch variance
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)m, varf = (float)var;
+  const float rstd = 1.0f / sqrtf(varf + kBnEps);
+  const float sc = a.gamma[slot] * rstd, sh = a.beta[slot] - meanf * sc;
+  if (tid < members) {
+    const int c = slot + tid * cstride;
+    a.scale[c] = sc;
+    a.shift[c] = sh;
+    a.mean[c] = meanf;
+    a.rstd[c] = rstd;
+  }
+  if (tid == 0 && a.update_moving) {
+    a.moving_mean[slot] = a.moving_mean[slot] * kBnMomentum + meanf * (1.0f - kBnMomentum);
+    a.moving_var[slot] = a.moving_var[slot] * kBnMomentum + varf * (1.0f - kBnMomentum);
+  }
+}
+
+struct GBnEvalArgs {
+  const float *gamma, *beta, *moving_mean, *moving_var;
+  float *scale, *shift;
+  int C, groups;
+};
+__global__ __launch_bounds__(kThreads) void gbn_eval_prepare_kernel(GBnEvalArgs a) {
+  for (int c = threadIdx.x; c < a.C; c += kThreads) {
+    const int slot = a.groups > 1 ? c % a.groups : c;
+    const float sc = a.gamma[slot] / sqrtf(a.moving_var[slot] + kBnEps);
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[slot] - a.moving_mean[slot] * sc;
+  }
+}
+
+struct GBnBwdArgs {
+  const float* gstat_part;   // [G][2][C]
+  int G, C, groups;
+  float inv_n;
+  const float* gamma;        // [slots]
+  const float* rstd;         // [C]
+  float *c1, *mg, *mgx;      // [C]
+  float *dgamma, *dbeta;     // [slots] -> flat gradient
+};
+__global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a) {
+  __shared__ double sAcc[2 * kThreads];
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  const int members = a.groups > 1 ? a.C / a.groups : 1, cstride = a.groups > 1 ? a.groups : 0;
+  double t1 = 0.0, t2 = 0.0;
+  for (int it = tid; it < a.G * members; it += kThreads) {
+    const int jj = it / members, c = slot + (it % members) * cstride;
+    t1 += (double)a.gstat_part[(size_t)jj * 2 * a.C + c];
+    t2 += (double)a.gstat_part[(size_t)jj * 2 * a.C + a.C + c];
+  }
+  block_sum2(t1, t2, sAcc, tid);
+  if (tid < members) {
+    const int c = slot + tid * cstride;
+    a.c1[c] = a.gamma[slot] * a.rstd[c];
+    a.mg[c] = (float)(t1 * (double)a.inv_n);
+    a.mgx[c] = (float)(t2 * (double)a.inv_n);
+  }
+  if (tid == 0) {
+    a.dbeta[slot] = (float)t1;
+    a.dgamma[slot] = (float)t2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: last op -> BN + ReLU -> Flatten -> Dropout -> Dense(1) -> sigmoid (inception.py:330-338)
+struct GHeadArgs {
+  const float* p;          // [B][T][C]
+  const float *scale, *shift, *mean, *rstd;
+  const float* wd;         // [T*C]
+  const float* bd;
+  const float* y;
+  const float* sw;
+  const float* keep;       // [B][T*C] 0 or 1/(1-rate); null = no dropout
+  float *z, *prob, *dz, *loss_part;
+  float* g;                // [B][T][C] gradient at the BN output of the last op
+  float* gstat_part;       // [grid][2][C]
+  int B, T, C;
+  float inv_b;
+  int training;
+};
+
+__global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
+  __shared__ float sRed[8];
+  __shared__ float sBcast[2];
+  __shared__ float sStat[2 * kThreads];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
+  const bool active = rg < nrg;
+  const int n = a.T * C;
+  const float sc = active ? a.scale[c] : 0.f, sh = active ? a.shift[c] : 0.f;
+  const float mu = (active && a.training) ? a.mean[c] : 0.f, rs = (active && a.training) ? a.rstd[c] : 0.f;
+  const float bias = a.bd[0];
+  float g1 = 0.f, g2 = 0.f;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float* pb = a.p + (size_t)b * n;
+    const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
+    float dot = 0.f;
+    if (active) {
+      for (int t = rg; t < a.T; t += nrg) {
+        const int i = t * C + c;
+        const float act = fmaxf(fmaf(pb[i], sc, sh), 0.f);
+        dot = fmaf(kb ? act * kb[i] : act, a.wd[i], dot);
+      }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) sRed[wave] = dot;
+    __syncthreads();
+    if (tid == 0) {
+      const float zz = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + bias;
+      const float pr = 1.0f / (1.0f + expf(-zz));
+      a.z[b] = zz;
+      a.prob[b] = pr;
+      float dzz = 0.f;
+      if (a.y != nullptr) {
+        const float yy = a.y[b];
+        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
+        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
+        if (a.training) {
+          const float w = a.sw[b];
+          a.loss_part[b] = w * bce * a.inv_b;
+          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
+          dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
+          a.dz[b] = dzz;
+        }
+      }
+      sBcast[0] = dzz;
+    }
+    __syncthreads();
+    if (a.training && active) {
+      const float dzz = sBcast[0];
+      float* gb = a.g + (size_t)b * n;
+      for (int t = rg; t < a.T; t += nrg) {
+        const int i = t * C + c;
+        const float raw = pb[i];
+        float gv = fmaf(raw, sc, sh) > 0.f ? dzz * a.wd[i] : 0.f;
+        if (kb) gv *= kb[i];
+        gb[i] = gv;
+        g1 += gv;
+        g2 = fmaf(gv, (raw - mu) * rs, g2);
+      }
+    }
+  }
+  if (a.training) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid);
+}
+
+// Dropout keep-mask of one step: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).
+// (Keras draws its mask from a stateful generator that is not reproducible across frameworks; the
+// parity tests inject an explicit mask instead.)
+struct DropoutMaskArgs {
+  float* keep;
+  long long n;
+  unsigned long long seed;
+  const unsigned* counter;   // [2] low / high word of this step's counter (mapped mailbox)
+  float rate;
+};
+__global__ __launch_bounds__(kThreads) void dropout_mask_kernel(DropoutMaskArgs a) {
+  const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= a.n) return;
+  const unsigned long long step = ((unsigned long long)a.counter[1] << 32) | a.counter[0];
+  unsigned long long h = a.seed * 0x9E3779B97F4A7C15ull + step * 0xD1B54A32D192ED03ull + (unsigned long long)e;
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 27; h *= 0x94D049BB133111EBull;
+  h ^= h >> 31;
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+  a.keep[e] = u >= a.rate ? 1.0f / (1.0f - a.rate) : 0.f;
+}
+
+}  // namespace mww

@@ -206,6 +206,7 @@ struct DenseGradArgs {
   const float* dz;      // [B]
   float* part;          // [n_chunks][stride]   (element n = dense bias gradient)
   int B, n, C, stride, chunk;
+  const float* keep;    // [B][n] dropout keep-scale in front of the dense layer, or null
 };
 
 __global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
         const bool ok = bb + u < b1;
         v[u] = ok ? a.p[(size_t)(bb + u) * a.n + e] : 0.f;
         d[u] = ok ? a.dz[bb + u] : 0.f;
+        if (ok && a.keep) d[u] *= a.keep[(size_t)(bb + u) * a.n + e];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh), 0.f), acc);

@@ -12,6 +12,7 @@
 #include "kernels_bwd.hip.h"
 #include "kernels_data.hip.h"
 #include "kernels_fwd.hip.h"
+#include "kernels_graph.hip.h"
 #include "kernels_head.hip.h"
 
 using namespace mww;
@@ -46,6 +47,19 @@ struct Layer {
   float* bn = nullptr;         // 9 x cout: scale, shift, mean, rstd, c1, mg, mgx, (spare x2)
 };
 
+// one conv -> BN/SSN -> ReLU op of a mww_convnet_desc graph (kernels_graph.hip.h)
+struct GOp {
+  int n_src = 0, src[kGMaxSrc] = {0, 0, 0}, toff[kGMaxSrc] = {0, 0, 0};
+  int k = 1, dil = 1, cin = 0, cout = 0, groups = 1, slots = 0, tin = 0, tout = 0;
+  int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
+  float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
+  int nq = 1;                 // frame subsets of the weight-gradient mapping
+  int first_consumer = -1;    // consumer that runs first in the backward pass (highest op index; n_ops = head)
+  int last_consumer = -1;     // consumer that runs last (lowest op index): it owns the BN statistics partials
+  bool needs_dx = false;
+  size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
+};
+
 struct ProfileEntry {
   std::string name;
   hipEvent_t a, b;
@@ -67,6 +81,16 @@ struct mww_ctx {
   int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
   int t_last = 0, c_last = 0, dwd_stride = 0;
   std::vector<Layer> L;
+  // conv/BN graph models (mww_create_convnet)
+  bool generic = false;
+  std::vector<GOp> G;
+  float dropout = 0.f;
+  float* keep = nullptr;            // [max_batch][t_last*c_last] dropout keep-scale
+  bool keep_explicit = false;       // set by mww_set_dropout_mask: do not regenerate
+  unsigned long long dropout_seed = 0x5EEDull, dropout_counter = 0;
+  float* wt = nullptr;              // transposed weights of the ops with a data gradient
+  int64_t wt_total = 0;
+  int grid_g = 0;
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr, *stage = nullptr;
   unsigned char* direct = nullptr;
   float* bn_state = nullptr;
@@ -227,7 +251,44 @@ int join_side(mww_ctx* c) {
   return MWW_OK;
 }
 
+// off the critical path: metric update and (training) the dense-weight gradient run on the side
+// stream while the backward chain proceeds; joined before the gradient assembly
+int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p_last, const float* scale,
+                      const float* shift, const float* keep) {
+  Launcher lp{c};
+  if (metrics || loss) {
+    hipStream_t ss = c->profile ? c->stream : c->side;
+    if (!c->profile) {
+      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
+    if (metrics) {
+      MetricsArgs ma{c->prob, c->y, c->metrics, B};
+      lp.begin("metrics");
+      hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
+      lp.end();
+    }
+    if (loss) {
+      const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
+      const int ndchunks = (B + dchunk - 1) / dchunk;
+      DenseGradArgs dg{p_last, scale, shift, c->dz, c->dwd_part, B, c->t_last * c->c_last, c->c_last, c->dwd_stride, dchunk, keep};
+      lp.begin("dense_grad");
+      hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
+      lp.end();
+    }
+    if (!c->profile) {
+      HIPCHK(hipEventRecord(c->ev_join, c->side));
+      c->side_pending = true;
+    }
+  }
+  return MWW_OK;
+}
+
+int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics);
+int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam);
+
 int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
+  if (c->generic) return g_enqueue_forward(c, B, training, update_moving, loss, metrics);
   Launcher lp{c};
   const mww_mixednet_desc& d = c->d;
   const int nb = d.n_blocks;
@@ -295,45 +356,55 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
   lp.end();
   if (rc) return rc;
-  // off the critical path: metric update and (training) the dense-weight gradient run on the side
-  // stream while the backward chain proceeds; joined before the gradient assembly
-  if (metrics || loss) {
-    hipStream_t ss = c->profile ? c->stream : c->side;
-    if (!c->profile) {
-      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    }
-    if (metrics) {
-      MetricsArgs ma{c->prob, c->y, c->metrics, B};
-      lp.begin("metrics");
-      hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
-      lp.end();
-    }
-    if (loss) {
-      const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
-      const int ndchunks = (B + dchunk - 1) / dchunk;
-      DenseGradArgs dg{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
-                       c->c_last, c->dwd_stride, dchunk};
-      lp.begin("dense_grad");
-      hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
-      lp.end();
-    }
-    if (!c->profile) {
-      HIPCHK(hipEventRecord(c->ev_join, c->side));
-      c->side_pending = true;
-    }
+  return enqueue_side_work(c, B, metrics, loss, ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), nullptr);
+}
+
+// gradient assembly: fixed-order sum of the per-workgroup partials (+ the dense layer's, which come
+// from the side stream), structural mask, optionally fused with the Adam update
+int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam) {
+  Launcher lp{c};
+  int rcj = join_side(c);
+  if (rcj) return rcj;
+  const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
+  const int ndchunks = (B + dchunk - 1) / dchunk;
+  {
+    GradSegment s;
+    s.part = c->dwd_part;
+    s.G = ndchunks;
+    s.stride = c->dwd_stride;
+    s.n = c->t_last * c->c_last + 1;
+    s.dst = (int)c->o_dense_w;
+    ga.seg[ga.nseg++] = s;
   }
+  int maxn = 0;
+  for (int i = 0; i < ga.nseg; ++i) maxn = std::max(maxn, ga.seg[i].n);
+  ga.stage = c->stage;
+  ga.P = (int)c->P;
+  lp.begin("grad_reduce");
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ga.nseg, kGradSplit), dim3(kThreads), 0,
+                     c->stream, ga);
+  lp.end();
+  GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
+  if (fuse_adam) {
+    AdamArgs aa{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
+    lp.begin("grad_finish_adam");
+    hipLaunchKernelGGL(grad_finish_adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf, aa);
+    lp.end();
+    return MWW_OK;
+  }
+  lp.begin("grad_finish");
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
+  lp.end();
   return MWW_OK;
 }
 
 int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
+  if (c->generic) return g_enqueue_backward(c, B, fuse_adam);
   Launcher lp{c};
   const mww_mixednet_desc& d = c->d;
   const int nb = d.n_blocks;
   const int gbwd = std::min(B, c->grid_bwd);
   const int ghead = std::min(B, c->grid_head);
-  const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
-  const int ndchunks = (B + dchunk - 1) / dchunk;
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -388,14 +459,9 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       if (rc) return rc;
     }
   }
-  // gradient assembly (needs the dense-weight partials from the side stream)
-  {
-    int rcj = join_side(c);
-    if (rcj) return rcj;
-  }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
-  int ns = 0, maxn = 0;
+  int ns = 0;
   for (int i = 0; i < nb; ++i) {
     Layer& l = c->L[i];
     GradSegment s;
@@ -405,38 +471,236 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     s.n = l.grad_part_stride;
     s.dst = (int)(i == 0 ? c->o_conv1 : l.o_dw_w);
     ga.seg[ns++] = s;
-    maxn = std::max(maxn, s.n);
-  }
-  {
-    GradSegment s;
-    s.part = c->dwd_part;
-    s.G = ndchunks;
-    s.stride = c->dwd_stride;
-    s.n = c->t_last * c->c_last + 1;
-    s.dst = (int)c->o_dense_w;
-    ga.seg[ns++] = s;
-    maxn = std::max(maxn, s.n);
   }
   ga.nseg = ns;
-  ga.stage = c->stage;
-  ga.P = (int)c->P;
-  lp.begin("grad_reduce");
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ns, kGradSplit), dim3(kThreads), 0,
-                     c->stream, ga);
-  lp.end();
-  GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
-  if (fuse_adam) {
-    AdamArgs aa{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
-    lp.begin("grad_finish_adam");
-    hipLaunchKernelGGL(grad_finish_adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf, aa);
-    lp.end();
-    return MWW_OK;
-  }
-  lp.begin("grad_finish");
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
-  lp.end();
-  return MWW_OK;
+  return enqueue_grad_assembly(c, B, ga, fuse_adam);
 }
+
+// ---------------------------------------------------------------------------------- conv/BN graphs
+#define MWW_G_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(30) X(32) X(36) X(40) X(48) X(60) X(64)
+
+bool g_width_supported(int n) {
+#define X(N) if (n == N) return true;
+  MWW_G_WIDTHS(X)
+#undef X
+  return false;
+}
+
+template <int MODE>
+int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, int grid, size_t lds) {
+#define X(N)                                                                                                   \
+  if (nc == N) {                                                                                               \
+    hipLaunchKernelGGL((gconv_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_G_WIDTHS(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "conv width not instantiated");
+}
+
+int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds) {
+#define X(N)                                                                                                   \
+  if (nc == N) {                                                                                               \
+    hipLaunchKernelGGL((gconv_wgrad_kernel<N>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+    return MWW_OK;                                                                                             \
+  }
+  MWW_G_WIDTHS(X)
+#undef X
+  return fail(MWW_ERR_UNSUPPORTED, "conv width not instantiated");
+}
+
+float* gbn_slot(GOp& o, int i) { return o.bn + (size_t)i * o.cout; }
+
+// source i of op `oi` as the kernels see it; `backward` adds the gradient routing flags
+GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
+  GOp& o = c->G[oi];
+  GSrc s;
+  memset(&s, 0, sizeof(s));
+  s.toff = o.toff[i];
+  if (o.src[i] < 0) {
+    s.p = c->x;
+    s.T = c->d.frames;
+    s.C = MWW_FEATURE_BINS;
+    s.flags = GSRC_IDENTITY;
+    return s;
+  }
+  GOp& pr = c->G[o.src[i]];
+  s.p = pr.p;
+  s.scale = gbn_slot(pr, BN_SCALE);
+  s.shift = gbn_slot(pr, BN_SHIFT);
+  s.mean = gbn_slot(pr, BN_MEAN);
+  s.rstd = gbn_slot(pr, BN_RSTD);
+  s.g = pr.g;
+  s.gstat_part = pr.gstat_part;
+  s.T = pr.tout;
+  s.C = pr.cout;
+  if (backward) s.flags = GSRC_GRAD | (oi != pr.first_consumer ? GSRC_ACCUM : 0) | (oi == pr.last_consumer ? GSRC_STATS : 0);
+  return s;
+}
+
+GBnBwd g_make_bnbwd(GOp& o) {
+  return GBnBwd{o.g, o.p, gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX)};
+}
+
+int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
+  Launcher lp{c};
+  const int n = (int)c->G.size();
+  const int gg = std::min(B, c->grid_g);
+  for (int i = 0; i < n; ++i) {
+    GOp& o = c->G[i];
+    if (!training) {
+      GBnEvalArgs e{c->params + o.o_gamma, c->params + o.o_beta, c->bn_state + o.o_mm, c->bn_state + o.o_mv,
+                    gbn_slot(o, BN_SCALE), gbn_slot(o, BN_SHIFT), o.cout, o.groups};
+      lp.begin("bn_eval_prepare", i);
+      hipLaunchKernelGGL(gbn_eval_prepare_kernel, dim3(1), dim3(kThreads), 0, c->stream, e);
+      lp.end();
+    }
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_src = o.n_src;
+    for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, false);
+    a.w = c->params + o.o_w;
+    a.k = o.k;
+    a.dil = o.dil;
+    a.cin = o.cin;
+    a.B = B;
+    a.Tin = o.tin;
+    a.Tout = o.tout;
+    a.out = o.p;
+    a.stat_part = o.stat_part;
+    lp.begin("conv_fwd", i);
+    int rc = launch_gconv<0>(c, o.cout, a, gg, o.lds_fwd);
+    lp.end();
+    if (rc) return rc;
+    if (training) {
+      const int members = o.groups > 1 ? o.cout / o.groups : 1;
+      GBnFwdArgs f{o.stat_part, gg, o.cout, o.groups, 1.0f / ((float)B * (float)o.tout * (float)members),
+                   c->params + o.o_gamma, c->params + o.o_beta, c->bn_state + o.o_mm, c->bn_state + o.o_mv,
+                   gbn_slot(o, BN_SCALE), gbn_slot(o, BN_SHIFT), gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), update_moving ? 1 : 0};
+      lp.begin("bn_fwd_finalize", i);
+      hipLaunchKernelGGL(gbn_fwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
+      lp.end();
+    }
+  }
+  GOp& lo = c->G[n - 1];
+  const bool drop = loss && c->dropout > 0.f;   // Dropout is active in the train step only (Keras training=True)
+  if (drop && !c->keep_explicit) {
+    const long long ne = (long long)B * c->t_last * c->c_last;
+    DropoutMaskArgs dm{c->keep, ne, c->dropout_seed, reinterpret_cast<const unsigned*>(mail_hyper(c)) + 2, c->dropout};
+    lp.begin("dropout_mask");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, c->stream, dm);
+    lp.end();
+  }
+  const int ghead = std::min(B, c->grid_head);
+  GHeadArgs h;
+  memset(&h, 0, sizeof(h));
+  h.p = lo.p;
+  h.scale = gbn_slot(lo, BN_SCALE);
+  h.shift = gbn_slot(lo, BN_SHIFT);
+  h.mean = gbn_slot(lo, BN_MEAN);
+  h.rstd = gbn_slot(lo, BN_RSTD);
+  h.wd = c->params + c->o_dense_w;
+  h.bd = c->params + c->o_dense_b;
+  h.y = (loss || metrics) ? c->y : nullptr;
+  h.sw = c->sw;
+  h.keep = drop ? c->keep : nullptr;
+  h.z = c->z;
+  h.prob = c->prob;
+  h.dz = c->dz;
+  h.loss_part = c->loss_part;
+  h.g = lo.g;
+  h.gstat_part = lo.gstat_part;
+  h.B = B;
+  h.T = lo.tout;
+  h.C = lo.cout;
+  h.inv_b = 1.0f / (float)B;
+  h.training = loss ? 1 : 0;
+  lp.begin("head");
+  hipLaunchKernelGGL(ghead_kernel, dim3(ghead), dim3(kThreads), 0, c->stream, h);
+  lp.end();
+  return enqueue_side_work(c, B, metrics, loss, lo.p, gbn_slot(lo, BN_SCALE), gbn_slot(lo, BN_SHIFT), drop ? c->keep : nullptr);
+}
+
+int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
+  Launcher lp{c};
+  const int n = (int)c->G.size();
+  const int gg = std::min(B, c->grid_g);
+  const int ghead = std::min(B, c->grid_head);
+  {
+    GTransposeArgs t;
+    memset(&t, 0, sizeof(t));
+    int ni = 0, maxn = 0;
+    for (int i = 0; i < n; ++i) {
+      GOp& o = c->G[i];
+      if (!o.needs_dx) continue;
+      t.item[ni++] = GTransposeItem{(int)o.o_w, (int)o.o_wt, o.k, o.cin, o.cout};
+      maxn = std::max(maxn, o.k * o.cin * o.cout);
+    }
+    t.params = c->params;
+    t.wt = c->wt;
+    if (ni) {
+      lp.begin("weights_transpose");
+      hipLaunchKernelGGL(gweights_transpose_kernel, dim3((maxn + kThreads - 1) / kThreads, ni), dim3(kThreads), 0, c->stream, t);
+      lp.end();
+    }
+  }
+  GradReduceArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  for (int i = n - 1; i >= 0; --i) {
+    GOp& o = c->G[i];
+    const int members = o.groups > 1 ? o.cout / o.groups : 1;
+    GBnBwdArgs f{o.gstat_part, i == n - 1 ? ghead : gg, o.cout, o.groups, 1.0f / ((float)B * (float)o.tout * (float)members),
+                 c->params + o.o_gamma, gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX),
+                 c->grads + o.o_gamma, c->grads + o.o_beta};
+    lp.begin("bn_bwd_finalize", i);
+    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
+    lp.end();
+    GWgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.n_src = o.n_src;
+    for (int s = 0; s < o.n_src; ++s) w.src[s] = g_make_src(c, i, s, false);
+    w.y = g_make_bnbwd(o);
+    w.k = o.k;
+    w.dil = o.dil;
+    w.cin = o.cin;
+    w.B = B;
+    w.Tin = o.tin;
+    w.Tout = o.tout;
+    w.nq = o.nq;
+    w.grad_part = o.grad_part;
+    lp.begin("conv_wgrad", i);
+    int rc = launch_gwgrad(c, o.cout, w, gg, o.lds_wg);
+    lp.end();
+    if (rc) return rc;
+    if (o.needs_dx) {
+      GConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n_src = o.n_src;
+      for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, true);
+      a.w = c->wt + o.o_wt;
+      a.k = o.k;
+      a.dil = o.dil;
+      a.cin = o.cout;
+      a.B = B;
+      a.Tin = o.tout;
+      a.Tout = o.tin;
+      a.y = g_make_bnbwd(o);
+      lp.begin("conv_dgrad", i);
+      rc = launch_gconv<1>(c, o.cin, a, gg, o.lds_dx);
+      lp.end();
+      if (rc) return rc;
+    }
+    GradSegment s;
+    s.part = o.grad_part;
+    s.G = gg * o.nq;
+    s.stride = o.k * o.cin * o.cout;
+    s.n = s.stride;
+    s.dst = (int)o.o_w;
+    ga.seg[ga.nseg++] = s;
+  }
+  return enqueue_grad_assembly(c, B, ga, fuse_adam);
+}
+
 
 int enqueue_adam(mww_ctx* c) {
   Launcher lp{c};
@@ -502,6 +766,98 @@ int dev_alloc(T** p, size_t n) {
   return MWW_OK;
 }
 
+struct BnSlots { int64_t o_gamma, o_beta, o_mv; int n; };
+
+// mask = 1 everywhere, direct flags on the BN gamma/beta slots; moving variance starts at 1
+int init_defaults(mww_ctx* c, const std::vector<BnSlots>& bn) {
+  std::vector<float> ones((size_t)c->P, 1.0f);
+  std::vector<unsigned char> dir((size_t)c->P, 0);
+  std::vector<float> st((size_t)c->S, 0.0f);
+  for (const BnSlots& b : bn)
+    for (int j = 0; j < b.n; ++j) {
+      dir[(size_t)b.o_gamma + j] = 1;
+      dir[(size_t)b.o_beta + j] = 1;
+      st[(size_t)b.o_mv + j] = 1.0f;
+    }
+  HIPCHK(hipMemcpy(c->mask, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->bn_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  return MWW_OK;
+}
+
+// buffers, mailboxes and streams that do not depend on the topology (needs P, S, t_last, c_last)
+int alloc_common(mww_ctx* c) {
+  const mww_mixednet_desc& d = c->d;
+  const size_t mb = (size_t)d.max_batch;
+  int rc = 0;
+#define A(call) if ((rc = (call)) != 0) return rc;
+#define H(call) if ((call) != hipSuccess) return fail(MWW_ERR_HIP, #call);
+  A(dev_alloc(&c->params, c->P));
+  A(dev_alloc(&c->grads, c->P));
+  A(dev_alloc(&c->adam_m, c->P));
+  A(dev_alloc(&c->adam_v, c->P));
+  A(dev_alloc(&c->mask, c->P));
+  A(dev_alloc(&c->direct, c->P));
+  A(dev_alloc(&c->stage, (size_t)kGradSplit * c->P));
+  A(dev_alloc(&c->bn_state, c->S));
+  A(dev_alloc(&c->x, mb * d.frames * MWW_FEATURE_BINS));
+  A(dev_alloc(&c->y, mb));
+  A(dev_alloc(&c->sw, mb));
+  A(dev_alloc(&c->z, mb));
+  A(dev_alloc(&c->prob, mb));
+  A(dev_alloc(&c->dz, mb));
+  A(dev_alloc(&c->loss_part, mb));
+  A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
+  A(dev_alloc(&c->metrics, 1));
+  A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * 8));
+  c->mail_off_masks = mb * sizeof(mww_window);
+  c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
+  c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
+  c->mail_off_hyper = c->mail_off_sw + mb * sizeof(float);
+  c->mail_bytes = c->mail_off_hyper + 16;
+  for (int i = 0; i < kRing; ++i) {
+    H(hipHostMalloc((void**)&c->mail_host[i], c->mail_bytes, hipHostMallocMapped));
+    memset(c->mail_host[i], 0, c->mail_bytes);
+    H(hipHostGetDevicePointer((void**)&c->mail_dev[i], c->mail_host[i], 0));
+    H(hipEventCreateWithFlags(&c->mail_ev[i], hipEventDisableTiming));
+  }
+  H(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < kRing; ++i) {
+    A(dev_alloc(&c->mail_hbm[i], c->mail_bytes));
+    H(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
+  }
+  H(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  H(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  H(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+#undef A
+#undef H
+  return MWW_OK;
+}
+
+// device / stream / launch-geometry part of context creation
+int open_device(mww_ctx* c, int device, void* stream) {
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(MWW_ERR_HIP, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MWW_ERR_INVALID, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  c->device = device;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  c->grid_fwd = c->n_cu * 4;
+  c->grid_bwd = c->n_cu * 2;
+  c->grid_head = c->n_cu * 4;
+  c->grid_g = c->n_cu * 2;
+  return MWW_OK;
+}
+
 }  // namespace
 
 // ====================================================================================== C ABI
@@ -525,26 +881,12 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   if (d.max_batch <= 0 || d.frames <= 0) return fail(MWW_ERR_INVALID, "frames and max_batch must be positive");
   std::string why;
   if (!shape_supported(d, &why)) return fail(MWW_ERR_UNSUPPORTED, why);
-  int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) return fail(MWW_ERR_HIP, "no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(MWW_ERR_INVALID, "device index out of range");
-  HIPCHK(hipSetDevice(device));
   mww_ctx* c = new mww_ctx();
   c->d = d;
-  c->device = device;
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, device));
-  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (stream) {
-    c->stream = (hipStream_t)stream;
-  } else {
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
+  {
+    int rco = open_device(c, device, stream);
+    if (rco) { delete c; return rco; }
   }
-  c->grid_fwd = c->n_cu * 4;
-  c->grid_bwd = c->n_cu * 2;
-  c->grid_head = c->n_cu * 4;
   // ---- parameter layout
   int64_t off = 0, soff = 0;
   c->o_conv1 = off;
@@ -558,7 +900,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     l.k = d.block_kernel[i];
     l.tin = t;
     l.tout = t - (l.k - 1);
-    if (l.tout <= 0) { delete c; return fail(MWW_ERR_INVALID, "spectrogram too short for the kernel sizes"); }
+    if (l.tout <= 0) { mww_destroy(c); return fail(MWW_ERR_INVALID, "spectrogram too short for the kernel sizes"); }
     l.o_dw_w = off; off += (int64_t)l.k * l.cin;
     l.o_dw_b = off; off += l.cin;
     l.o_pw_w = off; off += (int64_t)l.cin * l.cout;
@@ -580,24 +922,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   const int gmax_f = c->grid_fwd, gmax_b = c->grid_bwd, gmax_h = c->grid_head;
   int rc = 0;
 #define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
-  A(dev_alloc(&c->params, c->P));
-  A(dev_alloc(&c->grads, c->P));
-  A(dev_alloc(&c->adam_m, c->P));
-  A(dev_alloc(&c->adam_v, c->P));
-  A(dev_alloc(&c->mask, c->P));
-  A(dev_alloc(&c->direct, c->P));
-  A(dev_alloc(&c->stage, (size_t)kGradSplit * c->P));
-  A(dev_alloc(&c->bn_state, c->S));
-  A(dev_alloc(&c->x, mb * d.frames * MWW_FEATURE_BINS));
-  A(dev_alloc(&c->y, mb));
-  A(dev_alloc(&c->sw, mb));
-  A(dev_alloc(&c->z, mb));
-  A(dev_alloc(&c->prob, mb));
-  A(dev_alloc(&c->dz, mb));
-  A(dev_alloc(&c->loss_part, mb));
-  A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
-  A(dev_alloc(&c->metrics, 1));
-  A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * 8));
+  A(alloc_common(c));
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
@@ -609,45 +934,141 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     A(dev_alloc(&l.grad_part, (size_t)gmax_b * l.grad_part_stride));
     A(dev_alloc(&l.bn, (size_t)9 * l.cout));
   }
-  // mask = 1 everywhere, direct flags on the BN gamma/beta slots; moving variance starts at 1
   {
-    std::vector<float> ones((size_t)c->P, 1.0f);
-    std::vector<unsigned char> dir((size_t)c->P, 0);
-    std::vector<float> st((size_t)c->S, 0.0f);
-    for (int i = 0; i < d.n_blocks; ++i) {
-      Layer& l = c->L[i];
-      for (int j = 0; j < l.cout; ++j) {
-        dir[(size_t)l.o_gamma + j] = 1;
-        dir[(size_t)l.o_beta + j] = 1;
-        st[(size_t)l.o_mv + j] = 1.0f;
-      }
-    }
-    hipMemcpy(c->mask, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice);
-    hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice);
-    hipMemcpy(c->bn_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice);
+    std::vector<BnSlots> bn;
+    for (int i = 0; i < d.n_blocks; ++i) bn.push_back(BnSlots{c->L[i].o_gamma, c->L[i].o_beta, c->L[i].o_mv, c->L[i].cout});
+    A(init_defaults(c, bn));
   }
-  c->mail_off_masks = mb * sizeof(mww_window);
-  c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
-  c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
-  c->mail_off_hyper = c->mail_off_sw + mb * sizeof(float);
-  c->mail_bytes = c->mail_off_hyper + 16;
-  for (int i = 0; i < kRing; ++i) {
-    A(hipHostMalloc((void**)&c->mail_host[i], c->mail_bytes, hipHostMallocMapped) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostMalloc(mapped)"));
-    memset(c->mail_host[i], 0, c->mail_bytes);
-    A(hipHostGetDevicePointer((void**)&c->mail_dev[i], c->mail_host[i], 0) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipHostGetDevicePointer"));
-    A(hipEventCreateWithFlags(&c->mail_ev[i], hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
-  }
-  A(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipStreamCreate"));
-  for (int i = 0; i < kRing; ++i) {
-    A(dev_alloc(&c->mail_hbm[i], c->mail_bytes));
-    A(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
-  }
-  A(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipStreamCreate"));
-  A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
-  A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess ? 0 : fail(MWW_ERR_HIP, "hipEventCreate"));
 #undef A
   HIPCHK(hipDeviceSynchronize());
   *out = c;
+  return MWW_OK;
+}
+
+int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, mww_ctx** out) {
+  if (!desc || !out) return fail(MWW_ERR_INVALID, "null argument");
+  const mww_convnet_desc& d = *desc;
+  if (d.n_ops < 1 || d.n_ops > MWW_MAX_GRAPH_OPS) return fail(MWW_ERR_INVALID, "n_ops out of range");
+  if (d.max_batch <= 0 || d.frames <= 0) return fail(MWW_ERR_INVALID, "frames and max_batch must be positive");
+  if (!(d.dropout >= 0.f && d.dropout < 1.f)) return fail(MWW_ERR_INVALID, "dropout rate must be in [0, 1)");
+  std::vector<GOp> ops(d.n_ops);
+  std::vector<int> n_consumers(d.n_ops, 0);
+  int64_t off = 0, soff = 0, wtoff = 0;
+  for (int i = 0; i < d.n_ops; ++i) {
+    const mww_conv_bn_op& s = d.ops[i];
+    GOp& o = ops[i];
+    const std::string tag = "op " + std::to_string(i) + ": ";
+    if (s.n_src < 1 || s.n_src > MWW_MAX_OP_SOURCES) return fail(MWW_ERR_INVALID, tag + "1..3 sources");
+    if (s.kernel < 1 || s.dilation < 1 || s.filters < 1 || s.bn_groups < 1) return fail(MWW_ERR_INVALID, tag + "bad kernel / dilation / filters / groups");
+    if (s.filters % s.bn_groups) return fail(MWW_ERR_INVALID, tag + "filters must be a multiple of the sub-spectral groups");
+    o.n_src = s.n_src;
+    o.k = s.kernel;
+    o.dil = s.dilation;
+    o.cout = s.filters;
+    o.groups = s.bn_groups;
+    o.slots = s.bn_groups > 1 ? s.bn_groups : s.filters;
+    o.cin = 0;
+    o.tin = -1;
+    for (int j = 0; j < s.n_src; ++j) {
+      const int src = s.src[j];
+      if (src < -1 || src >= i) return fail(MWW_ERR_INVALID, tag + "sources must be earlier ops (or -1 for the spectrogram)");
+      for (int j2 = 0; j2 < j; ++j2)
+        if (s.src[j2] == src) return fail(MWW_ERR_UNSUPPORTED, tag + "the same source twice");
+      if (s.src_drop[j] < 0) return fail(MWW_ERR_INVALID, tag + "negative frame drop");
+      const int T = src < 0 ? d.frames : ops[src].tout, C = src < 0 ? MWW_FEATURE_BINS : ops[src].cout;
+      const int rows = T - s.src_drop[j];
+      if (o.tin >= 0 && rows != o.tin) return fail(MWW_ERR_INVALID, tag + "sources are not aligned to the same number of frames");
+      o.tin = rows;
+      o.cin += C;
+      o.src[j] = src;
+      o.toff[j] = s.src_drop[j];
+      if (src >= 0) {
+        o.needs_dx = true;
+        n_consumers[src]++;
+        ops[src].first_consumer = std::max(ops[src].first_consumer, i);
+        ops[src].last_consumer = ops[src].last_consumer < 0 ? i : std::min(ops[src].last_consumer, i);
+      }
+    }
+    o.tout = o.tin - (o.k - 1) * o.dil;
+    if (o.tout <= 0) return fail(MWW_ERR_INVALID, tag + "spectrogram too short for the kernel sizes");
+    if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
+    if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
+    if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
+    o.nq = std::max(1, std::min(8, kThreads / (o.k * o.cin)));
+    const int pad = (o.k - 1) * o.dil;
+    o.lds_fwd = ((size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
+    o.lds_dx = ((size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
+    o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
+    if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > 64 * 1024) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the 64 KB LDS tile");
+    o.o_w = off; off += (int64_t)o.k * o.cin * o.cout;
+    o.o_gamma = off; off += o.slots;
+    o.o_beta = off; off += o.slots;
+    o.o_mm = soff; soff += o.slots;
+    o.o_mv = soff; soff += o.slots;
+    if (o.needs_dx) { o.o_wt = wtoff; wtoff += (int64_t)o.k * o.cin * o.cout; }
+  }
+  for (int i = 0; i + 1 < d.n_ops; ++i)
+    if (n_consumers[i] == 0) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
+  if (n_consumers[d.n_ops - 1] != 0) return fail(MWW_ERR_INVALID, "the last op feeds the classifier head and cannot have other consumers");
+  ops[d.n_ops - 1].first_consumer = ops[d.n_ops - 1].last_consumer = d.n_ops;
+
+  mww_ctx* c = new mww_ctx();
+  memset(&c->d, 0, sizeof(c->d));
+  c->d.frames = d.frames;
+  c->d.max_batch = d.max_batch;
+  c->generic = true;
+  c->dropout = d.dropout;
+  c->G = ops;
+  {
+    int rco = open_device(c, device, stream);
+    if (rco) { mww_destroy(c); return rco; }
+  }
+  GOp& lo = c->G.back();
+  c->t_last = lo.tout;
+  c->c_last = lo.cout;
+  c->o_dense_w = off; off += (int64_t)lo.tout * lo.cout;
+  c->o_dense_b = off; off += 1;
+  c->P = off;
+  c->S = soff;
+  c->wt_total = wtoff;
+  c->dwd_stride = lo.tout * lo.cout + 4;
+  const size_t mb = (size_t)d.max_batch;
+  const int gmax = c->n_cu * 4;
+  int rc = 0;
+#define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
+  A(alloc_common(c));
+  A(dev_alloc(&c->wt, (size_t)wtoff));
+  A(dev_alloc(&c->keep, mb * lo.tout * lo.cout));
+  std::vector<BnSlots> bn;
+  for (GOp& o : c->G) {
+    A(dev_alloc(&o.p, mb * o.tout * o.cout));
+    A(dev_alloc(&o.g, mb * o.tout * o.cout));
+    A(dev_alloc(&o.stat_part, (size_t)gmax * 2 * o.cout));
+    A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
+    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.nq * o.k * o.cin * o.cout));
+    A(dev_alloc(&o.bn, (size_t)9 * o.cout));
+    bn.push_back(BnSlots{o.o_gamma, o.o_beta, o.o_mv, o.slots});
+  }
+  A(init_defaults(c, bn));
+#undef A
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return MWW_OK;
+}
+
+int mww_set_dropout_mask(mww_ctx* c, const uint8_t* keep, int B) {
+  if (!c || !c->generic) return fail(MWW_ERR_INVALID, "context has no dropout layer");
+  if (!keep) { c->keep_explicit = false; return MWW_OK; }
+  if (B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  if (!(c->dropout > 0.f)) return fail(MWW_ERR_STATE, "model was created with dropout = 0");
+  const size_t n = (size_t)B * c->t_last * c->c_last;
+  std::vector<float> h(n);
+  const float sc = 1.0f / (1.0f - c->dropout);
+  for (size_t i = 0; i < n; ++i) h[i] = keep[i] ? sc : 0.f;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->keep, h.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->keep_explicit = true;
   return MWW_OK;
 }
 
@@ -664,6 +1085,12 @@ void mww_destroy(mww_ctx* c) {
     void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
     for (void* p : lp) if (p) hipFree(p);
   }
+  for (auto& o : c->G) {
+    void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn};
+    for (void* p : op) if (p) hipFree(p);
+  }
+  if (c->wt) hipFree(c->wt);
+  if (c->keep) hipFree(c->keep);
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
   if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kRing; ++i) {
@@ -837,8 +1264,18 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     rc = push_hyper(c, adam_alpha(lr, c->step), 1.0f);
     if (rc) return rc;
   }
+  const bool gen_dropout = c->generic && c->dropout > 0.f && !c->keep_explicit;
+  if (gen_dropout) {
+    // the mask generator reads this step's counter from the mailbox (a graph node cannot carry it)
+    rc = mail_begin(c);
+    if (rc) return rc;
+    unsigned* h = reinterpret_cast<unsigned*>(c->mail_host[c->mail_cur] + c->mail_off_hyper);
+    h[2] = (unsigned)(c->dropout_counter & 0xFFFFFFFFull);
+    h[3] = (unsigned)(c->dropout_counter >> 32);
+    c->dropout_counter += 1;
+  }
   if (c->use_graphs && !c->profile) {
-    const int mail = apply ? c->mail_cur : -1;   // only the Adam node reads the mailbox
+    const int mail = (apply || gen_dropout) ? c->mail_cur : -1;   // only the Adam / dropout nodes read the mailbox
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail) exec = g.exec;
@@ -941,6 +1378,25 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
     return (k >= 1 && k <= nb && name[pl] >= '0' && name[pl] <= '9') ? k - 1 : -1;
   };
   int k;
+  if (c->generic) {
+    const int no = (int)c->G.size();
+    auto gidx = [&](const char* prefix) -> int {
+      const size_t pl = strlen(prefix);
+      if (strncmp(name, prefix, pl) != 0 || name[pl] < '0' || name[pl] > '9') return -1;
+      const int kk = atoi(name + pl);
+      return (kk >= 1 && kk <= no) ? kk - 1 : -1;
+    };
+    if ((k = gidx("p")) >= 0) { src = c->G[k].p; n = (int64_t)B * c->G[k].tout * c->G[k].cout; }
+    else if ((k = gidx("g")) >= 0) { src = c->G[k].g; n = (int64_t)B * c->G[k].tout * c->G[k].cout; }
+    else if ((k = gidx("bn")) >= 0) { src = c->G[k].bn; n = (int64_t)9 * c->G[k].cout; }
+    else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
+    else if (!strcmp(name, "keep")) { src = c->keep; n = (int64_t)B * c->t_last * c->c_last; }
+    else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
+    else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
+    if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");
+    int rcg = copy_out(c, host, src, (size_t)n * sizeof(float));
+    return rcg ? rcg : n;
+  }
   if ((k = idx("p")) >= 0) { src = c->L[k].p; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
   else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
   else if ((k = idx("bn")) >= 0) { src = c->L[k].bn; n = (int64_t)9 * c->L[k].cout; }
@@ -970,6 +1426,8 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
+  else if (!strcmp(name, "grid_graph")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_graph out of range"); c->grid_g = (int)v; }
+  else if (!strcmp(name, "dropout_seed")) { c->dropout_seed = (unsigned long long)v; c->dropout_counter = 0; }
   else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
   else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);

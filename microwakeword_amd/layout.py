@@ -215,6 +215,13 @@ class MixedNetLayout:
         seg += [("dense.kernel", self.t_last * self.c_last), ("dense.bias", 1)]
         return seg
 
+    def summary_lines(self):
+        yield "input                      [B, %d, %d]" % (self.frames, FEATURE_BINS)
+        yield "conv1 %dx1 /%d -> %d, relu    [B, %d, %d]" % (self.conv1_kernel, self.stride, self.conv1_filters, self.blocks[0].tin, self.conv1_filters)
+        for i, b in enumerate(self.blocks):
+            yield "block %d: mixconv %s + 1x1 %d->%d + BN + relu   [B, %d, %d]" % (i, list(b.kernel_sizes), b.cin, b.cout, b.tout, b.cout)
+        yield "flatten + dense(1, sigmoid)  [B, 1]"
+
     def grad_mask(self) -> np.ndarray:
         parts = [np.ones(self.conv1_kernel * FEATURE_BINS * self.conv1_filters, np.float32)]
         for b in self.blocks:
@@ -226,3 +233,127 @@ class MixedNetLayout:
             parts += [m.reshape(-1), np.ones(b.cin + b.cin * b.cout + 2 * b.cout, np.float32)]
         parts.append(np.ones(self.t_last * self.c_last + 1, np.float32))
         return np.concatenate(parts)
+
+
+class InceptionLayout:
+    """Shape derivation and Keras-order weight mapping of the reference's Inception model
+    (microwakeword/inception.py:232-340) as a list of conv -> BN/SSN -> ReLU ops for
+    ``mww_create_convnet`` (include/mww.h).  Ops are in layer-creation order, so the native parameter
+    vector is ``get_weights()`` order with the BN moving statistics split off into the state vector.
+
+      * stem: Conv2D(k x 1, valid, no bias) + SubSpectralNormalization + ReLU   inception.py:261-279
+      * block: branch1 1x1; branch2 1x1 -> kx1; branch3 1x1 -> kx1 -> kx1; StridedDrop of the leading
+        frames of branch1/2 to branch3's length; concatenate; 1x1 reduce         inception.py:281-328
+      * Flatten -> Dropout -> Dense(1, sigmoid)                                  inception.py:330-338
+      * ``spectrogram_slices_dropped``                                           inception.py:212-230
+    """
+
+    def __init__(self, flags, frames: int):
+        self.frames = int(frames)
+        self.dropout = float(_flag(flags, "dropout"))
+        stem = list(zip(parse(_flag(flags, "cnn1_filters")), parse(_flag(flags, "cnn1_kernel_sizes")),
+                        parse(_flag(flags, "cnn1_subspectral_groups"))))
+        blocks = list(zip(parse(_flag(flags, "cnn2_filters1")), parse(_flag(flags, "cnn2_filters2")),
+                          parse(_flag(flags, "cnn2_kernel_sizes")), parse(_flag(flags, "cnn2_subspectral_groups")),
+                          parse(_flag(flags, "cnn2_dilation"))))
+        self.ops: List[dict] = []
+        self.op_names: List[str] = []
+        self.keras_vars: List[Tuple[str, Tuple[int, ...], str]] = []
+        t, c, cur = self.frames, FEATURE_BINS, -1
+
+        def add(name, src, drop, cin, tin, k, dil, filters, groups):
+            if filters % groups:
+                # sub_spectral_normalization.py:41-45
+                raise ValueError("input_shape[3]: %d must be divisible by self.sub_groups %d " % (filters, groups))
+            tout = tin - (k - 1) * dil
+            if tout <= 0:
+                raise ValueError("spectrogram of %d frames is too short for this network" % frames)
+            slots = groups if groups > 1 else filters
+            self.ops.append(dict(src=list(src), drop=list(drop), kernel=int(k), dilation=int(dil), filters=int(filters),
+                                 bn_groups=int(groups), cin=int(cin), tin=int(tin), tout=int(tout), slots=int(slots)))
+            self.op_names.append(name)
+            self.keras_vars.append((name + ".kernel", (int(k), 1, int(cin), int(filters)), "param"))
+            self.keras_vars.append((name + ".bn.gamma", (slots,), "param"))
+            self.keras_vars.append((name + ".bn.beta", (slots,), "param"))
+            self.keras_vars.append((name + ".bn.moving_mean", (slots,), "state"))
+            self.keras_vars.append((name + ".bn.moving_variance", (slots,), "state"))
+            return len(self.ops) - 1, tout
+
+        for i, (f, k, g) in enumerate(stem):
+            cur, t = add("stem%d" % i, [cur], [0], c, t, k, 1, f, g)
+            c = int(f)
+        for i, (f1, f2, k, g, dil) in enumerate(blocks):
+            n = "i%d." % i
+            b1, t1 = add(n + "b1", [cur], [0], c, t, 1, 1, f1, g)
+            b2a, _ = add(n + "b2a", [cur], [0], c, t, 1, 1, f1, g)
+            b2, t2 = add(n + "b2b", [b2a], [0], f1, t, k, dil, f1, g)
+            b3a, _ = add(n + "b3a", [cur], [0], c, t, 1, 1, f1, g)
+            b3b, t3b = add(n + "b3b", [b3a], [0], f1, t, k, dil, f1, g)
+            b3, t3 = add(n + "b3c", [b3b], [0], f1, t3b, k, dil, f1, g)
+            cur, t = add(n + "red", [b1, b2, b3], [t1 - t3, t2 - t3, 0], 3 * f1, t3, 1, 1, f2, 1)
+            c = int(f2)
+        if not self.ops:
+            raise NotImplementedError("an Inception model without any convolution")
+        self.t_last, self.c_last = t, c
+        self.keras_vars.append(("dense.kernel", (t * c, 1), "param"))
+        self.keras_vars.append(("dense.bias", (1,), "param"))
+        self.n_params = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "param")
+        self.n_state = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "state")
+
+    def keras_param_counts(self):
+        total = sum(int(np.prod(s)) for _, s, _ in self.keras_vars)
+        return total, self.n_params
+
+    def engine_args(self, max_batch):
+        return dict(frames=self.frames, conv_ops=self.ops, dropout=self.dropout, max_batch=max_batch)
+
+    def pack(self, weights: Sequence[np.ndarray]):
+        if len(weights) != len(self.keras_vars):
+            raise ValueError("expected %d weight arrays, got %d" % (len(self.keras_vars), len(weights)))
+        params, state = [], []
+        for (name, shape, kind), w in zip(self.keras_vars, weights):
+            w = np.asarray(w, np.float32)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError("weight %s: expected shape %s, got %s" % (name, shape, w.shape))
+            (params if kind == "param" else state).append(w.reshape(-1))
+        return np.concatenate(params), np.concatenate(state)
+
+    def unpack(self, params: np.ndarray, state: np.ndarray) -> List[np.ndarray]:
+        params = np.asarray(params, np.float32).reshape(-1)
+        state = np.asarray(state, np.float32).reshape(-1)
+        if params.size != self.n_params or state.size != self.n_state:
+            raise ValueError("vector sizes do not match this model")
+        out, po, so = [], 0, 0
+        for _, shape, kind in self.keras_vars:
+            n = int(np.prod(shape))
+            if kind == "param":
+                out.append(params[po:po + n].reshape(shape).copy())
+                po += n
+            else:
+                out.append(state[so:so + n].reshape(shape).copy())
+                so += n
+        return out
+
+    def segments(self):
+        return [(name, int(np.prod(shape))) for name, shape, kind in self.keras_vars if kind == "param"]
+
+    def grad_mask(self) -> np.ndarray:
+        return np.ones(self.n_params, np.float32)
+
+    def summary_lines(self):
+        yield "input                                   [B, %d, %d]" % (self.frames, FEATURE_BINS)
+        for name, op in zip(self.op_names, self.ops):
+            norm = "SSN(%d)" % op["bn_groups"] if op["bn_groups"] > 1 else "BN"
+            yield "%-8s conv %dx1 d%d %d->%d + %s + relu   [B, %d, %d]" % (name, op["kernel"], op["dilation"], op["cin"], op["filters"],
+                                                                          norm, op["tout"], op["filters"])
+        yield "flatten + dropout(%g) + dense(1, sigmoid)   [B, 1]" % self.dropout
+
+
+def inception_slices_dropped(flags) -> int:
+    """inception.py:212-230."""
+    dropped = 0
+    for kernel_size in parse(_flag(flags, "cnn1_kernel_sizes")):
+        dropped += kernel_size - 1
+    for kernel_size, dilation in zip(parse(_flag(flags, "cnn2_kernel_sizes")), parse(_flag(flags, "cnn2_dilation"))):
+        dropped += 2 * dilation * (kernel_size - 1)
+    return dropped

@@ -78,11 +78,13 @@ class _Counts:
 
 
 class Model:
-    def __init__(self, flags, shape, batch_size, device=0, stream=None, lib=None, seed=None, max_batch=None):
+    def __init__(self, flags, shape, batch_size, device=0, stream=None, lib=None, seed=None, max_batch=None, layout=None,
+                 name="mixednet"):
         if tuple(shape)[1] != FEATURE_BINS:
             raise ValueError("input shape must be (spectrogram_length, 40)")
         self.flags = flags
-        self.layout = MixedNetLayout(flags, int(shape[0]))
+        self.name = name
+        self.layout = layout if layout is not None else MixedNetLayout(flags, int(shape[0]))
         self.input_shape = (batch_size, int(shape[0]), FEATURE_BINS)
         self.batch_size = batch_size
         mb = int(max_batch or max(int(batch_size or 1), 1024))
@@ -242,13 +244,9 @@ class Model:
 
     def summary(self, print_fn=print):
         total, trainable = self.layout.keras_param_counts()
-        lay = self.layout
-        print_fn("Model: mixednet on MI355X engine (%s)" % self.engine.nl.version())
-        print_fn("input                      [B, %d, %d]" % (lay.frames, FEATURE_BINS))
-        print_fn("conv1 %dx1 -> %d, relu       [B, %d, %d]" % (lay.conv1_kernel, lay.conv1_filters, lay.blocks[0].tin, lay.conv1_filters))
-        for i, b in enumerate(lay.blocks):
-            print_fn("block %d: mixconv %s + 1x1 %d->%d + BN + relu   [B, %d, %d]" % (i, list(b.kernel_sizes), b.cin, b.cout, b.tout, b.cout))
-        print_fn("flatten + dense(1, sigmoid)  [B, 1]")
+        print_fn("Model: %s on MI355X engine (%s)" % (self.name, self.engine.nl.version()))
+        for line in self.layout.summary_lines():
+            print_fn(line)
         print_fn("Total params: %d" % total)
         print_fn("Trainable params: %d" % trainable)
         print_fn("Non-trainable params: %d" % (total - trainable))

@@ -17,6 +17,7 @@ import sys
 
 import yaml
 
+from . import inception
 from . import mixednet
 from .data import FeatureHandler
 from . import train as train_mod
@@ -81,7 +82,7 @@ def build_parser():
     parser.add_argument("--verbosity", type=str, default="INFO")
     parser.add_argument("--device", type=int, default=0, help="HIP device index (one process per GPU)")
     subparsers = parser.add_subparsers(dest="model_name", help="NN model name")
-    subparsers.add_parser("inception")
+    inception.model_parameters(subparsers.add_parser("inception"))
     mixednet.model_parameters(subparsers.add_parser("mixednet"))
     return parser
 
@@ -94,7 +95,7 @@ def main(argv=None):
     if flags.model_name == "mixednet":
         model_module = mixednet
     elif flags.model_name == "inception":
-        raise NotImplementedError("the inception topology is not implemented by the MI355X engine yet (DESIGN.md §8)")
+        model_module = inception
     else:
         raise ValueError("Unknown model type: {}".format(flags.model_name))
     logging.basicConfig(level=getattr(logging, flags.verbosity.upper(), logging.INFO))

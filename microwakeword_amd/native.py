@@ -32,6 +32,20 @@ class MixedNetDesc(C.Structure):
                 ("block_kernel", C.c_int32 * MWW_MAX_BLOCKS), ("max_batch", C.c_int32)]
 
 
+MWW_MAX_GRAPH_OPS = 48
+MWW_MAX_OP_SOURCES = 3
+
+
+class ConvBnOp(C.Structure):
+    _fields_ = [("n_src", C.c_int32), ("src", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_drop", C.c_int32 * MWW_MAX_OP_SOURCES),
+                ("kernel", C.c_int32), ("dilation", C.c_int32), ("filters", C.c_int32), ("bn_groups", C.c_int32)]
+
+
+class ConvNetDesc(C.Structure):
+    _fields_ = [("frames", C.c_int32), ("n_ops", C.c_int32), ("ops", ConvBnOp * MWW_MAX_GRAPH_OPS),
+                ("dropout", C.c_float), ("max_batch", C.c_int32)]
+
+
 class Window(C.Structure):
     _fields_ = [("store", C.c_int32), ("pad_rows", C.c_int32), ("copy_rows", C.c_int32), ("reserved", C.c_int32),
                 ("src_elem", C.c_int64)]
@@ -60,7 +74,8 @@ class NativeError(RuntimeError):
 
 
 EXPORTS = [
-    "mww_version", "mww_last_error", "mww_device_count", "mww_create", "mww_destroy", "mww_synchronize",
+    "mww_version", "mww_last_error", "mww_device_count", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
+    "mww_destroy", "mww_synchronize",
     "mww_num_params", "mww_num_bn_state", "mww_set_params", "mww_get_params", "mww_set_bn_state", "mww_get_bn_state",
     "mww_set_grad_mask", "mww_set_opt_state", "mww_get_opt_state", "mww_get_grads", "mww_upload_store",
     "mww_assemble_batch", "mww_set_batch", "mww_get_batch", "mww_set_targets", "mww_train_step", "mww_apply_gradients",
@@ -95,6 +110,8 @@ class NativeLib:
         L.mww_version.restype = C.c_char_p
         L.mww_last_error.restype = C.c_char_p
         L.mww_create.argtypes = [C.POINTER(MixedNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mww_create_convnet.argtypes = [C.POINTER(ConvNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mww_set_dropout_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mww_destroy.argtypes = [C.c_void_p]
         L.mww_destroy.restype = None
         L.mww_synchronize.argtypes = [C.c_void_p]
@@ -153,9 +170,36 @@ class NativeLib:
 class Engine:
     """One device context (``mww_ctx``): model weights, HBM-resident feature stores, the train step."""
 
-    def __init__(self, frames, conv1_filters, conv1_kernel, conv1_stride, block_filters, block_kernel, max_batch,
-                 device=0, stream=None, lib: Optional[NativeLib] = None):
+    def __init__(self, frames, conv1_filters=None, conv1_kernel=None, conv1_stride=1, block_filters=(), block_kernel=(),
+                 max_batch=1024, device=0, stream=None, lib: Optional[NativeLib] = None, conv_ops=None, dropout=0.0):
+        """MixedNet topology from the ``conv1_*`` / ``block_*`` arguments, or — when ``conv_ops`` is given —
+        a conv/BN graph: a list of dicts ``{src: [...], drop: [...], kernel, dilation, filters, bn_groups}``
+        (``mww_conv_bn_op``) with the classifier head on the last one."""
         self.nl = lib or NativeLib.get()
+        self.max_batch = int(max_batch)
+        self.frames = int(frames)
+        if conv_ops is not None:
+            d = ConvNetDesc()
+            d.frames, d.n_ops, d.dropout, d.max_batch = int(frames), len(conv_ops), float(dropout), int(max_batch)
+            if len(conv_ops) > MWW_MAX_GRAPH_OPS:
+                raise ValueError("too many ops")
+            for i, op in enumerate(conv_ops):
+                o = d.ops[i]
+                src, drop = list(op["src"]), list(op.get("drop", [0] * len(op["src"])))
+                if len(src) > MWW_MAX_OP_SOURCES or len(src) != len(drop):
+                    raise ValueError("bad source lists")
+                o.n_src = len(src)
+                for j, (sj, dj) in enumerate(zip(src, drop)):
+                    o.src[j], o.src_drop[j] = int(sj), int(dj)
+                o.kernel, o.dilation, o.filters = int(op["kernel"]), int(op.get("dilation", 1)), int(op["filters"])
+                o.bn_groups = int(op.get("bn_groups", 1))
+            self.desc = d
+            h = C.c_void_p()
+            self.nl.check(self.nl.lib.mww_create_convnet(C.byref(d), int(device), C.c_void_p(stream or 0), C.byref(h)))
+            self.h = h
+            self.n_params = int(self.nl.lib.mww_num_params(h))
+            self.n_state = int(self.nl.lib.mww_num_bn_state(h))
+            return
         d = MixedNetDesc()
         d.frames, d.conv1_filters, d.conv1_kernel, d.conv1_stride = frames, conv1_filters, conv1_kernel, conv1_stride
         d.n_blocks = len(block_filters)
@@ -266,6 +310,14 @@ class Engine:
         if y.size != w.size:
             raise ValueError("labels and weights differ in length")
         self.nl.check(self.nl.lib.mww_set_targets(self.h, _fptr(y), _fptr(w), y.size))
+
+    def set_dropout_mask(self, keep):
+        """``keep`` [B, T_last*C_last] of 0/1 (None = built-in generator)."""
+        if keep is None:
+            self.nl.check(self.nl.lib.mww_set_dropout_mask(self.h, None, 0))
+            return
+        k = np.ascontiguousarray(np.asarray(keep) != 0, np.uint8)
+        self.nl.check(self.nl.lib.mww_set_dropout_mask(self.h, k.ctypes.data_as(C.c_void_p), k.shape[0]))
 
     # ---- compute
     def train_step(self, B, lr, flags=0):

@@ -281,17 +281,22 @@ def mixednet_logits(flags, tensors, x, training, taps=None):
 def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None):
     cur = _Cursor(tensors, training)
     net = x.transpose(1, 2)
+    def tap(name, t):
+        if taps is not None:
+            taps[name + ".pre_bn"] = t.transpose(1, 2)
+        return t
+
     for i, g in enumerate(parse(_get(flags, "cnn1_subspectral_groups"))):
-        net = torch.relu(cur.bn(cur.conv(net, "stem%d" % i), "stem%d.bn" % i, g))
+        net = torch.relu(cur.bn(tap("stem%d" % i, cur.conv(net, "stem%d" % i)), "stem%d.bn" % i, g))
     for i, (g, dil) in enumerate(zip(parse(_get(flags, "cnn2_subspectral_groups")), parse(_get(flags, "cnn2_dilation")))):
         def cb(inp, name, d=1):
-            return torch.relu(cur.bn(cur.conv(inp, "i%d.%s" % (i, name), dilation=d), "i%d.%s.bn" % (i, name), g))
+            return torch.relu(cur.bn(tap("i%d.%s" % (i, name), cur.conv(inp, "i%d.%s" % (i, name), dilation=d)), "i%d.%s.bn" % (i, name), g))
         b1 = cb(net, "b1")
         b2 = cb(cb(net, "b2a"), "b2b", dil)
         b3 = cb(cb(cb(net, "b3a"), "b3b", dil), "b3c", dil)
         t3 = b3.shape[2]
         net = torch.cat([b1[:, :, b1.shape[2] - t3:], b2[:, :, b2.shape[2] - t3:], b3], dim=1)
-        net = torch.relu(cur.bn(cur.conv(net, "i%d.red" % i), "i%d.red.bn" % i))
+        net = torch.relu(cur.bn(tap("i%d.red" % i, cur.conv(net, "i%d.red" % i)), "i%d.red.bn" % i))
     flat = net.transpose(1, 2).reshape(net.shape[0], -1)
     if training and _get(flags, "dropout", 0.0) > 0:
         keep = 1.0 - _get(flags, "dropout")

@@ -265,3 +265,147 @@ def check_training_reduces_loss(lib, B=8, T=194, steps=8):
     eng.close()
     assert losses[-1] < losses[0], losses
     return losses
+
+
+# ------------------------------------------------------------------------------------------ inception
+INC = dict(mo.INCEPTION_DEFAULTS)
+# every option away from its default: two stem layers, dilation, sub-spectral groups inside the blocks
+INC_VARIANT = dict(cnn1_filters="16,24", cnn1_kernel_sizes="3,5", cnn1_subspectral_groups="2,4", cnn2_filters1="12,16",
+                   cnn2_filters2="10,16", cnn2_kernel_sizes="3,5", cnn2_subspectral_groups="2,1", cnn2_dilation="2,1", dropout=0.3)
+
+
+def perturbed_inception_oracle(T, flags, seed=42):
+    om = mo.OracleModel("inception", flags, T, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    ws = []
+    for v, w in zip(om.vars, om.get_weights()):
+        if v.name.endswith(("bias", "beta", "moving_mean")):
+            w = w + rng.normal(0, 0.1, w.shape).astype(np.float32)
+        if v.name.endswith(("gamma", "moving_variance")):
+            w = w + np.abs(rng.normal(0, 0.2, w.shape)).astype(np.float32)
+        ws.append(w)
+    om.set_weights(ws)
+    return om
+
+
+def make_inception_engine(lib, T, max_batch, om, flags):
+    from microwakeword_amd.layout import InceptionLayout
+    lay = InceptionLayout(flags, T)
+    eng = native.Engine(lib=lib, **lay.engine_args(max_batch))
+    p, s = lay.pack(om.get_weights())
+    eng.set_params(p)
+    eng.set_bn_state(s)
+    return lay, eng
+
+
+def check_inception_forward(lib, B=3, T=194, training=False, grid=None, flags=INC):
+    om = perturbed_inception_oracle(T, flags)
+    lay, eng = make_inception_engine(lib, T, max(B, 2), om, flags)
+    if grid:
+        for k in ("grid_graph", "grid_head"):
+            eng.set_option(k, grid)
+    rng = np.random.default_rng(7)
+    x = synth_x(rng, B, T)
+    eng.set_batch(x)
+    # mww_forward(training=1) uses batch statistics but no dropout (Dropout belongs to the train step)
+    eng.forward(B, training=training)
+    pr, z, _ = eng.read_outputs(B, want_loss=False)
+    taps = {}
+    keep = np.ones((B, lay.t_last * lay.c_last), np.float32) * (1.0 - flags["dropout"])   # keep/(1-rate) == 1
+    zo, _ = om.logits(x, training, dropout_mask=keep if training else None, taps=taps)
+    po = torch.sigmoid(zo).numpy()
+    for k, (name, op) in enumerate(zip(lay.op_names, lay.ops)):
+        got = eng.debug_read("p%d" % (k + 1), B, B * op["tout"] * op["filters"]).reshape(B, op["tout"], op["filters"])
+        ref = taps[name + ".pre_bn"].detach().numpy()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+    assert np.abs(pr - po).max() <= FWD_TOL, (pr, po)
+    assert np.abs(z - zo.detach().numpy()).max() <= 1e-3 * max(1.0, np.abs(zo.detach().numpy()).max())
+    eng.close()
+    return float(np.abs(pr - po).max())
+
+
+def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=INC):
+    om = perturbed_inception_oracle(T, flags)
+    lay, eng = make_inception_engine(lib, T, B, om, flags)
+    if grid:
+        for k in ("grid_graph", "grid_head"):
+            eng.set_option(k, grid)
+    if graphs:
+        eng.set_option("graphs", 1)
+    rng = np.random.default_rng(11)
+    l2s = []
+    for s in range(steps):
+        x = synth_x(rng, B, T)
+        y = (rng.random(B) < 0.5).astype(np.float32)
+        w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
+        keep = (rng.random((B, lay.t_last * lay.c_last)) >= flags["dropout"]).astype(np.float32)
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+        eng.set_dropout_mask(keep)
+        eng.train_step(B, lr)
+        pr, z, loss = eng.read_outputs(B)
+        lo, po, grads, _ = om.loss_and_grads(x, y, w, dropout_mask=keep)
+        g = eng.get_grads()
+        gref = lay.pack([grads[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)
+                         for n, shape, kind in lay.keras_vars])[0]
+        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+        assert np.abs(pr - po).max() <= FWD_TOL
+        scale = max(1e-6, float(np.abs(gref).max()))
+        off = 0
+        for name, n in lay.segments():
+            a, r = g[off:off + n], gref[off:off + n]
+            off += n
+            seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
+            l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
+            assert l2 <= 1e-3, (s, name, l2)
+            assert np.abs(a - r).max() <= 5e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
+            l2s.append(l2)
+        om.train_step(x, y, w, lr, dropout_mask=keep)
+        p_ref, s_ref = lay.pack(om.get_weights())
+        p_got, s_got = eng.get_params(), eng.get_bn_state()
+        well = np.abs(gref) > 1e-4 * scale
+        assert np.abs(p_got - p_ref)[well].max() <= 0.05 * lr, (s, np.abs(p_got - p_ref)[well].max())
+        assert np.abs(p_got - p_ref).max() <= 2.0 * lr
+        assert np.abs(s_got - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+        eng.set_params(p_ref)
+        eng.set_bn_state(s_ref)
+    m = native.metrics_from_raw(eng.metrics_raw())
+    r = om.metrics.result()
+    for k in ("accuracy", "recall", "precision", "auc"):
+        assert abs(m[k] - r[k]) < 1e-6, (k, m[k], r[k])
+    for k in ("tp", "fp", "tn", "fn"):
+        np.testing.assert_array_equal(m[k], r[k])
+    assert np.median(l2s) <= 2e-5
+    eng.close()
+    return max(l2s)
+
+
+def check_inception_generated_dropout(lib, B=4, T=194, flags=INC):
+    """Built-in mask generator: the kept fraction matches the rate, the mask changes every step, the
+    same seed reproduces it, and forward/backward use the same mask (gradient of a dropped input is 0)."""
+    om = perturbed_inception_oracle(T, flags)
+    lay, eng = make_inception_engine(lib, T, B, om, flags)
+    rng = np.random.default_rng(5)
+    x = synth_x(rng, B, T)
+    y = (np.arange(B) % 2).astype(np.float32)
+    eng.set_batch(x)
+    eng.set_targets(y, np.ones(B, np.float32))
+    n = lay.t_last * lay.c_last
+    masks = []
+    for rep in range(2):
+        eng.set_option("dropout_seed", 1234)
+        for step in range(2):
+            eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
+            k = eng.debug_read("keep", B, B * n).reshape(B, n)
+            masks.append(k.copy())
+            vals = np.unique(k)
+            assert set(np.round(vals, 5)) <= {0.0, round(1.0 / (1.0 - flags["dropout"]), 5)}
+            assert abs((k > 0).mean() - (1.0 - flags["dropout"])) < 0.04
+            lo, po, grads, _ = om.loss_and_grads(x, y, np.ones(B), dropout_mask=(k > 0).astype(np.float32))
+            _, _, loss = eng.read_outputs(B)
+            assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo))
+    assert not np.array_equal(masks[0], masks[1])
+    np.testing.assert_array_equal(masks[0], masks[2])
+    np.testing.assert_array_equal(masks[1], masks[3])
+    eng.close()

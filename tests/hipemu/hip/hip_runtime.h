@@ -58,6 +58,7 @@ unsigned wave_exchange(unsigned v, int src_lane);                 // 32-bit shuf
 void wave_exchange2(float a, float b, const float** A, const float** B);  // publish 2 floats, get arrays
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 int lane_id();
+void* dyn_shared();                                               // dynamic LDS of the running block
 }  // namespace hipemu
 
 #define threadIdx (hipemu::g_threadIdx)
@@ -171,6 +172,7 @@ void enqueue(hipStream_t st, std::function<void()> fn);  // runs now, or records
 }
 
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_shared());
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                  \
   do {                                                                                               \
     dim3 hipemu_g = (grid), hipemu_b = (block);                                                      \

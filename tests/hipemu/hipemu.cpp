@@ -48,6 +48,9 @@ void yield(State s) {
 
 int lane_id() { return cur & 63; }
 
+static std::vector<float> g_dyn_shared;
+void* dyn_shared() { return g_dyn_shared.data(); }
+
 void sync_block() { yield(WAIT_BLOCK); }
 
 unsigned wave_exchange(unsigned v, int src_lane) {
@@ -145,13 +148,15 @@ static void run_block(dim3 block, const std::function<void()>& body) {
   }
 }
 
-void launch(dim3 grid, dim3 block, size_t, const std::function<void()>& body) {
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   g_gridDim = grid;
   g_blockDim = block;
+  g_dyn_shared.assign(shmem / sizeof(float) + 4, NAN);   // poisoned: reads of unwritten LDS show up
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) {
         g_blockIdx = {x, y, z};
+        std::fill(g_dyn_shared.begin(), g_dyn_shared.end(), NAN);
         run_block(block, body);
       }
 }

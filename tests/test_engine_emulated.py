@@ -66,3 +66,21 @@ def test_notebook_topology_stride3_mixconv_groups(emu_lib):
     """first conv 5x1 stride 3, 64 filters, MixConv [7,11] / [9,15] groups (fused with zero taps + gradient mask)."""
     ec.check_forward_parity(emu_lib, B=2, T=204, training=True, grid=2, flags=ec.NOTEBOOK)
     ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=ec.NOTEBOOK)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_inception_forward(emu_lib, training):
+    ec.check_inception_forward(emu_lib, B=3, T=194, training=training, grid=2)
+
+
+def test_inception_train_steps(emu_lib):
+    ec.check_inception_train_steps(emu_lib, B=4, T=194, steps=2, grid=2)
+
+
+def test_inception_variant_dilation_groups_two_stems(emu_lib):
+    ec.check_inception_forward(emu_lib, B=2, T=120, training=True, grid=1, flags=ec.INC_VARIANT)
+    ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=2, graphs=True, flags=ec.INC_VARIANT)
+
+
+def test_inception_generated_dropout(emu_lib):
+    ec.check_inception_generated_dropout(emu_lib, B=3, T=120)

@@ -94,3 +94,27 @@ def test_notebook_topology_stride3_mixconv_groups(lib):
     ec.check_forward_parity(lib, B=4, T=204, training=False, flags=ec.NOTEBOOK)
     ec.check_forward_parity(lib, B=9, T=204, training=True, flags=ec.NOTEBOOK)
     ec.check_train_steps(lib, B=8, T=204, steps=2, grid=0, flags=ec.NOTEBOOK)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_inception_forward(lib, training):
+    """BASELINE config 4: default Inception (stem SSN(4), three 3-branch blocks), forward parity."""
+    ec.check_inception_forward(lib, B=9, T=194, training=training)
+
+
+def test_inception_forward_batch1024(lib):
+    assert ec.check_inception_forward(lib, B=1024, T=194, training=False) <= ec.FWD_TOL
+
+
+def test_inception_train_steps(lib):
+    ec.check_inception_train_steps(lib, B=8, T=194, steps=3, grid=0)
+    ec.check_inception_train_steps(lib, B=6, T=194, steps=2, grid=0, graphs=True)
+
+
+def test_inception_variant_dilation_groups_two_stems(lib):
+    ec.check_inception_forward(lib, B=5, T=120, training=True, flags=ec.INC_VARIANT)
+    ec.check_inception_train_steps(lib, B=6, T=120, steps=2, grid=3, flags=ec.INC_VARIANT)
+
+
+def test_inception_generated_dropout(lib):
+    ec.check_inception_generated_dropout(lib, B=16, T=194)

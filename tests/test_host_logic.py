@@ -183,3 +183,40 @@ def test_synthetic_generators_agree_with_oracle_copy():
     for sa, sb in zip(a, b):
         for x, y in zip(sa, sb):
             np.testing.assert_array_equal(x, y)
+
+
+def test_inception_flags_layout_and_oracle_order(tmp_path):
+    from microwakeword_amd import inception
+    p = argparse.ArgumentParser()
+    inception.model_parameters(p)
+    flags = p.parse_args([])
+    for k, v in mo.INCEPTION_DEFAULTS.items():
+        assert str(getattr(flags, k)) == str(v), k
+    assert inception.spectrogram_slices_dropped(flags) == mo.inception_slices_dropped(flags) == 28
+    L = lay.InceptionLayout(flags, 194)
+    om = mo.OracleModel("inception", vars(flags), 194, seed=1)
+    assert [n for n, _, _ in L.keras_vars] == [v.name for v in om.vars]
+    assert [tuple(s) for _, s, _ in L.keras_vars] == [v.value.shape for v in om.vars]
+    assert L.keras_param_counts() == om.n_params()
+    assert (L.t_last, L.c_last) == (166, 16) and len(L.ops) == 22
+    # StridedDrop alignment of the reduce conv: branch1 / branch2 lose their leading 8 / 4 frames
+    red = L.ops[7]
+    assert red["src"] == [1, 3, 6] and red["drop"] == [8, 4, 0] and red["cin"] == 30
+    ws = [w + 0.01 * (i + 1) for i, w in enumerate(om.get_weights())]
+    pv, sv = L.pack(ws)
+    assert pv.size == L.n_params and sv.size == L.n_state
+    for a, b in zip(ws, L.unpack(pv, sv)):
+        np.testing.assert_array_equal(a.astype(np.float32), b)
+    # sub-spectral groups must divide the filters (sub_spectral_normalization.py:41-45)
+    with pytest.raises(ValueError, match="divisible"):
+        lay.InceptionLayout(dict(mo.INCEPTION_DEFAULTS, cnn1_subspectral_groups="5"), 194)
+    with pytest.raises(ValueError, match="too short"):
+        lay.InceptionLayout(mo.INCEPTION_DEFAULTS, 20)
+    # config derivation through the CLI surface
+    cfg = dict(window_step_ms=10, train_dir=str(tmp_path / "m"), features=[], training_steps=[10], batch_size=8, clip_duration_ms=1500,
+               eval_step_interval=5, target_minimization=0.9, minimization_metric=None, maximization_metric="average_viable_recall")
+    f = tmp_path / "c.yaml"
+    f.write_text(yaml.dump(cfg))
+    fl = model_train_eval.build_parser().parse_args(["--training_config", str(f), "inception"])
+    c = model_train_eval.load_config(fl, inception)
+    assert (c["spectrogram_length_final_layer"], c["spectrogram_length"]) == (148, 176)
