@@ -116,14 +116,17 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   __shared__ float sRed[2 * kThreads];
+  constexpr int NCP = (NC + 3) / 4 * 4;   // weight rows padded to whole float4 (broadcast ds_read_b128)
   const int tid = threadIdx.x;
   const int PI = a.cin | 1, PO = NC | 1;
   const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
   const int rows_in = a.Tin + 2 * pad;
-  float* sIn = g_smem;
-  float* sOut = g_smem + rows_in * PI;
+  float* sW = g_smem;                       // [k*cin][NCP], loaded once per workgroup
+  float* sIn = sW + a.k * a.cin * NCP;
+  float* sOut = sIn + rows_in * PI;
   float s1[kGMaxSrc] = {0.f, 0.f, 0.f}, s2[kGMaxSrc] = {0.f, 0.f, 0.f};
 
+  for (int i = tid; i < a.k * a.cin * NC; i += kThreads) sW[(i / NC) * NCP + (i % NC)] = a.w[i];
   if (MODE == 1) {
     // the zero frames around dp are written once: staging only touches the middle
     for (int i = tid; i < pad * PI; i += kThreads) {
@@ -137,16 +140,23 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
     else stage_dp(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid);
     __syncthreads();
     for (int t = tid; t < a.Tout; t += kThreads) {
-      float acc[NC];
+      float acc[NCP];
 #pragma unroll
-      for (int co = 0; co < NC; ++co) acc[co] = 0.f;
+      for (int co = 0; co < NCP; ++co) acc[co] = 0.f;
       for (int j = 0; j < a.k; ++j) {
         const float* row = sIn + (t + j * a.dil) * PI;
-        const float* wj = a.w + (size_t)j * a.cin * NC;
+        const float4* wj = reinterpret_cast<const float4*>(sW + j * a.cin * NCP);
+#pragma unroll 2
         for (int ci = 0; ci < a.cin; ++ci) {
           const float v = row[ci];
 #pragma unroll
-          for (int co = 0; co < NC; ++co) acc[co] = fmaf(v, wj[ci * NC + co], acc[co]);
+          for (int c4 = 0; c4 < NCP / 4; ++c4) {
+            const float4 w = wj[ci * (NCP / 4) + c4];
+            acc[c4 * 4 + 0] = fmaf(v, w.x, acc[c4 * 4 + 0]);
+            if (c4 * 4 + 1 < NC) acc[c4 * 4 + 1] = fmaf(v, w.y, acc[c4 * 4 + 1]);
+            if (c4 * 4 + 2 < NC) acc[c4 * 4 + 2] = fmaf(v, w.z, acc[c4 * 4 + 2]);
+            if (c4 * 4 + 3 < NC) acc[c4 * 4 + 3] = fmaf(v, w.w, acc[c4 * 4 + 3]);
+          }
         }
       }
 #pragma unroll

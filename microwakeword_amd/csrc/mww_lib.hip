@@ -486,10 +486,16 @@ bool g_width_supported(int n) {
   return false;
 }
 
+// gfx950 has 160 KB of LDS per CU; tiles above the 64 KB default need the function attribute
+constexpr size_t kMaxDynLds = 144 * 1024;
+
 template <int MODE>
 int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, int grid, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
+    if (lds > 64 * 1024)                                                                                       \
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<N, MODE>),                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
     hipLaunchKernelGGL((gconv_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
     return MWW_OK;                                                                                             \
   }
@@ -854,7 +860,7 @@ int open_device(mww_ctx* c, int device, void* stream) {
   c->grid_fwd = c->n_cu * 4;
   c->grid_bwd = c->n_cu * 2;
   c->grid_head = c->n_cu * 4;
-  c->grid_g = c->n_cu * 2;
+  c->grid_g = c->n_cu * 4;
   return MWW_OK;
 }
 
@@ -996,10 +1002,12 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
     o.nq = std::max(1, std::min(8, kThreads / (o.k * o.cin)));
     const int pad = (o.k - 1) * o.dil;
-    o.lds_fwd = ((size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
-    o.lds_dx = ((size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
+    const size_t wf = (size_t)o.k * o.cin * ((o.cout + 3) / 4 * 4), wb = (size_t)o.k * o.cout * ((o.cin + 3) / 4 * 4);
+    o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
+    o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
     o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
-    if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > 64 * 1024) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the 64 KB LDS tile");
+    if (!o.needs_dx) o.lds_dx = 0;
+    if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > kMaxDynLds) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the LDS tile");
     o.o_w = off; off += (int64_t)o.k * o.cin * o.cout;
     o.o_gamma = off; off += o.slots;
     o.o_beta = off; off += o.slots;
@@ -1426,7 +1434,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
-  else if (!strcmp(name, "grid_graph")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_graph out of range"); c->grid_g = (int)v; }
+  else if (!strcmp(name, "grid_graph")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_graph out of range"); c->grid_g = (int)v; }
   else if (!strcmp(name, "dropout_seed")) { c->dropout_seed = (unsigned long long)v; c->dropout_counter = 0; }
   else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
   else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);

@@ -318,6 +318,35 @@ class FeatureHandler:
         return np.array(win, native.WINDOW_DTYPE) if win else np.zeros(0, native.WINDOW_DTYPE), \
             np.array(labels), np.array(weights)
 
+    def evaluate_on_device(self, model, mode: str, features_length: int, truncation_strategy: str = "default",
+                           batch_size: int = 1024):
+        """``get_data(mode, ...)`` + ``model.evaluate(x, y, batch_size)`` (train.py:42-58,75-96) without the
+        host round trip of the spectrograms: the windows are gathered from the HBM-resident stores
+        straight into the engine's batch buffer, the inference-mode forward runs on them and the
+        threshold counters accumulate on the device.  Consumes the same ``np.random.shuffle`` draw as
+        ``get_data`` so the global RNG stream stays where the reference would leave it.  Like Keras'
+        ``evaluate`` it starts by calling ``model.reset_metrics()`` (looked up at call time, so the
+        reference's no-op swap still works).  Returns ``(n_windows, labels, model metric results)``."""
+        self._need_engine()
+        if model.engine is not self.engine:
+            raise ValueError("model and FeatureHandler must share one engine")
+        if truncation_strategy == "none":
+            raise NotImplementedError("variable-length ('none') evaluation is outside the MI355X path")
+        win, labels, _ = self._eval_windows(mode, features_length, truncation_strategy)
+        n = win.shape[0]
+        indices = np.arange(n)
+        np.random.shuffle(indices)
+        win, labels = win[indices], labels[indices].astype(np.float32)
+        model.reset_metrics()
+        bs = min(int(batch_size), self.engine.max_batch)
+        ones = np.ones(bs, np.float32)
+        for s in range(0, n, bs):
+            e = min(n, s + bs)
+            self.engine.set_targets(labels[s:e], ones[:e - s])
+            self.engine.assemble(win[s:e], None, 0, 0)
+            self.engine.forward(e - s, training=False, update_metrics=True)
+        return n, labels, model.evaluation_results()
+
     def get_data(self, mode: str, batch_size: int, features_length: int, truncation_strategy: str = "default",
                  augmentation_policy: dict = DEFAULT_POLICY):
         """Same contract as the reference (data.py:497-597): returns host arrays

@@ -204,13 +204,17 @@ class Model:
             self.engine.set_batch(x[s:e])
             self.engine.set_targets(y[s:e], np.ones(e - s, np.float32))
             self.engine.forward(e - s, training=False, update_metrics=True)
-        m = self._metric_results()
-        res = dict(accuracy=m["accuracy"], recall=m["recall"], precision=m["precision"], auc=m["auc"], loss=m["loss"],
-                   tp=_Counts(m["tp"]), fp=_Counts(m["fp"]), tn=_Counts(m["tn"]), fn=_Counts(m["fn"]))
+        res = self.evaluation_results()
         if return_dict:
             return res
         return [res["loss"], res["accuracy"], res["recall"], res["precision"], res["tp"], res["fp"], res["tn"], res["fn"],
                 res["auc"], res["loss"]]
+
+    def evaluation_results(self):
+        """The ``return_dict=True`` result of ``evaluate`` from the counters accumulated so far."""
+        m = self._metric_results()
+        return dict(accuracy=m["accuracy"], recall=m["recall"], precision=m["precision"], auc=m["auc"], loss=m["loss"],
+                    tp=_Counts(m["tp"]), fp=_Counts(m["fp"]), tn=_Counts(m["tn"]), fn=_Counts(m["fn"]))
 
     # ---- persistence
     def save_weights(self, path):

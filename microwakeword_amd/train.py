@@ -44,26 +44,39 @@ def _trapezoid(y, x):
     return fn(y, x)
 
 
+def _on_device(data_processor, model):
+    return hasattr(data_processor, "evaluate_on_device") and hasattr(model, "evaluation_results") \
+        and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
+
+
 def validate_nonstreaming(config, data_processor, model, test_set):
-    fingerprints, ground_truth, _ = data_processor.get_data(
-        test_set, batch_size=config["batch_size"], features_length=config["spectrogram_length"],
-        truncation_strategy="truncate_start")
-    ground_truth = ground_truth.reshape(-1, 1)
-    model.reset_metrics()
-    result = model.evaluate(fingerprints, ground_truth, batch_size=1024, return_dict=True, verbose=0)
+    fast = _on_device(data_processor, model)
+    if fast:
+        # spectrogram windows never leave HBM
+        _, _, result = data_processor.evaluate_on_device(model, test_set, config["spectrogram_length"], "truncate_start", 1024)
+    else:
+        fingerprints, ground_truth, _ = data_processor.get_data(
+            test_set, batch_size=config["batch_size"], features_length=config["spectrogram_length"],
+            truncation_strategy="truncate_start")
+        ground_truth = ground_truth.reshape(-1, 1)
+        model.reset_metrics()
+        result = model.evaluate(fingerprints, ground_truth, batch_size=1024, return_dict=True, verbose=0)
     metrics = {k: result[k] for k in ("accuracy", "recall", "precision", "auc", "loss")}
     metrics.update(recall_at_no_faph=0, cutoff_for_no_faph=0, ambient_false_positives=0,
                    ambient_false_positives_per_hour=0, average_viable_recall=0)
     test_set_fp = result["fp"].numpy()
 
     if data_processor.get_mode_size("validation_ambient") > 0:
-        amb_x, amb_y, _ = data_processor.get_data(
-            test_set + "_ambient", batch_size=config["batch_size"], features_length=config["spectrogram_length"],
-            truncation_strategy="split")
-        amb_y = amb_y.reshape(-1, 1)
         # keep accumulating into the same counters (the reference swaps reset_metrics for a no-op)
         with swap_attribute(model, "reset_metrics", lambda: None):
-            amb = model.evaluate(amb_x, amb_y, batch_size=1024, return_dict=True, verbose=0)
+            if fast:
+                _, _, amb = data_processor.evaluate_on_device(model, test_set + "_ambient", config["spectrogram_length"], "split", 1024)
+            else:
+                amb_x, amb_y, _ = data_processor.get_data(
+                    test_set + "_ambient", batch_size=config["batch_size"], features_length=config["spectrogram_length"],
+                    truncation_strategy="split")
+                amb_y = amb_y.reshape(-1, 1)
+                amb = model.evaluate(amb_x, amb_y, batch_size=1024, return_dict=True, verbose=0)
         hours = data_processor.get_mode_duration("validation_ambient") / 3600.0
         all_tp = amb["tp"].numpy()
         ambient_fp = amb["fp"].numpy() - test_set_fp

@@ -278,8 +278,19 @@ def mixednet_logits(flags, tensors, x, training, taps=None):
     return z, cur.new_stats
 
 
-def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None):
+def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None, relu_masks=None):
+    """``relu_masks`` (test aid): {op name: bool [B,C,T]} replaces the ReLU decisions ``v > 0`` of the
+    named ops — used to compare gradients under identical decisions when an activation sits within
+    float32 rounding of zero (the decision itself is checked separately)."""
     cur = _Cursor(tensors, training)
+
+    def act(v, name):
+        if taps is not None:
+            taps[name + ".bn_out"] = v.transpose(1, 2)
+        if relu_masks is not None and name in relu_masks:
+            return v * relu_masks[name].to(v.dtype)
+        return torch.relu(v)
+
     net = x.transpose(1, 2)
     def tap(name, t):
         if taps is not None:
@@ -287,16 +298,17 @@ def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None):
         return t
 
     for i, g in enumerate(parse(_get(flags, "cnn1_subspectral_groups"))):
-        net = torch.relu(cur.bn(tap("stem%d" % i, cur.conv(net, "stem%d" % i)), "stem%d.bn" % i, g))
+        net = act(cur.bn(tap("stem%d" % i, cur.conv(net, "stem%d" % i)), "stem%d.bn" % i, g), "stem%d" % i)
     for i, (g, dil) in enumerate(zip(parse(_get(flags, "cnn2_subspectral_groups")), parse(_get(flags, "cnn2_dilation")))):
         def cb(inp, name, d=1):
-            return torch.relu(cur.bn(tap("i%d.%s" % (i, name), cur.conv(inp, "i%d.%s" % (i, name), dilation=d)), "i%d.%s.bn" % (i, name), g))
+            return act(cur.bn(tap("i%d.%s" % (i, name), cur.conv(inp, "i%d.%s" % (i, name), dilation=d)), "i%d.%s.bn" % (i, name), g),
+                       "i%d.%s" % (i, name))
         b1 = cb(net, "b1")
         b2 = cb(cb(net, "b2a"), "b2b", dil)
         b3 = cb(cb(cb(net, "b3a"), "b3b", dil), "b3c", dil)
         t3 = b3.shape[2]
         net = torch.cat([b1[:, :, b1.shape[2] - t3:], b2[:, :, b2.shape[2] - t3:], b3], dim=1)
-        net = torch.relu(cur.bn(tap("i%d.red" % i, cur.conv(net, "i%d.red" % i)), "i%d.red.bn" % i))
+        net = act(cur.bn(tap("i%d.red" % i, cur.conv(net, "i%d.red" % i)), "i%d.red.bn" % i), "i%d.red" % i)
     flat = net.transpose(1, 2).reshape(net.shape[0], -1)
     if training and _get(flags, "dropout", 0.0) > 0:
         keep = 1.0 - _get(flags, "dropout")
@@ -433,34 +445,35 @@ class OracleModel:
             t[v.name] = x
         return t
 
-    def logits(self, x, training=False, tensors=None, dropout_mask=None, taps=None):
+    def logits(self, x, training=False, tensors=None, dropout_mask=None, taps=None, relu_masks=None):
         tensors = tensors or self._tensors(False)
         x = torch.as_tensor(np.asarray(x), dtype=self.dtype)
         if self.kind == "mixednet":
             return mixednet_logits(self.flags, tensors, x, training, taps)
         dm = None if dropout_mask is None else torch.as_tensor(np.asarray(dropout_mask), dtype=self.dtype)
-        return inception_logits(self.flags, tensors, x, training, dm, taps)
+        rm = None if relu_masks is None else {k: torch.as_tensor(np.asarray(v)) for k, v in relu_masks.items()}
+        return inception_logits(self.flags, tensors, x, training, dm, taps, rm)
 
     def predict(self, x, training=False):
         with torch.no_grad():
             z, _ = self.logits(x, training)
         return torch.sigmoid(z).numpy()
 
-    def loss_and_grads(self, x, y, w, dropout_mask=None):
+    def loss_and_grads(self, x, y, w, dropout_mask=None, relu_masks=None):
         """-> (loss, probs, {name: grad}, new_moving_stats) for one batch, training mode."""
         t = self._tensors(True)
-        z, new_stats = self.logits(x, True, t, dropout_mask)
+        z, new_stats = self.logits(x, True, t, dropout_mask, relu_masks=relu_masks)
         yt = torch.as_tensor(np.asarray(y, np.float64).reshape(-1), dtype=self.dtype)
         wt = torch.as_tensor(np.asarray(w, np.float64).reshape(-1), dtype=self.dtype)
         loss, p = weighted_loss(z, yt, wt)
         names = [v.name for v in self.vars if v.trainable]
         grads = torch.autograd.grad(loss, [t[n] for n in names])
-        return float(loss), p.detach().numpy(), dict(zip(names, grads)), new_stats
+        return float(loss.detach()), p.detach().numpy(), dict(zip(names, grads)), new_stats
 
-    def train_step(self, x, y, w, lr, dropout_mask=None):
+    def train_step(self, x, y, w, lr, dropout_mask=None, relu_masks=None):
         """One ``train_on_batch`` (train.py:295-299): forward(training) -> weighted BCE -> grads ->
         Keras Adam -> BN moving stats -> metric update.  Returns (loss, probs)."""
-        loss, p, grads, new_stats = self.loss_and_grads(x, y, w, dropout_mask)
+        loss, p, grads, new_stats = self.loss_and_grads(x, y, w, dropout_mask, relu_masks)
         tr = [v for v in self.vars if v.trainable]
         if self.adam is None:
             self.adam = KerasAdam([v.value.shape for v in tr], self.dtype)

@@ -345,7 +345,25 @@ def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graph
         eng.set_dropout_mask(keep)
         eng.train_step(B, lr)
         pr, z, loss = eng.read_outputs(B)
-        lo, po, grads, _ = om.loss_and_grads(x, y, w, dropout_mask=keep)
+        # fp32 (engine) vs fp64 (oracle): a BN output within float32 rounding of zero can land on the other
+        # side of the ReLU (a few per million activations).  The decisions the engine took are read back
+        # (exact sign of fma(p, scale, shift)), checked to differ from the oracle's only at such near-zero
+        # values, and then imposed on the oracle so that the gradient comparison is between identical graphs.
+        taps = {}
+        om.logits(x, True, dropout_mask=keep, taps=taps)
+        masks, flips = {}, 0
+        for k, (name, op) in enumerate(zip(lay.op_names, lay.ops)):
+            n_el = B * op["tout"] * op["filters"]
+            pk = eng.debug_read("p%d" % (k + 1), B, n_el).reshape(B, op["tout"], op["filters"]).astype(np.float64)
+            bn = eng.debug_read("bn%d" % (k + 1), B, 9 * op["filters"]).reshape(9, op["filters"]).astype(np.float64)
+            m = (pk * bn[0] + bn[1]) > 0
+            ref = taps[name + ".bn_out"].detach().numpy()
+            diff = m != (ref > 0)
+            flips += int(diff.sum())
+            assert np.abs(ref[diff]).max(initial=0.0) <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(ref[diff]).max())
+            masks[name] = np.ascontiguousarray(m.transpose(0, 2, 1))
+        assert flips <= 8, flips
+        lo, po, grads, _ = om.loss_and_grads(x, y, w, dropout_mask=keep, relu_masks=masks)
         g = eng.get_grads()
         gref = lay.pack([grads[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)
                          for n, shape, kind in lay.keras_vars])[0]
@@ -358,10 +376,10 @@ def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graph
             off += n
             seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
             l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
-            assert l2 <= 1e-3, (s, name, l2)
-            assert np.abs(a - r).max() <= 5e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
+            assert l2 <= 1e-4, (s, name, l2)
+            assert np.abs(a - r).max() <= 1e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
             l2s.append(l2)
-        om.train_step(x, y, w, lr, dropout_mask=keep)
+        om.train_step(x, y, w, lr, dropout_mask=keep, relu_masks=masks)
         p_ref, s_ref = lay.pack(om.get_weights())
         p_got, s_got = eng.get_params(), eng.get_bn_state()
         well = np.abs(gref) > 1e-4 * scale
@@ -409,3 +427,62 @@ def check_inception_generated_dropout(lib, B=4, T=194, flags=INC):
     np.testing.assert_array_equal(masks[0], masks[2])
     np.testing.assert_array_equal(masks[1], masks[3])
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------ validation
+class _HostOnly:
+    """Hides the device fast path of a FeatureHandler so validate_nonstreaming takes the reference's
+    get_data -> evaluate route."""
+
+    def __init__(self, fh):
+        self._fh = fh
+
+    def get_data(self, *a, **k):
+        return self._fh.get_data(*a, **k)
+
+    def get_mode_size(self, m):
+        return self._fh.get_mode_size(m)
+
+    def get_mode_duration(self, m):
+        return self._fh.get_mode_duration(m)
+
+
+def check_validation_on_device(lib, gold, tag="u16"):
+    """validate_nonstreaming (train.py:41-163) with the windows kept in HBM gives the same numbers as the
+    host-array route, consumes the same RNG draws, and its counters match the oracle's Keras-metric
+    restatement fed with the oracle model's own predictions."""
+    from microwakeword_amd import train as tr
+    from microwakeword_amd.model import Model
+    T = 194
+    om = perturbed_oracle(T)
+    model = Model(DEF, (T, 40), 16, lib=lib, max_batch=16)
+    model.set_weights(om.get_weights())
+    cfg = dict(golden_config(gold, tag), batch_size=16, spectrogram_length=T)
+    fh = FeatureHandler(cfg, engine=model.engine)
+    random.seed(5)
+    np.random.seed(5)
+    fast = tr.validate_nonstreaming(cfg, fh, model, "validation")
+    tail_fast = np.random.random()
+    fast_counts = {k: model.evaluation_results()[k].numpy().copy() for k in ("tp", "fp", "tn", "fn")}
+    random.seed(5)
+    np.random.seed(5)
+    slow = tr.validate_nonstreaming(cfg, _HostOnly(fh), model, "validation")
+    assert tail_fast == np.random.random()
+    assert set(fast) == set(slow)
+    for k in fast:
+        assert np.allclose(fast[k], slow[k], rtol=0, atol=1e-12), (k, fast[k], slow[k])
+    for k, v in fast_counts.items():
+        np.testing.assert_array_equal(v, model.evaluation_results()[k].numpy())
+    # oracle: same windows through the CPU restatement + Keras-metric bucketing
+    np.random.seed(5)
+    xv, yv, _ = fh.get_data("validation", 16, T, "truncate_start")
+    xa, ya, _ = fh.get_data("validation_ambient", 16, T, "split")
+    met = mo.Metrics()
+    met.update(om.predict(xv), yv)
+    met.update(om.predict(xa), ya)
+    r = met.result()
+    for k in ("tp", "fp", "tn", "fn"):
+        np.testing.assert_array_equal(fast_counts[k], r[k])
+    assert abs(fast["auc"] - r["auc"]) < 1e-6 and abs(fast["loss"] - r["loss"]) < 1e-5
+    model.engine.close()
+    return fast

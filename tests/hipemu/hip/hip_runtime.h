@@ -171,6 +171,8 @@ namespace hipemu {
 void enqueue(hipStream_t st, std::function<void()> fn);  // runs now, or records when capturing
 }
 
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_shared());
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                  \

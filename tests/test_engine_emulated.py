@@ -84,3 +84,7 @@ def test_inception_variant_dilation_groups_two_stems(emu_lib):
 
 def test_inception_generated_dropout(emu_lib):
     ec.check_inception_generated_dropout(emu_lib, B=3, T=120)
+
+
+def test_validation_on_device(emu_lib, gold):
+    ec.check_validation_on_device(emu_lib, gold, "u16")

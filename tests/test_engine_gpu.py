@@ -118,3 +118,9 @@ def test_inception_variant_dilation_groups_two_stems(lib):
 
 def test_inception_generated_dropout(lib):
     ec.check_inception_generated_dropout(lib, B=16, T=194)
+
+
+@pytest.mark.parametrize("tag", ["u16", "f32"])
+def test_validation_on_device(lib, gold, tag):
+    """validation forward + threshold metrics with the windows resident in HBM."""
+    ec.check_validation_on_device(lib, gold, tag)
