@@ -151,6 +151,21 @@ int mww_set_targets(mww_ctx* ctx, const float* host_y, const float* host_w, int 
 int mww_train_step(mww_ctx* ctx, int B, float learning_rate, int flags);
 int mww_apply_gradients(mww_ctx* ctx, float learning_rate, float grad_scale);
 
+/* ---- data-parallel exchange.  The caller owns the communicator (RCCL through
+ * torch.distributed, one process per GPU); the library calls back whenever a buffer has to be summed
+ * over the ranks.  The callback must ENQUEUE an in-place sum all-reduce of device_buf[0..n) on the
+ * context's stream (no host synchronisation needed) and return 0.
+ *   sync_bn = 1: BatchNorm statistics are exchanged in every train step — per BN layer one all-reduce of
+ *                (sum x, sum x^2) in the forward and one of (sum g, sum g*xhat) in the backward — so the W
+ *                ranks normalise over the GLOBAL batch exactly like the single-device reference ("parity
+ *                mode"; 2 x layers tiny all-reduces on the critical path, no hipGraph replay).
+ *   sync_bn = 0: local-batch statistics ("throughput mode").
+ *   reduce_grads = 1: mww_train_step also all-reduces the flat gradient through the callback and applies
+ *                Adam to the rank average, i.e. it is the complete data-parallel step.
+ * fn = NULL removes the hook. */
+typedef int (*mww_allreduce_fn)(void* user, float* device_buf, int64_t n);
+int mww_set_allreduce_hook(mww_ctx* ctx, mww_allreduce_fn fn, void* user, int world_size, int sync_bn, int reduce_grads);
+
 /* ---- inference forward on the current batch: replaces model(x, training=...) /
  * model.evaluate's per-batch forward (train.py:50-58). training=1 uses batch statistics without
  * touching the moving averages. update_metrics=1 also accumulates the compiled metrics. */

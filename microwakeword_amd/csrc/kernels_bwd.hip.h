@@ -614,6 +614,7 @@ struct BnBwdFinalizeArgs {
   float* mgx;               // mean g*xhat
   float* dgamma;            // -> flat gradient
   float* dbeta;
+  float dscale;             // 1 (local statistics) or 1/W (sums already all-reduced: the gradient all-reduce adds them W times)
 };
 
 __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
@@ -630,8 +631,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalize
   __syncthreads();
   if (tid == 0) {
     const double s1 = sOut[0], s2 = sOut[1];
-    a.dbeta[c] = (float)s1;
-    a.dgamma[c] = (float)s2;
+    a.dbeta[c] = (float)s1 * a.dscale;
+    a.dgamma[c] = (float)s2 * a.dscale;
     a.c1[c] = gam * rs;
     a.mg[c] = (float)(s1 * (double)a.inv_n);
     a.mgx[c] = (float)(s2 * (double)a.inv_n);

@@ -462,6 +462,19 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalize
   }
 }
 
+// sync-BN: this rank's partials [G][2][C] -> sums [2][C] in a fixed order, ready to be all-reduced
+struct StatCollapseArgs {
+  const float* part;
+  int G, C;
+  float* out;   // [2][C]
+};
+__global__ __launch_bounds__(kThreads) void stat_collapse_kernel(StatCollapseArgs a) {
+  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  const double r = reduce_partials_256(a.part, a.G, a.C, c, sAcc, tid);
+  if ((tid & 127) == 0) a.out[(tid >> 7) * a.C + c] = (float)r;
+}
+
 // inference: fold the moving statistics of every BN layer (state = [mean|var] per layer, packed)
 struct BnEvalPrepareArgs {
   const float* gamma;

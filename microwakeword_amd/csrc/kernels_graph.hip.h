@@ -375,6 +375,7 @@ struct GBnBwdArgs {
   const float* rstd;         // [C]
   float *c1, *mg, *mgx;      // [C]
   float *dgamma, *dbeta;     // [slots] -> flat gradient
+  float dscale;              // 1, or 1/W when the sums were all-reduced (see BnBwdFinalizeArgs)
 };
 __global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a) {
   __shared__ double sAcc[2 * kThreads];
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a
     a.mgx[c] = (float)(t2 * (double)a.inv_n);
   }
   if (tid == 0) {
-    a.dbeta[slot] = (float)t1;
-    a.dgamma[slot] = (float)t2;
+    a.dbeta[slot] = (float)t1 * a.dscale;
+    a.dgamma[slot] = (float)t2 * a.dscale;
   }
 }
 

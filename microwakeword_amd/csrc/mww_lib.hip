@@ -91,6 +91,13 @@ struct mww_ctx {
   float* wt = nullptr;              // transposed weights of the ops with a data gradient
   int64_t wt_total = 0;
   int grid_g = 0;
+  // data-parallel exchange hook (mww_set_allreduce_hook)
+  mww_allreduce_fn hook = nullptr;
+  void* hook_user = nullptr;
+  int world = 1;
+  bool sync_bn = false, reduce_grads = false;
+  float* sync_buf = nullptr;        // [layers][fwd 2C | bwd 2C] statistics sums being exchanged
+  std::vector<int64_t> sync_off;    // offset of layer i in sync_buf
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr, *stage = nullptr;
   unsigned char* direct = nullptr;
   float* bn_state = nullptr;
@@ -284,6 +291,31 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
   return MWW_OK;
 }
 
+// sync-BN: collapse this rank's partials, sum them over the ranks through the caller's hook, and hand
+// the result to the finalize kernel as a single "partial" row.  Returns the pointer / row count /
+// element count the finalize kernel should use.
+struct StatSource { const float* part; int G; float inv_n; float dscale; };
+
+int exchange_stats(mww_ctx* c, Launcher& lp, const char* what, int layer, const float* part, int G, int C, int bwd,
+                   float local_inv_n, StatSource* out) {
+  out->part = part;
+  out->G = G;
+  out->inv_n = local_inv_n;
+  out->dscale = 1.0f;
+  if (!(c->hook && c->sync_bn)) return MWW_OK;
+  float* buf = c->sync_buf + c->sync_off[layer] + (bwd ? 2 * C : 0);
+  StatCollapseArgs a{part, G, C, buf};
+  lp.begin(what, layer);
+  hipLaunchKernelGGL(stat_collapse_kernel, dim3(C), dim3(kThreads), 0, c->stream, a);
+  lp.end();
+  if (c->hook(c->hook_user, buf, 2 * C) != 0) return fail(MWW_ERR_STATE, "all-reduce hook failed");
+  out->part = buf;
+  out->G = 1;
+  out->inv_n = local_inv_n / (float)c->world;
+  out->dscale = 1.0f / (float)c->world;
+  return MWW_OK;
+}
+
 int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics);
 int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam);
 
@@ -322,7 +354,10 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       if (rc) return rc;
     }
     if (training) {
-      BnFwdFinalizeArgs f{l.stat_part, grid, l.cout, 1.0f / ((float)B * (float)l.tout), c->params + l.o_gamma,
+      StatSource ss;
+      int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, l.stat_part, grid, l.cout, 0, 1.0f / ((float)B * (float)l.tout), &ss);
+      if (rcs) return rcs;
+      BnFwdFinalizeArgs f{ss.part, ss.G, l.cout, ss.inv_n, c->params + l.o_gamma,
                           c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv, bn_slot(l, BN_SCALE),
                           bn_slot(l, BN_SHIFT), bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), update_moving ? 1 : 0};
       lp.begin("bn_fwd_finalize", i);
@@ -361,6 +396,8 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
 
 // gradient assembly: fixed-order sum of the per-workgroup partials (+ the dense layer's, which come
 // from the side stream), structural mask, optionally fused with the Adam update
+int enqueue_adam(mww_ctx* c);
+
 int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam) {
   Launcher lp{c};
   int rcj = join_side(c);
@@ -385,6 +422,15 @@ int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam)
                      c->stream, ga);
   lp.end();
   GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
+  if (fuse_adam && c->hook && c->reduce_grads) {
+    // complete data-parallel step: local gradient -> sum over the ranks -> Adam on the average
+    // (the 1/W factor travels as the gradient scale next to the step size, see mww_train_step)
+    lp.begin("grad_finish");
+    hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
+    lp.end();
+    if (c->hook(c->hook_user, c->grads, c->P) != 0) return fail(MWW_ERR_STATE, "all-reduce hook failed");
+    return enqueue_adam(c);
+  }
   if (fuse_adam) {
     AdamArgs aa{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
     lp.begin("grad_finish_adam");
@@ -408,9 +454,13 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
-    BnBwdFinalizeArgs f{l.gstat_part, last ? ghead : gbwd, l.cout, 1.0f / ((float)B * (float)l.tout),
+    StatSource ss;
+    int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, l.gstat_part, last ? ghead : gbwd, l.cout, 1,
+                             1.0f / ((float)B * (float)l.tout), &ss);
+    if (rcs) return rcs;
+    BnBwdFinalizeArgs f{ss.part, ss.G, l.cout, ss.inv_n,
                         c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
-                        bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta};
+                        bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta, ss.dscale};
     lp.begin("bn_bwd_finalize", i);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(l.cout), dim3(kThreads), 0, c->stream, f);
     lp.end();
@@ -580,7 +630,11 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     if (rc) return rc;
     if (training) {
       const int members = o.groups > 1 ? o.cout / o.groups : 1;
-      GBnFwdArgs f{o.stat_part, gg, o.cout, o.groups, 1.0f / ((float)B * (float)o.tout * (float)members),
+      StatSource ss;
+      int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, o.stat_part, gg, o.cout, 0,
+                               1.0f / ((float)B * (float)o.tout * (float)members), &ss);
+      if (rcs) return rcs;
+      GBnFwdArgs f{ss.part, ss.G, o.cout, o.groups, ss.inv_n,
                    c->params + o.o_gamma, c->params + o.o_beta, c->bn_state + o.o_mm, c->bn_state + o.o_mv,
                    gbn_slot(o, BN_SCALE), gbn_slot(o, BN_SHIFT), gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), update_moving ? 1 : 0};
       lp.begin("bn_fwd_finalize", i);
@@ -655,9 +709,13 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   for (int i = n - 1; i >= 0; --i) {
     GOp& o = c->G[i];
     const int members = o.groups > 1 ? o.cout / o.groups : 1;
-    GBnBwdArgs f{o.gstat_part, i == n - 1 ? ghead : gg, o.cout, o.groups, 1.0f / ((float)B * (float)o.tout * (float)members),
+    StatSource ss;
+    int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, o.gstat_part, i == n - 1 ? ghead : gg, o.cout, 1,
+                             1.0f / ((float)B * (float)o.tout * (float)members), &ss);
+    if (rcs) return rcs;
+    GBnBwdArgs f{ss.part, ss.G, o.cout, o.groups, ss.inv_n,
                  c->params + o.o_gamma, gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX),
-                 c->grads + o.o_gamma, c->grads + o.o_beta};
+                 c->grads + o.o_gamma, c->grads + o.o_beta, ss.dscale};
     lp.begin("bn_bwd_finalize", i);
     hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
     lp.end();
@@ -1064,6 +1122,27 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   return MWW_OK;
 }
 
+int mww_set_allreduce_hook(mww_ctx* c, mww_allreduce_fn fn, void* user, int world_size, int sync_bn, int reduce_grads) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  if (fn && world_size < 1) return fail(MWW_ERR_INVALID, "world size must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->hook = fn;
+  c->hook_user = user;
+  c->world = fn ? world_size : 1;
+  c->sync_bn = fn && sync_bn;
+  c->reduce_grads = fn && reduce_grads;
+  if (c->sync_bn && !c->sync_buf) {
+    int64_t off = 0;
+    c->sync_off.clear();
+    if (c->generic) for (auto& o : c->G) { c->sync_off.push_back(off); off += 4 * (int64_t)o.cout; }
+    else for (auto& l : c->L) { c->sync_off.push_back(off); off += 4 * (int64_t)l.cout; }
+    int rc = dev_alloc(&c->sync_buf, (size_t)off);
+    if (rc) return rc;
+  }
+  return MWW_OK;
+}
+
 int mww_set_dropout_mask(mww_ctx* c, const uint8_t* keep, int B) {
   if (!c || !c->generic) return fail(MWW_ERR_INVALID, "context has no dropout layer");
   if (!keep) { c->keep_explicit = false; return MWW_OK; }
@@ -1097,6 +1176,7 @@ void mww_destroy(mww_ctx* c) {
     void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn};
     for (void* p : op) if (p) hipFree(p);
   }
+  if (c->sync_buf) hipFree(c->sync_buf);
   if (c->wt) hipFree(c->wt);
   if (c->keep) hipFree(c->keep);
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
@@ -1269,7 +1349,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
   const bool apply = !(flags & MWW_STEP_NO_APPLY);
   if (apply) {
     c->step += 1;
-    rc = push_hyper(c, adam_alpha(lr, c->step), 1.0f);
+    rc = push_hyper(c, adam_alpha(lr, c->step), (c->hook && c->reduce_grads) ? 1.0f / (float)c->world : 1.0f);
     if (rc) return rc;
   }
   const bool gen_dropout = c->generic && c->dropout > 0.f && !c->keep_explicit;
@@ -1282,7 +1362,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     h[3] = (unsigned)(c->dropout_counter >> 32);
     c->dropout_counter += 1;
   }
-  if (c->use_graphs && !c->profile) {
+  if (c->use_graphs && !c->profile && !c->hook) {   // the exchange hook enqueues foreign work: no capture
     const int mail = (apply || gen_dropout) ? c->mail_cur : -1;   // only the Adam / dropout nodes read the mailbox
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)

@@ -69,12 +69,16 @@ class SamplerDesc(C.Structure):
                 ("cutoff_offsets", C.POINTER(C.c_int32)), ("cutoffs", C.POINTER(C.c_int32))]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)   # mww_allreduce_fn
+
+
 class NativeError(RuntimeError):
     pass
 
 
 EXPORTS = [
     "mww_version", "mww_last_error", "mww_device_count", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
+    "mww_set_allreduce_hook",
     "mww_destroy", "mww_synchronize",
     "mww_num_params", "mww_num_bn_state", "mww_set_params", "mww_get_params", "mww_set_bn_state", "mww_get_bn_state",
     "mww_set_grad_mask", "mww_set_opt_state", "mww_get_opt_state", "mww_get_grads", "mww_upload_store",
@@ -112,6 +116,7 @@ class NativeLib:
         L.mww_create.argtypes = [C.POINTER(MixedNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mww_create_convnet.argtypes = [C.POINTER(ConvNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mww_set_dropout_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.mww_set_allreduce_hook.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.mww_destroy.argtypes = [C.c_void_p]
         L.mww_destroy.restype = None
         L.mww_synchronize.argtypes = [C.c_void_p]
@@ -318,6 +323,27 @@ class Engine:
             return
         k = np.ascontiguousarray(np.asarray(keep) != 0, np.uint8)
         self.nl.check(self.nl.lib.mww_set_dropout_mask(self.h, k.ctypes.data_as(C.c_void_p), k.shape[0]))
+
+    def set_allreduce_hook(self, fn, world_size=1, sync_bn=False, reduce_grads=False):
+        """``fn(device_ptr: int, n: int) -> None`` must enqueue an in-place sum all-reduce of ``n`` floats
+        at ``device_ptr`` on this engine's stream (see ``parallel.DataParallel``); ``None`` removes it."""
+        if fn is None:
+            self._hook = ALLREDUCE_FN(0)
+            self.nl.check(self.nl.lib.mww_set_allreduce_hook(self.h, self._hook, None, 1, 0, 0))
+            return
+
+        def tramp(_user, ptr, n):
+            try:
+                fn(int(ptr), int(n))
+                return 0
+            except Exception:   # a Python exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        self._hook = ALLREDUCE_FN(tramp)   # keep the trampoline alive as long as the engine uses it
+        self.nl.check(self.nl.lib.mww_set_allreduce_hook(self.h, self._hook, None, int(world_size), int(bool(sync_bn)),
+                                                         int(bool(reduce_grads))))
 
     # ---- compute
     def train_step(self, B, lr, flags=0):

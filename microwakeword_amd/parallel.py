@@ -9,8 +9,11 @@ new work defined by SURVEY §8(e):
   * local forward/backward -> flat gradient of the LOCAL mean loss;
   * all-reduce(sum), then Adam consumes grad/W (== gradient of the global-batch mean loss);
   * weights, Adam slots and the step counter stay bit-identical across ranks because every rank
-    applies the same reduced gradient; BN moving statistics are rank-local batch statistics
-    ("local-BN" throughput mode; sync-BN is not implemented yet and is stated as such in DESIGN.md).
+    applies the same reduced gradient;
+  * BatchNorm: ``sync_bn=False`` ("throughput mode", the default and what bench.py measures) normalises
+    over the rank's own batch; ``sync_bn=True`` ("parity mode") exchanges the per-channel statistics
+    sums of every BN layer in the forward and in the backward through ``mww_set_allreduce_hook``, so
+    W ranks x B/W windows reproduce the single-device step on the global batch (no hipGraph replay).
 """
 from __future__ import annotations
 
@@ -52,19 +55,38 @@ class DataParallel:
     engine's flat gradient / parameter vectors (device memory on the GPU path)."""
 
     def __init__(self, engine, grad_view: torch.Tensor, param_view: torch.Tensor, state_view: Optional[torch.Tensor] = None,
-                 group=None):
+                 group=None, sync_bn: bool = False, wrap=None):
+        """``wrap(ptr, n) -> tensor`` turns a device address handed out by the engine into a tensor the
+        process group can reduce in place (defaults to a zero-copy view of HBM on the engine's device)."""
         self.engine = engine
         self.grad_view, self.param_view, self.state_view = grad_view, param_view, state_view
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sync_bn = bool(sync_bn)
+        self._wrap = wrap
+        self._views = {}
+        if self.sync_bn:
+            if wrap is None:
+                raise ValueError("sync_bn needs a wrap(ptr, n) function")
+            # the engine calls back for every BN layer (and for the gradient): the complete DP step
+            engine.set_allreduce_hook(self._allreduce, self.world, sync_bn=True, reduce_grads=True)
 
     @classmethod
-    def for_engine(cls, engine: native.Engine, device, group=None):
+    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False):
         g = wrap_device_floats(engine.device_ptr(native.BUF_GRADS), engine.n_params, device)
         p = wrap_device_floats(engine.device_ptr(native.BUF_PARAMS), engine.n_params, device)
         s = wrap_device_floats(engine.device_ptr(native.BUF_BN_STATE), engine.n_state, device)
-        return cls(engine, g, p, s, group)
+        return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=lambda ptr, n: wrap_device_floats(ptr, n, device))
+
+    def _allreduce(self, ptr: int, n: int):
+        """Hook target: enqueue sum-all-reduce of n floats at ptr (views are cached per buffer).  With
+        the engine created on torch's current stream the collective is ordered with its kernels."""
+        t = self._views.get((ptr, n))
+        if t is None:
+            t = self._views[(ptr, n)] = self._wrap(ptr, n)
+        if dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_parameters(self, src=0):
         if dist.is_initialized():
@@ -75,6 +97,9 @@ class DataParallel:
 
     def train_step(self, B, lr, flags=0):
         """Local forward/backward, gradient all-reduce, Adam on the averaged gradient."""
+        if self.sync_bn:
+            self.engine.train_step(B, lr, flags)   # statistics and gradient exchanges happen inside, via the hook
+            return
         self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
         if dist.is_initialized():
             dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group)

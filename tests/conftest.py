@@ -20,3 +20,33 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+EMU = os.path.join(ROOT, "tests", "hipemu", "libmww_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build_emulator_lib():
+    """TEST INFRASTRUCTURE: compiles the unchanged product HIP sources as host C++ against tests/hipemu
+    (fibers + emulated wave ops) and returns the path of the resulting library, or None without clang++."""
+    import subprocess
+    csrc = os.path.join(ROOT, "microwakeword_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("mww_lib.hip", "sampler.cpp")] + [os.path.join(ROOT, "tests", "hipemu", "hipemu.cpp")]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    deps += [os.path.join(ROOT, "include", "mww.h"), os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")]
+    if not os.path.isfile(CLANG):
+        return None
+    if not os.path.isfile(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "hipemu"),
+               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value"] + srcs + ["-o", EMU]
+        subprocess.run(cmd, check=True)
+    return EMU
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    from microwakeword_amd import native
+    path = build_emulator_lib()
+    if path is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    return native.NativeLib(path)

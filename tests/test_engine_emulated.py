@@ -2,32 +2,12 @@
 checks them against oracle/.  This is a *debugging aid for the kernels' index logic* — it is not a
 product path and proves nothing about the GPU build; the real parity tests are tests/test_engine_gpu.py."""
 import os
-import subprocess
 
 import numpy as np
 import pytest
 
 import engine_checks as ec
 from microwakeword_amd import native
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "hipemu", "libmww_emu.so")
-CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-
-
-@pytest.fixture(scope="session")
-def emu_lib():
-    srcs = [os.path.join(ROOT, "microwakeword_amd", "csrc", f) for f in ("mww_lib.hip", "sampler.cpp")] + [os.path.join(ROOT, "tests", "hipemu", "hipemu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "microwakeword_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "microwakeword_amd", "csrc"))]
-    deps += [os.path.join(ROOT, "include", "mww.h"), os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")]
-    if not os.path.isfile(CLANG):
-        pytest.skip("clang++ not available for the host-side emulator build")
-    if not os.path.isfile(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
-        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "hipemu"),
-               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value"] + srcs + ["-o", EMU]
-        subprocess.run(cmd, check=True)
-    return native.NativeLib(EMU)
-
 
 @pytest.fixture(scope="module")
 def gold(golden_dir):

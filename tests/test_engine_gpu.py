@@ -124,3 +124,56 @@ def test_inception_generated_dropout(lib):
 def test_validation_on_device(lib, gold, tag):
     """validation forward + threshold metrics with the windows resident in HBM."""
     ec.check_validation_on_device(lib, gold, tag)
+
+
+def test_sync_bn_exchange_through_rccl_world1(lib):
+    """The statistics / gradient exchange hook on the real device path: engine on a torch stream, RCCL
+    process group of one rank, zero-copy views of the engine's HBM.  With W=1 the step must equal the
+    plain one; what is exercised is the collapse -> all-reduce -> single-row finalize route, the hook
+    trampoline and the stream ordering between the engine's kernels and the collectives."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from microwakeword_amd.layout import MixedNetLayout
+    from microwakeword_amd.parallel import DataParallel
+    T, B = 194, 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    device = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    try:
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            om = ec.perturbed_oracle(T)
+            lay = MixedNetLayout(ec.DEF, T)
+            eng = native.Engine(lib=lib, stream=stream.cuda_stream, **lay.engine_args(B))
+            p, st = lay.pack(om.get_weights())
+            eng.set_params(p)
+            eng.set_bn_state(st)
+            dp = DataParallel.for_engine(eng, device, sync_bn=True)
+            rng = np.random.default_rng(11)
+            x = ec.synth_x(rng, B, T)
+            y = (rng.random(B) < 0.5).astype(np.float32)
+            w = np.ones(B, np.float32)
+            eng.set_batch(x)
+            eng.set_targets(y, w)
+            dp.train_step(B, 1e-3)
+            pr, _, loss = eng.read_outputs(B)
+            g = eng.get_grads()
+            lo, po, grads, _ = om.loss_and_grads(x, y, w)
+            gref = ec.oracle_grads_native_order(lay, om, grads)
+            assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo))
+            assert np.abs(pr - po).max() <= ec.FWD_TOL
+            assert np.linalg.norm(g - gref) <= 2e-3 * np.linalg.norm(gref)
+            om.train_step(x, y, w, 1e-3)
+            p_ref, s_ref = lay.pack(om.get_weights())
+            well = np.abs(gref) > 1e-4 * np.abs(gref).max()
+            assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * 1e-3
+            assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+            eng.close()
+    finally:
+        dist.destroy_process_group()

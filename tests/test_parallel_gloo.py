@@ -138,3 +138,95 @@ def test_sharding_partitions_every_provider_and_splits_rng_streams():
         h = _Handler()
         h.feature_providers = [_Prov(2)]
         shard_feature_handler(h, 2, 3, seed=0)
+
+
+# ------------------------------------------------------------------------------------------ sync-BN
+# Two ranks, each running the PRODUCT kernels (host-emulated, tests/hipemu) on half of a global batch with
+# sync_bn=True, against the single-process oracle on the whole batch: W ranks x B/W windows must
+# reproduce the single-device train step (loss normalisation, BN statistics, gradients, Adam, moving stats).
+def _sync_worker(rank, world, port, out_dir, emu_path, kind):
+    import ctypes as C
+
+    import engine_checks as ec
+    from microwakeword_amd import native
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    lib = native.NativeLib(emu_path)
+    Bl = 3
+    z = np.load(os.path.join(out_dir, "inputs.npz"))
+    if kind == "mixednet":
+        om = ec.perturbed_oracle(T)
+        lay, eng = ec.make_engine(lib, T, Bl, om)
+    else:
+        om = ec.perturbed_inception_oracle(T, ec.INC)
+        lay, eng = ec.make_inception_engine(lib, T, Bl, om, ec.INC)
+        eng.set_dropout_mask(z["keep"][rank * Bl:(rank + 1) * Bl])
+
+    def wrap(ptr, n):   # emulated "device" memory is host memory
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_float * n).from_address(ptr)))
+
+    g = wrap(eng.device_ptr(native.BUF_GRADS), eng.n_params)
+    p = wrap(eng.device_ptr(native.BUF_PARAMS), eng.n_params)
+    dp = DataParallel(eng, g, p, None, sync_bn=True, wrap=wrap)
+    assert dp.world == world
+    eng.set_batch(z["x"][rank * Bl:(rank + 1) * Bl])
+    eng.set_targets(z["y"][rank * Bl:(rank + 1) * Bl], z["w"][rank * Bl:(rank + 1) * Bl])
+    dp.train_step(Bl, 1e-3)
+    pr, _, loss = eng.read_outputs(Bl)
+    np.savez(os.path.join(out_dir, "out%d.npz" % rank), grads=eng.get_grads(), params=eng.get_params(), state=eng.get_bn_state(),
+             probs=pr, loss=loss)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["mixednet", "inception"])
+def test_sync_bn_two_ranks_equal_single_device_step(tmp_path, kind):
+    import conftest
+    import engine_checks as ec
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W, Bl = 2, 3
+    rng = np.random.default_rng(3)
+    x = ec.synth_x(rng, W * Bl, T)
+    y = (rng.random(W * Bl) < 0.5).astype(np.float32)
+    w = rng.choice([0.5, 1.0, 2.0], size=W * Bl).astype(np.float32)
+    if kind == "mixednet":
+        om = ec.perturbed_oracle(T)
+        from microwakeword_amd.layout import MixedNetLayout
+        lay = MixedNetLayout(ec.DEF, T)
+        keep = None
+    else:
+        om = ec.perturbed_inception_oracle(T, ec.INC)
+        from microwakeword_amd.layout import InceptionLayout
+        lay = InceptionLayout(ec.INC, T)
+        keep = (rng.random((W * Bl, lay.t_last * lay.c_last)) >= ec.INC["dropout"]).astype(np.float32)
+    np.savez(tmp_path / "inputs.npz", x=x, y=y, w=w, keep=keep if keep is not None else np.zeros(1))
+    mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, kind), nprocs=W, join=True)
+    outs = [np.load(tmp_path / ("out%d.npz" % r)) for r in range(W)]
+    # every rank holds the same reduced gradient, weights and moving statistics
+    for k in ("grads", "params", "state"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+    lo, po, grads, _ = om.loss_and_grads(x, y, w, **({"dropout_mask": keep} if keep is not None else {}))
+    if kind == "mixednet":
+        gref = ec.oracle_grads_native_order(lay, om, grads)
+    else:
+        gref = lay.pack([grads[n].numpy().astype(np.float32) if kd == "param" else np.zeros(sh, np.float32)
+                         for n, sh, kd in lay.keras_vars])[0]
+    # rank losses are local means over B/W windows: their average is the global-batch loss
+    assert abs(np.mean([float(o["loss"]) for o in outs]) - lo) <= 1e-5 * max(1.0, abs(lo))
+    np.testing.assert_allclose(np.concatenate([o["probs"] for o in outs]), po, atol=1e-3)
+    g = outs[0]["grads"] / W   # the buffer holds the SUM over ranks; Adam consumed it times 1/W
+    scale = float(np.abs(gref).max())
+    off = 0
+    for name, n in lay.segments():
+        a, r = g[off:off + n], gref[off:off + n]
+        off += n
+        tol = 2e-3 * scale if name.endswith("dw.bias") else 1e-3 * max(float(np.linalg.norm(r)), 1e-3 * scale * np.sqrt(n))
+        assert np.linalg.norm(a - r) <= tol if not name.endswith("dw.bias") else np.abs(a - r).max() <= tol, (name, np.abs(a - r).max())
+    om.train_step(x, y, w, 1e-3, **({"dropout_mask": keep} if keep is not None else {}))
+    p_ref, s_ref = lay.pack(om.get_weights())
+    well = np.abs(gref) > 1e-4 * scale
+    assert np.abs(outs[0]["params"] - p_ref)[well].max() <= 0.05 * 1e-3
+    assert np.abs(outs[0]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
