@@ -96,6 +96,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
     ap.add_argument("--model", choices=("mixednet", "inception"), default="mixednet",
                     help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="multi-GPU parity mode: BatchNorm statistics exchanged over RCCL (default: local-BN throughput mode)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--store-samples", type=int, default=4096)
@@ -210,7 +212,7 @@ def main():
             shard_feature_handler(fh, rank, world, seed=0)
         else:
             fh.use_private_rng()
-        dp = DataParallel.for_engine(eng, device)
+        dp = DataParallel.for_engine(eng, device, sync_bn=args.sync_bn and (world > 1 or force_dp))
         dp.broadcast_parameters(0)
         for opt, v in (("grid_fwd", args.grid_fwd), ("grid_bwd", args.grid_bwd), ("grid_head", args.grid_head)):
             if v:
@@ -262,6 +264,9 @@ def main():
             eng.set_option("profile", 1)
             for _ in range(args.profile_steps):
                 fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
+                if dp.sync_bn:
+                    dp.train_step(B, lr)
+                    continue
                 eng.train_step(B, lr, native.STEP_NO_APPLY if (world > 1 or force_dp) else 0)
                 if world > 1 or force_dp:
                     eng.apply_gradients(lr, 1.0)
@@ -296,7 +301,7 @@ def main():
                                % (args.model, " + residual_connection 0,0,0,0" if args.model == "mixednet" else ", dropout 0.2 from the built-in generator",
                                   B, args.store_samples),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graphs,
-                   "bn": "local" if world > 1 else "batch"},
+                   "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
