@@ -224,11 +224,24 @@ def main():
         policy = synthetic.SPEC_AUGMENT_POLICY
         lr = 1e-3
 
-        def one_step():
+        def next_batch():
             fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)  # class weights 1/1 (train.py:176-187 defaults)
-            if world > 1 or force_dp:
+
+        if (world > 1 or force_dp) and os.environ.get("MWW_BENCH_DP_PREFETCH", "0") == "1":
+            # opt-in: software-pipelined by one batch — every step still draws + assembles exactly one batch, but
+            # that batch is the NEXT step's, gathered while RCCL reduces this step's gradient.  Measured at W=1
+            # (all-reduce ~free) it costs 10 us/step, so it is off until it can be measured at W>1.
+            next_batch()
+
+            def one_step():
+                dp.train_step(B, lr, prefetch=next_batch)
+        elif world > 1 or force_dp:
+            def one_step():
+                next_batch()
                 dp.train_step(B, lr)
-            else:
+        else:
+            def one_step():
+                next_batch()
                 eng.train_step(B, lr)
 
         def fence():

@@ -95,12 +95,24 @@ class DataParallel:
             if self.state_view is not None:
                 dist.broadcast(self.state_view, src=src, group=self.group)
 
-    def train_step(self, B, lr, flags=0):
-        """Local forward/backward, gradient all-reduce, Adam on the averaged gradient."""
+    def train_step(self, B, lr, flags=0, prefetch=None):
+        """Local forward/backward, gradient all-reduce, Adam on the averaged gradient.
+
+        ``prefetch`` (optional callable) is run between launching the all-reduce and waiting for it: the
+        train loop passes the assembly of the NEXT batch, whose gather kernel then runs on the compute
+        stream while RCCL moves the 88 KB gradient on its own stream (the step's backward has finished
+        with the batch buffers by then, so the single set of buffers suffices)."""
         if self.sync_bn:
             self.engine.train_step(B, lr, flags)   # statistics and gradient exchanges happen inside, via the hook
+            if prefetch is not None:
+                prefetch()
             return
         self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
+        work = None
         if dist.is_initialized():
-            dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group)
+            work = dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if prefetch is not None:
+            prefetch()
+        if work is not None:
+            work.wait()   # orders the compute stream after the collective; no host block on RCCL
         self.engine.apply_gradients(lr, 1.0 / self.world)
