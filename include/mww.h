@@ -196,7 +196,9 @@ void* mww_device_ptr(mww_ctx* ctx, int which);
  * the BN outputs, "bn_mean<k>", "bn_rstd<k>"); returns the element count or a negative error */
 int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64_t capacity);
 
-/* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head" */
+/* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head", "grid_graph",
+ * "dropout_seed", "pointwise_bf16" (0 = exact fp32 MFMA, the default; 1 = the MixedNet 1x1 convolutions and
+ * their two backward contractions take bf16-rounded operands with fp32 accumulation — BASELINE configs[4]) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing of the last N steps measured with HIP events on the context's stream:

@@ -29,6 +29,22 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Optional reduced-precision mode of the 1x1 contractions (BASELINE configs[4] "bf16 with MFMA pointwise"):
+// operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32), products exact, fp32 accumulation.  One
+// v_mfma_f32_16x16x16_bf16 covers K = 16 in the time the f32 form covers K = 4.  Lane l supplies
+// A[i = l&15][k = 4*(l>>4) + j] and B[k = 4*(l>>4) + j][n = l&15], j < 4; C/D as the f32 form.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x4 a, bf16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) {
+  bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return v;
+}
+
 __device__ __forceinline__ f32x4 zero4() {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return z;

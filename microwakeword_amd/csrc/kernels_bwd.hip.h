@@ -112,32 +112,62 @@ __device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
 // MFMA part shared by both backward kernels:
 //   dwacc[mt][nt] += U^T DP over this wave's 16 rows;  du = DP W^T -> sDU rows [K-1+16*wave, ...)
 //   sWt = W_pw^T staged in LDS as [COUT][pitch(CIN)] (B[k=co][n=ci] = W[ci][co])
-template <int CIN, int COUT, int K>
+template <int CIN, int COUT, int K, bool BF>
 __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const float* sDP, float* sDU, int wave, int r16,
                                                         int g, const float* sWt,
                                                         f32x4 (&dwacc)[CIN / 16][COUT / 16]) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT), MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int row = wave * 16 + kk * 4 + g;
-    float av[MT], bv[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) av[mt] = sU[row * CPI + mt * 16 + r16];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[row * CPO + nt * 16 + r16];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma4(av[mt], bv[nt], dwacc[mt][nt]);
-  }
   f32x4 du[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) du[mt] = zero4();
+  if constexpr (!BF) {
 #pragma unroll
-  for (int kk = 0; kk < KSO; ++kk) {
-    const float av = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
+    for (int kk = 0; kk < 4; ++kk) {
+      const int row = wave * 16 + kk * 4 + g;
+      float av[MT], bv[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, sWt[(kk * 4 + g) * CPI + mt * 16 + r16], du[mt]);
+      for (int mt = 0; mt < MT; ++mt) av[mt] = sU[row * CPI + mt * 16 + r16];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[row * CPO + nt * 16 + r16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma4(av[mt], bv[nt], dwacc[mt][nt]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KSO; ++kk) {
+      const float av = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, sWt[(kk * 4 + g) * CPI + mt * 16 + r16], du[mt]);
+    }
+  } else {
+    // bf16 operands: one MFMA spans the wave's 16 rows (dW) / 16 output channels (du)
+    const int row = wave * 16 + 4 * g;
+    bf16x4 av[MT], bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float* col = sU + row * CPI + mt * 16 + r16;
+      av[mt] = to_bf16x4(col[0], col[CPI], col[2 * CPI], col[3 * CPI]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float* col = sDP + row * CPO + nt * 16 + r16;
+      bv[nt] = to_bf16x4(col[0], col[CPO], col[2 * CPO], col[3 * CPO]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma_bf16(av[mt], bv[nt], dwacc[mt][nt]);
+#pragma unroll
+    for (int kk = 0; kk < COUT / 16; ++kk) {
+      const float4 v = *reinterpret_cast<const float4*>(sDP + (wave * 16 + r16) * CPO + kk * 16 + 4 * g);
+      const bf16x4 a4 = to_bf16x4(v.x, v.y, v.z, v.w);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float* col = sWt + (kk * 16 + 4 * g) * CPI + mt * 16 + r16;
+        du[mt] = mfma_bf16(a4, to_bf16x4(col[0], col[CPI], col[2 * CPI], col[3 * CPI]), du[mt]);
+      }
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -206,7 +236,7 @@ __device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, in
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int K, bool LAST>
+template <int CIN, int COUT, int K, bool LAST, bool BF>
 __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (!(a.ablate & 8)) __syncthreads();
     MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-    if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
     MWW_PC_MARK(4);   // MFMA (dW_pw, du)
     if (!(a.ablate & 8)) __syncthreads();
     MWW_PC_MARK(5);   // barrier 3
@@ -400,7 +430,7 @@ struct BwdFirstArgs {
   int B, T, Tout;         // a0 frames Ta = (T-K1)/S+1 ; Tout = Ta-(K-1)
 };
 
-template <int K1, int C1, int COUT, int K, int S>
+template <int K1, int C1, int COUT, int K, int S, bool BF>
 __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) {
   constexpr int CIN = C1;
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
       }
     }
     __syncthreads();
-    pointwise_backward_tile<CIN, COUT, K>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
     __syncthreads();
     // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
     if (dw_active) {

@@ -77,6 +77,70 @@ __device__ __forceinline__ void pw_rowtile(const float* sU, int cpi, int row0, i
   }
 }
 
+// register-resident 1x1 weights of a workgroup + the row-tile contraction, in exact fp32 (BF = false) or
+// with bf16 operands (BF = true)
+template <int CIN, int NT, bool BF>
+struct PwWeights;
+
+template <int CIN, int NT>
+struct PwWeights<CIN, NT, false> {
+  float f[CIN / 4][NT];
+  __device__ __forceinline__ void load(const float* w, int cout, int g, int r16) {
+#pragma unroll
+    for (int kk = 0; kk < CIN / 4; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) f[kk][nt] = w[(kk * 4 + g) * cout + nt * 16 + r16];
+  }
+  __device__ __forceinline__ void retire() {
+#pragma unroll
+    for (int kk = 0; kk < CIN / 4; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pin(f[kk][nt]);
+  }
+  __device__ __forceinline__ void tile(const float* sU, int cpi, int row0, int r16, int g, f32x4 (&acc)[NT]) const {
+    pw_rowtile<CIN / 4, NT>(sU, cpi, row0, r16, g, f, acc);
+  }
+};
+
+template <int CIN, int NT>
+struct PwWeights<CIN, NT, true> {
+  bf16x4 f[CIN / 16][NT];
+  __device__ __forceinline__ void load(const float* w, int cout, int g, int r16) {
+#pragma unroll
+    for (int kk = 0; kk < CIN / 16; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* col = w + (size_t)(kk * 16 + 4 * g) * cout + nt * 16 + r16;
+        f[kk][nt] = to_bf16x4(col[0], col[cout], col[2 * cout], col[3 * cout]);
+      }
+  }
+  __device__ __forceinline__ void retire() {
+#pragma unroll
+    for (int kk = 0; kk < CIN / 16; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = __builtin_bit_cast(f32x2, f[kk][nt]);
+        float lo = t.x, hi = t.y;
+        pin(lo);
+        pin(hi);
+        const f32x2 u = {lo, hi};
+        f[kk][nt] = __builtin_bit_cast(bf16x4, u);
+      }
+  }
+  __device__ __forceinline__ void tile(const float* sU, int cpi, int row0, int r16, int g, f32x4 (&acc)[NT]) const {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+#pragma unroll
+    for (int kk = 0; kk < CIN / 16; ++kk) {
+      const float4 v = *reinterpret_cast<const float4*>(sU + (row0 + r16) * cpi + kk * 16 + 4 * g);
+      const bf16x4 av = to_bf16x4(v.x, v.y, v.z, v.w);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(av, f[kk][nt], acc[nt]);
+    }
+  }
+};
+
 // store a 16 x (NT*16) accumulator tile to global rows and accumulate per-channel sum / sum^2
 template <int NT, int COUT>
 __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* out_rows, int row0, int rows_valid,
@@ -129,7 +193,7 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 }
 
 // ------------------------------------------------------------------------------------------
-template <int K1, int C1, int COUT, int K, int S>
+template <int K1, int C1, int COUT, int K, int S, bool BF>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
   constexpr int CP1 = pitch(C1);
   constexpr int RA = TT + K - 1;               // a0 rows per tile
@@ -179,11 +243,8 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   float w1frag[KS1];
 #pragma unroll
   for (int kk = 0; kk < KS1; ++kk) w1frag[kk] = a.w1[(kk * 4 + g) * C1 + nt1 * 16 + r16];
-  float bfrag[KS][NT];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bfrag[kk][nt] = a.pw_w[(kk * 4 + g) * COUT + nt * 16 + r16];
+  PwWeights<C1, NT, BF> pw;
+  pw.load(a.pw_w, COUT, g, r16);
   float dww[K];
   float dwb = 0.f;
   if (dw_active) {
@@ -200,10 +261,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
 
 #pragma unroll
   for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) pin(bfrag[kk][nt]);
+  pw.retire();
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
@@ -248,7 +306,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     __syncthreads();
     // pointwise
     f32x4 acc[NT];
-    pw_rowtile<KS, NT>(sU, CP1, wave * 16, r16, g, bfrag, acc);
+    pw.tile(sU, CP1, wave * 16, r16, g, acc);
     store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
     __syncthreads();
   }
@@ -256,7 +314,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int K>
+template <int CIN, int COUT, int K, bool BF>
 __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int CPI = pitch(CIN);
   constexpr int RA = TT + K - 1;
@@ -301,11 +359,8 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   };
   if (nitems > 0) issue(0);
   MWW_PC_DECL
-  float bfrag[KS][NT];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bfrag[kk][nt] = a.pw_w[(kk * 4 + g) * COUT + nt * 16 + r16];
+  PwWeights<CIN, NT, BF> pw;
+  pw.load(a.pw_w, COUT, g, r16);
   float dww[K];
   float dwb = 0.f;
   if (dw_active) {
@@ -319,10 +374,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) pin(bfrag[kk][nt]);
+  pw.retire();
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
@@ -367,7 +419,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     if (!(a.ablate & 8)) __syncthreads();
     MWW_PC_MARK(4);   // barrier 2
     f32x4 acc[NT];
-    if (!(a.ablate & 2)) pw_rowtile<KS, NT>(sU, CPI, wave * 16, r16, g, bfrag, acc);
+    if (!(a.ablate & 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
     else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
     MWW_PC_MARK(5);   // pointwise MFMA
     if (!(a.ablate & 4)) store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);

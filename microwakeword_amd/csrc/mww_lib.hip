@@ -131,6 +131,7 @@ struct mww_ctx {
   int64_t step = 0;
   int have_batch = 0, have_targets = 0;
   bool use_graphs = false, profile = false;
+  bool pw_bf16 = false;   // 1x1 contractions with bf16 operands (mww_set_option "pointwise_bf16")
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
@@ -171,7 +172,10 @@ struct Launcher {
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
+    if (c->pw_bf16)                                                                                            \
+      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else                                                                                                       \
+      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     return MWW_OK;                                                                                             \
   }
   MWW_FIRST_SHAPES(X)
@@ -182,7 +186,10 @@ int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S>), dim3(grid), dim3(kThreads), 0, c->stream, a);     \
+    if (c->pw_bf16)                                                                                            \
+      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else                                                                                                       \
+      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     return MWW_OK;                                                                                             \
   }
   MWW_FIRST_SHAPES(X)
@@ -193,7 +200,10 @@ int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a, int grid) {
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && cout == CO && k == K) {                                                                     \
-    hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K>), dim3(grid), dim3(kThreads), 0, c->stream, a);            \
+    if (c->pw_bf16)                                                                                            \
+      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
     return MWW_OK;                                                                                             \
   }
   MWW_BLOCK_SHAPES(X)
@@ -204,10 +214,14 @@ int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a
 int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (last)                                                                                                  \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);    \
+    if (last && c->pw_bf16)                                                                                    \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+    else if (last)                                                                                             \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else if (c->pw_bf16)                                                                                       \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     else                                                                                                       \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     return MWW_OK;                                                                                             \
   }
   MWW_BLOCK_SHAPES(X)
@@ -1512,6 +1526,10 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
     c->prof.clear();
   }
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
+  else if (!strcmp(name, "pointwise_bf16")) {
+    if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");
+    c->pw_bf16 = v != 0;
+  }
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_graph")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_graph out of range"); c->grid_g = (int)v; }

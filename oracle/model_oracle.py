@@ -195,6 +195,29 @@ def inception_build(flags, T, seed=42) -> List[Var]:
 
 # ----------------------------------------------------------------------------- forward graphs
 
+def _round_bf16(t):
+    """RNE to bfloat16 of the float32 value (what v_cvt_pk_bf16_f32 does to the engine's fp32 operands)."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16Pointwise(torch.autograd.Function):
+    """1x1 convolution in the optional "bf16 with MFMA pointwise" mode (BASELINE configs[4]): every
+    contraction — forward, input gradient, weight gradient — takes bf16-rounded operands and
+    accumulates exactly.  x [B,Cin,T], w [Cout,Cin]."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xr, wr = _round_bf16(x), _round_bf16(w)
+        ctx.save_for_backward(xr, wr)
+        return torch.einsum("oc,bct->bot", wr, xr)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = _round_bf16(gy)
+        return torch.einsum("oc,bot->bct", wr, gr), torch.einsum("bot,bct->oc", gr, xr)
+
+
 class _Cursor:
     def __init__(self, tensors: Dict[str, torch.Tensor], training: bool):
         self.t = tensors
@@ -235,8 +258,10 @@ class _Cursor:
         return y.reshape(B, C, T)
 
 
-def mixednet_logits(flags, tensors, x, training, taps=None):
-    """x [B,T,40] -> logits [B].  ``taps`` (dict) receives named intermediates ([B,T,C] layout)."""
+def mixednet_logits(flags, tensors, x, training, taps=None, relu_masks=None):
+    """x [B,T,40] -> logits [B].  ``taps`` (dict) receives named intermediates ([B,T,C] layout).
+    ``relu_masks`` (test aid, see inception_logits): {"b<i>.r<j>": bool [B,C,T]} replaces the ReLU
+    decisions of the named block outputs."""
     cur = _Cursor(tensors, training)
     net = x.transpose(1, 2)  # [B,40,T]
     f0, stride = _get(flags, "first_conv_filters"), _get(flags, "stride")
@@ -265,14 +290,22 @@ def mixednet_logits(flags, tensors, x, training, taps=None):
                     net = torch.cat([o[:, :, o.shape[2] - last_t:] for o in outs], dim=1)
                 if taps is not None:
                     taps[p + ".dw"] = net.transpose(1, 2)
-            net = cur.conv(net, p + ".pw")
+            if _get(flags, "pw_bf16", False):
+                net = _Bf16Pointwise.apply(net, tensors[p + ".pw.kernel"][0, 0].t())
+            else:
+                net = cur.conv(net, p + ".pw")
             if taps is not None:
                 taps[p + ".pre_bn"] = net.transpose(1, 2)
             net = cur.bn(net, p + ".bn")
             if r:
                 residual = residual[:, :, residual.shape[2] - net.shape[2]:]
                 net = net + residual
-            net = torch.relu(net)
+            if taps is not None:
+                taps[p + ".bn_out"] = net.transpose(1, 2)
+            if relu_masks is not None and p in relu_masks:
+                net = net * relu_masks[p].to(net.dtype)
+            else:
+                net = torch.relu(net)
     flat = net.transpose(1, 2).reshape(net.shape[0], -1)  # Keras Flatten of [B,T,1,C]: index t*C+c
     z = flat @ tensors["dense.kernel"][:, 0] + tensors["dense.bias"][0]
     return z, cur.new_stats
@@ -448,10 +481,10 @@ class OracleModel:
     def logits(self, x, training=False, tensors=None, dropout_mask=None, taps=None, relu_masks=None):
         tensors = tensors or self._tensors(False)
         x = torch.as_tensor(np.asarray(x), dtype=self.dtype)
-        if self.kind == "mixednet":
-            return mixednet_logits(self.flags, tensors, x, training, taps)
-        dm = None if dropout_mask is None else torch.as_tensor(np.asarray(dropout_mask), dtype=self.dtype)
         rm = None if relu_masks is None else {k: torch.as_tensor(np.asarray(v)) for k, v in relu_masks.items()}
+        if self.kind == "mixednet":
+            return mixednet_logits(self.flags, tensors, x, training, taps, rm)
+        dm = None if dropout_mask is None else torch.as_tensor(np.asarray(dropout_mask), dtype=self.dtype)
         return inception_logits(self.flags, tensors, x, training, dm, taps, rm)
 
     def predict(self, x, training=False):

@@ -37,6 +37,8 @@ def make_engine(lib, T, max_batch, om=None, flags=DEF):
     lay = MixedNetLayout(flags, T)
     eng = native.Engine(lib=lib, **lay.engine_args(max_batch))
     eng.set_grad_mask(lay.grad_mask())
+    if flags.get("pw_bf16"):
+        eng.set_option("pointwise_bf16", 1)
     if om is not None:
         p, s = lay.pack(om.get_weights())
         eng.set_params(p)
@@ -143,6 +145,8 @@ def check_sampler_matches_oracle_descriptors(lib, B=64, n_samples=48, seed=0):
 # ------------------------------------------------------------------------------------------ model
 # the topology of the reference's training notebook (cell 10): first conv 5x1 stride 3, 64 pointwise
 # filters, multi-kernel MixConv groups; spectrogram_length 204
+# BASELINE configs[4]: 1x1 contractions with bf16 operands (the oracle rounds the same operands)
+BF16 = dict(DEF, pw_bf16=True)
 NOTEBOOK = dict(DEF, first_conv_kernel_size=5, stride=3, first_conv_filters=32, pointwise_filters="64,64,64,64",
                 mixconv_kernel_sizes="[5],[7,11],[9,15],[23]")
 
@@ -166,7 +170,10 @@ def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
     for k, b in enumerate(lay.blocks):
         got = eng.debug_read("p%d" % (k + 1), B, B * b.tout * b.cout).reshape(B, b.tout, b.cout)
         ref = taps["b%d.r0.pre_bn" % k].detach().numpy()
-        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (k, np.abs(got - ref).max())
+        # bf16 mode: an engine fp32 operand and its oracle fp64 twin ~1e-6 apart round to different bf16
+        # values with probability ~3e-4, each a 0.4 % operand error
+        tap_tol = 1e-3 if flags.get("pw_bf16") else 2e-5
+        assert np.abs(got - ref).max() <= tap_tol * max(1.0, np.abs(ref).max()), (k, np.abs(got - ref).max())
     eng.close()
     return float(np.abs(pr - po).max())
 
@@ -183,6 +190,15 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         eng.set_option("graphs", 1)
     rng = np.random.default_rng(11)
     worst = {}
+    # bf16-operand mode: the oracle rounds the same operands, but an fp32 value (engine) and its fp64 twin
+    # (oracle) within 1e-7 of a bf16 rounding boundary round apart (a few per 1e5 operands, each a 0.4 %
+    # operand error), so the bounds are those of that noise instead of fp32 rounding
+    # In that mode a ReLU network's gradient is also far more exposed to decision flips (an operand error
+    # eps flips ~0.4*eps of the units, moving the gradient by ~sqrt of that), so the engine's own ReLU
+    # decisions are read back, checked to differ from the oracle's only at near-zero values, and imposed
+    # on the oracle (as in the Inception check): what is compared are identical graphs.
+    lowp = bool(flags.get("pw_bf16"))
+    loss_tol, l2_tol, el_tol, med_tol = (1e-3, 2e-2, 6e-2, 6e-3) if lowp else (1e-5, 1e-3, 5e-3, 2e-5)
     for s in range(steps):
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
@@ -191,12 +207,26 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         eng.set_targets(y, w)
         eng.train_step(B, lr)
         pr, z, loss = eng.read_outputs(B)
-        lo, po, grads, _ = om.loss_and_grads(x, y, w)
+        masks = None
+        if lowp:
+            taps, masks, flips = {}, {}, 0
+            om.logits(x, True, taps=taps)
+            for k, b in enumerate(lay.blocks):
+                pk = eng.debug_read("p%d" % (k + 1), B, B * b.tout * b.cout).reshape(B, b.tout, b.cout).astype(np.float64)
+                bn = eng.debug_read("bn%d" % (k + 1), B, 9 * b.cout).reshape(9, b.cout).astype(np.float64)
+                m = (pk * bn[0] + bn[1]) > 0
+                ref = taps["b%d.r0.bn_out" % k].detach().numpy()
+                diff = m != (ref > 0)
+                flips += int(diff.sum())
+                assert np.abs(ref[diff]).max(initial=0.0) <= 2e-2 * max(1.0, np.abs(ref).max()), (k, np.abs(ref[diff]).max())
+                masks["b%d.r0" % k] = np.ascontiguousarray(m.transpose(0, 2, 1))
+            assert flips <= 2e-3 * sum(B * b.tout * b.cout for b in lay.blocks), flips
+        lo, po, grads, _ = om.loss_and_grads(x, y, w, relu_masks=masks)
         g = eng.get_grads()
         gref = oracle_grads_native_order(lay, om, grads)
         scale = max(1e-6, float(np.abs(gref).max()))
         worst["grad"] = max(worst.get("grad", 0), float(np.abs(g - gref).max() / scale))
-        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+        assert abs(loss - lo) <= loss_tol * max(1.0, abs(lo)), (loss, lo)
         assert np.abs(pr - po).max() <= FWD_TOL
         # per parameter tensor: error relative to that tensor's own gradient scale.  The depthwise
         # biases are followed by a BatchNorm, so their true gradient is exactly zero: what any fp32
@@ -216,33 +246,39 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
                 seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
                 l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
                 # measured: 1e-6 typical; 2e-4..4e-4 on the rare step where one activation flips (B=6)
-                assert l2 <= 1e-3, (s, name, l2)
-                assert np.abs(a - r).max() <= 5e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
+                assert l2 <= l2_tol, (s, name, l2)
+                assert np.abs(a - r).max() <= el_tol * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
                 worst["grad"] = max(worst.get("grad", 0), l2)
                 worst.setdefault("l2s", []).append(l2)
-        om.train_step(x, y, w, lr)
+        om.train_step(x, y, w, lr, relu_masks=masks)
         p_ref, s_ref = lay.pack(om.get_weights())
         p_got, s_got = eng.get_params(), eng.get_bn_state()
         # Adam normalises every step to ~lr, so compare in units of lr.  Parameters whose true gradient
         # is (mathematically) zero — the depthwise biases, cancelled by the BatchNorm that follows —
         # carry only fp32 rounding noise that Adam amplifies to O(lr) in ANY fp32 implementation:
         # they are excluded here and bounded by 2*lr instead.
-        well = np.abs(gref) > 1e-4 * scale
-        assert np.abs(p_got - p_ref)[well].max() <= 0.05 * lr, (s, np.abs(p_got - p_ref)[well].max())
+        well = np.abs(gref) > (1e-2 if lowp else 1e-4) * scale
+        assert np.abs(p_got - p_ref)[well].max() <= (0.2 if lowp else 0.05) * lr, (s, np.abs(p_got - p_ref)[well].max())
         assert np.abs(p_got - p_ref).max() <= 2.0 * lr
-        assert np.abs(s_got - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+        assert np.abs(s_got - s_ref).max() <= (1e-4 if lowp else 1e-5) * max(1.0, np.abs(s_ref).max())
         worst["param"] = max(worst.get("param", 0), float(np.abs(p_got - p_ref)[well].max()))
         # keep both sides on identical weights so that errors do not compound between steps
         eng.set_params(p_ref)
         eng.set_bn_state(s_ref)
     m = native.metrics_from_raw(eng.metrics_raw())
     r = om.metrics.result()
-    for k in ("accuracy", "recall", "precision", "auc"):
-        assert abs(m[k] - r[k]) < 1e-6, (k, m[k], r[k])
-    assert abs(m["loss"] - r["loss"]) < 1e-5
-    for k in ("tp", "fp", "tn", "fn"):
-        np.testing.assert_array_equal(m[k], r[k])
-    assert np.median(worst.pop("l2s")) <= 2e-5   # the typical tensor agrees to fp32 rounding
+    if lowp:
+        # a probability 1e-4 away from one of the 101 cutoffs may be bucketed on the other side
+        for k in ("tp", "fp", "tn", "fn"):
+            assert np.abs(m[k] - r[k]).max() <= 1 and np.count_nonzero(m[k] != r[k]) <= 2, k
+    else:
+        for k in ("accuracy", "recall", "precision", "auc"):
+            assert abs(m[k] - r[k]) < 1e-6, (k, m[k], r[k])
+        for k in ("tp", "fp", "tn", "fn"):
+            np.testing.assert_array_equal(m[k], r[k])
+    assert abs(m["loss"] - r["loss"]) < (loss_tol if lowp else 1e-5)
+    worst["l2_max"], worst["l2_median"] = float(np.max(worst["l2s"])), float(np.median(worst["l2s"]))
+    assert np.median(worst.pop("l2s")) <= med_tol   # the typical tensor agrees to fp32 rounding (bf16 mode: to its boundary noise)
     mm, vv, step = eng.get_opt_state()
     assert step == steps
     eng.close()

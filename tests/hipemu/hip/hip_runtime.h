@@ -56,6 +56,7 @@ extern dim3 g_blockDim, g_gridDim;
 void sync_block();
 unsigned wave_exchange(unsigned v, int src_lane);                 // 32-bit shuffle primitive
 void wave_exchange2(float a, float b, const float** A, const float** B);  // publish 2 floats, get arrays
+const unsigned long long* wave_publish2(unsigned long long a, unsigned long long b);  // publish 2 x 64 bit, get [64][2]
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 int lane_id();
 void* dyn_shared();                                               // dynamic LDS of the running block
@@ -104,6 +105,29 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+// D = A(16x16) * B(16x16) + C with bf16 operands: lane l holds A[i=l&15][k=4*(l>>4)+j], B[k=4*(l>>4)+j][n=l&15]
+typedef short hipemu_s16x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 hipemu_mfma_16x16x16bf16(hipemu_s16x4 a, hipemu_s16x4 b, hipemu_f32x4 c, int, int, int) {
+  unsigned long long ua, ub;
+  std::memcpy(&ua, &a, 8);
+  std::memcpy(&ub, &b, 8);
+  const unsigned long long* all = hipemu::wave_publish2(ua, ub);
+  auto elem = [&](int lane, int which, int j) {
+    unsigned bits = (unsigned)((all[lane * 2 + which] >> (16 * j)) & 0xFFFFull) << 16;
+    float f; std::memcpy(&f, &bits, 4); return f;
+  };
+  const int l = hipemu::lane_id(), col = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int gg = 0; gg < 4; ++gg)
+      for (int j = 0; j < 4; ++j) acc += elem(gg * 16 + row, 0, j) * elem(gg * 16 + col, 1, j);
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k hipemu_mfma_16x16x16bf16
 static inline unsigned long long hipemu_memtime() { return 0ull; }
 #define __builtin_amdgcn_s_memtime hipemu_memtime
 

@@ -30,6 +30,7 @@ const std::function<void()>* cur_body = nullptr;
 struct WaveBuf {
   unsigned v[2][64];
   float a[2][64], b[2][64];
+  unsigned long long q[2][128];
   int gen = 0;
 };
 std::vector<WaveBuf> waves;
@@ -70,6 +71,15 @@ void wave_exchange2(float a, float b, const float** A, const float** B) {
   yield(WAIT_WAVE);
   *A = w.a[g];
   *B = w.b[g];
+}
+
+const unsigned long long* wave_publish2(unsigned long long a, unsigned long long b) {
+  WaveBuf& w = waves[cur >> 6];
+  int g = w.gen & 1;
+  w.q[g][(cur & 63) * 2] = a;
+  w.q[g][(cur & 63) * 2 + 1] = b;
+  yield(WAIT_WAVE);
+  return w.q[g];
 }
 
 static int sched_order() {

