@@ -98,6 +98,8 @@ def parse_args():
                     help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology")
     ap.add_argument("--sync-bn", action="store_true",
                     help="multi-GPU parity mode: BatchNorm statistics exchanged over RCCL (default: local-BN throughput mode)")
+    ap.add_argument("--pointwise-bf16", action="store_true",
+                    help="BASELINE configs[4]: bf16-operand MFMA for the 1x1 contractions (not the headline configuration)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--store-samples", type=int, default=4096)
@@ -219,6 +221,8 @@ def main():
                 eng.set_option(opt, v)
         if args.ablate:
             eng.set_option("ablate", args.ablate)
+        if args.pointwise_bf16:
+            eng.set_option("pointwise_bf16", 1)
         if not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY
@@ -308,7 +312,8 @@ def main():
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 storage/accumulate, bf16-operand MFMA in the 1x1 contractions" if args.pointwise_bf16 else "f32",
+        "data": "synthetic",
         "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, fp32, "
                                "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM"
                                % (args.model, " + residual_connection 0,0,0,0" if args.model == "mixednet" else ", dropout 0.2 from the built-in generator",
