@@ -102,6 +102,7 @@ def parse_args():
                     help="BASELINE configs[4]: bf16-operand MFMA for the 1x1 contractions (not the headline configuration)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-validation", action="store_true", help="skip the (untimed-for-value) validation-throughput leg")
     ap.add_argument("--store-samples", type=int, default=4096)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--grid-fwd", type=int, default=0)
@@ -206,7 +207,8 @@ def main():
                           seed=42, max_batch=B)
             kernel_elems, step_bytes = KERNEL_ELEMS, BYTES_PER_WINDOW_STEP
         eng = model.engine
-        cfg, _ = synthetic.benchmark_config(args.store_samples, 1234)
+        n_val = 4096 if (world == 1 and not force_dp and not args.no_validation) else 0
+        cfg, _ = synthetic.benchmark_config(args.store_samples, 1234, n_val=n_val, n_ambient=n_val // 8)
         random.seed(0)
         np.random.seed(0)
         fh = FeatureHandler(cfg, engine=eng)
@@ -274,6 +276,25 @@ def main():
             elapsed = float(tt.item())
         _, _, last_loss = eng.read_outputs(B)
 
+        # ---- validation leg (N=1 only, not part of `value`): validate_nonstreaming's two
+        # passes (validation set, truncate_start; ambient set, 100 ms-stride split) with the windows gathered and
+        # scored in HBM, threshold counters accumulated on the device
+        validation = None
+        if n_val and rank == 0:
+            fh.evaluate_on_device(model, "validation", T_FRAMES, "truncate_start", 1024)   # warm-up (index build, caches)
+            eng.synchronize()
+            tv0 = time.perf_counter()
+            nv1, _, _ = fh.evaluate_on_device(model, "validation", T_FRAMES, "truncate_start", 1024)
+            eng.synchronize()
+            tv1 = time.perf_counter()
+            nv2, _, res = fh.evaluate_on_device(model, "validation_ambient", T_FRAMES, "split", 1024)
+            eng.synchronize()
+            tv2 = time.perf_counter()
+            validation = {"windows": int(nv1 + nv2), "windows_per_s": round((nv1 + nv2) / (tv2 - tv0), 1),
+                          "validation_set": {"windows": int(nv1), "s": round(tv1 - tv0, 4)},
+                          "ambient_split": {"windows": int(nv2), "s": round(tv2 - tv1, 4)},
+                          "note": "host window indexing + HBM gather + inference forward + threshold metrics, batches of 1024"}
+
         # ---- per-kernel durations with HIP events on the engine's stream (eager launches, separate pass)
         prof = {}
         if rank == 0:
@@ -327,6 +348,8 @@ def main():
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "final_loss": round(float(last_loss), 5),
     }
+    if validation is not None:
+        out["validation"] = validation
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, model=args.model)
     line = json.dumps(out) + "\n"

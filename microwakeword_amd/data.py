@@ -149,6 +149,7 @@ class FeatureHandler:
                 p.store_id[key] = next_id
                 next_id += 1
         self._sampler = None
+        self._eval_cache = {}
 
     def _need_engine(self):
         if self.engine is None:
@@ -282,6 +283,18 @@ class FeatureHandler:
         return y, w
 
     def _eval_windows(self, mode, features_length, truncation_strategy):
+        """Window descriptors, labels and weights of a whole evaluation mode.  Deterministic strategies are
+        indexed once and cached (validation runs every eval_step_interval steps on the same windows)."""
+        key = (mode, int(features_length), truncation_strategy)
+        cache = self.__dict__.setdefault("_eval_cache", {})
+        if key in cache:
+            return cache[key]
+        out = self._index_eval_windows(mode, features_length, truncation_strategy)
+        if all(p.strategy(truncation_strategy) != "random" for p in self.feature_providers):
+            cache[key] = out
+        return out
+
+    def _index_eval_windows(self, mode, features_length, truncation_strategy):
         win, labels, weights = [], [], []
         for p in self.feature_providers:
             strat = p.strategy(truncation_strategy)

@@ -18,13 +18,26 @@ def synthetic_stores(n_samples=4096, seed=1234, dtype=np.uint16, min_len=150, ma
     return out
 
 
-def benchmark_config(n_samples=4096, seed=1234, dtype=np.uint16):
-    """A ``config`` dict for :class:`microwakeword_amd.data.FeatureHandler` holding the stores in RAM."""
+def benchmark_config(n_samples=4096, seed=1234, dtype=np.uint16, n_val=0, n_ambient=0):
+    """A ``config`` dict for :class:`microwakeword_amd.data.FeatureHandler` holding the stores in RAM.
+    ``n_val`` adds that many validation samples to each provider, ``n_ambient`` long negative
+    "validation_ambient" recordings (600..1500 frames) that the split strategy cuts into windows."""
     pos, neg = synthetic_stores(n_samples, seed, dtype)
+    rng = np.random.default_rng(seed + 1)
+
+    def extra(n, lo, hi):
+        return [rng.integers(0, 667, size=(int(l), 40), dtype=np.uint16) for l in rng.integers(lo, hi + 1, size=n)]
+
+    pos_modes, neg_modes = {"training": [pos]}, {"training": [neg]}
+    if n_val:
+        pos_modes["validation"] = [extra(n_val, 150, 400)]
+        neg_modes["validation"] = [extra(n_val, 150, 400)]
+    if n_ambient:
+        neg_modes["validation_ambient"] = [extra(n_ambient, 600, 1500)]
     return {"stride": 1, "window_step_ms": 10, "features": [
-        dict(type="mmap", stores={"training": [pos]}, truth=True, sampling_weight=2.0, penalty_weight=1.0,
+        dict(type="mmap", stores=pos_modes, truth=True, sampling_weight=2.0, penalty_weight=1.0,
              truncation_strategy="truncate_start"),
-        dict(type="mmap", stores={"training": [neg]}, truth=False, sampling_weight=10.0, penalty_weight=1.0,
+        dict(type="mmap", stores=neg_modes, truth=False, sampling_weight=10.0, penalty_weight=1.0,
              truncation_strategy="random")]}, (pos, neg)
 
 
