@@ -62,11 +62,15 @@ def inception_kernel_elems(layout):
             if s >= 0:
                 consumers.setdefault(s, []).append(i)
 
+    def width(op, j):
+        s = op["src"][j]
+        return op["slice"][j][1] or (40 if s < 0 else ops[s]["filters"])
+
     def src_elems(op, full):
         n = 0
-        for s, d in zip(op["src"], op["drop"]):
-            t, c = (layout.frames, 40) if s < 0 else (ops[s]["tout"], ops[s]["filters"])
-            n += (t if full else t - d) * c
+        for j, (s, d) in enumerate(zip(op["src"], op["drop"])):
+            t = layout.frames if s < 0 else ops[s]["tout"]
+            n += (t if full else t - d) * width(op, j)
         return n
 
     for i, op in enumerate(ops):
@@ -75,10 +79,12 @@ def inception_kernel_elems(layout):
         elems["conv_wgrad%d" % (i + 1)] = src_elems(op, False) + 2 * out
         if any(s >= 0 for s in op["src"]):
             n = 2 * out
-            for s in op["src"]:
+            for j, s in enumerate(op["src"]):
                 if s >= 0:
-                    e = ops[s]["tout"] * ops[s]["filters"]
-                    n += 2 * e + (e if i != max(consumers[s]) else 0)
+                    e = ops[s]["tout"] * width(op, j)
+                    same = [i2 for i2 in consumers[s] if any(ops[i2]["src"][j2] == s and ops[i2]["slice"][j2] == op["slice"][j]
+                                                             for j2 in range(len(ops[i2]["src"])))]
+                    n += 2 * e + (e if i != max(same) else 0)
             elems["conv_dgrad%d" % (i + 1)] = n
     last = ops[-1]["tout"] * ops[-1]["filters"]
     elems["head"] = 2 * last + (last if layout.dropout > 0 else 0)          # read p, write g (+ keep mask)

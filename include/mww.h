@@ -80,6 +80,12 @@ typedef struct {
   int32_t n_src;                        /* inputs concatenated along channels, in this order */
   int32_t src[MWW_MAX_OP_SOURCES];      /* producing op (index < this op's) or -1 for the spectrogram */
   int32_t src_drop[MWW_MAX_OP_SOURCES]; /* leading frames of that input dropped to align the branches */
+  int32_t src_c0[MWW_MAX_OP_SOURCES];   /* first channel of the slice of that input this op reads ... */
+  int32_t src_cn[MWW_MAX_OP_SOURCES];   /* ... and its width (0 = the whole tensor).  Sibling convolutions that read
+                                           the same input (Inception's three 1x1 branch heads) can be fused by the caller
+                                           into one op with the concatenated filters; each consumer then names its slice.
+                                           The slices different consumers take from one producer must be identical or
+                                           disjoint and together cover all of its channels. */
   int32_t kernel, dilation, filters;
   int32_t bn_groups;                    /* 1 = BatchNormalization, g > 1 = SubSpectralNormalization(g) */
 } mww_conv_bn_op;

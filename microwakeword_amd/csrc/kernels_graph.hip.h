@@ -38,8 +38,9 @@ struct GSrc {
   const float* mean;    // producer's batch statistics (backward only)
   const float* rstd;
   float* g;             // gradient at the producer's BN output, ReLU mask applied [B][T][C]
-  float* gstat_part;    // [grid][2][C]
+  float* gstat_part;    // [grid][2][ld]
   int T, C, toff, flags;
+  int ld, c0;           // the source is channels [c0, c0+C) of a producer tensor with ld channels per frame
 };
 
 struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - xhat * mgx)
@@ -57,10 +58,10 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
     const int C = s.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
     if (rg < nrg) {
       const bool ident = (s.flags & GSRC_IDENTITY) != 0;
-      const float sc = ident ? 1.f : s.scale[c], sh = ident ? 0.f : s.shift[c];
-      const float* base = s.p + ((size_t)b * s.T + s.toff) * C + c;
+      const float sc = ident ? 1.f : s.scale[s.c0 + c], sh = ident ? 0.f : s.shift[s.c0 + c];
+      const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
       for (int t = rg; t < rows; t += nrg) {
-        const float v = base[(size_t)t * C];
+        const float v = base[(size_t)t * s.ld];
         sIn[t * PI + c0 + c] = ident ? v : fmaxf(fmaf(v, sc, sh), 0.f);
       }
     }
@@ -80,8 +81,9 @@ __device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows
   }
 }
 
-// per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][C] of this workgroup
-__device__ __forceinline__ void write_channel_partials(float s1, float s2, int C, float* sRed, float* part, int tid) {
+// per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][ld] of this workgroup
+// (columns [0, C) of each statistic's row; ld = C unless the channels are a slice of a wider tensor)
+__device__ __forceinline__ void write_channel_partials(float s1, float s2, int C, float* sRed, float* part, int tid, int ld) {
   const int nrg = kThreads / C, c = tid % C, rg = tid / C;
   __syncthreads();
   if (rg < nrg) {
@@ -92,7 +94,7 @@ __device__ __forceinline__ void write_channel_partials(float s1, float s2, int C
   if (tid < 2 * C) {
     float v = 0.f;
     for (int r = 0; r < nrg; ++r) v += sRed[r * 2 * C + tid];
-    part[tid] = v;
+    part[(tid / C) * ld + (tid % C)] = v;
   }
 }
 
@@ -184,13 +186,13 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
         if (s.flags & GSRC_GRAD) {
           const int nrg = kThreads / C, c = tid % C, rg = tid / C;
           if (rg < nrg) {
-            const float sc = s.scale[c], sh = s.shift[c];
+            const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
             const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
-            const float mu = stats ? s.mean[c] : 0.f, rs = stats ? s.rstd[c] : 0.f;
-            const size_t base = (size_t)b * s.T * C + c;
+            const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
+            const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
             float t1 = 0.f, t2 = 0.f;
             for (int t = rg; t < s.T; t += nrg) {
-              const size_t idx = base + (size_t)t * C;
+              const size_t idx = base + (size_t)t * s.ld;
               const float p = s.p[idx];
               const int r = t - s.toff;
               float gv = (r >= 0 && fmaf(p, sc, sh) > 0.f) ? sOut[r * PO + c0 + c] : 0.f;
@@ -208,14 +210,14 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
     }
   }
   if (MODE == 0) {
-    write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid);
+    write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
   } else {
 #pragma unroll
     for (int i = 0; i < kGMaxSrc; ++i) {
       if (i >= a.n_src) break;
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
-        write_channel_partials(s1[i], s2[i], s.C, sRed, s.gstat_part + (size_t)blockIdx.x * 2 * s.C, tid);
+        write_channel_partials(s1[i], s2[i], s.C, sRed, s.gstat_part + (size_t)blockIdx.x * 2 * s.ld + s.c0, tid, s.ld);
     }
   }
 }
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       }
     }
   }
-  if (a.training) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid);
+  if (a.training) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
 }
 
 // Dropout keep-mask of one step: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).

@@ -50,12 +50,12 @@ struct Layer {
 // one conv -> BN/SSN -> ReLU op of a mww_convnet_desc graph (kernels_graph.hip.h)
 struct GOp {
   int n_src = 0, src[kGMaxSrc] = {0, 0, 0}, toff[kGMaxSrc] = {0, 0, 0};
+  int sc0[kGMaxSrc] = {0, 0, 0}, scn[kGMaxSrc] = {0, 0, 0};   // channel slice of each source
+  bool src_first[kGMaxSrc] = {false, false, false}, src_last[kGMaxSrc] = {false, false, false};   // this op's place among the consumers of that slice (backward order)
   int k = 1, dil = 1, cin = 0, cout = 0, groups = 1, slots = 0, tin = 0, tout = 0;
   int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   int nq = 1;                 // frame subsets of the weight-gradient mapping
-  int first_consumer = -1;    // consumer that runs first in the backward pass (highest op index; n_ops = head)
-  int last_consumer = -1;     // consumer that runs last (lowest op index): it owns the BN statistics partials
   bool needs_dx = false;
   size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
 };
@@ -590,7 +590,7 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
   if (o.src[i] < 0) {
     s.p = c->x;
     s.T = c->d.frames;
-    s.C = MWW_FEATURE_BINS;
+    s.C = s.ld = MWW_FEATURE_BINS;
     s.flags = GSRC_IDENTITY;
     return s;
   }
@@ -603,8 +603,10 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
   s.g = pr.g;
   s.gstat_part = pr.gstat_part;
   s.T = pr.tout;
-  s.C = pr.cout;
-  if (backward) s.flags = GSRC_GRAD | (oi != pr.first_consumer ? GSRC_ACCUM : 0) | (oi == pr.last_consumer ? GSRC_STATS : 0);
+  s.C = o.scn[i];
+  s.ld = pr.cout;
+  s.c0 = o.sc0[i];
+  if (backward) s.flags = GSRC_GRAD | (o.src_first[i] ? 0 : GSRC_ACCUM) | (o.src_last[i] ? GSRC_STATS : 0);
   return s;
 }
 
@@ -1053,18 +1055,20 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       for (int j2 = 0; j2 < j; ++j2)
         if (s.src[j2] == src) return fail(MWW_ERR_UNSUPPORTED, tag + "the same source twice");
       if (s.src_drop[j] < 0) return fail(MWW_ERR_INVALID, tag + "negative frame drop");
-      const int T = src < 0 ? d.frames : ops[src].tout, C = src < 0 ? MWW_FEATURE_BINS : ops[src].cout;
+      const int T = src < 0 ? d.frames : ops[src].tout, Cfull = src < 0 ? MWW_FEATURE_BINS : ops[src].cout;
+      const int c0 = s.src_cn[j] > 0 ? s.src_c0[j] : 0, C = s.src_cn[j] > 0 ? s.src_cn[j] : Cfull;
+      if (c0 < 0 || c0 + C > Cfull || (src < 0 && C != Cfull)) return fail(MWW_ERR_INVALID, tag + "bad channel slice");
       const int rows = T - s.src_drop[j];
       if (o.tin >= 0 && rows != o.tin) return fail(MWW_ERR_INVALID, tag + "sources are not aligned to the same number of frames");
       o.tin = rows;
       o.cin += C;
       o.src[j] = src;
       o.toff[j] = s.src_drop[j];
+      o.sc0[j] = c0;
+      o.scn[j] = C;
       if (src >= 0) {
         o.needs_dx = true;
         n_consumers[src]++;
-        ops[src].first_consumer = std::max(ops[src].first_consumer, i);
-        ops[src].last_consumer = ops[src].last_consumer < 0 ? i : std::min(ops[src].last_consumer, i);
       }
     }
     o.tout = o.tin - (o.k - 1) * o.dil;
@@ -1089,8 +1093,33 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   }
   for (int i = 0; i + 1 < d.n_ops; ++i)
     if (n_consumers[i] == 0) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
+  // gradient routing: per producer, the slices its consumers read must be identical or disjoint and cover
+  // every channel; in the backward pass (descending op index) the first consumer of a slice stores, later
+  // ones accumulate and the last one also emits the BN statistics partials of that slice
+  for (int pi = 0; pi + 1 < d.n_ops; ++pi) {
+    std::vector<int> covered(ops[pi].cout, 0);
+    for (int i = d.n_ops - 1; i > pi; --i)
+      for (int j = 0; j < ops[i].n_src; ++j) {
+        if (ops[i].src[j] != pi) continue;
+        const int c0 = ops[i].sc0[j], cn = ops[i].scn[j];
+        bool first = true, last = true;
+        for (int i2 = pi + 1; i2 < d.n_ops; ++i2)
+          for (int j2 = 0; j2 < ops[i2].n_src; ++j2) {
+            if (ops[i2].src[j2] != pi || (i2 == i && j2 == j)) continue;
+            const int d0 = ops[i2].sc0[j2], dn = ops[i2].scn[j2];
+            if (d0 + dn <= c0 || c0 + cn <= d0) continue;   // disjoint
+            if (d0 != c0 || dn != cn) return fail(MWW_ERR_UNSUPPORTED, "op " + std::to_string(pi) + ": consumers read overlapping, unequal channel slices");
+            if (i2 > i) first = false;
+            if (i2 < i) last = false;
+          }
+        ops[i].src_first[j] = first;
+        ops[i].src_last[j] = last;
+        for (int cc = c0; cc < c0 + cn; ++cc) covered[cc] = 1;
+      }
+    for (int cc = 0; cc < ops[pi].cout; ++cc)
+      if (!covered[cc]) return fail(MWW_ERR_UNSUPPORTED, "op " + std::to_string(pi) + ": channel " + std::to_string(cc) + " has no consumer");
+  }
   if (n_consumers[d.n_ops - 1] != 0) return fail(MWW_ERR_INVALID, "the last op feeds the classifier head and cannot have other consumers");
-  ops[d.n_ops - 1].first_consumer = ops[d.n_ops - 1].last_consumer = d.n_ops;
 
   mww_ctx* c = new mww_ctx();
   memset(&c->d, 0, sizeof(c->d));

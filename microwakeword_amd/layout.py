@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ast
 from dataclasses import dataclass
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -238,17 +238,22 @@ class MixedNetLayout:
 class InceptionLayout:
     """Shape derivation and Keras-order weight mapping of the reference's Inception model
     (microwakeword/inception.py:232-340) as a list of conv -> BN/SSN -> ReLU ops for
-    ``mww_create_convnet`` (include/mww.h).  Ops are in layer-creation order, so the native parameter
-    vector is ``get_weights()`` order with the BN moving statistics split off into the state vector.
+    ``mww_create_convnet`` (include/mww.h).
 
       * stem: Conv2D(k x 1, valid, no bias) + SubSpectralNormalization + ReLU   inception.py:261-279
       * block: branch1 1x1; branch2 1x1 -> kx1; branch3 1x1 -> kx1 -> kx1; StridedDrop of the leading
         frames of branch1/2 to branch3's length; concatenate; 1x1 reduce         inception.py:281-328
       * Flatten -> Dropout -> Dense(1, sigmoid)                                  inception.py:330-338
       * ``spectrogram_slices_dropped``                                           inception.py:212-230
+
+    ``keras_vars`` is ``get_weights()`` order (layer-creation order).  The native order differs in one
+    place: with plain BatchNormalization (sub-spectral groups == 1) the three 1x1 branch heads of a block
+    read the same input, so they run as ONE convolution with the concatenated filters (``fuse_heads``);
+    its kernel / gamma / beta / moving statistics are the three layers' arrays concatenated along the
+    channel axis, and each consumer names its channel slice.  ``pack`` / ``unpack`` do that permutation.
     """
 
-    def __init__(self, flags, frames: int):
+    def __init__(self, flags, frames: int, fuse_heads: bool = True):
         self.frames = int(frames)
         self.dropout = float(_flag(flags, "dropout"))
         stem = list(zip(parse(_flag(flags, "cnn1_filters")), parse(_flag(flags, "cnn1_kernel_sizes")),
@@ -258,45 +263,73 @@ class InceptionLayout:
                           parse(_flag(flags, "cnn2_dilation"))))
         self.ops: List[dict] = []
         self.op_names: List[str] = []
+        self.op_members: List[List[Tuple[str, int, int]]] = []   # per native op: (keras layer name, first channel, width)
         self.keras_vars: List[Tuple[str, Tuple[int, ...], str]] = []
-        t, c, cur = self.frames, FEATURE_BINS, -1
+        kidx = {}   # keras layer name -> index of its kernel in keras_vars (gamma +1, beta +2, mean +3, var +4)
+        t, c = self.frames, FEATURE_BINS
+        cur = (-1, 0, 0)   # (op index, first channel, width) of the running tensor; width 0 = whole
 
-        def add(name, src, drop, cin, tin, k, dil, filters, groups):
+        def keras_layer(name, k, cin, filters, groups):
             if filters % groups:
                 # sub_spectral_normalization.py:41-45
                 raise ValueError("input_shape[3]: %d must be divisible by self.sub_groups %d " % (filters, groups))
-            tout = tin - (k - 1) * dil
-            if tout <= 0:
-                raise ValueError("spectrogram of %d frames is too short for this network" % frames)
             slots = groups if groups > 1 else filters
-            self.ops.append(dict(src=list(src), drop=list(drop), kernel=int(k), dilation=int(dil), filters=int(filters),
-                                 bn_groups=int(groups), cin=int(cin), tin=int(tin), tout=int(tout), slots=int(slots)))
-            self.op_names.append(name)
+            kidx[name] = len(self.keras_vars)
             self.keras_vars.append((name + ".kernel", (int(k), 1, int(cin), int(filters)), "param"))
             self.keras_vars.append((name + ".bn.gamma", (slots,), "param"))
             self.keras_vars.append((name + ".bn.beta", (slots,), "param"))
             self.keras_vars.append((name + ".bn.moving_mean", (slots,), "state"))
             self.keras_vars.append((name + ".bn.moving_variance", (slots,), "state"))
+
+        def add(names, srcs, cin, tin, k, dil, filters_each, groups):
+            """one native op computing the Keras layers ``names`` (same input, same shape) side by side"""
+            tout = tin - (k - 1) * dil
+            if tout <= 0:
+                raise ValueError("spectrogram of %d frames is too short for this network" % frames)
+            filters = filters_each * len(names)
+            self.ops.append(dict(src=[s[0] for s in srcs], drop=[s[3] for s in srcs], slice=[(s[1], s[2]) for s in srcs],
+                                 kernel=int(k), dilation=int(dil), filters=int(filters), bn_groups=int(groups), cin=int(cin),
+                                 tin=int(tin), tout=int(tout), slots=int(groups if groups > 1 else filters)))
+            self.op_names.append("+".join(names))
+            self.op_members.append([(n, i * filters_each, filters_each) for i, n in enumerate(names)])
             return len(self.ops) - 1, tout
 
         for i, (f, k, g) in enumerate(stem):
-            cur, t = add("stem%d" % i, [cur], [0], c, t, k, 1, f, g)
-            c = int(f)
+            keras_layer("stem%d" % i, k, c, f, g)
+            oi, t = add(["stem%d" % i], [cur + (0,)], c, t, k, 1, f, g)
+            cur, c = (oi, 0, 0), int(f)
         for i, (f1, f2, k, g, dil) in enumerate(blocks):
             n = "i%d." % i
-            b1, t1 = add(n + "b1", [cur], [0], c, t, 1, 1, f1, g)
-            b2a, _ = add(n + "b2a", [cur], [0], c, t, 1, 1, f1, g)
-            b2, t2 = add(n + "b2b", [b2a], [0], f1, t, k, dil, f1, g)
-            b3a, _ = add(n + "b3a", [cur], [0], c, t, 1, 1, f1, g)
-            b3b, t3b = add(n + "b3b", [b3a], [0], f1, t, k, dil, f1, g)
-            b3, t3 = add(n + "b3c", [b3b], [0], f1, t3b, k, dil, f1, g)
-            cur, t = add(n + "red", [b1, b2, b3], [t1 - t3, t2 - t3, 0], 3 * f1, t3, 1, 1, f2, 1)
-            c = int(f2)
+            for nm, kk, ci in (("b1", 1, c), ("b2a", 1, c), ("b2b", k, f1), ("b3a", 1, c), ("b3b", k, f1), ("b3c", k, f1)):
+                keras_layer(n + nm, kk, ci, f1, g)
+            keras_layer(n + "red", 1, 3 * f1, f2, 1)
+            if fuse_heads and g == 1:
+                heads, _ = add([n + "b1", n + "b2a", n + "b3a"], [cur + (0,)], c, t, 1, 1, f1, 1)
+                b1, b2a, b3a = (heads, 0, f1), (heads, f1, f1), (heads, 2 * f1, f1)
+            else:
+                b1 = (add([n + "b1"], [cur + (0,)], c, t, 1, 1, f1, g)[0], 0, 0)
+                b2a = (add([n + "b2a"], [cur + (0,)], c, t, 1, 1, f1, g)[0], 0, 0)
+                b3a = (add([n + "b3a"], [cur + (0,)], c, t, 1, 1, f1, g)[0], 0, 0)
+            b2, t2 = add([n + "b2b"], [b2a + (0,)], f1, t, k, dil, f1, g)
+            b3b, t3b = add([n + "b3b"], [b3a + (0,)], f1, t, k, dil, f1, g)
+            b3, t3 = add([n + "b3c"], [(b3b, 0, 0, 0)], f1, t3b, k, dil, f1, g)
+            red, t = add([n + "red"], [b1 + (t - t3,), (b2, 0, 0, t2 - t3), (b3, 0, 0, 0)], 3 * f1, t3, 1, 1, f2, 1)
+            cur, c = (red, 0, 0), int(f2)
         if not self.ops:
             raise NotImplementedError("an Inception model without any convolution")
         self.t_last, self.c_last = t, c
+        self._dense = len(self.keras_vars)
         self.keras_vars.append(("dense.kernel", (t * c, 1), "param"))
         self.keras_vars.append(("dense.bias", (1,), "param"))
+        # native segments: (name, [keras var indices concatenated along the last axis], kind)
+        self.native_segs: List[Tuple[str, List[int], str]] = []
+        for name, members in zip(self.op_names, self.op_members):
+            base = [kidx[m[0]] for m in members]
+            for off, suffix, kind in ((0, ".kernel", "param"), (1, ".bn.gamma", "param"), (2, ".bn.beta", "param"),
+                                      (3, ".bn.moving_mean", "state"), (4, ".bn.moving_variance", "state")):
+                self.native_segs.append((name + suffix, [b + off for b in base], kind))
+        self.native_segs.append(("dense.kernel", [self._dense], "param"))
+        self.native_segs.append(("dense.bias", [self._dense + 1], "param"))
         self.n_params = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "param")
         self.n_state = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "state")
 
@@ -310,12 +343,16 @@ class InceptionLayout:
     def pack(self, weights: Sequence[np.ndarray]):
         if len(weights) != len(self.keras_vars):
             raise ValueError("expected %d weight arrays, got %d" % (len(self.keras_vars), len(weights)))
-        params, state = [], []
-        for (name, shape, kind), w in zip(self.keras_vars, weights):
+        ws = []
+        for (name, shape, _), w in zip(self.keras_vars, weights):
             w = np.asarray(w, np.float32)
             if tuple(w.shape) != tuple(shape):
                 raise ValueError("weight %s: expected shape %s, got %s" % (name, shape, w.shape))
-            (params if kind == "param" else state).append(w.reshape(-1))
+            ws.append(w)
+        params, state = [], []
+        for _, idxs, kind in self.native_segs:
+            v = ws[idxs[0]] if len(idxs) == 1 else np.concatenate([ws[i] for i in idxs], axis=-1)
+            (params if kind == "param" else state).append(v.reshape(-1))
         return np.concatenate(params), np.concatenate(state)
 
     def unpack(self, params: np.ndarray, state: np.ndarray) -> List[np.ndarray]:
@@ -323,19 +360,24 @@ class InceptionLayout:
         state = np.asarray(state, np.float32).reshape(-1)
         if params.size != self.n_params or state.size != self.n_state:
             raise ValueError("vector sizes do not match this model")
-        out, po, so = [], 0, 0
-        for _, shape, kind in self.keras_vars:
-            n = int(np.prod(shape))
+        out: List[Optional[np.ndarray]] = [None] * len(self.keras_vars)
+        po = so = 0
+        for _, idxs, kind in self.native_segs:
+            shapes = [self.keras_vars[i][1] for i in idxs]
+            n = sum(int(np.prod(sh)) for sh in shapes)
             if kind == "param":
-                out.append(params[po:po + n].reshape(shape).copy())
-                po += n
+                flat, po = params[po:po + n], po + n
             else:
-                out.append(state[so:so + n].reshape(shape).copy())
-                so += n
+                flat, so = state[so:so + n], so + n
+            merged = flat.reshape(shapes[0][:-1] + (sum(sh[-1] for sh in shapes),))
+            c0 = 0
+            for i, sh in zip(idxs, shapes):
+                out[i] = merged[..., c0:c0 + sh[-1]].copy()
+                c0 += sh[-1]
         return out
 
     def segments(self):
-        return [(name, int(np.prod(shape))) for name, shape, kind in self.keras_vars if kind == "param"]
+        return [(name, sum(int(np.prod(self.keras_vars[i][1])) for i in idxs)) for name, idxs, kind in self.native_segs if kind == "param"]
 
     def grad_mask(self) -> np.ndarray:
         return np.ones(self.n_params, np.float32)
@@ -344,8 +386,8 @@ class InceptionLayout:
         yield "input                                   [B, %d, %d]" % (self.frames, FEATURE_BINS)
         for name, op in zip(self.op_names, self.ops):
             norm = "SSN(%d)" % op["bn_groups"] if op["bn_groups"] > 1 else "BN"
-            yield "%-8s conv %dx1 d%d %d->%d + %s + relu   [B, %d, %d]" % (name, op["kernel"], op["dilation"], op["cin"], op["filters"],
-                                                                          norm, op["tout"], op["filters"])
+            yield "%-22s conv %dx1 d%d %d->%d + %s + relu   [B, %d, %d]" % (name, op["kernel"], op["dilation"], op["cin"], op["filters"],
+                                                                           norm, op["tout"], op["filters"])
         yield "flatten + dropout(%g) + dense(1, sigmoid)   [B, 1]" % self.dropout
 
 

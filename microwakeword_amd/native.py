@@ -38,6 +38,7 @@ MWW_MAX_OP_SOURCES = 3
 
 class ConvBnOp(C.Structure):
     _fields_ = [("n_src", C.c_int32), ("src", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_drop", C.c_int32 * MWW_MAX_OP_SOURCES),
+                ("src_c0", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_cn", C.c_int32 * MWW_MAX_OP_SOURCES),
                 ("kernel", C.c_int32), ("dilation", C.c_int32), ("filters", C.c_int32), ("bn_groups", C.c_int32)]
 
 
@@ -178,7 +179,7 @@ class Engine:
     def __init__(self, frames, conv1_filters=None, conv1_kernel=None, conv1_stride=1, block_filters=(), block_kernel=(),
                  max_batch=1024, device=0, stream=None, lib: Optional[NativeLib] = None, conv_ops=None, dropout=0.0):
         """MixedNet topology from the ``conv1_*`` / ``block_*`` arguments, or — when ``conv_ops`` is given —
-        a conv/BN graph: a list of dicts ``{src: [...], drop: [...], kernel, dilation, filters, bn_groups}``
+        a conv/BN graph: a list of dicts ``{src: [...], drop: [...], slice: [(c0, width), ...], kernel, dilation, filters, bn_groups}``
         (``mww_conv_bn_op``) with the classifier head on the last one."""
         self.nl = lib or NativeLib.get()
         self.max_batch = int(max_batch)
@@ -194,8 +195,10 @@ class Engine:
                 if len(src) > MWW_MAX_OP_SOURCES or len(src) != len(drop):
                     raise ValueError("bad source lists")
                 o.n_src = len(src)
+                sl = list(op.get("slice", [(0, 0)] * len(src)))   # (first channel, width); width 0 = whole tensor
                 for j, (sj, dj) in enumerate(zip(src, drop)):
                     o.src[j], o.src_drop[j] = int(sj), int(dj)
+                    o.src_c0[j], o.src_cn[j] = int(sl[j][0]), int(sl[j][1])
                 o.kernel, o.dilation, o.filters = int(op["kernel"]), int(op.get("dilation", 1)), int(op["filters"])
                 o.bn_groups = int(op.get("bn_groups", 1))
             self.desc = d

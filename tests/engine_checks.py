@@ -326,9 +326,9 @@ def perturbed_inception_oracle(T, flags, seed=42):
     return om
 
 
-def make_inception_engine(lib, T, max_batch, om, flags):
+def make_inception_engine(lib, T, max_batch, om, flags, fuse_heads=True):
     from microwakeword_amd.layout import InceptionLayout
-    lay = InceptionLayout(flags, T)
+    lay = InceptionLayout(flags, T, fuse_heads=fuse_heads)
     eng = native.Engine(lib=lib, **lay.engine_args(max_batch))
     p, s = lay.pack(om.get_weights())
     eng.set_params(p)
@@ -336,9 +336,9 @@ def make_inception_engine(lib, T, max_batch, om, flags):
     return lay, eng
 
 
-def check_inception_forward(lib, B=3, T=194, training=False, grid=None, flags=INC):
+def check_inception_forward(lib, B=3, T=194, training=False, grid=None, flags=INC, fuse_heads=True):
     om = perturbed_inception_oracle(T, flags)
-    lay, eng = make_inception_engine(lib, T, max(B, 2), om, flags)
+    lay, eng = make_inception_engine(lib, T, max(B, 2), om, flags, fuse_heads)
     if grid:
         for k in ("grid_graph", "grid_head"):
             eng.set_option(k, grid)
@@ -352,20 +352,21 @@ def check_inception_forward(lib, B=3, T=194, training=False, grid=None, flags=IN
     keep = np.ones((B, lay.t_last * lay.c_last), np.float32) * (1.0 - flags["dropout"])   # keep/(1-rate) == 1
     zo, _ = om.logits(x, training, dropout_mask=keep if training else None, taps=taps)
     po = torch.sigmoid(zo).numpy()
-    for k, (name, op) in enumerate(zip(lay.op_names, lay.ops)):
+    for k, (members, op) in enumerate(zip(lay.op_members, lay.ops)):
         got = eng.debug_read("p%d" % (k + 1), B, B * op["tout"] * op["filters"]).reshape(B, op["tout"], op["filters"])
-        ref = taps[name + ".pre_bn"].detach().numpy()
-        assert got.shape == ref.shape, (name, got.shape, ref.shape)
-        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+        # a fused op holds its Keras layers side by side along the channel axis
+        ref = np.concatenate([taps[name + ".pre_bn"].detach().numpy() for name, _, _ in members], axis=2)
+        assert got.shape == ref.shape, (members, got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (members, np.abs(got - ref).max())
     assert np.abs(pr - po).max() <= FWD_TOL, (pr, po)
     assert np.abs(z - zo.detach().numpy()).max() <= 1e-3 * max(1.0, np.abs(zo.detach().numpy()).max())
     eng.close()
     return float(np.abs(pr - po).max())
 
 
-def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=INC):
+def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=INC, fuse_heads=True):
     om = perturbed_inception_oracle(T, flags)
-    lay, eng = make_inception_engine(lib, T, B, om, flags)
+    lay, eng = make_inception_engine(lib, T, B, om, flags, fuse_heads)
     if grid:
         for k in ("grid_graph", "grid_head"):
             eng.set_option(k, grid)
@@ -390,16 +391,18 @@ def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graph
         taps = {}
         om.logits(x, True, dropout_mask=keep, taps=taps)
         masks, flips = {}, 0
-        for k, (name, op) in enumerate(zip(lay.op_names, lay.ops)):
+        for k, (members, op) in enumerate(zip(lay.op_members, lay.ops)):
             n_el = B * op["tout"] * op["filters"]
             pk = eng.debug_read("p%d" % (k + 1), B, n_el).reshape(B, op["tout"], op["filters"]).astype(np.float64)
             bn = eng.debug_read("bn%d" % (k + 1), B, 9 * op["filters"]).reshape(9, op["filters"]).astype(np.float64)
-            m = (pk * bn[0] + bn[1]) > 0
-            ref = taps[name + ".bn_out"].detach().numpy()
-            diff = m != (ref > 0)
-            flips += int(diff.sum())
-            assert np.abs(ref[diff]).max(initial=0.0) <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(ref[diff]).max())
-            masks[name] = np.ascontiguousarray(m.transpose(0, 2, 1))
+            m_all = (pk * bn[0] + bn[1]) > 0
+            for name, c0, cn in members:
+                m = m_all[:, :, c0:c0 + cn]
+                ref = taps[name + ".bn_out"].detach().numpy()
+                diff = m != (ref > 0)
+                flips += int(diff.sum())
+                assert np.abs(ref[diff]).max(initial=0.0) <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(ref[diff]).max())
+                masks[name] = np.ascontiguousarray(m.transpose(0, 2, 1))
         assert flips <= 8, flips
         lo, po, grads, _ = om.loss_and_grads(x, y, w, dropout_mask=keep, relu_masks=masks)
         g = eng.get_grads()

@@ -74,3 +74,9 @@ def test_bf16_pointwise_mode(emu_lib):
     """BASELINE configs[4]: 1x1 contractions with bf16 operands, against the oracle rounding the same operands."""
     ec.check_forward_parity(emu_lib, B=2, T=111, training=True, grid=2, flags=ec.BF16)
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=2, flags=ec.BF16)
+
+
+def test_inception_unfused_branch_heads(emu_lib):
+    """The 22-op form (one op per Keras layer) stays available and agrees as well."""
+    ec.check_inception_forward(emu_lib, B=2, T=194, training=True, grid=2, fuse_heads=False)
+    ec.check_inception_train_steps(emu_lib, B=3, T=194, steps=1, grid=2, fuse_heads=False)

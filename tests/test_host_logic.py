@@ -193,20 +193,32 @@ def test_inception_flags_layout_and_oracle_order(tmp_path):
     for k, v in mo.INCEPTION_DEFAULTS.items():
         assert str(getattr(flags, k)) == str(v), k
     assert inception.spectrogram_slices_dropped(flags) == mo.inception_slices_dropped(flags) == 28
-    L = lay.InceptionLayout(flags, 194)
     om = mo.OracleModel("inception", vars(flags), 194, seed=1)
-    assert [n for n, _, _ in L.keras_vars] == [v.name for v in om.vars]
-    assert [tuple(s) for _, s, _ in L.keras_vars] == [v.value.shape for v in om.vars]
-    assert L.keras_param_counts() == om.n_params()
-    assert (L.t_last, L.c_last) == (166, 16) and len(L.ops) == 22
-    # StridedDrop alignment of the reduce conv: branch1 / branch2 lose their leading 8 / 4 frames
-    red = L.ops[7]
-    assert red["src"] == [1, 3, 6] and red["drop"] == [8, 4, 0] and red["cin"] == 30
     ws = [w + 0.01 * (i + 1) for i, w in enumerate(om.get_weights())]
-    pv, sv = L.pack(ws)
-    assert pv.size == L.n_params and sv.size == L.n_state
-    for a, b in zip(ws, L.unpack(pv, sv)):
-        np.testing.assert_array_equal(a.astype(np.float32), b)
+    for fuse in (False, True):
+        L = lay.InceptionLayout(flags, 194, fuse_heads=fuse)
+        assert [n for n, _, _ in L.keras_vars] == [v.name for v in om.vars]
+        assert [tuple(s) for _, s, _ in L.keras_vars] == [v.value.shape for v in om.vars]
+        assert L.keras_param_counts() == om.n_params()
+        assert (L.t_last, L.c_last) == (166, 16) and len(L.ops) == (16 if fuse else 22)
+        # StridedDrop alignment of the reduce conv: branch1 / branch2 lose their leading 8 / 4 frames
+        red = L.ops[5 if fuse else 7]
+        assert red["drop"] == [8, 4, 0] and red["cin"] == 30
+        if fuse:   # the three 1x1 branch heads run as one 24->30 convolution; consumers name their slices
+            assert L.ops[1]["filters"] == 30 and red["src"] == [1, 2, 4] and red["slice"][0] == (0, 10)
+            assert L.ops[2]["src"] == [1] and L.ops[2]["slice"] == [(10, 10)] and L.ops[3]["slice"] == [(20, 10)]
+            k = ws[[n for n, _, _ in L.keras_vars].index("i0.b2a.kernel")]
+            off = dict((n, sum(m for _, m in L.segments()[:i])) for i, (n, _) in enumerate(L.segments()))["i0.b1+i0.b2a+i0.b3a.kernel"]
+            fused = L.pack(ws)[0][off:off + 24 * 30].reshape(24, 30)
+            np.testing.assert_array_equal(fused[:, 10:20], k[0, 0].astype(np.float32))
+        else:
+            assert red["src"] == [1, 4, 6]   # native op order: the three heads first, then b2b, b3b, b3c
+        pv, sv = L.pack(ws)
+        assert pv.size == L.n_params and sv.size == L.n_state
+        for a, b in zip(ws, L.unpack(pv, sv)):
+            np.testing.assert_array_equal(a.astype(np.float32), b)
+    # sub-spectral groups inside a block keep the heads separate (their BN slots interleave per branch)
+    assert len(lay.InceptionLayout(dict(mo.INCEPTION_DEFAULTS, cnn2_subspectral_groups="2,1,1"), 194).ops) == 18
     # sub-spectral groups must divide the filters (sub_spectral_normalization.py:41-45)
     with pytest.raises(ValueError, match="divisible"):
         lay.InceptionLayout(dict(mo.INCEPTION_DEFAULTS, cnn1_subspectral_groups="5"), 194)
