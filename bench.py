@@ -231,6 +231,8 @@ def main():
             eng.set_option("ablate", args.ablate)
         if args.pointwise_bf16:
             eng.set_option("pointwise_bf16", 1)
+        if os.environ.get("MWW_BENCH_SIDE_STREAM") is not None:
+            eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
         if not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY
