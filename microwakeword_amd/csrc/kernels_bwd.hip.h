@@ -647,10 +647,7 @@ struct BnBwdFinalizeArgs {
   float dscale;             // 1 (local statistics) or 1/W (sums already all-reduced: the gradient all-reduce adds them W times)
 };
 
-__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
-  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
-  __shared__ double sOut[2];
-  const int tid = threadIdx.x, c = blockIdx.x;
+__device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinalizeArgs& a, int c, double* sAcc, double* sOut, int tid) {
   float gam = 0.f, rs = 0.f;
   if (tid == 0) {
     gam = a.gamma[c];
@@ -667,6 +664,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalize
     a.mg[c] = (float)(s1 * (double)a.inv_n);
     a.mgx[c] = (float)(s2 * (double)a.inv_n);
   }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
+  __shared__ double sOut[2];
+  bn_bwd_finalize_body(a, blockIdx.x, sAcc, sOut, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

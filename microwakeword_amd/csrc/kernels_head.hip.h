@@ -150,18 +150,15 @@ struct MetricsArgs {
   int B;
 };
 
-__global__ __launch_bounds__(1024) void metrics_kernel(MetricsArgs a) {
-  __shared__ unsigned sH101[2][101];
-  __shared__ unsigned sH200[2][200];
-  __shared__ unsigned sCnt[8];       // n, correct, tp5, fp5, fn5, pos, neg
-  __shared__ double sBce[1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 202; i += 1024) (&sH101[0][0])[i] = 0u;
-  for (int i = tid; i < 400; i += 1024) (&sH200[0][0])[i] = 0u;
+template <int NT>
+__device__ __forceinline__ void metrics_body(const MetricsArgs& a, unsigned (*sH101)[101], unsigned (*sH200)[200], unsigned* sCnt,
+                                             double* sBce, int tid) {
+  for (int i = tid; i < 202; i += NT) (&sH101[0][0])[i] = 0u;
+  for (int i = tid; i < 400; i += NT) (&sH200[0][0])[i] = 0u;
   if (tid < 8) sCnt[tid] = 0u;
   __syncthreads();
   double bce = 0.0;
-  for (int b = tid; b < a.B; b += 1024) {
+  for (int b = tid; b < a.B; b += NT) {
     const float pr = a.prob[b], yy = a.y[b];
     const int lab = yy > 0.5f ? 1 : 0;
     const float p01 = fminf(fmaxf(pr, 0.f), 1.f);
@@ -182,23 +179,31 @@ __global__ __launch_bounds__(1024) void metrics_kernel(MetricsArgs a) {
   }
   sBce[tid] = bce;
   __syncthreads();
-  for (int i = tid; i < 202; i += 1024) {
+  for (int i = tid; i < 202; i += NT) {
     const unsigned v = (&sH101[0][0])[i];
     if (v) atomicAdd(&a.m->hist101[0][0] + i, (unsigned long long)v);
   }
-  for (int i = tid; i < 400; i += 1024) {
+  for (int i = tid; i < 400; i += NT) {
     const unsigned v = (&sH200[0][0])[i];
     if (v) atomicAdd(&a.m->hist200[0][0] + i, (unsigned long long)v);
   }
   if (tid < 7 && sCnt[tid]) atomicAdd(&a.m->n + tid, (unsigned long long)sCnt[tid]);
   if (tid == 0) {
     double s = 0.0;
-    for (int i = 0; i < 1024; ++i) s += sBce[i];
+    for (int i = 0; i < NT; ++i) s += sBce[i];
     a.m->bce_sum += s;   // single workgroup, single writer
   }
 }
 
-// grid = (ceil(T*C / 256), n_chunks): thread e owns dense weight e and sums one chunk of the batch.
+__global__ __launch_bounds__(1024) void metrics_kernel(MetricsArgs a) {
+  __shared__ unsigned sH101[2][101];
+  __shared__ unsigned sH200[2][200];
+  __shared__ unsigned sCnt[8];       // n, correct, tp5, fp5, fn5, pos, neg
+  __shared__ double sBce[1024];
+  metrics_body<1024>(a, sH101, sH200, sCnt, sBce, threadIdx.x);
+}
+
+// Dense-weight gradient of the classifier head (second read of p_L) as a batch-chunked reduction
 struct DenseGradArgs {
   const float* p;       // p_L [B][T*C]
   const float* scale;   // [C]
@@ -209,9 +214,9 @@ struct DenseGradArgs {
   const float* keep;    // [B][n] dropout keep-scale in front of the dense layer, or null
 };
 
-__global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  const int b0 = blockIdx.y * a.chunk, b1 = min(a.B, b0 + a.chunk);
+__device__ __forceinline__ void dense_grad_body(const DenseGradArgs& a, int bx, int by, int tid) {
+  const int e = bx * kThreads + tid;
+  const int b0 = by * a.chunk, b1 = min(a.B, b0 + a.chunk);
   if (e < a.n) {
     const int c = e % a.C;
     const float sc = a.scale[c], sh = a.shift[c];
@@ -228,12 +233,16 @@ __global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh), 0.f), acc);
     }
-    a.part[(size_t)blockIdx.y * a.stride + e] = acc;
+    a.part[(size_t)by * a.stride + e] = acc;
   } else if (e == a.n) {
     float s = 0.f;
     for (int b = b0; b < b1; ++b) s += a.dz[b];
-    a.part[(size_t)blockIdx.y * a.stride + a.n] = s;
+    a.part[(size_t)by * a.stride + a.n] = s;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void dense_grad_kernel(DenseGradArgs a) {
+  dense_grad_body(a, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 }  // namespace mww

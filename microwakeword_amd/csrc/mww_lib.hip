@@ -14,6 +14,7 @@
 #include "kernels_fwd.hip.h"
 #include "kernels_graph.hip.h"
 #include "kernels_head.hip.h"
+#include "kernels_tail.hip.h"
 
 using namespace mww;
 
@@ -125,6 +126,7 @@ struct mww_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  bool tail_pending = false, tail_metrics = false;   // dense gradient (+ metrics) ride in the first backward launch
   void* store[MWW_MAX_STORES] = {};
   int store_dtype[MWW_MAX_STORES] = {};
   int64_t store_elems[MWW_MAX_STORES] = {};
@@ -408,6 +410,13 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
   lp.end();
   if (rc) return rc;
+  if (loss && !(c->hook && c->sync_bn)) {
+    // train step: the dense-weight gradient and the metric update share the launch of the last block's
+    // BN-backward finalize (head_tail_kernel, first thing in enqueue_backward)
+    c->tail_pending = true;
+    c->tail_metrics = metrics;
+    return MWW_OK;
+  }
   return enqueue_side_work(c, B, metrics, loss, ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), nullptr);
 }
 
@@ -478,9 +487,26 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     BnBwdFinalizeArgs f{ss.part, ss.G, l.cout, ss.inv_n,
                         c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
                         bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta, ss.dscale};
-    lp.begin("bn_bwd_finalize", i);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(l.cout), dim3(kThreads), 0, c->stream, f);
-    lp.end();
+    if (last && c->tail_pending) {
+      c->tail_pending = false;
+      const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
+      HeadTailArgs ht;
+      ht.fin = f;
+      ht.dense = DenseGradArgs{l.p, bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
+                               c->c_last, c->dwd_stride, dchunk, nullptr};
+      ht.met = MetricsArgs{c->prob, c->y, c->metrics, B};
+      ht.n_fin = l.cout;
+      ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
+      ht.ndy = (B + dchunk - 1) / dchunk;
+      ht.do_metrics = c->tail_metrics ? 1 : 0;
+      lp.begin("head_tail");
+      hipLaunchKernelGGL(head_tail_kernel, dim3(ht.n_fin + ht.ndx * ht.ndy + ht.do_metrics), dim3(kThreads), 0, c->stream, ht);
+      lp.end();
+    } else {
+      lp.begin("bn_bwd_finalize", i);
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(l.cout), dim3(kThreads), 0, c->stream, f);
+      lp.end();
+    }
     if (i > 0) {
       Layer& pl = c->L[i - 1];
       BwdBlockArgs a;
