@@ -31,17 +31,17 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
   const int j = blockIdx.x;
   const int tid = threadIdx.x;
   const int nm = a.ntm + a.nfm;
+  const mww_window w = a.win[j];   // issued together with the mask loads: one memory round trip, not two
   if (tid < nm * 2) sMask[tid] = a.masks[(size_t)j * nm * 2 + tid];
   if (j < a.n_targets && tid == 64) a.y_dst[j] = a.y_src[j];
   if (j < a.n_targets && tid == 128) a.sw_dst[j] = a.sw_src[j];
   __syncthreads();
-  const mww_window w = a.win[j];
   const int dtype = a.dtype[w.store];
   const unsigned short* s16 = reinterpret_cast<const unsigned short*>(a.store[w.store]);
   const float* s32 = reinterpret_cast<const float*>(a.store[w.store]);
   float* dst = a.x + (size_t)j * a.T * FBINS;
   constexpr int Q = FBINS / 4;
-  constexpr int U = 4;   // float4 groups in flight per thread: all loads of a batch are issued before the first store
+  constexpr int U = 8;   // float4 groups in flight per thread: all loads of a batch (the whole 194-frame window) are issued before the first store
   for (int i0 = tid; i0 < a.T * Q; i0 += kThreads * U) {
     float4 v[U];
     int tt[U], qq[U];

@@ -527,3 +527,70 @@ def check_validation_on_device(lib, gold, tag="u16"):
     assert abs(fast["auc"] - r["auc"]) < 1e-6 and abs(fast["loss"] - r["loss"]) < 1e-5
     model.engine.close()
     return fast
+
+
+# ------------------------------------------------------------------------------------------ the whole loop
+def learnable_config(n=64, seed=0, T=60):
+    """Two providers whose windows differ by a band of raised energy: a tiny separable wake-word task."""
+    rng = np.random.default_rng(seed)
+
+    def samples(count, positive, lo, hi):
+        out = []
+        for _ in range(count):
+            L = int(rng.integers(lo, hi))
+            s = rng.integers(0, 200, size=(L, 40)).astype(np.uint16)
+            if positive:
+                s[-40:-20, 8:24] += 400
+            out.append(s)
+        return out
+
+    pos = {"training": [samples(n, True, T + 5, T + 40)], "validation": [samples(n // 2, True, T + 5, T + 40)]}
+    neg = {"training": [samples(n, False, T + 5, T + 40)], "validation": [samples(n // 2, False, T + 5, T + 40)],
+           "validation_ambient": [samples(4, False, 4 * T, 6 * T)]}
+    return {"stride": 1, "window_step_ms": 10, "features": [
+        dict(type="mmap", stores=pos, truth=True, sampling_weight=1.0, penalty_weight=1.0, truncation_strategy="truncate_start"),
+        dict(type="mmap", stores=neg, truth=False, sampling_weight=1.0, penalty_weight=1.0, truncation_strategy="truncate_start")]}
+
+
+def check_train_loop_end_to_end(lib, tmp_path, B=16, steps=12, kind="mixednet", min_val_accuracy=None):
+    """model_train_eval's objects through microwakeword_amd.train.train: schedule, on-device batches, periodic
+    validation (device-resident), best-weights rule, checkpoint + restore — and the model learns the task."""
+    from microwakeword_amd import inception, mixednet
+    from microwakeword_amd import train as tr
+    T = 60
+    flags = DEF if kind == "mixednet" else dict(INC, dropout=0.1)
+    module = mixednet if kind == "mixednet" else inception
+    cfg = dict(learnable_config(T=T), train_dir=str(tmp_path / "run"), summaries_dir=str(tmp_path / "run" / "logs"), batch_size=B,
+               spectrogram_length=T, training_steps=[steps // 2, steps - steps // 2], learning_rates=[0.01, 0.003],
+               time_mask_max_size=[0], time_mask_count=[0], freq_mask_max_size=[0], freq_mask_count=[0],
+               positive_class_weight=[1.0], negative_class_weight=[1.0], eval_step_interval=steps // 3, target_minimization=0.9,
+               minimization_metric=None, maximization_metric="accuracy")
+    random.seed(1)
+    np.random.seed(1)
+    model = module.model(flags, (T, 40), B, lib=lib, seed=7, max_batch=64)
+    fh = FeatureHandler(cfg, engine=model.engine)
+    out = tr.train(model, cfg, fh, verbose=False)
+    if min_val_accuracy is not None:
+        # validation runs in inference mode on the BN moving averages (momentum 0.99): they need a few hundred
+        # steps to converge, so the learning claim is only made for long enough runs
+        assert out["best_maximization"] >= min_val_accuracy, out
+    run = tmp_path / "run"
+    for f in ("best_weights.weights.h5.npz", "last_weights.weights.h5.npz", "restore/ckpt.weights.npz", "restore/ckpt.opt.npz",
+              "logs/train/scalars.jsonl", "logs/validation/scalars.jsonl"):
+        assert (run / f).exists(), f
+    # restore: a fresh model picks up weights + Adam state and keeps the validation quality
+    w_last = model.get_weights()
+    m2 = module.model(flags, (T, 40), B, lib=lib, seed=99, max_batch=64)
+    m2.load_weights(str(run / "last_weights.weights.h5"))
+    for a, b in zip(w_last, m2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    m2.load_optimizer_state(str(run / "restore" / "ckpt.opt.npz"))
+    assert m2.engine.get_opt_state()[2] == steps
+    fh2 = FeatureHandler(cfg, engine=m2.engine)
+    nm = tr.validate_nonstreaming(dict(cfg), fh2, m2, "validation")
+    assert 0.0 <= nm["ambient_false_positives_per_hour"]
+    if min_val_accuracy is not None:
+        assert nm["accuracy"] >= min_val_accuracy - 0.05, nm
+    model.engine.close()
+    m2.engine.close()
+    return out

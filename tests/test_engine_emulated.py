@@ -80,3 +80,7 @@ def test_inception_unfused_branch_heads(emu_lib):
     """The 22-op form (one op per Keras layer) stays available and agrees as well."""
     ec.check_inception_forward(emu_lib, B=2, T=194, training=True, grid=2, fuse_heads=False)
     ec.check_inception_train_steps(emu_lib, B=3, T=194, steps=1, grid=2, fuse_heads=False)
+
+
+def test_train_loop_end_to_end(emu_lib, tmp_path):
+    ec.check_train_loop_end_to_end(emu_lib, tmp_path, B=8, steps=9)

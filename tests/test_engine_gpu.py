@@ -196,3 +196,10 @@ def test_bf16_pointwise_mode(lib):
     pr, _, _ = eng.read_outputs(B, want_loss=False)
     assert np.abs(pr - om.predict(x)).max() <= 5e-3
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["mixednet", "inception"])
+def test_train_loop_end_to_end(lib, tmp_path, kind):
+    """The whole host loop (schedule, device-resident batches and validation, best-weights rule, checkpoint and
+    restore) on a small separable task: the model has to learn it."""
+    ec.check_train_loop_end_to_end(lib, tmp_path, B=32, steps=450, kind=kind, min_val_accuracy=0.95)
