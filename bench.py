@@ -203,8 +203,7 @@ def main():
     with torch.cuda.stream(stream):
         if args.model == "inception":
             from microwakeword_amd import inception
-            from oracle.model_oracle import INCEPTION_DEFAULTS   # flag defaults only (no compute)
-            model = inception.model(dict(INCEPTION_DEFAULTS), (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
+            model = inception.model(dict(synthetic.DEFAULT_INCEPTION_FLAGS), (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                                     seed=42, max_batch=B)
             kernel_elems = inception_kernel_elems(model.layout)
             step_bytes = 4 * sum(kernel_elems.values())

@@ -44,4 +44,7 @@ def benchmark_config(n_samples=4096, seed=1234, dtype=np.uint16, n_val=0, n_ambi
 DEFAULT_MIXEDNET_FLAGS = dict(pointwise_filters="48, 48, 48, 48", residual_connection="0,0,0,0", repeat_in_block="1,1,1,1",
                               mixconv_kernel_sizes="[5], [9], [13], [21]", max_pool=0, first_conv_filters=32,
                               first_conv_kernel_size=3, spatial_attention=0, pooled=0, stride=1)
+DEFAULT_INCEPTION_FLAGS = dict(cnn1_filters="24", cnn1_kernel_sizes="5", cnn1_subspectral_groups="4", cnn2_filters1="10,10,16",
+                               cnn2_filters2="10,10,16", cnn2_kernel_sizes="5,5,5", cnn2_subspectral_groups="1,1,1",
+                               cnn2_dilation="1,1,1", dropout=0.2)
 SPEC_AUGMENT_POLICY = dict(freq_mix_prob=0.0, time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)

@@ -232,3 +232,23 @@ def test_inception_flags_layout_and_oracle_order(tmp_path):
     fl = model_train_eval.build_parser().parse_args(["--training_config", str(f), "inception"])
     c = model_train_eval.load_config(fl, inception)
     assert (c["spectrogram_length_final_layer"], c["spectrogram_length"]) == (148, 176)
+
+
+def test_package_and_bench_main_path_never_import_the_oracle():
+    """oracle/ is test infrastructure: the package must not reference it, bench.py only inside cpu_baseline()."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "microwakeword_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            tree = ast.parse(open(os.path.join(pkg, f)).read())
+            for node in ast.walk(tree):
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                    ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+                assert not any(n.split(".")[0] == "oracle" for n in names), (f, names)
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                assert fn.name == "cpu_baseline", fn.name
+    assert synthetic.DEFAULT_INCEPTION_FLAGS == mo.INCEPTION_DEFAULTS
