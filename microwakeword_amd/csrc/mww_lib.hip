@@ -597,10 +597,10 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, int grid, size_t lds) {
   return fail(MWW_ERR_UNSUPPORTED, "conv width not instantiated");
 }
 
-int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds, hipStream_t st) {
+int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
-    hipLaunchKernelGGL((gconv_wgrad_kernel<N>), dim3(grid), dim3(kThreads), lds, st, a);                       \
+    hipLaunchKernelGGL((gconv_wgrad_kernel<N>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
     return MWW_OK;                                                                                             \
   }
   MWW_G_WIDTHS(X)
@@ -751,7 +751,6 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
-  bool wgrad_on_side = false;
   for (int i = n - 1; i >= 0; --i) {
     GOp& o = c->G[i];
     const int members = o.groups > 1 ? o.cout / o.groups : 1;
@@ -778,19 +777,8 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     w.Tout = o.tout;
     w.nq = o.nq;
     w.grad_part = o.grad_part;
-    // The weight gradient of an op feeds nothing but the final gradient assembly, so the whole chain of
-    // weight-gradient kernels runs on the side stream next to the finalize -> data-gradient chain.  These
-    // kernels are latency-bound (tens of MFLOP each): unlike the MixedNet block kernels they gain from
-    // running side by side.  (Profiling mode keeps one stream so that every launch can be timed.)
-    hipStream_t ws = c->stream;
-    if (!c->profile) {
-      HIPCHK(hipEventRecord(c->ev_fork, c->stream));      // after this op's BN-backward finalize
-      HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-      ws = c->side;
-      wgrad_on_side = true;
-    }
     lp.begin("conv_wgrad", i);
-    int rc = launch_gwgrad(c, o.cout, w, gg, o.lds_wg, ws);
+    int rc = launch_gwgrad(c, o.cout, w, gg, o.lds_wg);
     lp.end();
     if (rc) return rc;
     if (o.needs_dx) {
@@ -818,10 +806,6 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     s.n = s.stride;
     s.dst = (int)o.o_w;
     ga.seg[ga.nseg++] = s;
-  }
-  if (wgrad_on_side) {
-    HIPCHK(hipEventRecord(c->ev_join, c->side));
-    c->side_pending = true;   // joined at the top of the gradient assembly
   }
   return enqueue_grad_assembly(c, B, ga, fuse_adam);
 }
