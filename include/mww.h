@@ -71,8 +71,9 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
  * three-branch block's StridedDrop + Concatenate (:143-209; strided_drop.py:42 drops LEADING frames).
  * The head is Flatten -> Dropout(rate) -> Dense(1, sigmoid) (:330-338) on the LAST op.
  * Ops are listed in layer-creation order, so the flat parameter vector is Keras get_weights() order:
- *   per op: kernel[k*Cin*filters] gamma[slots] beta[slots] ; dense.kernel[T_last*C_last] dense.bias[1]
- *   (slots = bn_groups if bn_groups > 1 else filters); BN state: per op moving_mean[slots] moving_variance[slots].
+ *   per op: kernel[k*Cin*filters] (depthwise: [k*filters]) then gamma[slots] beta[slots] (MWW_NORM_BN) or
+ *   bias[filters] (MWW_NORM_BIAS) ; dense.kernel[T_last*C_last] dense.bias[1]
+ *   (slots = bn_groups if bn_groups > 1 else filters); BN state: per BN op moving_mean[slots] moving_variance[slots].
  * Every other entry point of this header works on such a context exactly as on a MixedNet one. */
 #define MWW_MAX_GRAPH_OPS 48
 #define MWW_MAX_OP_SOURCES 3
@@ -88,7 +89,22 @@ typedef struct {
                                            disjoint and together cover all of its channels. */
   int32_t kernel, dilation, filters;
   int32_t bn_groups;                    /* 1 = BatchNormalization, g > 1 = SubSpectralNormalization(g) */
+  /* the four fields below default to 0 = the Inception vocabulary (dense conv, stride 1, BN/SSN, ReLU); the others
+   * express any MixedNet flag combination the specialised block kernels do not cover (mixednet.py:307-360:
+   * first conv with --stride and no BN, MixConv depthwise + bias with no activation, repeat_in_block > 1, ...) */
+  int32_t kind;                         /* MWW_OP_CONV: k x 1 convolution over all input channels;
+                                           MWW_OP_DEPTHWISE: per-channel k x 1 taps [k][C] (one source, filters == its channels) */
+  int32_t stride;                       /* time stride (0/1 = none); only for ops fed by the spectrogram */
+  int32_t norm;                         /* MWW_NORM_BN (gamma, beta + moving statistics), MWW_NORM_BIAS (bias[filters]), MWW_NORM_NONE */
+  int32_t act;                          /* MWW_ACT_RELU or MWW_ACT_LINEAR */
 } mww_conv_bn_op;
+#define MWW_OP_CONV 0
+#define MWW_OP_DEPTHWISE 1
+#define MWW_NORM_BN 0
+#define MWW_NORM_BIAS 1
+#define MWW_NORM_NONE 2
+#define MWW_ACT_RELU 0
+#define MWW_ACT_LINEAR 1
 typedef struct {
   int32_t frames;
   int32_t n_ops;

@@ -29,7 +29,7 @@
 namespace mww {
 
 constexpr int kGMaxSrc = 3;
-enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8 };
+enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8, GSRC_LINEAR = 16 };   // LINEAR: affine only, no ReLU
 
 struct GSrc {
   const float* p;       // [B][T][C] pre-BN output of the producer (or the spectrogram)
@@ -59,10 +59,11 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
     if (rg < nrg) {
       const bool ident = (s.flags & GSRC_IDENTITY) != 0;
       const float sc = ident ? 1.f : s.scale[s.c0 + c], sh = ident ? 0.f : s.shift[s.c0 + c];
+      const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
       const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
       for (int t = rg; t < rows; t += nrg) {
         const float v = base[(size_t)t * s.ld];
-        sIn[t * PI + c0 + c] = ident ? v : fmaxf(fmaf(v, sc, sh), 0.f);
+        sIn[t * PI + c0 + c] = fmaxf(fmaf(v, sc, sh), lo);
       }
     }
     c0 += C;
@@ -105,11 +106,12 @@ struct GConvArgs {
   int n_src;
   const float* w;       // MODE 0: [k][cin][NC];  MODE 1: reversed taps, transposed: [k][cin = fwd cout][NC = fwd cin]
   int k, dil, cin;      // cin = channels reduced over
+  int stride;           // MODE 0 only: time stride (ops fed by the spectrogram, e.g. MixedNet's first conv); else 1
   int B;
   int Tin;              // MODE 0: aligned input frames;   MODE 1: frames of the op's output (dp)
-  int Tout;             // MODE 0: Tin - (k-1)*dil;        MODE 1: Tin + (k-1)*dil (= aligned input frames)
+  int Tout;             // MODE 0: (Tin - (k-1)*dil - 1)/stride + 1;   MODE 1: Tin + (k-1)*dil (= aligned input frames)
   float* out;           // MODE 0: pre-BN output [B][Tout][NC]
-  float* stat_part;     // MODE 0: [grid][2][NC]
+  float* stat_part;     // MODE 0: [grid][2][NC], or null when the op has no batch statistics
   GBnBwd y;             // MODE 1
 };
 
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
 #pragma unroll
       for (int co = 0; co < NCP; ++co) acc[co] = 0.f;
       for (int j = 0; j < a.k; ++j) {
-        const float* row = sIn + (t + j * a.dil) * PI;
+        const float* row = sIn + ((MODE == 0 ? t * a.stride : t) + j * a.dil) * PI;
         const float4* wj = reinterpret_cast<const float4*>(sW + j * a.cin * NCP);
 #pragma unroll 2
         for (int ci = 0; ci < a.cin; ++ci) {
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
           if (rg < nrg) {
             const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
             const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
+            const bool linear = (s.flags & GSRC_LINEAR) != 0;
             const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
             const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
             float t1 = 0.f, t2 = 0.f;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
               const size_t idx = base + (size_t)t * s.ld;
               const float p = s.p[idx];
               const int r = t - s.toff;
-              float gv = (r >= 0 && fmaf(p, sc, sh) > 0.f) ? sOut[r * PO + c0 + c] : 0.f;
+              float gv = (r >= 0 && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
               if (accum) gv += s.g[idx];
               s.g[idx] = gv;
               t1 += gv;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
     }
   }
   if (MODE == 0) {
-    write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
+    if (a.stat_part) write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
   } else {
 #pragma unroll
     for (int i = 0; i < kGMaxSrc; ++i) {
@@ -229,6 +232,7 @@ struct GWgradArgs {
   int n_src;
   GBnBwd y;
   int k, dil, cin, B, Tin, Tout;
+  int stride;           // time stride of the forward convolution
   int nq;               // frame subsets per (tap, channel) task: nq * k * cin <= 256
   float* grad_part;     // [grid * nq][k*cin*NC]
 };
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
     if (active) {
       const float* col = sA + j * a.dil * PI + ci;
       for (int t = q; t < a.Tout; t += nq) {
-        const float v = col[t * PI];
+        const float v = col[t * a.stride * PI];
         const float4* row = reinterpret_cast<const float4*>(sDP + t * PO);
 #pragma unroll
         for (int c4 = 0; c4 < PO / 4; ++c4) {
@@ -278,6 +282,115 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
     float* dst = a.grad_part + ((size_t)blockIdx.x * nq + q) * ((size_t)tasks * NC) + (size_t)task * NC;
 #pragma unroll
     for (int co = 0; co < NC; ++co) dst[co] = acc[co];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise k x 1 convolution ops (MixedNet's MixConv, mixednet.py:168-231, for shapes the specialised
+// block kernels do not cover): one source, C channels in and out, taps w[k][C] (multi-kernel MixConv
+// groups arrive fused: right-aligned, zero leading taps, gradient mask), bias handled as the op's "shift".
+// thread <-> (channel, frame group) everywhere, so reads of a wave are C-contiguous rows.
+struct GDwArgs {
+  GSrc src;
+  const float* w;       // [k][C]
+  int k, C, B, Tin, Tout;
+  float* out;           // MODE 0: [B][Tout][C]
+  GBnBwd y;             // MODE 1 / weight gradient: the op's output gradient (coefficients are the constants 1, 0, 0)
+  float* grad_part;     // weight gradient: [grid][k*C]
+};
+
+// MODE 0: forward.  MODE 1: data gradient da[s] = sum_j w[j] dp[s-j], scattered into the source's gradient.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
+  HIP_DYNAMIC_SHARED(float4, g_smem4)
+  float* g_smem = reinterpret_cast<float*>(g_smem4);
+  __shared__ float sRed[2 * kThreads];
+  const int tid = threadIdx.x, C = a.C, PI = C | 1;
+  const int pad = MODE == 1 ? a.k - 1 : 0;
+  const int rows_in = (MODE == 0 ? a.Tin : a.Tout + 2 * pad);
+  float* sW = g_smem;               // [k][C]
+  float* sIn = sW + a.k * C;        // MODE 0: activated source rows; MODE 1: zero-padded dp rows
+  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < a.k * C; i += kThreads) sW[i] = a.w[i];
+  if (MODE == 1)
+    for (int i = tid; i < pad * PI; i += kThreads) {
+      sIn[i] = 0.f;
+      sIn[(pad + a.Tout) * PI + i] = 0.f;
+    }
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    if (MODE == 0) stage_sources(&a.src, 1, b, a.Tin, sIn, PI, tid);
+    else stage_dp(a.y, C, b, a.Tout, sIn + pad * PI, PI, tid);
+    __syncthreads();
+    if (rg < nrg) {
+      if (MODE == 0) {
+        float* dst = a.out + (size_t)b * a.Tout * C + c;
+        for (int t = rg; t < a.Tout; t += nrg) {
+          float acc = 0.f;
+          for (int j = 0; j < a.k; ++j) acc = fmaf(sW[j * C + c], sIn[(t + j) * PI + c], acc);
+          dst[(size_t)t * C] = acc;
+        }
+      } else {
+        const GSrc& s = a.src;
+        const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
+        const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0, linear = (s.flags & GSRC_LINEAR) != 0;
+        const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
+        const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
+        for (int t = rg; t < s.T; t += nrg) {
+          const size_t idx = base + (size_t)t * s.ld;
+          const float p = s.p[idx];
+          const int r = t - s.toff;   // frame of the (aligned) input; da[r] = sum_j w[j] dp[r - j]
+          float gv = 0.f;
+          if (r >= 0 && r < a.Tin && (linear || fmaf(p, sc, sh) > 0.f)) {
+            float acc = 0.f;
+            for (int j = 0; j < a.k; ++j) acc = fmaf(sW[j * C + c], sIn[(r - j + pad) * PI + c], acc);
+            gv = acc;
+          }
+          if (accum) gv += s.g[idx];
+          s.g[idx] = gv;
+          s1 += gv;
+          s2 = fmaf(gv, (p - mu) * rs, s2);
+        }
+      }
+    }
+  }
+  if (MODE == 1 && (a.src.flags & GSRC_STATS))
+    write_channel_partials(s1, s2, C, sRed, a.src.gstat_part + (size_t)blockIdx.x * 2 * a.src.ld + a.src.c0, tid, a.src.ld);
+}
+
+// dw[j][c] = sum_{b,t} act[b][t+j][c] * dp[b][t][c]; task (j, c) -> thread (task % 256), up to kGDwTasks per thread
+constexpr int kGDwTasks = 8;
+__global__ __launch_bounds__(kThreads) void gdw_wgrad_kernel(GDwArgs a) {
+  HIP_DYNAMIC_SHARED(float4, g_smem4)
+  float* g_smem = reinterpret_cast<float*>(g_smem4);
+  const int tid = threadIdx.x, C = a.C, PI = C | 1;
+  float* sA = g_smem;
+  float* sDP = g_smem + a.Tin * PI;
+  const int tasks = a.k * C;
+  float acc[kGDwTasks];
+#pragma unroll
+  for (int u = 0; u < kGDwTasks; ++u) acc[u] = 0.f;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    __syncthreads();
+    stage_sources(&a.src, 1, b, a.Tin, sA, PI, tid);
+    stage_dp(a.y, C, b, a.Tout, sDP, PI, tid);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kGDwTasks; ++u) {
+      const int task = tid + u * kThreads;
+      if (task < tasks) {
+        const int j = task / C, c = task - j * C;
+        float v = acc[u];
+        for (int t = 0; t < a.Tout; ++t) v = fmaf(sA[(t + j) * PI + c], sDP[t * PI + c], v);
+        acc[u] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kGDwTasks; ++u) {
+    const int task = tid + u * kThreads;
+    if (task < tasks) a.grad_part[(size_t)blockIdx.x * tasks + task] = acc[u];
   }
 }
 
@@ -378,6 +491,8 @@ struct GBnBwdArgs {
   float *c1, *mg, *mgx;      // [C]
   float *dgamma, *dbeta;     // [slots] -> flat gradient
   float dscale;              // 1, or 1/W when the sums were all-reduced (see BnBwdFinalizeArgs)
+  int bias_only;             // the op has a bias instead of a BN (depthwise convolution): only dbeta = sum g is needed,
+                             // the backward coefficients are the constants c1 = 1, mg = mgx = 0
 };
 __global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a) {
   __shared__ double sAcc[2 * kThreads];
@@ -390,6 +505,10 @@ __global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a
     t2 += (double)a.gstat_part[(size_t)jj * 2 * a.C + a.C + c];
   }
   block_sum2(t1, t2, sAcc, tid);
+  if (a.bias_only) {
+    if (tid == 0) a.dbeta[slot] = (float)t1 * a.dscale;
+    return;
+  }
   if (tid < members) {
     const int c = slot + tid * cstride;
     a.c1[c] = a.gamma[slot] * a.rstd[c];

@@ -54,6 +54,7 @@ struct GOp {
   int sc0[kGMaxSrc] = {0, 0, 0}, scn[kGMaxSrc] = {0, 0, 0};   // channel slice of each source
   bool src_first[kGMaxSrc] = {false, false, false}, src_last[kGMaxSrc] = {false, false, false};   // this op's place among the consumers of that slice (backward order)
   int k = 1, dil = 1, cin = 0, cout = 0, groups = 1, slots = 0, tin = 0, tout = 0;
+  int kind = MWW_OP_CONV, stride = 1, norm = MWW_NORM_BN, act = MWW_ACT_RELU;
   int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   int nq = 1;                 // frame subsets of the weight-gradient mapping
@@ -89,6 +90,7 @@ struct mww_ctx {
   float* keep = nullptr;            // [max_batch][t_last*c_last] dropout keep-scale
   bool keep_explicit = false;       // set by mww_set_dropout_mask: do not regenerate
   unsigned long long dropout_seed = 0x5EEDull, dropout_counter = 0;
+  float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   float* wt = nullptr;              // transposed weights of the ops with a data gradient
   int64_t wt_total = 0;
   int grid_g = 0;
@@ -625,22 +627,48 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
   }
   GOp& pr = c->G[o.src[i]];
   s.p = pr.p;
-  s.scale = gbn_slot(pr, BN_SCALE);
-  s.shift = gbn_slot(pr, BN_SHIFT);
-  s.mean = gbn_slot(pr, BN_MEAN);
-  s.rstd = gbn_slot(pr, BN_RSTD);
+  if (pr.norm == MWW_NORM_BN) {
+    s.scale = gbn_slot(pr, BN_SCALE);
+    s.shift = gbn_slot(pr, BN_SHIFT);
+    s.mean = gbn_slot(pr, BN_MEAN);
+    s.rstd = gbn_slot(pr, BN_RSTD);
+  } else {   // a bias (or nothing) instead of a BN: y = p * 1 + bias
+    s.scale = c->ones;
+    s.shift = pr.norm == MWW_NORM_BIAS ? c->params + pr.o_beta : c->zeros;
+    s.mean = c->zeros;
+    s.rstd = c->ones;
+  }
   s.g = pr.g;
   s.gstat_part = pr.gstat_part;
   s.T = pr.tout;
   s.C = o.scn[i];
   s.ld = pr.cout;
   s.c0 = o.sc0[i];
-  if (backward) s.flags = GSRC_GRAD | (o.src_first[i] ? 0 : GSRC_ACCUM) | (o.src_last[i] ? GSRC_STATS : 0);
+  if (pr.act == MWW_ACT_LINEAR) s.flags |= GSRC_LINEAR;
+  if (backward) s.flags |= GSRC_GRAD | (o.src_first[i] ? 0 : GSRC_ACCUM) | (o.src_last[i] ? GSRC_STATS : 0);
   return s;
 }
 
-GBnBwd g_make_bnbwd(GOp& o) {
+GBnBwd g_make_bnbwd(mww_ctx* c, GOp& o) {
+  if (o.norm != MWW_NORM_BN) return GBnBwd{o.g, o.p, c->zeros, c->ones, c->ones, c->zeros, c->zeros};   // dp = g
   return GBnBwd{o.g, o.p, gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX)};
+}
+
+GDwArgs g_make_dw(mww_ctx* c, int oi, int B, bool backward) {
+  GOp& o = c->G[oi];
+  GDwArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = g_make_src(c, oi, 0, backward);
+  a.w = c->params + o.o_w;
+  a.k = o.k;
+  a.C = o.cout;
+  a.B = B;
+  a.Tin = o.tin;
+  a.Tout = o.tout;
+  a.out = o.p;
+  a.y = g_make_bnbwd(c, o);
+  a.grad_part = o.grad_part;
+  return a;
 }
 
 int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
@@ -649,12 +677,19 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   const int gg = std::min(B, c->grid_g);
   for (int i = 0; i < n; ++i) {
     GOp& o = c->G[i];
-    if (!training) {
+    if (!training && o.norm == MWW_NORM_BN) {
       GBnEvalArgs e{c->params + o.o_gamma, c->params + o.o_beta, c->bn_state + o.o_mm, c->bn_state + o.o_mv,
                     gbn_slot(o, BN_SCALE), gbn_slot(o, BN_SHIFT), o.cout, o.groups};
       lp.begin("bn_eval_prepare", i);
       hipLaunchKernelGGL(gbn_eval_prepare_kernel, dim3(1), dim3(kThreads), 0, c->stream, e);
       lp.end();
+    }
+    if (o.kind == MWW_OP_DEPTHWISE) {
+      GDwArgs dw = g_make_dw(c, i, B, false);
+      lp.begin("dw_fwd", i);
+      hipLaunchKernelGGL(gdw_kernel<0>, dim3(gg), dim3(kThreads), o.lds_fwd, c->stream, dw);
+      lp.end();
+      continue;
     }
     GConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -664,16 +699,17 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     a.k = o.k;
     a.dil = o.dil;
     a.cin = o.cin;
+    a.stride = o.stride;
     a.B = B;
     a.Tin = o.tin;
     a.Tout = o.tout;
     a.out = o.p;
-    a.stat_part = o.stat_part;
+    a.stat_part = (training && o.norm == MWW_NORM_BN) ? o.stat_part : nullptr;
     lp.begin("conv_fwd", i);
     int rc = launch_gconv<0>(c, o.cout, a, gg, o.lds_fwd);
     lp.end();
     if (rc) return rc;
-    if (training) {
+    if (training && o.norm == MWW_NORM_BN) {
       const int members = o.groups > 1 ? o.cout / o.groups : 1;
       StatSource ss;
       int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, o.stat_part, gg, o.cout, 0,
@@ -737,7 +773,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     int ni = 0, maxn = 0;
     for (int i = 0; i < n; ++i) {
       GOp& o = c->G[i];
-      if (!o.needs_dx) continue;
+      if (!o.needs_dx || o.kind != MWW_OP_CONV) continue;
       t.item[ni++] = GTransposeItem{(int)o.o_w, (int)o.o_wt, o.k, o.cin, o.cout};
       maxn = std::max(maxn, o.k * o.cin * o.cout);
     }
@@ -754,24 +790,52 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   for (int i = n - 1; i >= 0; --i) {
     GOp& o = c->G[i];
     const int members = o.groups > 1 ? o.cout / o.groups : 1;
-    StatSource ss;
-    int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, o.gstat_part, i == n - 1 ? ghead : gg, o.cout, 1,
-                             1.0f / ((float)B * (float)o.tout * (float)members), &ss);
-    if (rcs) return rcs;
-    GBnBwdArgs f{ss.part, ss.G, o.cout, o.groups, ss.inv_n,
-                 c->params + o.o_gamma, gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX),
-                 c->grads + o.o_gamma, c->grads + o.o_beta, ss.dscale};
-    lp.begin("bn_bwd_finalize", i);
-    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
-    lp.end();
+    if (o.norm == MWW_NORM_BN) {
+      StatSource ss;
+      int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, o.gstat_part, i == n - 1 ? ghead : gg, o.cout, 1,
+                               1.0f / ((float)B * (float)o.tout * (float)members), &ss);
+      if (rcs) return rcs;
+      GBnBwdArgs f{ss.part, ss.G, o.cout, o.groups, ss.inv_n,
+                   c->params + o.o_gamma, gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX),
+                   c->grads + o.o_gamma, c->grads + o.o_beta, ss.dscale, 0};
+      lp.begin("bn_bwd_finalize", i);
+      hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
+      lp.end();
+    } else if (o.norm == MWW_NORM_BIAS) {
+      // d bias = sum of the output gradient = the first statistic the consumers already accumulated
+      GBnBwdArgs f{o.gstat_part, gg, o.cout, 1, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->grads + o.o_beta, 1.0f, 1};
+      lp.begin("bias_grad", i);
+      hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.cout), dim3(kThreads), 0, c->stream, f);
+      lp.end();
+    }
+    if (o.kind == MWW_OP_DEPTHWISE) {
+      GDwArgs dw = g_make_dw(c, i, B, true);
+      lp.begin("dw_wgrad", i);
+      hipLaunchKernelGGL(gdw_wgrad_kernel, dim3(gg), dim3(kThreads), o.lds_wg, c->stream, dw);
+      lp.end();
+      if (o.needs_dx) {
+        lp.begin("dw_dgrad", i);
+        hipLaunchKernelGGL(gdw_kernel<1>, dim3(gg), dim3(kThreads), o.lds_dx, c->stream, dw);
+        lp.end();
+      }
+      GradSegment s;
+      s.part = o.grad_part;
+      s.G = gg;
+      s.stride = o.k * o.cout;
+      s.n = s.stride;
+      s.dst = (int)o.o_w;
+      ga.seg[ga.nseg++] = s;
+      continue;
+    }
     GWgradArgs w;
     memset(&w, 0, sizeof(w));
     w.n_src = o.n_src;
     for (int s = 0; s < o.n_src; ++s) w.src[s] = g_make_src(c, i, s, false);
-    w.y = g_make_bnbwd(o);
+    w.y = g_make_bnbwd(c, o);
     w.k = o.k;
     w.dil = o.dil;
     w.cin = o.cin;
+    w.stride = o.stride;
     w.B = B;
     w.Tin = o.tin;
     w.Tout = o.tout;
@@ -790,10 +854,11 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.k = o.k;
       a.dil = o.dil;
       a.cin = o.cout;
+      a.stride = 1;
       a.B = B;
       a.Tin = o.tout;
       a.Tout = o.tin;
-      a.y = g_make_bnbwd(o);
+      a.y = g_make_bnbwd(c, o);
       lp.begin("conv_dgrad", i);
       rc = launch_gconv<1>(c, o.cin, a, gg, o.lds_dx);
       lp.end();
@@ -886,7 +951,7 @@ int init_defaults(mww_ctx* c, const std::vector<BnSlots>& bn) {
     for (int j = 0; j < b.n; ++j) {
       dir[(size_t)b.o_gamma + j] = 1;
       dir[(size_t)b.o_beta + j] = 1;
-      st[(size_t)b.o_mv + j] = 1.0f;
+      if (b.o_mv >= 0) st[(size_t)b.o_mv + j] = 1.0f;
     }
   HIPCHK(hipMemcpy(c->mask, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice));
@@ -1070,12 +1135,18 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     if (s.n_src < 1 || s.n_src > MWW_MAX_OP_SOURCES) return fail(MWW_ERR_INVALID, tag + "1..3 sources");
     if (s.kernel < 1 || s.dilation < 1 || s.filters < 1 || s.bn_groups < 1) return fail(MWW_ERR_INVALID, tag + "bad kernel / dilation / filters / groups");
     if (s.filters % s.bn_groups) return fail(MWW_ERR_INVALID, tag + "filters must be a multiple of the sub-spectral groups");
+    if (s.kind != MWW_OP_CONV && s.kind != MWW_OP_DEPTHWISE) return fail(MWW_ERR_INVALID, tag + "unknown op kind");
+    if (s.norm < MWW_NORM_BN || s.norm > MWW_NORM_NONE || (s.act != MWW_ACT_RELU && s.act != MWW_ACT_LINEAR)) return fail(MWW_ERR_INVALID, tag + "unknown norm / activation");
+    o.kind = s.kind;
+    o.stride = s.stride > 1 ? s.stride : 1;
+    o.norm = s.norm;
+    o.act = s.act;
     o.n_src = s.n_src;
     o.k = s.kernel;
     o.dil = s.dilation;
     o.cout = s.filters;
     o.groups = s.bn_groups;
-    o.slots = s.bn_groups > 1 ? s.bn_groups : s.filters;
+    o.slots = s.norm == MWW_NORM_BN ? (s.bn_groups > 1 ? s.bn_groups : s.filters) : 0;
     o.cin = 0;
     o.tin = -1;
     for (int j = 0; j < s.n_src; ++j) {
@@ -1100,25 +1171,42 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
         n_consumers[src]++;
       }
     }
-    o.tout = o.tin - (o.k - 1) * o.dil;
-    if (o.tout <= 0) return fail(MWW_ERR_INVALID, tag + "spectrogram too short for the kernel sizes");
-    if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
-    if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
-    if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
-    o.nq = std::max(1, std::min(8, kThreads / (o.k * o.cin)));
+    const int span = o.tin - (o.k - 1) * o.dil;
+    if (span <= 0) return fail(MWW_ERR_INVALID, tag + "spectrogram too short for the kernel sizes");
+    o.tout = (span - 1) / o.stride + 1;
+    if (o.stride > 1 && o.needs_dx) return fail(MWW_ERR_UNSUPPORTED, tag + "a time stride is only implemented for ops fed by the spectrogram");
     const int pad = (o.k - 1) * o.dil;
-    const size_t wf = (size_t)o.k * o.cin * ((o.cout + 3) / 4 * 4), wb = (size_t)o.k * o.cout * ((o.cin + 3) / 4 * 4);
-    o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
-    o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
-    o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
-    if (!o.needs_dx) o.lds_dx = 0;
+    if (o.kind == MWW_OP_DEPTHWISE) {
+      if (o.n_src != 1 || o.cin != o.cout || o.dil != 1 || o.stride != 1) return fail(MWW_ERR_INVALID, tag + "a depthwise op has one source with as many channels as filters, no dilation, no stride");
+      if (o.norm == MWW_NORM_BN) return fail(MWW_ERR_UNSUPPORTED, tag + "depthwise + BatchNorm is not implemented (bias or nothing)");
+      if (o.cout > kThreads || o.k * o.cout > kGDwTasks * kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "depthwise op too large (channels <= 256, taps x channels <= 2048)");
+      const size_t pi = (size_t)(o.cout | 1), wsz = (size_t)o.k * o.cout;
+      o.lds_fwd = (wsz + (size_t)o.tin * pi) * sizeof(float);
+      o.lds_dx = o.needs_dx ? (wsz + (size_t)(o.tout + 2 * pad) * pi) * sizeof(float) : 0;
+      o.lds_wg = ((size_t)o.tin * pi + (size_t)o.tout * pi) * sizeof(float);
+      o.nq = 1;
+    } else {
+      if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
+      if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
+      if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
+      o.nq = std::max(1, std::min(8, kThreads / (o.k * o.cin)));
+      const size_t wf = (size_t)o.k * o.cin * ((o.cout + 3) / 4 * 4), wb = (size_t)o.k * o.cout * ((o.cin + 3) / 4 * 4);
+      o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
+      o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
+      o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
+      if (!o.needs_dx) o.lds_dx = 0;
+    }
     if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > kMaxDynLds) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the LDS tile");
-    o.o_w = off; off += (int64_t)o.k * o.cin * o.cout;
-    o.o_gamma = off; off += o.slots;
-    o.o_beta = off; off += o.slots;
-    o.o_mm = soff; soff += o.slots;
-    o.o_mv = soff; soff += o.slots;
-    if (o.needs_dx) { o.o_wt = wtoff; wtoff += (int64_t)o.k * o.cin * o.cout; }
+    o.o_w = off; off += o.kind == MWW_OP_DEPTHWISE ? (int64_t)o.k * o.cout : (int64_t)o.k * o.cin * o.cout;
+    if (o.norm == MWW_NORM_BN) {
+      o.o_gamma = off; off += o.slots;
+      o.o_beta = off; off += o.slots;
+      o.o_mm = soff; soff += o.slots;
+      o.o_mv = soff; soff += o.slots;
+    } else if (o.norm == MWW_NORM_BIAS) {
+      o.o_beta = off; off += o.cout;
+    }
+    if (o.needs_dx && o.kind == MWW_OP_CONV) { o.o_wt = wtoff; wtoff += (int64_t)o.k * o.cin * o.cout; }
   }
   for (int i = 0; i + 1 < d.n_ops; ++i)
     if (n_consumers[i] == 0) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
@@ -1149,6 +1237,11 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       if (!covered[cc]) return fail(MWW_ERR_UNSUPPORTED, "op " + std::to_string(pi) + ": channel " + std::to_string(cc) + " has no consumer");
   }
   if (n_consumers[d.n_ops - 1] != 0) return fail(MWW_ERR_INVALID, "the last op feeds the classifier head and cannot have other consumers");
+  {
+    const GOp& lo = ops[d.n_ops - 1];
+    if (lo.kind != MWW_OP_CONV || lo.norm != MWW_NORM_BN || lo.act != MWW_ACT_RELU)
+      return fail(MWW_ERR_UNSUPPORTED, "the classifier head expects a convolution + BatchNorm + ReLU as the last op");
+  }
 
   mww_ctx* c = new mww_ctx();
   memset(&c->d, 0, sizeof(c->d));
@@ -1183,9 +1276,16 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     A(dev_alloc(&o.g, mb * o.tout * o.cout));
     A(dev_alloc(&o.stat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
-    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.nq * o.k * o.cin * o.cout));
+    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.nq * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));
     A(dev_alloc(&o.bn, (size_t)9 * o.cout));
-    bn.push_back(BnSlots{o.o_gamma, o.o_beta, o.o_mv, o.slots});
+    if (o.norm == MWW_NORM_BN) bn.push_back(BnSlots{o.o_gamma, o.o_beta, o.o_mv, o.slots});
+    else if (o.norm == MWW_NORM_BIAS) bn.push_back(BnSlots{o.o_beta, o.o_beta, -1, o.cout});   // bias gradient is written directly too
+  }
+  {
+    A(dev_alloc(&c->ones, (size_t)kThreads));
+    A(dev_alloc(&c->zeros, (size_t)kThreads));
+    std::vector<float> one((size_t)kThreads, 1.0f);
+    if (hipMemcpy(c->ones, one.data(), one.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { mww_destroy(c); return fail(MWW_ERR_HIP, "hipMemcpy"); }
   }
   A(init_defaults(c, bn));
 #undef A
@@ -1249,6 +1349,8 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : op) if (p) hipFree(p);
   }
   if (c->sync_buf) hipFree(c->sync_buf);
+  if (c->ones) hipFree(c->ones);
+  if (c->zeros) hipFree(c->zeros);
   if (c->wt) hipFree(c->wt);
   if (c->keep) hipFree(c->keep);
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);

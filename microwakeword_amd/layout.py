@@ -399,3 +399,189 @@ def inception_slices_dropped(flags) -> int:
     for kernel_size, dilation in zip(parse(_flag(flags, "cnn2_kernel_sizes")), parse(_flag(flags, "cnn2_dilation"))):
         dropped += 2 * dilation * (kernel_size - 1)
     return dropped
+
+
+class GraphMixedNetLayout:
+    """Any MixedNet flag combination as a conv/BN graph for ``mww_create_convnet`` — the route taken when the
+    specialised block kernels do not cover a shape (other filter counts / kernel sizes, ``repeat_in_block`` > 1,
+    blocks without a depthwise convolution, ``first_conv_filters`` 0).  Per mixednet.py:307-360:
+
+      first conv  : Conv2D(k1 x 1, stride, valid, no bias) -> ReLU                 -> op(conv, norm none, relu)
+      every repeat: MixConv (depthwise + bias, groups fused to one [K_last, C] tap table with structural
+                    zero taps, right-aligned like StridedDrop)                      -> op(depthwise, norm bias, linear)
+                    Conv2D 1x1 (no bias) -> BatchNormalization -> ReLU              -> op(conv, norm bn, relu)
+
+    ``residual_connection``, ``spatial_attention`` and ``pooled`` are not built (NotImplementedError).
+    ``keras_vars`` is ``get_weights()`` order; pack / unpack / grad_mask follow MixedNetLayout's conventions.
+    """
+
+    def __init__(self, flags, frames: int):
+        pf = list(parse(_flag(flags, "pointwise_filters")))
+        rep = list(parse(_flag(flags, "repeat_in_block")))
+        ksz = [tuple(k) if isinstance(k, (list, tuple)) else (k,) for k in parse(_flag(flags, "mixconv_kernel_sizes"))]
+        res = list(parse(_flag(flags, "residual_connection")))
+        for lst in (pf, rep, ksz, res):
+            if len(pf) != len(lst):
+                raise ValueError("all input lists have to be the same length")  # mixednet.py:298-305
+        unsupported = [n for n, v in (("residual_connection", any(res)), ("spatial_attention", _flag(flags, "spatial_attention")),
+                                      ("pooled", _flag(flags, "pooled"))) if v]
+        if unsupported:
+            raise NotImplementedError("MixedNet options not implemented by the MI355X engine yet: " + ", ".join(unsupported))
+        self.frames = int(frames)
+        self.dropout = 0.0
+        f0, k0, stride = int(_flag(flags, "first_conv_filters")), int(_flag(flags, "first_conv_kernel_size")), int(_flag(flags, "stride"))
+        self.ops: List[dict] = []
+        self.op_names: List[str] = []
+        self.keras_vars: List[Tuple[str, Tuple[int, ...], str]] = []
+        self.items: List[dict] = []   # per op: how its native parameter block maps to Keras variables
+        t, c, cur = self.frames, FEATURE_BINS, -1
+        if f0 > 0:
+            tout = (t - k0) // stride + 1
+            if tout <= 0:
+                raise ValueError("spectrogram of %d frames is too short for this network" % frames)
+            self.ops.append(dict(src=[cur], drop=[0], kernel=k0, filters=f0, stride=stride, norm="none", act="relu", kind="conv",
+                                 cin=c, tin=t, tout=tout))
+            self.op_names.append("conv1")
+            self.items.append(dict(kind="conv", kernel=len(self.keras_vars), shape=(k0, 1, c, f0)))
+            self.keras_vars.append(("conv1.kernel", (k0, 1, c, f0), "param"))
+            cur, t, c = 0, tout, f0
+        for bi, (filters, repeat, ks) in enumerate(zip(pf, rep, ksz)):
+            filters = int(filters)
+            if any(k > ks[-1] for k in ks):
+                raise ValueError("mixconv kernel sizes must be ascending: alignment uses the last one (mixednet.py:227)")
+            for ri in range(int(repeat)):
+                p = "b%d.r%d" % (bi, ri)
+                if max(ks) > 1:
+                    K = int(ks[-1])
+                    groups = tuple(split_channels(c, len(ks))) if len(ks) > 1 else (c,)
+                    tout = t - (K - 1)
+                    if tout <= 0:
+                        raise ValueError("spectrogram of %d frames is too short for this network" % frames)
+                    self.ops.append(dict(src=[cur], drop=[0], kernel=K, filters=c, norm="bias", act="linear", kind="depthwise",
+                                         cin=c, tin=t, tout=tout))
+                    self.op_names.append(p + ".dw")
+                    it = dict(kind="depthwise", K=K, C=c, groups=[])
+                    for gi, (gc, k) in enumerate(zip(groups, ks)):
+                        it["groups"].append((len(self.keras_vars), int(gc), int(k)))
+                        self.keras_vars.append(("%s.dw%d.kernel" % (p, gi), (int(k), 1, int(gc), 1), "param"))
+                        self.keras_vars.append(("%s.dw%d.bias" % (p, gi), (int(gc),), "param"))
+                    self.items.append(it)
+                    cur, t = len(self.ops) - 1, tout
+                self.ops.append(dict(src=[cur], drop=[0], kernel=1, filters=filters, norm="bn", act="relu", kind="conv",
+                                     cin=c, tin=t, tout=t))
+                self.op_names.append(p + ".pw")
+                self.items.append(dict(kind="pw", kernel=len(self.keras_vars), shape=(1, 1, c, filters)))
+                self.keras_vars.append((p + ".pw.kernel", (1, 1, c, filters), "param"))
+                for suffix, kind in (("gamma", "param"), ("beta", "param"), ("moving_mean", "state"), ("moving_variance", "state")):
+                    self.keras_vars.append(("%s.bn.%s" % (p, suffix), (filters,), kind))
+                cur, c = len(self.ops) - 1, filters
+        if not self.ops or self.ops[-1]["norm"] != "bn":
+            raise NotImplementedError("a MixedNet without any block")
+        self.t_last, self.c_last = t, c
+        self._dense = len(self.keras_vars)
+        self.keras_vars.append(("dense.kernel", (t * c, 1), "param"))
+        self.keras_vars.append(("dense.bias", (1,), "param"))
+        self.n_params = sum(self._item_size(it) for it in self.items) + t * c + 1
+        self.n_state = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "state")
+
+    @staticmethod
+    def _item_size(it):
+        if it["kind"] == "depthwise":
+            return it["K"] * it["C"] + it["C"]
+        n = int(np.prod(it["shape"]))
+        return n + (2 * it["shape"][3] if it["kind"] == "pw" else 0)
+
+    def keras_param_counts(self):
+        total = sum(int(np.prod(s)) for _, s, _ in self.keras_vars)
+        return total, sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "param")
+
+    def engine_args(self, max_batch):
+        return dict(frames=self.frames, conv_ops=self.ops, dropout=0.0, max_batch=max_batch)
+
+    def pack(self, weights: Sequence[np.ndarray]):
+        if len(weights) != len(self.keras_vars):
+            raise ValueError("expected %d weight arrays, got %d" % (len(self.keras_vars), len(weights)))
+        ws = []
+        for (name, shape, _), w in zip(self.keras_vars, weights):
+            w = np.asarray(w, np.float32)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError("weight %s: expected shape %s, got %s" % (name, shape, w.shape))
+            ws.append(w)
+        params, state = [], []
+        for it in self.items:
+            if it["kind"] == "depthwise":
+                dw, bias, c0 = np.zeros((it["K"], it["C"]), np.float32), np.zeros(it["C"], np.float32), 0
+                for vi, gc, k in it["groups"]:
+                    dw[it["K"] - k:, c0:c0 + gc] = ws[vi][:, 0, :, 0]
+                    bias[c0:c0 + gc] = ws[vi + 1]
+                    c0 += gc
+                params += [dw.reshape(-1), bias]
+            else:
+                params.append(ws[it["kernel"]].reshape(-1))
+                if it["kind"] == "pw":
+                    params += [ws[it["kernel"] + 1], ws[it["kernel"] + 2]]
+                    state += [ws[it["kernel"] + 3], ws[it["kernel"] + 4]]
+        params += [ws[self._dense].reshape(-1), ws[self._dense + 1]]
+        return np.concatenate(params), (np.concatenate(state) if state else np.zeros(0, np.float32))
+
+    def unpack(self, params: np.ndarray, state: np.ndarray) -> List[np.ndarray]:
+        params = np.asarray(params, np.float32).reshape(-1)
+        state = np.asarray(state, np.float32).reshape(-1)
+        if params.size != self.n_params or state.size != self.n_state:
+            raise ValueError("vector sizes do not match this model")
+        out: List[Optional[np.ndarray]] = [None] * len(self.keras_vars)
+        po = so = 0
+        for it in self.items:
+            if it["kind"] == "depthwise":
+                K, C = it["K"], it["C"]
+                dw, bias = params[po:po + K * C].reshape(K, C), params[po + K * C:po + K * C + C]
+                po += K * C + C
+                c0 = 0
+                for vi, gc, k in it["groups"]:
+                    out[vi] = dw[K - k:, c0:c0 + gc].reshape(k, 1, gc, 1).copy()
+                    out[vi + 1] = bias[c0:c0 + gc].copy()
+                    c0 += gc
+            else:
+                n = int(np.prod(it["shape"]))
+                out[it["kernel"]] = params[po:po + n].reshape(it["shape"]).copy()
+                po += n
+                if it["kind"] == "pw":
+                    f = it["shape"][3]
+                    out[it["kernel"] + 1], out[it["kernel"] + 2] = params[po:po + f].copy(), params[po + f:po + 2 * f].copy()
+                    out[it["kernel"] + 3], out[it["kernel"] + 4] = state[so:so + f].copy(), state[so + f:so + 2 * f].copy()
+                    po, so = po + 2 * f, so + 2 * f
+        n = self.t_last * self.c_last
+        out[self._dense], out[self._dense + 1] = params[po:po + n].reshape(-1, 1).copy(), params[po + n:po + n + 1].copy()
+        return out
+
+    def segments(self):
+        seg = []
+        for name, it in zip(self.op_names, self.items):
+            if it["kind"] == "depthwise":
+                seg += [(name + ".kernel", it["K"] * it["C"]), (name + ".bias", it["C"])]
+            else:
+                seg.append((name + ".kernel", int(np.prod(it["shape"]))))
+                if it["kind"] == "pw":
+                    seg += [(name + ".bn.gamma", it["shape"][3]), (name + ".bn.beta", it["shape"][3])]
+        return seg + [("dense.kernel", self.t_last * self.c_last), ("dense.bias", 1)]
+
+    def grad_mask(self) -> np.ndarray:
+        parts = []
+        for it in self.items:
+            if it["kind"] == "depthwise":
+                m, c0 = np.zeros((it["K"], it["C"]), np.float32), 0
+                for _, gc, k in it["groups"]:
+                    m[it["K"] - k:, c0:c0 + gc] = 1.0
+                    c0 += gc
+                parts += [m.reshape(-1), np.ones(it["C"], np.float32)]
+            else:
+                parts.append(np.ones(self._item_size(it), np.float32))
+        parts.append(np.ones(self.t_last * self.c_last + 1, np.float32))
+        return np.concatenate(parts)
+
+    def summary_lines(self):
+        yield "input                                   [B, %d, %d]" % (self.frames, FEATURE_BINS)
+        for name, op in zip(self.op_names, self.ops):
+            yield "%-12s %-9s %dx1 %s %d->%d, %s, %s   [B, %d, %d]" % (name, op["kind"], op["kernel"], "/%d" % op.get("stride", 1), op["cin"],
+                                                                       op["filters"], op["norm"], op["act"], op["tout"], op["filters"])
+        yield "flatten + dense(1, sigmoid)   [B, 1]"

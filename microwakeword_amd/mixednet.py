@@ -2,7 +2,10 @@
 ``model_parameters(parser_nn)``, ``spectrogram_slices_dropped(flags)``, ``model(flags, shape, batch_size)``
 — same flags and defaults as microwakeword/mixednet.py:43-105,108-129,278-386, returning the
 MI355X-engine-backed :class:`microwakeword_amd.model.Model` instead of a ``tf.keras.Model``."""
+import logging
+
 from . import layout as _layout
+from . import native as _native
 from .model import Model
 
 parse = _layout.parse
@@ -40,4 +43,13 @@ def model(flags, shape, batch_size, **engine_kwargs):
     """Raises ValueError("all input lists have to be the same length") exactly where the reference
     does (mixednet.py:298-305) — note the reference's own default ``--residual_connection`` has five
     entries against four blocks, so default flags need ``--residual_connection "0,0,0,0"``."""
-    return Model(flags, shape, batch_size, **engine_kwargs)
+    try:
+        return Model(flags, shape, batch_size, **engine_kwargs)   # specialised MFMA block kernels
+    except (NotImplementedError, _native.NativeError) as e:
+        if isinstance(e, _native.NativeError) and "error -3" not in str(e):   # anything but MWW_ERR_UNSUPPORTED
+            raise
+        # shapes / options the block kernels do not cover run as a generic conv/BN graph (slower VALU kernels);
+        # residual / attention / pooled heads still raise NotImplementedError from the layout below
+        lay = _layout.GraphMixedNetLayout(flags, int(shape[0]))
+        logging.getLogger("microwakeword_amd").warning("mixednet: %s -> generic graph kernels", e)
+        return Model(flags, shape, batch_size, layout=lay, name="mixednet (generic graph kernels)", **engine_kwargs)

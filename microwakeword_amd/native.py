@@ -32,6 +32,9 @@ class MixedNetDesc(C.Structure):
                 ("block_kernel", C.c_int32 * MWW_MAX_BLOCKS), ("max_batch", C.c_int32)]
 
 
+OP_KINDS = {"conv": 0, "depthwise": 1}
+NORMS = {"bn": 0, "bias": 1, "none": 2}
+ACTS = {"relu": 0, "linear": 1}
 MWW_MAX_GRAPH_OPS = 48
 MWW_MAX_OP_SOURCES = 3
 
@@ -39,7 +42,8 @@ MWW_MAX_OP_SOURCES = 3
 class ConvBnOp(C.Structure):
     _fields_ = [("n_src", C.c_int32), ("src", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_drop", C.c_int32 * MWW_MAX_OP_SOURCES),
                 ("src_c0", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_cn", C.c_int32 * MWW_MAX_OP_SOURCES),
-                ("kernel", C.c_int32), ("dilation", C.c_int32), ("filters", C.c_int32), ("bn_groups", C.c_int32)]
+                ("kernel", C.c_int32), ("dilation", C.c_int32), ("filters", C.c_int32), ("bn_groups", C.c_int32),
+                ("kind", C.c_int32), ("stride", C.c_int32), ("norm", C.c_int32), ("act", C.c_int32)]
 
 
 class ConvNetDesc(C.Structure):
@@ -201,6 +205,10 @@ class Engine:
                     o.src_c0[j], o.src_cn[j] = int(sl[j][0]), int(sl[j][1])
                 o.kernel, o.dilation, o.filters = int(op["kernel"]), int(op.get("dilation", 1)), int(op["filters"])
                 o.bn_groups = int(op.get("bn_groups", 1))
+                o.kind = OP_KINDS[op.get("kind", "conv")]
+                o.stride = int(op.get("stride", 1))
+                o.norm = NORMS[op.get("norm", "bn")]
+                o.act = ACTS[op.get("act", "relu")]
             self.desc = d
             h = C.c_void_p()
             self.nl.check(self.nl.lib.mww_create_convnet(C.byref(d), int(device), C.c_void_p(stream or 0), C.byref(h)))

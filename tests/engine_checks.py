@@ -594,3 +594,89 @@ def check_train_loop_end_to_end(lib, tmp_path, B=16, steps=12, kind="mixednet", 
     model.engine.close()
     m2.engine.close()
     return out
+
+
+# ------------------------------------------------------------------------------------------ generic MixedNet
+# flag combinations outside the specialised block kernels: odd filter counts, a block without depthwise,
+# repeat_in_block 2, multi-kernel groups, strided 5x1 first conv — and one without a first conv at all
+GRAPH_MIXEDNET = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0,0", pointwise_filters="24,32,40", repeat_in_block="1,2,1",
+                      mixconv_kernel_sizes="[3],[1],[3,5]", first_conv_filters=16, first_conv_kernel_size=5, stride=2)
+GRAPH_MIXEDNET_NOCONV1 = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="16,24", repeat_in_block="1,1",
+                              mixconv_kernel_sizes="[5],[7,9]", first_conv_filters=0)
+
+
+def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, graphs=False, lr=1e-3):
+    """Forward intermediates and train step of a MixedNet running on the generic conv/BN graph kernels."""
+    from microwakeword_amd.layout import GraphMixedNetLayout
+    om = perturbed_oracle(T, flags=flags)
+    lay = GraphMixedNetLayout(flags, T)
+    assert [n for n, _, _ in lay.keras_vars] == [v.name for v in om.vars]
+    eng = native.Engine(lib=lib, **lay.engine_args(B))
+    eng.set_grad_mask(lay.grad_mask())
+    p, s = lay.pack(om.get_weights())
+    eng.set_params(p)
+    eng.set_bn_state(s)
+    if grid:
+        for k in ("grid_graph", "grid_head"):
+            eng.set_option(k, grid)
+    if graphs:
+        eng.set_option("graphs", 1)
+    rng = np.random.default_rng(13)
+    wts = dict(zip([n for n, _, _ in lay.keras_vars], om.get_weights()))
+    for training in (False, True):
+        x = synth_x(rng, B, T)
+        eng.set_batch(x)
+        eng.forward(B, training=training)
+        pr, z, _ = eng.read_outputs(B, want_loss=False)
+        taps = {}
+        zo, _ = om.logits(x, training, taps=taps)
+        for k, (name, op) in enumerate(zip(lay.op_names, lay.ops)):
+            got = eng.debug_read("p%d" % (k + 1), B, B * op["tout"] * op["filters"]).reshape(B, op["tout"], op["filters"])
+            if name == "conv1":
+                got, ref = np.maximum(got, 0), taps["conv1"].detach().numpy()
+            elif name.endswith(".dw"):
+                it = lay.items[k]
+                bias = np.concatenate([wts[lay.keras_vars[vi + 1][0]] for vi, _, _ in it["groups"]])
+                got, ref = got + bias, taps[name].detach().numpy()
+            else:
+                ref = taps[name[:-3] + ".pre_bn"].detach().numpy()
+            assert got.shape == ref.shape, (name, got.shape, ref.shape)
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
+        assert np.abs(pr - torch.sigmoid(zo).numpy()).max() <= FWD_TOL
+    l2s = []
+    for st in range(steps):
+        x = synth_x(rng, B, T)
+        y = (rng.random(B) < 0.5).astype(np.float32)
+        w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+        eng.train_step(B, lr)
+        pr, z, loss = eng.read_outputs(B)
+        lo, po, grads, _ = om.loss_and_grads(x, y, w)
+        g = eng.get_grads()
+        gref = lay.pack([grads[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)
+                         for n, shape, kind in lay.keras_vars])[0]
+        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+        scale = max(1e-6, float(np.abs(gref).max()))
+        off = 0
+        for name, n in lay.segments():
+            a, r = g[off:off + n], gref[off:off + n]
+            off += n
+            if name.endswith(".dw.bias"):   # followed by a BatchNorm: the true gradient is zero, what remains is cancellation noise
+                assert np.abs(a - r).max() <= 2e-3 * scale, (st, name, np.abs(a - r).max())
+                continue
+            l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
+            assert l2 <= 1e-3, (st, name, l2)
+            l2s.append(l2)
+        # structural zero taps of fused MixConv groups stay exactly zero in the gradient
+        assert np.all(g[lay.grad_mask() == 0] == 0)
+        om.train_step(x, y, w, lr)
+        p_ref, s_ref = lay.pack(om.get_weights())
+        well = np.abs(gref) > 1e-4 * scale
+        assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * lr
+        assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+        eng.set_params(p_ref)
+        eng.set_bn_state(s_ref)
+    assert np.median(l2s) <= 2e-5
+    eng.close()
+    return max(l2s)

@@ -84,3 +84,29 @@ def test_inception_unfused_branch_heads(emu_lib):
 
 def test_train_loop_end_to_end(emu_lib, tmp_path):
     ec.check_train_loop_end_to_end(emu_lib, tmp_path, B=8, steps=9)
+
+
+def test_mixednet_on_generic_graph_kernels(emu_lib):
+    """Flag combinations outside the specialised kernels (repeat 2, a block without depthwise, odd filters,
+    strided 5x1 first conv; and no first conv at all) run on the conv/BN graph kernels."""
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2)
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_NOCONV1, B=2, T=60, steps=1, grid=1, graphs=True)
+
+
+def test_mixednet_model_selects_kernels_by_shape(emu_lib):
+    """mixednet.model(): specialised block kernels when the shape is instantiated, generic graph kernels
+    otherwise, NotImplementedError for the options nothing implements."""
+    from microwakeword_amd import mixednet
+    m = mixednet.model(ec.DEF, (194, 40), 4, lib=emu_lib, max_batch=4)
+    assert m.name == "mixednet" and m.engine.n_params == 22177
+    m.engine.close()
+    g = mixednet.model(ec.GRAPH_MIXEDNET, (100, 40), 4, lib=emu_lib, max_batch=4)
+    assert "generic" in g.name
+    x = ec.synth_x(np.random.default_rng(0), 3, 100)
+    assert g.predict_on_batch(x).shape == (3, 1)
+    lines = []
+    g.summary(print_fn=lines.append)
+    assert any("depthwise" in ln for ln in lines)
+    g.engine.close()
+    with pytest.raises(NotImplementedError):
+        mixednet.model(dict(ec.DEF, residual_connection="0,1,0,0"), (194, 40), 4, lib=emu_lib, max_batch=4)
