@@ -97,6 +97,9 @@ typedef struct {
   int32_t stride;                       /* time stride (0/1 = none); only for ops fed by the spectrogram */
   int32_t norm;                         /* MWW_NORM_BN (gamma, beta + moving statistics), MWW_NORM_BIAS (bias[filters]), MWW_NORM_NONE */
   int32_t act;                          /* MWW_ACT_RELU or MWW_ACT_LINEAR */
+  int32_t residual;                     /* 1 + index of an earlier conv + BN + linear op whose normalised output is added to
+                                           this op's normalised output before the activation (mixednet.py:340-358); 0 = none */
+  int32_t residual_drop;                /* leading frames of that op dropped to align it (StridedDrop) */
 } mww_conv_bn_op;
 #define MWW_OP_CONV 0
 #define MWW_OP_DEPTHWISE 1

@@ -41,7 +41,21 @@ struct GSrc {
   float* gstat_part;    // [grid][2][ld]
   int T, C, toff, flags;
   int ld, c0;           // the source is channels [c0, c0+C) of a producer tensor with ld channels per frame
+  // residual branch added to the producer's normalised output before its activation (mixednet.py:340-358:
+  // residual = BN(conv1x1(block input)); net = relu(BN(...) + StridedDrop(residual))): frame t of the producer
+  // pairs with frame t + rdrop of the residual op's pre-BN tensor rp [B][rT][C]; null = none
+  const float* rp;
+  const float* rscale;
+  const float* rshift;
+  int rT, rdrop;
 };
+
+// value of a source element before its activation clamp
+__device__ __forceinline__ float src_affine(const GSrc& s, float v, float sc, float sh, float rv, float rsc, float rsh) {
+  float y = fmaf(v, sc, sh);
+  if (s.rp) y += fmaf(rv, rsc, rsh);
+  return y;
+}
 
 struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - xhat * mgx)
   const float* g;         // [B][Tout][C]
@@ -61,9 +75,12 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
       const float sc = ident ? 1.f : s.scale[s.c0 + c], sh = ident ? 0.f : s.shift[s.c0 + c];
       const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
       const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
+      const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
+      const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.toff + s.rdrop) * C + c : nullptr;
       for (int t = rg; t < rows; t += nrg) {
         const float v = base[(size_t)t * s.ld];
-        sIn[t * PI + c0 + c] = fmaxf(fmaf(v, sc, sh), lo);
+        const float rv = rbase ? rbase[(size_t)t * C] : 0.f;
+        sIn[t * PI + c0 + c] = fmaxf(src_affine(s, v, sc, sh, rv, rsc, rsh), lo);
       }
     }
     c0 += C;
@@ -193,12 +210,15 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
             const bool linear = (s.flags & GSRC_LINEAR) != 0;
             const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
             const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
+            const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
+            const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.rdrop) * C + c : nullptr;
             float t1 = 0.f, t2 = 0.f;
             for (int t = rg; t < s.T; t += nrg) {
               const size_t idx = base + (size_t)t * s.ld;
               const float p = s.p[idx];
+              const float rv = rbase ? rbase[(size_t)t * C] : 0.f;
               const int r = t - s.toff;
-              float gv = (r >= 0 && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
+              float gv = (r >= 0 && (linear || src_affine(s, p, sc, sh, rv, rsc, rsh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
               if (accum) gv += s.g[idx];
               s.g[idx] = gv;
               t1 += gv;
@@ -337,12 +357,15 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
         const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0, linear = (s.flags & GSRC_LINEAR) != 0;
         const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
         const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
+        const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
+        const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.rdrop) * C + c : nullptr;
         for (int t = rg; t < s.T; t += nrg) {
           const size_t idx = base + (size_t)t * s.ld;
           const float p = s.p[idx];
+          const float rv = rbase ? rbase[(size_t)t * C] : 0.f;
           const int r = t - s.toff;   // frame of the (aligned) input; da[r] = sum_j w[j] dp[r - j]
           float gv = 0.f;
-          if (r >= 0 && r < a.Tin && (linear || fmaf(p, sc, sh) > 0.f)) {
+          if (r >= 0 && r < a.Tin && (linear || src_affine(s, p, sc, sh, rv, rsc, rsh) > 0.f)) {
             float acc = 0.f;
             for (int j = 0; j < a.k; ++j) acc = fmaf(sW[j * C + c], sIn[(r - j + pad) * PI + c], acc);
             gv = acc;
@@ -392,6 +415,42 @@ __global__ __launch_bounds__(kThreads) void gdw_wgrad_kernel(GDwArgs a) {
     const int task = tid + u * kThreads;
     if (task < tasks) a.grad_part[(size_t)blockIdx.x * tasks + task] = acc[u];
   }
+}
+
+// Gradient of a residual op R: the ops that add it (one per repeat of the block) already hold the gradient at
+// their own outputs, masked by their ReLU; R's gradient is their sum, frame t of adder X landing on frame
+// t + drop_X of R.  Also emits R's BN-backward statistics partials.
+constexpr int kGMaxAdders = 8;
+struct GResGatherArgs {
+  const float* gx[kGMaxAdders];   // [B][Tx][C] gradients of the adders
+  int Tx[kGMaxAdders], drop[kGMaxAdders];
+  int n;
+  const float* p;                 // R's pre-BN output [B][T][C]
+  const float *mean, *rstd;
+  float* g;                       // [B][T][C]
+  float* gstat_part;              // [grid][2][C]
+  int B, T, C;
+};
+__global__ __launch_bounds__(kThreads) void gres_gather_kernel(GResGatherArgs a) {
+  __shared__ float sRed[2 * kThreads];
+  const int tid = threadIdx.x, C = a.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
+  float s1 = 0.f, s2 = 0.f;
+  if (rg < nrg) {
+    const float mu = a.mean[c], rs = a.rstd[c];
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x)
+      for (int t = rg; t < a.T; t += nrg) {
+        float gv = 0.f;
+        for (int i = 0; i < a.n; ++i) {
+          const int tx = t - a.drop[i];
+          if (tx >= 0 && tx < a.Tx[i]) gv += a.gx[i][((size_t)b * a.Tx[i] + tx) * C + c];
+        }
+        const size_t idx = ((size_t)b * a.T + t) * C + c;
+        a.g[idx] = gv;
+        s1 += gv;
+        s2 = fmaf(gv, (a.p[idx] - mu) * rs, s2);
+      }
+  }
+  write_channel_partials(s1, s2, C, sRed, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
 }
 
 // W[k][cin][cout] -> WT[k][cout][cin] with reversed taps, for every op that needs a data gradient
@@ -537,6 +596,8 @@ struct GHeadArgs {
   int B, T, C;
   float inv_b;
   int training;
+  const float *rp, *rscale, *rshift;   // residual branch of the last op (see GSrc), or null
+  int rT, rdrop;
 };
 
 __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
@@ -549,16 +610,18 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const int n = a.T * C;
   const float sc = active ? a.scale[c] : 0.f, sh = active ? a.shift[c] : 0.f;
   const float mu = (active && a.training) ? a.mean[c] : 0.f, rs = (active && a.training) ? a.rstd[c] : 0.f;
+  const float rsc = (active && a.rp) ? a.rscale[c] : 0.f, rsh = (active && a.rp) ? a.rshift[c] : 0.f;
   const float bias = a.bd[0];
   float g1 = 0.f, g2 = 0.f;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* pb = a.p + (size_t)b * n;
     const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
+    const float* rb = a.rp ? a.rp + ((size_t)b * a.rT + a.rdrop) * C : nullptr;
     float dot = 0.f;
     if (active) {
       for (int t = rg; t < a.T; t += nrg) {
         const int i = t * C + c;
-        const float act = fmaxf(fmaf(pb[i], sc, sh), 0.f);
+        const float act = fmaxf(fmaf(pb[i], sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f), 0.f);
         dot = fmaf(kb ? act * kb[i] : act, a.wd[i], dot);
       }
     }
@@ -592,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       for (int t = rg; t < a.T; t += nrg) {
         const int i = t * C + c;
         const float raw = pb[i];
-        float gv = fmaf(raw, sc, sh) > 0.f ? dzz * a.wd[i] : 0.f;
+        float gv = (fmaf(raw, sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f)) > 0.f ? dzz * a.wd[i] : 0.f;
         if (kb) gv *= kb[i];
         gb[i] = gv;
         g1 += gv;

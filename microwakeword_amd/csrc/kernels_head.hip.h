@@ -212,6 +212,8 @@ struct DenseGradArgs {
   float* part;          // [n_chunks][stride]   (element n = dense bias gradient)
   int B, n, C, stride, chunk;
   const float* keep;    // [B][n] dropout keep-scale in front of the dense layer, or null
+  const float *rp, *rscale, *rshift;   // residual branch added before the last ReLU ([B][rT][C], frame t + rdrop), or null
+  int rT, rdrop;
 };
 
 __device__ __forceinline__ void dense_grad_body(const DenseGradArgs& a, int bx, int by, int tid) {
@@ -220,18 +222,21 @@ __device__ __forceinline__ void dense_grad_body(const DenseGradArgs& a, int bx, 
   if (e < a.n) {
     const int c = e % a.C;
     const float sc = a.scale[c], sh = a.shift[c];
+    const float rsc = a.rp ? a.rscale[c] : 0.f, rsh = a.rp ? a.rshift[c] : 0.f;
+    const size_t roff = a.rp ? (size_t)a.rdrop * a.C + e : 0, rstride = (size_t)a.rT * a.C;
     float acc = 0.f;
     for (int bb = b0; bb < b1; bb += 8) {
-      float v[8], d[8];
+      float v[8], d[8], r[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const bool ok = bb + u < b1;
         v[u] = ok ? a.p[(size_t)(bb + u) * a.n + e] : 0.f;
         d[u] = ok ? a.dz[bb + u] : 0.f;
+        r[u] = (ok && a.rp) ? fmaf(a.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
         if (ok && a.keep) d[u] *= a.keep[(size_t)(bb + u) * a.n + e];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh), 0.f), acc);
+      for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), acc);
     }
     a.part[(size_t)by * a.stride + e] = acc;
   } else if (e == a.n) {

@@ -55,6 +55,8 @@ struct GOp {
   bool src_first[kGMaxSrc] = {false, false, false}, src_last[kGMaxSrc] = {false, false, false};   // this op's place among the consumers of that slice (backward order)
   int k = 1, dil = 1, cin = 0, cout = 0, groups = 1, slots = 0, tin = 0, tout = 0;
   int kind = MWW_OP_CONV, stride = 1, norm = MWW_NORM_BN, act = MWW_ACT_RELU;
+  int res_src = -1, res_drop = 0;     // residual branch added before this op's activation
+  std::vector<int> adders;           // (residual ops) the ops that add this one
   int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   int nq = 1;                 // frame subsets of the weight-gradient mapping
@@ -299,7 +301,16 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
     if (loss) {
       const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
       const int ndchunks = (B + dchunk - 1) / dchunk;
-      DenseGradArgs dg{p_last, scale, shift, c->dz, c->dwd_part, B, c->t_last * c->c_last, c->c_last, c->dwd_stride, dchunk, keep};
+      DenseGradArgs dg{p_last, scale, shift, c->dz, c->dwd_part, B, c->t_last * c->c_last, c->c_last, c->dwd_stride, dchunk, keep,
+                       nullptr, nullptr, nullptr, 0, 0};
+      if (c->generic && c->G.back().res_src >= 0) {
+        GOp& rr = c->G[c->G.back().res_src];
+        dg.rp = rr.p;
+        dg.rscale = rr.bn + (size_t)BN_SCALE * rr.cout;
+        dg.rshift = rr.bn + (size_t)BN_SHIFT * rr.cout;
+        dg.rT = rr.tout;
+        dg.rdrop = c->G.back().res_drop;
+      }
       lp.begin("dense_grad");
       hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
       lp.end();
@@ -495,7 +506,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       HeadTailArgs ht;
       ht.fin = f;
       ht.dense = DenseGradArgs{l.p, bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
-                               c->c_last, c->dwd_stride, dchunk, nullptr};
+                               c->c_last, c->dwd_stride, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
       ht.met = MetricsArgs{c->prob, c->y, c->metrics, B};
       ht.n_fin = l.cout;
       ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
@@ -645,6 +656,14 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
   s.ld = pr.cout;
   s.c0 = o.sc0[i];
   if (pr.act == MWW_ACT_LINEAR) s.flags |= GSRC_LINEAR;
+  if (pr.res_src >= 0) {
+    GOp& rr = c->G[pr.res_src];
+    s.rp = rr.p;
+    s.rscale = gbn_slot(rr, BN_SCALE);
+    s.rshift = gbn_slot(rr, BN_SHIFT);
+    s.rT = rr.tout;
+    s.rdrop = pr.res_drop;
+  }
   if (backward) s.flags |= GSRC_GRAD | (o.src_first[i] ? 0 : GSRC_ACCUM) | (o.src_last[i] ? GSRC_STATS : 0);
   return s;
 }
@@ -756,6 +775,14 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   h.C = lo.cout;
   h.inv_b = 1.0f / (float)B;
   h.training = loss ? 1 : 0;
+  if (lo.res_src >= 0) {
+    GOp& rr = c->G[lo.res_src];
+    h.rp = rr.p;
+    h.rscale = gbn_slot(rr, BN_SCALE);
+    h.rshift = gbn_slot(rr, BN_SHIFT);
+    h.rT = rr.tout;
+    h.rdrop = lo.res_drop;
+  }
   lp.begin("head");
   hipLaunchKernelGGL(ghead_kernel, dim3(ghead), dim3(kThreads), 0, c->stream, h);
   lp.end();
@@ -790,6 +817,28 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   for (int i = n - 1; i >= 0; --i) {
     GOp& o = c->G[i];
     const int members = o.groups > 1 ? o.cout / o.groups : 1;
+    if (!o.adders.empty()) {
+      GResGatherArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.n = (int)o.adders.size();
+      for (int q = 0; q < ra.n; ++q) {
+        GOp& x = c->G[o.adders[q]];
+        ra.gx[q] = x.g;
+        ra.Tx[q] = x.tout;
+        ra.drop[q] = x.res_drop;
+      }
+      ra.p = o.p;
+      ra.mean = gbn_slot(o, BN_MEAN);
+      ra.rstd = gbn_slot(o, BN_RSTD);
+      ra.g = o.g;
+      ra.gstat_part = o.gstat_part;
+      ra.B = B;
+      ra.T = o.tout;
+      ra.C = o.cout;
+      lp.begin("residual_gather", i);
+      hipLaunchKernelGGL(gres_gather_kernel, dim3(gg), dim3(kThreads), 0, c->stream, ra);
+      lp.end();
+    }
     if (o.norm == MWW_NORM_BN) {
       StatSource ss;
       int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, o.gstat_part, i == n - 1 ? ghead : gg, o.cout, 1,
@@ -1137,6 +1186,8 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     if (s.filters % s.bn_groups) return fail(MWW_ERR_INVALID, tag + "filters must be a multiple of the sub-spectral groups");
     if (s.kind != MWW_OP_CONV && s.kind != MWW_OP_DEPTHWISE) return fail(MWW_ERR_INVALID, tag + "unknown op kind");
     if (s.norm < MWW_NORM_BN || s.norm > MWW_NORM_NONE || (s.act != MWW_ACT_RELU && s.act != MWW_ACT_LINEAR)) return fail(MWW_ERR_INVALID, tag + "unknown norm / activation");
+    o.res_src = s.residual > 0 ? s.residual - 1 : -1;
+    o.res_drop = s.residual_drop;
     o.kind = s.kind;
     o.stride = s.stride > 1 ? s.stride : 1;
     o.norm = s.norm;
@@ -1208,12 +1259,29 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     }
     if (o.needs_dx && o.kind == MWW_OP_CONV) { o.o_wt = wtoff; wtoff += (int64_t)o.k * o.cin * o.cout; }
   }
+  for (int i = 0; i < d.n_ops; ++i) {
+    GOp& o = ops[i];
+    if (o.res_src < 0) continue;
+    const std::string tag = "op " + std::to_string(i) + ": ";
+    if (o.res_src >= i) return fail(MWW_ERR_INVALID, tag + "the residual op must come earlier");
+    GOp& r = ops[o.res_src];
+    if (r.kind != MWW_OP_CONV || r.norm != MWW_NORM_BN || r.act != MWW_ACT_LINEAR || o.norm != MWW_NORM_BN)
+      return fail(MWW_ERR_UNSUPPORTED, tag + "a residual is a conv + BatchNorm + linear op added to a BatchNorm output");
+    if (r.cout != o.cout || o.res_drop < 0 || r.tout - o.res_drop != o.tout) return fail(MWW_ERR_INVALID, tag + "residual shape does not match");
+    if (n_consumers[o.res_src] != 0) return fail(MWW_ERR_UNSUPPORTED, tag + "a residual op cannot also be a regular source");
+    if ((int)r.adders.size() >= kGMaxAdders) return fail(MWW_ERR_UNSUPPORTED, tag + "too many ops add the same residual");
+    r.adders.push_back(i);
+    for (int i2 = i + 1; i2 < d.n_ops; ++i2)
+      for (int j2 = 0; j2 < ops[i2].n_src; ++j2)
+        if (ops[i2].src[j2] == i && ops[i2].scn[j2] != o.cout) return fail(MWW_ERR_UNSUPPORTED, tag + "an op with a residual must be read whole (no channel slice)");
+  }
   for (int i = 0; i + 1 < d.n_ops; ++i)
-    if (n_consumers[i] == 0) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
+    if (n_consumers[i] == 0 && ops[i].adders.empty()) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
   // gradient routing: per producer, the slices its consumers read must be identical or disjoint and cover
   // every channel; in the backward pass (descending op index) the first consumer of a slice stores, later
   // ones accumulate and the last one also emits the BN statistics partials of that slice
   for (int pi = 0; pi + 1 < d.n_ops; ++pi) {
+    if (!ops[pi].adders.empty()) continue;   // residual ops: gradient gathered from their adders
     std::vector<int> covered(ops[pi].cout, 0);
     for (int i = d.n_ops - 1; i > pi; --i)
       for (int j = 0; j < ops[i].n_src; ++j) {

@@ -411,7 +411,11 @@ class GraphMixedNetLayout:
                     zero taps, right-aligned like StridedDrop)                      -> op(depthwise, norm bias, linear)
                     Conv2D 1x1 (no bias) -> BatchNormalization -> ReLU              -> op(conv, norm bn, relu)
 
-    ``residual_connection``, ``spatial_attention`` and ``pooled`` are not built (NotImplementedError).
+      residual    : Conv2D 1x1 (no bias) -> BatchNormalization of the block input (mixednet.py:340-345), added to
+                    every repeat's BN output before its ReLU after StridedDrop of its leading frames (:354-358)
+                                                                                    -> op(conv, norm bn, linear) + ``residual`` links
+
+    ``spatial_attention`` and ``pooled`` are not built (NotImplementedError).
     ``keras_vars`` is ``get_weights()`` order; pack / unpack / grad_mask follow MixedNetLayout's conventions.
     """
 
@@ -423,8 +427,7 @@ class GraphMixedNetLayout:
         for lst in (pf, rep, ksz, res):
             if len(pf) != len(lst):
                 raise ValueError("all input lists have to be the same length")  # mixednet.py:298-305
-        unsupported = [n for n, v in (("residual_connection", any(res)), ("spatial_attention", _flag(flags, "spatial_attention")),
-                                      ("pooled", _flag(flags, "pooled"))) if v]
+        unsupported = [n for n, v in (("spatial_attention", _flag(flags, "spatial_attention")), ("pooled", _flag(flags, "pooled"))) if v]
         if unsupported:
             raise NotImplementedError("MixedNet options not implemented by the MI355X engine yet: " + ", ".join(unsupported))
         self.frames = int(frames)
@@ -445,10 +448,20 @@ class GraphMixedNetLayout:
             self.items.append(dict(kind="conv", kernel=len(self.keras_vars), shape=(k0, 1, c, f0)))
             self.keras_vars.append(("conv1.kernel", (k0, 1, c, f0), "param"))
             cur, t, c = 0, tout, f0
-        for bi, (filters, repeat, ks) in enumerate(zip(pf, rep, ksz)):
+        for bi, (filters, repeat, ks, r) in enumerate(zip(pf, rep, ksz, res)):
             filters = int(filters)
             if any(k > ks[-1] for k in ks):
                 raise ValueError("mixconv kernel sizes must be ascending: alignment uses the last one (mixednet.py:227)")
+            res_op, res_t = None, 0
+            if r:
+                self.ops.append(dict(src=[cur], drop=[0], kernel=1, filters=filters, norm="bn", act="linear", kind="conv",
+                                     cin=c, tin=t, tout=t))
+                self.op_names.append("b%d.res" % bi)
+                self.items.append(dict(kind="pw", kernel=len(self.keras_vars), shape=(1, 1, c, filters)))
+                self.keras_vars.append(("b%d.res.kernel" % bi, (1, 1, c, filters), "param"))
+                for suffix, kind in (("gamma", "param"), ("beta", "param"), ("moving_mean", "state"), ("moving_variance", "state")):
+                    self.keras_vars.append(("b%d.res.bn.%s" % (bi, suffix), (filters,), kind))
+                res_op, res_t = len(self.ops) - 1, t
             for ri in range(int(repeat)):
                 p = "b%d.r%d" % (bi, ri)
                 if max(ks) > 1:
@@ -468,7 +481,7 @@ class GraphMixedNetLayout:
                     self.items.append(it)
                     cur, t = len(self.ops) - 1, tout
                 self.ops.append(dict(src=[cur], drop=[0], kernel=1, filters=filters, norm="bn", act="relu", kind="conv",
-                                     cin=c, tin=t, tout=t))
+                                     cin=c, tin=t, tout=t, residual=res_op, residual_drop=res_t - t))
                 self.op_names.append(p + ".pw")
                 self.items.append(dict(kind="pw", kernel=len(self.keras_vars), shape=(1, 1, c, filters)))
                 self.keras_vars.append((p + ".pw.kernel", (1, 1, c, filters), "param"))

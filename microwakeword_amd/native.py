@@ -43,7 +43,8 @@ class ConvBnOp(C.Structure):
     _fields_ = [("n_src", C.c_int32), ("src", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_drop", C.c_int32 * MWW_MAX_OP_SOURCES),
                 ("src_c0", C.c_int32 * MWW_MAX_OP_SOURCES), ("src_cn", C.c_int32 * MWW_MAX_OP_SOURCES),
                 ("kernel", C.c_int32), ("dilation", C.c_int32), ("filters", C.c_int32), ("bn_groups", C.c_int32),
-                ("kind", C.c_int32), ("stride", C.c_int32), ("norm", C.c_int32), ("act", C.c_int32)]
+                ("kind", C.c_int32), ("stride", C.c_int32), ("norm", C.c_int32), ("act", C.c_int32),
+                ("residual", C.c_int32), ("residual_drop", C.c_int32)]
 
 
 class ConvNetDesc(C.Structure):
@@ -209,6 +210,8 @@ class Engine:
                 o.stride = int(op.get("stride", 1))
                 o.norm = NORMS[op.get("norm", "bn")]
                 o.act = ACTS[op.get("act", "relu")]
+                o.residual = 0 if op.get("residual") is None else int(op["residual"]) + 1
+                o.residual_drop = int(op.get("residual_drop", 0))
             self.desc = d
             h = C.c_void_p()
             self.nl.check(self.nl.lib.mww_create_convnet(C.byref(d), int(device), C.c_void_p(stream or 0), C.byref(h)))

@@ -93,6 +93,12 @@ def test_mixednet_on_generic_graph_kernels(emu_lib):
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_NOCONV1, B=2, T=60, steps=1, grid=1, graphs=True)
 
 
+def test_mixednet_residual_connections(emu_lib):
+    """residual_connection (1x1 conv + BN of the block input, StridedDrop, added before every repeat's ReLU,
+    including the last block that feeds the classifier head) on the graph kernels."""
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_RESIDUAL, B=3, T=80, steps=1, grid=2)
+
+
 def test_mixednet_model_selects_kernels_by_shape(emu_lib):
     """mixednet.model(): specialised block kernels when the shape is instantiated, generic graph kernels
     otherwise, NotImplementedError for the options nothing implements."""
@@ -108,5 +114,8 @@ def test_mixednet_model_selects_kernels_by_shape(emu_lib):
     g.summary(print_fn=lines.append)
     assert any("depthwise" in ln for ln in lines)
     g.engine.close()
+    r = mixednet.model(dict(ec.DEF, residual_connection="0,1,0,0"), (194, 40), 4, lib=emu_lib, max_batch=4)
+    assert "generic" in r.name
+    r.engine.close()
     with pytest.raises(NotImplementedError):
-        mixednet.model(dict(ec.DEF, residual_connection="0,1,0,0"), (194, 40), 4, lib=emu_lib, max_batch=4)
+        mixednet.model(dict(ec.DEF, spatial_attention=1), (194, 40), 4, lib=emu_lib, max_batch=4)

@@ -212,3 +212,10 @@ def test_mixednet_on_generic_graph_kernels(lib):
     ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET_NOCONV1, B=6, T=60, steps=2, grid=0, graphs=True)
     # the default topology through the generic route agrees with the oracle as well (cross-check of both kernel families)
     ec.check_graph_mixednet(lib, ec.DEF, B=4, T=194, steps=1, grid=0)
+
+
+def test_mixednet_residual_connections(lib):
+    """residual_connection: 1x1 conv + BN branch of the block input added before every repeat's ReLU (also in
+    front of the classifier head)."""
+    ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET_RESIDUAL, B=8, T=80, steps=2, grid=0)
+    ec.check_graph_mixednet(lib, dict(ec.DEF, residual_connection="1,1,1,1"), B=5, T=194, steps=1, grid=0, graphs=True)
