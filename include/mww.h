@@ -114,6 +114,11 @@ typedef struct {
   mww_conv_bn_op ops[MWW_MAX_GRAPH_OPS];
   float dropout;                        /* --dropout (inception.py:330), active in the train step only */
   int32_t max_batch;
+  /* MixedNet's optional heads (mixednet.py:234-275,362-384), applied to the last op's activations when more than one
+   * frame remains; both 0 = Flatten -> Dense.  With attention the flat parameter vector carries the attention
+   * kernel[4*2] (Keras [4,1,2,1]) between the last op and dense.kernel. */
+  int32_t head_attention;               /* --spatial_attention: SpatialAttention(kernel_size = 4) */
+  int32_t head_pool;                    /* --pooled: 0 none, 1 average (AveragePooling2D), 2 max (--max_pool) over the remaining frames */
 } mww_convnet_desc;
 int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, mww_ctx** out);
 /* Dropout keep decisions for the next train steps, [B][T_last*C_last] bytes (0 = dropped); NULL

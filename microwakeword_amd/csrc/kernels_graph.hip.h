@@ -666,6 +666,190 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   if (a.training) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MixedNet's optional heads (mixednet.py:234-275 SpatialAttention, :362-384): on the last op's activations a
+//   attention : per frame mean and max over the channels -> Conv2D(1, (4,1), valid, no bias, sigmoid) over time
+//               -> gate s[t'] for the LAST T-3 frames:  out[t'][c] = a[t'+3][c] * s[t']
+//   pooling   : average or max of out over all remaining frames -> [C]     (else Flatten of out)
+//   Dense(1, sigmoid), Keras BCE, and the complete backward of the above down to the gradient at the last
+//   op's BN output.  One workgroup per window with the window's activations in LDS.  What the dense layer
+//   sees is written to hact so that dense_grad_kernel can form the dense-weight gradient from it.
+struct GHead2Args {
+  GHeadArgs h;
+  const float* watt;     // [4][2] attention taps (tap j: weight of the mean, weight of the max); null = no attention
+  int pool;              // 0 Flatten, 1 average, 2 max
+  float* hact;           // [B][n_dense]
+  float* watt_part;      // [grid][8]
+};
+
+__global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
+  HIP_DYNAMIC_SHARED(float4, g_smem4)
+  float* sm = reinterpret_cast<float*>(g_smem4);
+  __shared__ float sStat[2 * kThreads];
+  __shared__ float sRed[8];
+  __shared__ float sBcast[2];
+  const GHeadArgs& h = a.h;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = h.C, T = h.T, PA = C | 1;
+  const bool att = a.watt != nullptr;
+  const int Toff = att ? 3 : 0, To = T - Toff;
+  const int nd = a.pool ? C : To * C;
+  float* sA = sm;
+  float* sAvg = sA + T * PA;
+  float* sMax = sAvg + T;
+  float* sDavg = sMax + T;
+  float* sDmx = sDavg + T;
+  float* sS = sDmx + T;
+  float* sDpre = sS + T;
+  int* sArg = reinterpret_cast<int*>(sDpre + T);
+  float* sV = reinterpret_cast<float*>(sArg + T);
+  int* sArgT = reinterpret_cast<int*>(sV + C);
+  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  const bool active = rg < nrg;
+  const float sc = active ? h.scale[c] : 0.f, sh = active ? h.shift[c] : 0.f;
+  const float mu = (active && h.training) ? h.mean[c] : 0.f, rs = (active && h.training) ? h.rstd[c] : 0.f;
+  const float rsc = (active && h.rp) ? h.rscale[c] : 0.f, rsh = (active && h.rp) ? h.rshift[c] : 0.f;
+  float w8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w8[i] = att ? a.watt[i] : 0.f;
+  const float bias = h.bd[0];
+  float g1 = 0.f, g2 = 0.f, wacc = 0.f;
+  // gradient of the dense layer's input element (t', cc) per unit of dL/dz
+  auto dout = [&](int tp, int cc) -> float {
+    if (a.pool == 0) return h.wd[tp * C + cc];
+    if (a.pool == 1) return h.wd[cc] / (float)To;
+    return sArgT[cc] == tp ? h.wd[cc] : 0.f;
+  };
+  for (int b = blockIdx.x; b < h.B; b += gridDim.x) {
+    const float* pb = h.p + (size_t)b * T * C;
+    const float* rb = h.rp ? h.rp + ((size_t)b * h.rT + h.rdrop) * C : nullptr;
+    __syncthreads();
+    if (active)
+      for (int t = rg; t < T; t += nrg) {
+        const int i = t * C + c;
+        sA[t * PA + c] = fmaxf(fmaf(pb[i], sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f), 0.f);
+      }
+    __syncthreads();
+    if (att) {
+      for (int t = tid; t < T; t += kThreads) {
+        float sum = 0.f, mx = -3.0e38f;
+        int arg = 0;
+        for (int cc = 0; cc < C; ++cc) {
+          const float v = sA[t * PA + cc];
+          sum += v;
+          if (v > mx) { mx = v; arg = cc; }
+        }
+        sAvg[t] = sum / (float)C;
+        sMax[t] = mx;
+        sArg[t] = arg;
+      }
+      __syncthreads();
+      for (int t = tid; t < To; t += kThreads) {
+        float pre = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre += w8[2 * j] * sAvg[t + j] + w8[2 * j + 1] * sMax[t + j];
+        sS[t] = 1.0f / (1.0f + expf(-pre));
+      }
+      __syncthreads();
+    }
+    float dot = 0.f;
+    if (a.pool) {
+      if (tid < C) {
+        float acc = a.pool == 1 ? 0.f : -3.0e38f;
+        int arg = 0;
+        for (int t = 0; t < To; ++t) {
+          const float v = sA[(t + Toff) * PA + tid] * (att ? sS[t] : 1.f);
+          if (a.pool == 1) acc += v;
+          else if (v > acc) { acc = v; arg = t; }
+        }
+        if (a.pool == 1) acc /= (float)To;
+        sV[tid] = acc;
+        sArgT[tid] = arg;
+        dot = acc * h.wd[tid];
+        if (h.training) a.hact[(size_t)b * nd + tid] = acc;
+      }
+    } else if (active) {
+      for (int t = rg; t < To; t += nrg) {
+        const float v = sA[(t + Toff) * PA + c] * (att ? sS[t] : 1.f);
+        dot = fmaf(v, h.wd[t * C + c], dot);
+        if (h.training) a.hact[(size_t)b * nd + t * C + c] = v;
+      }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) sRed[wave] = dot;
+    __syncthreads();
+    if (tid == 0) {
+      const float zz = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + bias;
+      const float pr = 1.0f / (1.0f + expf(-zz));
+      h.z[b] = zz;
+      h.prob[b] = pr;
+      float dzz = 0.f;
+      if (h.y != nullptr) {
+        const float yy = h.y[b];
+        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
+        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
+        if (h.training) {
+          const float w = h.sw[b];
+          h.loss_part[b] = w * bce * h.inv_b;
+          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
+          dzz = clipped ? 0.f : w * (pr - yy) * h.inv_b;
+          h.dz[b] = dzz;
+        }
+      }
+      sBcast[0] = dzz;
+    }
+    __syncthreads();
+    if (!h.training) continue;
+    const float dzz = sBcast[0];
+    if (att) {
+      for (int t = tid; t < To; t += kThreads) {
+        float ds = 0.f;
+        for (int cc = 0; cc < C; ++cc) ds = fmaf(dout(t, cc), sA[(t + 3) * PA + cc], ds);
+        const float s = sS[t];
+        sDpre[t] = dzz * ds * s * (1.0f - s);
+      }
+      __syncthreads();
+      if (tid < 8) {
+        const int j = tid >> 1;
+        const float* src = (tid & 1) ? sMax : sAvg;
+        float acc = 0.f;
+        for (int t = 0; t < To; ++t) acc = fmaf(sDpre[t], src[t + j], acc);
+        wacc += acc;
+      }
+      for (int t = tid; t < T; t += kThreads) {
+        float da = 0.f, dm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tp = t - j;
+          if (tp >= 0 && tp < To) {
+            da = fmaf(sDpre[tp], w8[2 * j], da);
+            dm = fmaf(sDpre[tp], w8[2 * j + 1], dm);
+          }
+        }
+        sDavg[t] = da / (float)C;
+        sDmx[t] = dm;
+      }
+      __syncthreads();
+    }
+    if (active) {
+      float* gb = h.g + (size_t)b * T * C;
+      for (int t = rg; t < T; t += nrg) {
+        const int tp = t - Toff;
+        float da = tp >= 0 ? dzz * dout(tp, c) * (att ? sS[tp] : 1.f) : 0.f;
+        if (att) da += sDavg[t] + (sArg[t] == c ? sDmx[t] : 0.f);
+        const float gv = sA[t * PA + c] > 0.f ? da : 0.f;
+        gb[t * C + c] = gv;
+        g1 += gv;
+        g2 = fmaf(gv, (pb[t * C + c] - mu) * rs, g2);
+      }
+    }
+  }
+  if (h.training) {
+    write_channel_partials(g1, g2, C, sStat, h.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
+    if (att && tid < 8) a.watt_part[(size_t)blockIdx.x * 8 + tid] = wacc;
+  }
+}
+
 // Dropout keep-mask of one step: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).
 // (Keras draws its mask from a stateful generator that is not reproducible across frameworks; the
 // parity tests inject an explicit mask instead.)

@@ -92,6 +92,12 @@ struct mww_ctx {
   float* keep = nullptr;            // [max_batch][t_last*c_last] dropout keep-scale
   bool keep_explicit = false;       // set by mww_set_dropout_mask: do not regenerate
   unsigned long long dropout_seed = 0x5EEDull, dropout_counter = 0;
+  bool head2 = false;               // attention / pooled head (ghead_att_kernel)
+  bool head_att = false;
+  int head_pool = 0;
+  int64_t o_att = 0;
+  float *hact = nullptr, *watt_part = nullptr;
+  size_t lds_head2 = 0;
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   float* wt = nullptr;              // transposed weights of the ops with a data gradient
   int64_t wt_total = 0;
@@ -303,7 +309,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
       const int ndchunks = (B + dchunk - 1) / dchunk;
       DenseGradArgs dg{p_last, scale, shift, c->dz, c->dwd_part, B, c->t_last * c->c_last, c->c_last, c->dwd_stride, dchunk, keep,
                        nullptr, nullptr, nullptr, 0, 0};
-      if (c->generic && c->G.back().res_src >= 0) {
+      if (c->generic && !c->head2 && c->G.back().res_src >= 0) {
         GOp& rr = c->G[c->G.back().res_src];
         dg.rp = rr.p;
         dg.rscale = rr.bn + (size_t)BN_SCALE * rr.cout;
@@ -783,6 +789,21 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     h.rT = rr.tout;
     h.rdrop = lo.res_drop;
   }
+  if (c->head2) {
+    GHead2Args h2;
+    h2.h = h;
+    h2.watt = c->head_att ? c->params + c->o_att : nullptr;
+    h2.pool = c->head_pool;
+    h2.hact = c->hact;
+    h2.watt_part = c->watt_part;
+    if (c->lds_head2 > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ghead_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_head2));
+    lp.begin("head");
+    hipLaunchKernelGGL(ghead_att_kernel, dim3(ghead), dim3(kThreads), c->lds_head2, c->stream, h2);
+    lp.end();
+    // the dense layer sees hact (already activated): identity "BN" for the dense-weight gradient
+    return enqueue_side_work(c, B, metrics, loss, c->hact, c->ones, c->zeros, nullptr);
+  }
   lp.begin("head");
   hipLaunchKernelGGL(ghead_kernel, dim3(ghead), dim3(kThreads), 0, c->stream, h);
   lp.end();
@@ -919,6 +940,15 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     s.stride = o.k * o.cin * o.cout;
     s.n = s.stride;
     s.dst = (int)o.o_w;
+    ga.seg[ga.nseg++] = s;
+  }
+  if (c->head2 && c->head_att) {
+    GradSegment s;
+    s.part = c->watt_part;
+    s.G = ghead;
+    s.stride = 8;
+    s.n = 8;
+    s.dst = (int)c->o_att;
     ga.seg[ga.nseg++] = s;
   }
   return enqueue_grad_assembly(c, B, ga, fuse_adam);
@@ -1325,12 +1355,25 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   GOp& lo = c->G.back();
   c->t_last = lo.tout;
   c->c_last = lo.cout;
-  c->o_dense_w = off; off += (int64_t)lo.tout * lo.cout;
+  if (lo.tout > 1 && (d.head_attention || d.head_pool)) {   // mixednet.py:362: only if more than one frame remains
+    if (d.head_pool < 0 || d.head_pool > 2) { mww_destroy(c); return fail(MWW_ERR_INVALID, "head_pool must be 0, 1 or 2"); }
+    if (d.head_attention && lo.tout < 4) { mww_destroy(c); return fail(MWW_ERR_INVALID, "spatial attention needs at least 4 frames"); }
+    if (d.dropout > 0.f) { mww_destroy(c); return fail(MWW_ERR_UNSUPPORTED, "dropout with the attention / pooled head"); }
+    c->head2 = true;
+    c->head_att = d.head_attention != 0;
+    c->head_pool = d.head_pool;
+    const int to = lo.tout - (c->head_att ? 3 : 0);
+    c->t_last = c->head_pool ? 1 : to;
+    if (c->head_att) { c->o_att = off; off += 8; }
+    c->lds_head2 = ((size_t)lo.tout * (lo.cout | 1) + 7 * (size_t)lo.tout + 3 * (size_t)lo.cout) * sizeof(float);
+    if (c->lds_head2 > kMaxDynLds) { mww_destroy(c); return fail(MWW_ERR_UNSUPPORTED, "window does not fit the head's LDS tile"); }
+  }
+  c->o_dense_w = off; off += (int64_t)c->t_last * lo.cout;
   c->o_dense_b = off; off += 1;
   c->P = off;
   c->S = soff;
   c->wt_total = wtoff;
-  c->dwd_stride = lo.tout * lo.cout + 4;
+  c->dwd_stride = c->t_last * lo.cout + 4;
   const size_t mb = (size_t)d.max_batch;
   const int gmax = c->n_cu * 4;
   int rc = 0;
@@ -1338,6 +1381,10 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   A(alloc_common(c));
   A(dev_alloc(&c->wt, (size_t)wtoff));
   A(dev_alloc(&c->keep, mb * lo.tout * lo.cout));
+  if (c->head2) {
+    A(dev_alloc(&c->hact, mb * c->t_last * lo.cout));
+    A(dev_alloc(&c->watt_part, (size_t)gmax * 8));
+  }
   std::vector<BnSlots> bn;
   for (GOp& o : c->G) {
     A(dev_alloc(&o.p, mb * o.tout * o.cout));
@@ -1417,6 +1464,8 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : op) if (p) hipFree(p);
   }
   if (c->sync_buf) hipFree(c->sync_buf);
+  if (c->hact) hipFree(c->hact);
+  if (c->watt_part) hipFree(c->watt_part);
   if (c->ones) hipFree(c->ones);
   if (c->zeros) hipFree(c->zeros);
   if (c->wt) hipFree(c->wt);

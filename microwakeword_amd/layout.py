@@ -415,7 +415,8 @@ class GraphMixedNetLayout:
                     every repeat's BN output before its ReLU after StridedDrop of its leading frames (:354-358)
                                                                                     -> op(conv, norm bn, linear) + ``residual`` links
 
-    ``spatial_attention`` and ``pooled`` are not built (NotImplementedError).
+      heads       : ``spatial_attention`` (SpatialAttention(kernel_size=4), mixednet.py:234-275) and ``pooled`` /
+                    ``max_pool`` (global average / max pooling, :372-381) when more than one frame remains -> engine head options
     ``keras_vars`` is ``get_weights()`` order; pack / unpack / grad_mask follow MixedNetLayout's conventions.
     """
 
@@ -427,9 +428,6 @@ class GraphMixedNetLayout:
         for lst in (pf, rep, ksz, res):
             if len(pf) != len(lst):
                 raise ValueError("all input lists have to be the same length")  # mixednet.py:298-305
-        unsupported = [n for n, v in (("spatial_attention", _flag(flags, "spatial_attention")), ("pooled", _flag(flags, "pooled"))) if v]
-        if unsupported:
-            raise NotImplementedError("MixedNet options not implemented by the MI355X engine yet: " + ", ".join(unsupported))
         self.frames = int(frames)
         self.dropout = 0.0
         f0, k0, stride = int(_flag(flags, "first_conv_filters")), int(_flag(flags, "first_conv_kernel_size")), int(_flag(flags, "stride"))
@@ -490,11 +488,23 @@ class GraphMixedNetLayout:
                 cur, c = len(self.ops) - 1, filters
         if not self.ops or self.ops[-1]["norm"] != "bn":
             raise NotImplementedError("a MixedNet without any block")
+        self.head_attention, self.head_pool, self._att = False, 0, None
+        if t > 1:   # mixednet.py:362
+            if _flag(flags, "spatial_attention"):
+                if t < 4:
+                    raise ValueError("spatial attention needs at least 4 frames after the last block")
+                self.head_attention = True
+                self._att = len(self.keras_vars)
+                self.keras_vars.append(("attention.kernel", (4, 1, 2, 1), "param"))
+                t -= 3
+            if _flag(flags, "pooled"):
+                self.head_pool = 2 if _flag(flags, "max_pool") else 1
+                t = 1
         self.t_last, self.c_last = t, c
         self._dense = len(self.keras_vars)
         self.keras_vars.append(("dense.kernel", (t * c, 1), "param"))
         self.keras_vars.append(("dense.bias", (1,), "param"))
-        self.n_params = sum(self._item_size(it) for it in self.items) + t * c + 1
+        self.n_params = sum(self._item_size(it) for it in self.items) + (8 if self.head_attention else 0) + t * c + 1
         self.n_state = sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "state")
 
     @staticmethod
@@ -509,7 +519,8 @@ class GraphMixedNetLayout:
         return total, sum(int(np.prod(s)) for _, s, kind in self.keras_vars if kind == "param")
 
     def engine_args(self, max_batch):
-        return dict(frames=self.frames, conv_ops=self.ops, dropout=0.0, max_batch=max_batch)
+        return dict(frames=self.frames, conv_ops=self.ops, dropout=0.0, max_batch=max_batch,
+                    head_attention=self.head_attention, head_pool=self.head_pool)
 
     def pack(self, weights: Sequence[np.ndarray]):
         if len(weights) != len(self.keras_vars):
@@ -534,6 +545,8 @@ class GraphMixedNetLayout:
                 if it["kind"] == "pw":
                     params += [ws[it["kernel"] + 1], ws[it["kernel"] + 2]]
                     state += [ws[it["kernel"] + 3], ws[it["kernel"] + 4]]
+        if self._att is not None:
+            params.append(ws[self._att].reshape(-1))
         params += [ws[self._dense].reshape(-1), ws[self._dense + 1]]
         return np.concatenate(params), (np.concatenate(state) if state else np.zeros(0, np.float32))
 
@@ -563,6 +576,9 @@ class GraphMixedNetLayout:
                     out[it["kernel"] + 1], out[it["kernel"] + 2] = params[po:po + f].copy(), params[po + f:po + 2 * f].copy()
                     out[it["kernel"] + 3], out[it["kernel"] + 4] = state[so:so + f].copy(), state[so + f:so + 2 * f].copy()
                     po, so = po + 2 * f, so + 2 * f
+        if self._att is not None:
+            out[self._att] = params[po:po + 8].reshape(4, 1, 2, 1).copy()
+            po += 8
         n = self.t_last * self.c_last
         out[self._dense], out[self._dense + 1] = params[po:po + n].reshape(-1, 1).copy(), params[po + n:po + n + 1].copy()
         return out
@@ -576,6 +592,8 @@ class GraphMixedNetLayout:
                 seg.append((name + ".kernel", int(np.prod(it["shape"]))))
                 if it["kind"] == "pw":
                     seg += [(name + ".bn.gamma", it["shape"][3]), (name + ".bn.beta", it["shape"][3])]
+        if self._att is not None:
+            seg.append(("attention.kernel", 8))
         return seg + [("dense.kernel", self.t_last * self.c_last), ("dense.bias", 1)]
 
     def grad_mask(self) -> np.ndarray:
@@ -589,7 +607,7 @@ class GraphMixedNetLayout:
                 parts += [m.reshape(-1), np.ones(it["C"], np.float32)]
             else:
                 parts.append(np.ones(self._item_size(it), np.float32))
-        parts.append(np.ones(self.t_last * self.c_last + 1, np.float32))
+        parts.append(np.ones((8 if self._att is not None else 0) + self.t_last * self.c_last + 1, np.float32))
         return np.concatenate(parts)
 
     def summary_lines(self):
@@ -597,4 +615,5 @@ class GraphMixedNetLayout:
         for name, op in zip(self.op_names, self.ops):
             yield "%-12s %-9s %dx1 %s %d->%d, %s, %s   [B, %d, %d]" % (name, op["kind"], op["kernel"], "/%d" % op.get("stride", 1), op["cin"],
                                                                        op["filters"], op["norm"], op["act"], op["tout"], op["filters"])
-        yield "flatten + dense(1, sigmoid)   [B, 1]"
+        head = ("spatial attention(4) + " if self.head_attention else "") + {0: "flatten", 1: "average pool", 2: "max pool"}[self.head_pool]
+        yield "%s + dense(1, sigmoid)   [B, 1]" % head

@@ -49,7 +49,7 @@ class ConvBnOp(C.Structure):
 
 class ConvNetDesc(C.Structure):
     _fields_ = [("frames", C.c_int32), ("n_ops", C.c_int32), ("ops", ConvBnOp * MWW_MAX_GRAPH_OPS),
-                ("dropout", C.c_float), ("max_batch", C.c_int32)]
+                ("dropout", C.c_float), ("max_batch", C.c_int32), ("head_attention", C.c_int32), ("head_pool", C.c_int32)]
 
 
 class Window(C.Structure):
@@ -182,7 +182,8 @@ class Engine:
     """One device context (``mww_ctx``): model weights, HBM-resident feature stores, the train step."""
 
     def __init__(self, frames, conv1_filters=None, conv1_kernel=None, conv1_stride=1, block_filters=(), block_kernel=(),
-                 max_batch=1024, device=0, stream=None, lib: Optional[NativeLib] = None, conv_ops=None, dropout=0.0):
+                 max_batch=1024, device=0, stream=None, lib: Optional[NativeLib] = None, conv_ops=None, dropout=0.0,
+                 head_attention=False, head_pool=0):
         """MixedNet topology from the ``conv1_*`` / ``block_*`` arguments, or — when ``conv_ops`` is given —
         a conv/BN graph: a list of dicts ``{src: [...], drop: [...], slice: [(c0, width), ...], kernel, dilation, filters, bn_groups}``
         (``mww_conv_bn_op``) with the classifier head on the last one."""
@@ -192,6 +193,7 @@ class Engine:
         if conv_ops is not None:
             d = ConvNetDesc()
             d.frames, d.n_ops, d.dropout, d.max_batch = int(frames), len(conv_ops), float(dropout), int(max_batch)
+            d.head_attention, d.head_pool = int(bool(head_attention)), int(head_pool)
             if len(conv_ops) > MWW_MAX_GRAPH_OPS:
                 raise ValueError("too many ops")
             for i, op in enumerate(conv_ops):

@@ -131,8 +131,6 @@ def mixednet_build(flags, T, seed=42) -> List[Var]:
     for lst in (pf, rep, ksz, res):
         if len(pf) != len(lst):
             raise ValueError("all input lists have to be the same length")
-    if _get(flags, "spatial_attention") or _get(flags, "pooled"):
-        raise NotImplementedError("spatial_attention / pooled heads are outside the oracle")
     rng = np.random.default_rng(seed)
     vs: List[Var] = []
     c = FEATURE_BINS
@@ -160,6 +158,13 @@ def mixednet_build(flags, T, seed=42) -> List[Var]:
             vs.append(Var(p + ".pw.kernel", glorot_uniform(rng, (1, 1, c, filters), c, filters)))
             vs += _bn_vars(p + ".bn", filters)
             c = filters
+    # head (mixednet.py:362-384): SpatialAttention(kernel_size=4) and/or global pooling, only if frames remain
+    if t > 1:
+        if _get(flags, "spatial_attention"):
+            vs.append(Var("attention.kernel", glorot_uniform(rng, (4, 1, 2, 1), 4 * 2, 4 * 1)))
+            t = t - 3
+        if _get(flags, "pooled"):
+            t = 1
     vs.append(Var("dense.kernel", glorot_uniform(rng, (t * c, 1), t * c, 1)))
     vs.append(Var("dense.bias", np.zeros(1, np.float32)))
     return vs
@@ -306,6 +311,19 @@ def mixednet_logits(flags, tensors, x, training, taps=None, relu_masks=None):
                 net = net * relu_masks[p].to(net.dtype)
             else:
                 net = torch.relu(net)
+    if net.shape[2] > 1:
+        if _get(flags, "spatial_attention"):
+            # mixednet.py:244-275: per-frame mean and max over the channels -> Conv2D(1, (4,1), valid, no bias,
+            # sigmoid) over time -> gate for the LAST T-3 frames of the input
+            avg, mx = net.mean(dim=1, keepdim=True), net.max(dim=1, keepdim=True).values          # [B,1,T]
+            wa = tensors["attention.kernel"][:, 0, :, 0].t().unsqueeze(0)                             # [1,2,4]
+            att = torch.sigmoid(F.conv1d(torch.cat([avg, mx], dim=1), wa))                            # [B,1,T-3]
+            net = net[:, :, net.shape[2] - att.shape[2]:] * att
+            if taps is not None:
+                taps["attention.out"] = net.transpose(1, 2)
+        if _get(flags, "pooled"):
+            # mixednet.py:372-381: pooling over the whole remaining time axis
+            net = net.max(dim=2, keepdim=True).values if _get(flags, "max_pool") else net.mean(dim=2, keepdim=True)
     flat = net.transpose(1, 2).reshape(net.shape[0], -1)  # Keras Flatten of [B,T,1,C]: index t*C+c
     z = flat @ tensors["dense.kernel"][:, 0] + tensors["dense.bias"][0]
     return z, cur.new_stats

@@ -603,6 +603,9 @@ GRAPH_MIXEDNET = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0,0", pointwi
                       mixconv_kernel_sizes="[3],[1],[3,5]", first_conv_filters=16, first_conv_kernel_size=5, stride=2)
 GRAPH_MIXEDNET_RESIDUAL = dict(mo.MIXEDNET_DEFAULTS, residual_connection="1,0,1", pointwise_filters="24,24,32", repeat_in_block="2,1,1",
                                mixconv_kernel_sizes="[5],[3,7],[1]", first_conv_filters=16, first_conv_kernel_size=3, stride=1)
+GRAPH_MIXEDNET_HEADS = [dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="24,32", repeat_in_block="1,1",
+                             mixconv_kernel_sizes="[5],[7]", first_conv_filters=16, spatial_attention=sa, pooled=po, max_pool=mp)
+                        for sa, po, mp in ((1, 0, 0), (0, 1, 0), (0, 1, 1), (1, 1, 0), (1, 1, 1))]
 GRAPH_MIXEDNET_NOCONV1 = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="16,24", repeat_in_block="1,1",
                               mixconv_kernel_sizes="[5],[7,9]", first_conv_filters=0)
 
@@ -638,6 +641,8 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
                 got, ref = np.maximum(got, 0), taps["conv1"].detach().numpy()
             elif name.endswith(".res"):
                 continue   # residual branch: checked through the block outputs it is added to
+            elif name not in ("conv1",) and not name.endswith((".dw", ".pw")):
+                continue
             elif name.endswith(".dw"):
                 it = lay.items[k]
                 bias = np.concatenate([wts[lay.keras_vars[vi + 1][0]] for vi, _, _ in it["groups"]])

@@ -99,6 +99,12 @@ def test_mixednet_residual_connections(emu_lib):
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_RESIDUAL, B=3, T=80, steps=1, grid=2)
 
 
+def test_mixednet_attention_and_pooled_heads(emu_lib):
+    """spatial_attention / pooled / max_pool heads (mixednet.py:234-275,362-381), forward and the full backward."""
+    for flags in ec.GRAPH_MIXEDNET_HEADS:
+        ec.check_graph_mixednet(emu_lib, flags, B=3, T=64, steps=1, grid=2)
+
+
 def test_mixednet_model_selects_kernels_by_shape(emu_lib):
     """mixednet.model(): specialised block kernels when the shape is instantiated, generic graph kernels
     otherwise, NotImplementedError for the options nothing implements."""
@@ -117,5 +123,6 @@ def test_mixednet_model_selects_kernels_by_shape(emu_lib):
     r = mixednet.model(dict(ec.DEF, residual_connection="0,1,0,0"), (194, 40), 4, lib=emu_lib, max_batch=4)
     assert "generic" in r.name
     r.engine.close()
-    with pytest.raises(NotImplementedError):
-        mixednet.model(dict(ec.DEF, spatial_attention=1), (194, 40), 4, lib=emu_lib, max_batch=4)
+    a = mixednet.model(dict(ec.DEF, spatial_attention=1, pooled=1), (194, 40), 4, lib=emu_lib, max_batch=4)
+    assert "generic" in a.name and a.layout.t_last == 1
+    a.engine.close()

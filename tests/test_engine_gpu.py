@@ -219,3 +219,10 @@ def test_mixednet_residual_connections(lib):
     front of the classifier head)."""
     ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET_RESIDUAL, B=8, T=80, steps=2, grid=0)
     ec.check_graph_mixednet(lib, dict(ec.DEF, residual_connection="1,1,1,1"), B=5, T=194, steps=1, grid=0, graphs=True)
+
+
+def test_mixednet_attention_and_pooled_heads(lib):
+    """--spatial_attention / --pooled / --max_pool heads of MixedNet (mixednet.py:234-275,362-381)."""
+    for flags in ec.GRAPH_MIXEDNET_HEADS:
+        ec.check_graph_mixednet(lib, flags, B=6, T=64, steps=2, grid=0)
+    ec.check_graph_mixednet(lib, dict(ec.DEF, spatial_attention=1, pooled=1), B=5, T=194, steps=1, grid=0, graphs=True)
