@@ -92,7 +92,8 @@ class MixedNetLayout:
         if _flag(flags, "pooled"):
             unsupported.append("pooled")
         if unsupported:
-            raise NotImplementedError("MixedNet options not implemented by the MI355X engine yet: " + ", ".join(unsupported))
+            raise NotImplementedError("MixedNet options outside the specialised block kernels (GraphMixedNetLayout covers them): "
+                                      + ", ".join(unsupported))
         t = (self.frames - self.conv1_kernel) // self.stride + 1
         c = self.conv1_filters
         self.blocks: List[BlockSpec] = []
