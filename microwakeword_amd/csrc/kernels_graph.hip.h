@@ -145,7 +145,13 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
   float* sW = g_smem;                       // [k*cin][NCP], loaded once per workgroup
   float* sIn = sW + a.k * a.cin * NCP;
   float* sOut = sIn + rows_in * PI;
-  float s1[kGMaxSrc] = {0.f, 0.f, 0.f}, s2[kGMaxSrc] = {0.f, 0.f, 0.f};
+  // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source, kept
+  // in LDS so that the sources can be walked by a real loop (their descriptors stay in the kernel-argument
+  // segment instead of pinning ~100 SGPRs)
+  float s1o = 0.f, s2o = 0.f;
+  __shared__ float sSrcAcc[MODE == 1 ? kGMaxSrc * 2 * kThreads : 1];
+  if (MODE == 1)
+    for (int i = 0; i < kGMaxSrc * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
 
   for (int i = tid; i < a.k * a.cin * NC; i += kThreads) sW[(i / NC) * NCP + (i % NC)] = a.w[i];
   if (MODE == 1) {
@@ -191,15 +197,13 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
         for (int t = rg; t < a.Tout; t += nrg) {
           const float v = sOut[t * PO + c];
           dst[(size_t)t * NC] = v;
-          s1[0] += v;
-          s2[0] = fmaf(v, v, s2[0]);
+          s1o += v;
+          s2o = fmaf(v, v, s2o);
         }
       }
     } else {
       int c0 = 0;
-#pragma unroll
-      for (int i = 0; i < kGMaxSrc; ++i) {
-        if (i >= a.n_src) break;
+      for (int i = 0; i < a.n_src; ++i) {
         const GSrc& s = a.src[i];
         const int C = s.C;
         if (s.flags & GSRC_GRAD) {
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
               t1 += gv;
               t2 = fmaf(gv, (p - mu) * rs, t2);
             }
-            s1[i] += t1;
-            s2[i] += t2;
+            sSrcAcc[(i * 2 + 0) * kThreads + tid] += t1;
+            sSrcAcc[(i * 2 + 1) * kThreads + tid] += t2;
           }
         }
         c0 += C;
@@ -233,14 +237,13 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
     }
   }
   if (MODE == 0) {
-    if (a.stat_part) write_channel_partials(s1[0], s2[0], NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
+    if (a.stat_part) write_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
   } else {
-#pragma unroll
-    for (int i = 0; i < kGMaxSrc; ++i) {
-      if (i >= a.n_src) break;
+    for (int i = 0; i < a.n_src; ++i) {
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
-        write_channel_partials(s1[i], s2[i], s.C, sRed, s.gstat_part + (size_t)blockIdx.x * 2 * s.ld + s.c0, tid, s.ld);
+        write_channel_partials(sSrcAcc[(i * 2 + 0) * kThreads + tid], sSrcAcc[(i * 2 + 1) * kThreads + tid], s.C, sRed,
+                               s.gstat_part + (size_t)blockIdx.x * 2 * s.ld + s.c0, tid, s.ld);
     }
   }
 }

@@ -1,0 +1,36 @@
+#!/bin/bash
+# End-of-round GPU session: full GPU suite, smoke, the three bench configurations, kernel trace and PMC passes.
+TAG=${1:-final}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 600 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+echo "== pytest -m gpu"
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider 2>&1 | tail -6 | tee $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log
+echo "== bench default"
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3200 $OUT/bench.json; tail -2 $OUT/bench.err
+echo "== bench inception"
+timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; tail -c 400 $OUT/bench_inception.json | head -c 400; echo
+echo "== bench bf16-operand"
+timeout 900 python bench.py --pointwise-bf16 --no-cpu-baseline --no-validation > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; head -c 300 $OUT/bench_bf16.json; echo
+echo "== rocprofv3"
+export TMPDIR=/tmp
+B="python $R/bench.py --steps 6 --warmup 2 --no-graphs --no-cpu-baseline --no-validation --profile-steps 0"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > /dev/null 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o p -- $B > /dev/null 2> $OUT/pmc1.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- $B > /dev/null 2> $OUT/pmc2.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $B > /dev/null 2> $OUT/pmc3.err
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $B > /dev/null 2> $OUT/pmc4.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inc -o t -- $B --model inception > /dev/null 2> $OUT/trace_inc.err
+cd $R
+python tools/pmc_summary.py $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 > $OUT/kernel_stats_and_pmc.txt 2>&1
+python tools/pmc_summary.py $OUT/trace_inc > $OUT/kernel_stats_inception.txt 2>&1
+head -30 $OUT/kernel_stats_and_pmc.txt | cut -c1-160
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -size +12M -delete
+echo "== done"
