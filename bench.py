@@ -86,6 +86,7 @@ def inception_kernel_elems(layout):
                                                              for j2 in range(len(ops[i2]["src"])))]
                     n += 2 * e + (e if i != max(same) else 0)
             elems["conv_dgrad%d" % (i + 1)] = n
+            elems["conv_bwd%d" % (i + 1)] = n + elems["conv_wgrad%d" % (i + 1)]   # both halves in one launch
     last = ops[-1]["tout"] * ops[-1]["filters"]
     elems["head"] = 2 * last + (last if layout.dropout > 0 else 0)          # read p, write g (+ keep mask)
     elems["dense_grad"] = last + (last if layout.dropout > 0 else 0)
@@ -206,7 +207,7 @@ def main():
             model = inception.model(dict(synthetic.DEFAULT_INCEPTION_FLAGS), (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                                     seed=42, max_batch=B)
             kernel_elems = inception_kernel_elems(model.layout)
-            step_bytes = 4 * sum(kernel_elems.values())
+            step_bytes = 4 * sum(v for k, v in kernel_elems.items() if not k.startswith("conv_bwd"))
         else:
             model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                           seed=42, max_batch=B)

@@ -132,8 +132,9 @@ struct GConvArgs {
   GBnBwd y;             // MODE 1
 };
 
+// bid / nb: this workgroup's index and the number of workgroups sharing the batch (a launch may hold several roles)
 template <int NC, int MODE>
-__global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
+__device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   __shared__ float sRed[2 * kThreads];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
       sIn[(pad + a.Tin) * PI + i] = 0.f;
     }
   }
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = bid; b < a.B; b += nb) {
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
     if (MODE == 0) stage_sources(a.src, a.n_src, b, a.Tin, sIn, PI, tid);
     else stage_dp(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid);
@@ -237,15 +238,20 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
     }
   }
   if (MODE == 0) {
-    if (a.stat_part) write_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)blockIdx.x * 2 * NC, tid, NC);
+    if (a.stat_part) write_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)bid * 2 * NC, tid, NC);
   } else {
     for (int i = 0; i < a.n_src; ++i) {
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
         write_channel_partials(sSrcAcc[(i * 2 + 0) * kThreads + tid], sSrcAcc[(i * 2 + 1) * kThreads + tid], s.C, sRed,
-                               s.gstat_part + (size_t)blockIdx.x * 2 * s.ld + s.c0, tid, s.ld);
+                               s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld);
     }
   }
+}
+
+template <int NC, int MODE>
+__global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
+  gconv_body<NC, MODE>(a, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -261,7 +267,7 @@ struct GWgradArgs {
 };
 
 template <int NC>
-__global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
+__device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   constexpr int PO = (NC + 3) / 4 * 4;
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
     // columns NC..PO-1 of dp stay zero
     for (int i = tid; i < a.Tout * PO; i += kThreads) sDP[i] = 0.f;
   }
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = bid; b < a.B; b += nb) {
     __syncthreads();
     stage_sources(a.src, a.n_src, b, a.Tin, sA, PI, tid);
     stage_dp(a.y, NC, b, a.Tout, sDP, PO, tid);
@@ -302,10 +308,24 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
     }
   }
   if (active) {
-    float* dst = a.grad_part + ((size_t)blockIdx.x * nq + q) * ((size_t)tasks * NC) + (size_t)task * NC;
+    float* dst = a.grad_part + ((size_t)bid * nq + q) * ((size_t)tasks * NC) + (size_t)task * NC;
 #pragma unroll
     for (int co = 0; co < NC; ++co) dst[co] = acc[co];
   }
+}
+
+template <int NC>
+__global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
+  gconv_wgrad_body<NC>(a, blockIdx.x, gridDim.x);
+}
+
+// Both halves of an op's backward in one launch: workgroups [0, nb) form the weight gradient, [nb, 2 nb) the data
+// gradient.  They are independent (both only read the op's output gradient) and each is latency-bound on its
+// own, so sharing the launch hides one of the two.
+template <int NCO, int NCI>
+__global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nb) {
+  if ((int)blockIdx.x < nb) gconv_wgrad_body<NCO>(w, blockIdx.x, nb);
+  else gconv_body<NCI, 1>(d, blockIdx.x - nb, nb);
 }
 
 // ---------------------------------------------------------------------------------------------
