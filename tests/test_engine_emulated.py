@@ -126,3 +126,9 @@ def test_mixednet_model_selects_kernels_by_shape(emu_lib):
     a = mixednet.model(dict(ec.DEF, spatial_attention=1, pooled=1), (194, 40), 4, lib=emu_lib, max_batch=4)
     assert "generic" in a.name and a.layout.t_last == 1
     a.engine.close()
+
+
+def test_smallest_spectrogram(emu_lib):
+    """T = 47: exactly one output frame after the last block."""
+    ec.check_forward_parity(emu_lib, B=2, T=47, training=True, grid=1)
+    ec.check_train_steps(emu_lib, B=2, T=47, steps=1, grid=1)

@@ -226,3 +226,32 @@ def test_mixednet_attention_and_pooled_heads(lib):
     for flags in ec.GRAPH_MIXEDNET_HEADS:
         ec.check_graph_mixednet(lib, flags, B=6, T=64, steps=2, grid=0)
     ec.check_graph_mixednet(lib, dict(ec.DEF, spatial_attention=1, pooled=1), B=5, T=194, steps=1, grid=0, graphs=True)
+
+
+@pytest.mark.parametrize("B,T", [(1, 47), (2, 48), (3, 300), (1023, 194), (257, 111)])
+def test_edge_batch_sizes_and_lengths(lib, B, T):
+    """Smallest spectrogram the default network accepts (one output frame), lengths off the tile grid, batch
+    sizes that are neither powers of two nor multiples of the grid."""
+    ec.check_forward_parity(lib, B=B, T=T, training=True)
+    if B <= 3:
+        ec.check_train_steps(lib, B=max(B, 2), T=T, steps=1, grid=0)
+
+
+def test_long_run_stays_finite(lib):
+    """2000 steps on random data at lr 1e-2: loss, weights and BN state stay finite and bounded."""
+    om = ec.perturbed_oracle(194)
+    lay, eng = ec.make_engine(lib, 194, 64, om)
+    eng.set_option("graphs", 1)
+    rng = np.random.default_rng(0)
+    x = ec.synth_x(rng, 64, 194)
+    y = (rng.random(64) < 0.5).astype(np.float32)
+    eng.set_batch(x)
+    eng.set_targets(y, np.ones(64, np.float32))
+    losses = []
+    for s in range(2000):
+        eng.train_step(64, 1e-2)
+        if s % 400 == 399:
+            losses.append(eng.read_outputs(64)[2])
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses   # it memorises the fixed batch
+    assert np.all(np.isfinite(eng.get_params())) and np.all(np.isfinite(eng.get_bn_state()))
+    eng.close()
