@@ -101,8 +101,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
-    ap.add_argument("--model", choices=("mixednet", "inception"), default="mixednet",
-                    help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology")
+    ap.add_argument("--model", choices=("mixednet", "inception", "notebook"), default="mixednet",
+                    help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology; notebook = the "
+                         "MixedNet flags of the reference's training notebook (5x1 stride-3 first conv, 64 filters, MixConv groups, T=204)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="multi-GPU parity mode: BatchNorm statistics exchanged over RCCL (default: local-BN throughput mode)")
     ap.add_argument("--pointwise-bf16", action="store_true",
@@ -138,7 +139,10 @@ def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
     provs = do.synthetic_providers(512, 1234)
     if model == "inception":
         flags = dict(mo.INCEPTION_DEFAULTS)
-    om = mo.OracleModel(model, flags, T_FRAMES, seed=42, dtype=torch.float32)
+    elif model == "notebook":
+        from microwakeword_amd import synthetic
+        flags = dict(synthetic.NOTEBOOK_MIXEDNET_FLAGS)
+    om = mo.OracleModel("inception" if model == "inception" else "mixednet", flags, T_FRAMES, seed=42, dtype=torch.float32)
     n_keep = (T_FRAMES - mo.inception_slices_dropped(flags)) * 16 if model == "inception" else 0
 
     def keep_mask():
@@ -169,6 +173,7 @@ def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
 
 
 def main():
+    global T_FRAMES
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -208,6 +213,16 @@ def main():
                                     seed=42, max_batch=B)
             kernel_elems = inception_kernel_elems(model.layout)
             step_bytes = 4 * sum(v for k, v in kernel_elems.items() if not k.startswith("conv_bwd"))
+        elif args.model == "notebook":
+            from microwakeword_amd import mixednet
+            T_FRAMES = 204
+            model = mixednet.model(synthetic.NOTEBOOK_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
+                                   seed=42, max_batch=B)
+            lay = model.layout
+            # same accounting as SURVEY 8(d): x + 2 p_k forward; 2 p_k + x + 2 (g_1..g_{L-1}) backward
+            pk = [b.tout * b.cout for b in lay.blocks]
+            step_bytes = 4 * (2 * T_FRAMES * 40 + 4 * sum(pk) + 2 * sum(pk[:-1]))
+            kernel_elems = {"assemble": T_FRAMES * 40 * 3 // 2}
         else:
             model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                           seed=42, max_batch=B)

@@ -44,6 +44,9 @@ def benchmark_config(n_samples=4096, seed=1234, dtype=np.uint16, n_val=0, n_ambi
 DEFAULT_MIXEDNET_FLAGS = dict(pointwise_filters="48, 48, 48, 48", residual_connection="0,0,0,0", repeat_in_block="1,1,1,1",
                               mixconv_kernel_sizes="[5], [9], [13], [21]", max_pool=0, first_conv_filters=32,
                               first_conv_kernel_size=3, spatial_attention=0, pooled=0, stride=1)
+# the MixedNet flags of the reference's training notebook (cell 10); spectrogram_length 204
+NOTEBOOK_MIXEDNET_FLAGS = dict(DEFAULT_MIXEDNET_FLAGS, first_conv_kernel_size=5, stride=3, first_conv_filters=32,
+                               pointwise_filters="64,64,64,64", mixconv_kernel_sizes="[5],[7,11],[9,15],[23]")
 DEFAULT_INCEPTION_FLAGS = dict(cnn1_filters="24", cnn1_kernel_sizes="5", cnn1_subspectral_groups="4", cnn2_filters1="10,10,16",
                                cnn2_filters2="10,10,16", cnn2_kernel_sizes="5,5,5", cnn2_subspectral_groups="1,1,1",
                                cnn2_dilation="1,1,1", dropout=0.2)
