@@ -167,14 +167,14 @@ struct Launcher {
     ProfileEntry e;
     e.name = n;
     if (layer >= 0) e.name += std::to_string(layer + 1);
-    hipEventCreate(&e.a);
-    hipEventCreate(&e.b);
-    hipEventRecord(e.a, c->stream);
+    (void)hipEventCreate(&e.a);
+    (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, c->stream);
     c->prof.push_back(e);
   }
   void end() {
     if (!c->profile) return;
-    hipEventRecord(c->prof.back().b, c->stream);
+    (void)hipEventRecord(c->prof.back().b, c->stream);
   }
 };
 
@@ -950,8 +950,8 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, gg, std::max(o.lds_wg, o.lds_dx));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
-        hipEventDestroy(c->prof.back().a);
-        hipEventDestroy(c->prof.back().b);
+        (void)hipEventDestroy(c->prof.back().a);
+        (void)hipEventDestroy(c->prof.back().b);
         c->prof.pop_back();
       }
     }
@@ -1481,40 +1481,40 @@ int mww_set_dropout_mask(mww_ctx* c, const uint8_t* keep, int B) {
 
 void mww_destroy(mww_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
-  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
-  for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+  for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
                   c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk};
-  for (void* p : flat) if (p) hipFree(p);
+  for (void* p : flat) if (p) (void)hipFree(p);
   for (auto& l : c->L) {
     void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
-    for (void* p : lp) if (p) hipFree(p);
+    for (void* p : lp) if (p) (void)hipFree(p);
   }
   for (auto& o : c->G) {
     void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn};
-    for (void* p : op) if (p) hipFree(p);
+    for (void* p : op) if (p) (void)hipFree(p);
   }
-  if (c->sync_buf) hipFree(c->sync_buf);
-  if (c->hact) hipFree(c->hact);
-  if (c->watt_part) hipFree(c->watt_part);
-  if (c->ones) hipFree(c->ones);
-  if (c->zeros) hipFree(c->zeros);
-  if (c->wt) hipFree(c->wt);
-  if (c->keep) hipFree(c->keep);
-  for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) hipFree(c->store[i]);
-  if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+  if (c->sync_buf) (void)hipFree(c->sync_buf);
+  if (c->hact) (void)hipFree(c->hact);
+  if (c->watt_part) (void)hipFree(c->watt_part);
+  if (c->ones) (void)hipFree(c->ones);
+  if (c->zeros) (void)hipFree(c->zeros);
+  if (c->wt) (void)hipFree(c->wt);
+  if (c->keep) (void)hipFree(c->keep);
+  for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) (void)hipFree(c->store[i]);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < kRing; ++i) {
-    if (c->mail_host[i]) hipHostFree(c->mail_host[i]);
-    if (c->mail_ev[i]) hipEventDestroy(c->mail_ev[i]);
-    if (c->mail_hbm[i]) hipFree(c->mail_hbm[i]);
-    if (c->ev_copy[i]) hipEventDestroy(c->ev_copy[i]);
+    if (c->mail_host[i]) (void)hipHostFree(c->mail_host[i]);
+    if (c->mail_ev[i]) (void)hipEventDestroy(c->mail_ev[i]);
+    if (c->mail_hbm[i]) (void)hipFree(c->mail_hbm[i]);
+    if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   }
-  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
-  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -1832,7 +1832,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   if (!strcmp(name, "graphs")) c->use_graphs = v != 0;
   else if (!strcmp(name, "profile")) {
     c->profile = v != 0;
-    for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     c->prof.clear();
   }
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
@@ -1848,7 +1848,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "dropout_seed")) { c->dropout_seed = (unsigned long long)v; c->dropout_counter = 0; }
   else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
   else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);
-  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   c->graphs.clear();
   return MWW_OK;
 }
@@ -1860,7 +1860,7 @@ int mww_profile_read(mww_ctx* c, char* names, int names_cap, float* ms, int cap)
   for (auto& e : c->prof) {
     if (n >= cap) break;
     float t = 0.f;
-    hipEventElapsedTime(&t, e.a, e.b);
+    (void)hipEventElapsedTime(&t, e.a, e.b);
     ms[n] = t;
     const int len = (int)e.name.size();
     if (names && pos + len + 1 < names_cap) {
@@ -1871,7 +1871,7 @@ int mww_profile_read(mww_ctx* c, char* names, int names_cap, float* ms, int cap)
     ++n;
   }
   if (names && names_cap > 0) names[pos < names_cap ? pos : names_cap - 1] = 0;
-  for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   c->prof.clear();
   return n;
 }
