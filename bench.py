@@ -95,6 +95,34 @@ def inception_kernel_elems(layout):
     return elems
 
 
+def pmc_traffic(kernel, model):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round1_k_*:
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run of `bench.py --no-graphs`), corrected
+    as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE (KB) counts half the bytes of wide coalesced
+    reads -> x2; WRITE_SIZE (KB) as reported.  Returns (bytes, source) or (None, None).  The counters cannot be
+    read from inside this process; the figure belongs to the kernel binary profiled at the end of the round."""
+    import re
+    path = os.path.join(ROOT, "profiles", "round1_k_kernel_stats_and_pmc.txt")
+    if model != "mixednet" or not os.path.isfile(path):
+        return None, None
+    want = {"bwd_block1": r"bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
+            "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
+            "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
+            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}.get(kernel)
+    if not want:
+        return None, None
+    fetch = write = None
+    for line in open(path):
+        if line.startswith(want.replace("\\", "")) or re.match(re.escape(want), line):
+            m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
+            fetch = float(m.group(1)) if m else fetch
+            m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
+            write = float(m.group(1)) if m else write
+    if fetch is None or write is None:
+        return None, None
+    return int(2 * fetch * 1024 + write * 1024), "profiles/round1_k_kernel_stats_and_pmc.txt (FETCH_SIZE x2 + WRITE_SIZE, KB)"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +380,7 @@ def main():
     else:  # --profile-steps 0 (e.g. under rocprofv3): whole-step figure only
         dominant, dom_bytes, achieved = "train_step(all kernels)", step_bytes * B, value / world * step_bytes
         kern[dominant] = 1e3 * elapsed / args.steps
+    traffic, traffic_src = pmc_traffic(dominant, args.model) if B == 1024 and not args.pointwise_bf16 else (None, None)
     out = {
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,7 +394,7 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": not args.no_graphs,
                    "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
