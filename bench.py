@@ -105,7 +105,7 @@ def pmc_traffic(kernel, model):
     path = os.path.join(ROOT, "profiles", "round1_k_kernel_stats_and_pmc.txt")
     if model != "mixednet" or not os.path.isfile(path):
         return None, None
-    want = {"bwd_block1": r"bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
+    want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
             "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
             "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
             "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}.get(kernel)
@@ -113,7 +113,7 @@ def pmc_traffic(kernel, model):
         return None, None
     fetch = write = None
     for line in open(path):
-        if line.startswith(want.replace("\\", "")) or re.match(re.escape(want), line):
+        if line.startswith(want):
             m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
             fetch = float(m.group(1)) if m else fetch
             m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
