@@ -132,3 +132,53 @@ def test_smallest_spectrogram(emu_lib):
     """T = 47: exactly one output frame after the last block."""
     ec.check_forward_parity(emu_lib, B=2, T=47, training=True, grid=1)
     ec.check_train_steps(emu_lib, B=2, T=47, steps=1, grid=1)
+
+
+def test_cli_end_to_end_from_disk(emu_lib, tmp_path, monkeypatch):
+    """`python -m microwakeword_amd.model_train_eval --training_config cfg.yaml mixednet ...` (model_train_eval.py:
+    277-439): YAML config, `<features_dir>/<mode>/*_mmap` stores on disk, shape derivation, model summary, train
+    loop with validation and checkpoints — and a second invocation that restores the checkpoint."""
+    import yaml
+
+    from microwakeword_amd import model_train_eval, ragged
+    rng = np.random.default_rng(0)
+    for prov, positive in (("wake", True), ("background", False)):
+        for mode, n in (("training", 12), ("validation", 6), ("validation_ambient", 2)):
+            if mode == "validation_ambient" and positive:
+                continue
+            lo, hi = (200, 260) if mode == "validation_ambient" else (62, 90)
+            samples = []
+            for _ in range(n):
+                s = rng.integers(0, 200, size=(int(rng.integers(lo, hi)), 40)).astype(np.uint16)
+                if positive:
+                    s[-30:-10, 8:24] += 400
+                samples.append(s)
+            ragged.write_ragged_store(str(tmp_path / prov / mode / ("%s_mmap" % mode)), samples)
+    cfg = dict(window_step_ms=10, train_dir=str(tmp_path / "trained"), clip_duration_ms=160, batch_size=4, training_steps=[4],
+               learning_rates=[0.001], eval_step_interval=2, target_minimization=0.9, minimization_metric=None,
+               maximization_metric="average_viable_recall", time_mask_max_size=[3], time_mask_count=[1], freq_mask_max_size=[3],
+               freq_mask_count=[1], positive_class_weight=[1], negative_class_weight=[2],
+               features=[dict(features_dir=str(tmp_path / "wake"), sampling_weight=1.0, penalty_weight=1.0, truth=True,
+                              truncation_strategy="truncate_start", type="mmap"),
+                         dict(features_dir=str(tmp_path / "background"), sampling_weight=2.0, penalty_weight=1.0, truth=False,
+                              truncation_strategy="random", type="mmap")])
+    (tmp_path / "cfg.yaml").write_text(yaml.dump(cfg))
+    monkeypatch.setenv("MWW_HIP_LIB", emu_lib.path)   # the CLI builds its own engine: point it at the emulator build
+    argv = ["--training_config", str(tmp_path / "cfg.yaml"), "--verbosity", "ERROR", "mixednet", "--residual_connection", "0,0,0,0"]
+    out = model_train_eval.main(argv)
+    assert set(out) == {"best_minimization", "best_maximization", "best_no_faph_cutoff"}
+    run = tmp_path / "trained"
+    for f in ("training_config.yaml", "model_summary.txt", "best_weights.weights.h5.npz", "last_weights.weights.h5.npz",
+              "restore/ckpt.weights.npz", "restore/ckpt.opt.npz", "logs/train/scalars.jsonl", "logs/validation/scalars.jsonl"):
+        assert (run / f).exists(), f
+    saved = yaml.load((run / "training_config.yaml").read_text(), yaml.Loader)   # the reference's dump carries a python tuple
+    assert saved["spectrogram_length"] == 60 and saved["spectrogram_length_final_layer"] == 14
+    from microwakeword_amd.layout import MixedNetLayout
+    total = MixedNetLayout(ec.DEF, 60).keras_param_counts()[0]
+    assert total == 22561 - 48 * (148 - 14) and "Total params: %d" % total in (run / "model_summary.txt").read_text()
+    with pytest.raises(ValueError, match="already exists"):
+        model_train_eval.main(argv)                                  # model_train_eval.py:118-120
+    out2 = model_train_eval.main(argv[:2] + ["--restore_checkpoint", "1"] + argv[2:])
+    assert set(out2) == set(out)
+    z = np.load(run / "restore" / "ckpt.opt.npz")
+    assert int(z["step"]) == 8                                        # 4 restored + 4 new optimizer steps
