@@ -190,3 +190,49 @@ def test_train_step_reduces_loss():
     x[y > 0.5, 50:60, :] += 10.0
     losses = [m.train_step(x, y, np.ones(8), 1e-3)[0] for _ in range(6)]
     assert losses[-1] < losses[0]
+
+
+def test_mixednet_heads_restatement_against_a_plain_numpy_forward():
+    """SpatialAttention / pooled heads (mixednet.py:234-275,362-381): the torch graph of the oracle against an
+    independent loop-level numpy forward on a tiny case; parameter bookkeeping of the extra attention kernel."""
+    flags = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="8,8", repeat_in_block="1,1",
+                 mixconv_kernel_sizes="[3],[3]", first_conv_filters=8, spatial_attention=1, pooled=1, max_pool=1)
+    T = 20
+    om = mo.OracleModel("mixednet", flags, T, seed=5)
+    names = [v.name for v in om.vars]
+    assert names[-3:] == ["attention.kernel", "dense.kernel", "dense.bias"]
+    assert om.vars[-3].value.shape == (4, 1, 2, 1) and om.vars[-2].value.shape == (8, 1)   # pooled: one frame left
+    rng = np.random.default_rng(0)
+    x = rng.random((2, T, 40)) * 5
+    taps = {}
+    z, _ = om.logits(x, False, taps=taps)
+    # numpy: last block output a [B,T',C] -> attention -> max pool -> dense
+    t = {v.name: v.value.astype(np.float64) for v in om.vars}
+    pre = taps["b1.r0.pre_bn"].detach().numpy()
+    a = np.maximum((pre - t["b1.r0.bn.moving_mean"]) / np.sqrt(t["b1.r0.bn.moving_variance"] + 1e-3) * t["b1.r0.bn.gamma"]
+                   + t["b1.r0.bn.beta"], 0.0)
+    B, Ta, C = a.shape
+    wa = t["attention.kernel"][:, 0, :, 0]                       # [4][2]
+    out = np.zeros((B, Ta - 3, C))
+    for b in range(B):
+        avg, mx = a[b].mean(axis=1), a[b].max(axis=1)
+        for tt in range(Ta - 3):
+            pre_s = sum(wa[j, 0] * avg[tt + j] + wa[j, 1] * mx[tt + j] for j in range(4))
+            out[b, tt] = a[b, tt + 3] * (1.0 / (1.0 + np.exp(-pre_s)))
+    zz = out.max(axis=1) @ t["dense.kernel"][:, 0] + t["dense.bias"][0]
+    np.testing.assert_allclose(z.detach().numpy(), zz, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(taps["attention.out"].detach().numpy(), out, rtol=1e-10, atol=1e-12)
+
+
+def test_bf16_pointwise_function_gradients_use_rounded_operands():
+    x = torch.tensor(np.random.default_rng(1).normal(size=(2, 5, 7)), dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(np.random.default_rng(2).normal(size=(3, 5)), dtype=torch.float64, requires_grad=True)
+    y = mo._Bf16Pointwise.apply(x, w)
+    xr, wr = mo._round_bf16(x.detach()), mo._round_bf16(w.detach())
+    np.testing.assert_allclose(y.detach().numpy(), torch.einsum("oc,bct->bot", wr, xr).numpy(), rtol=0, atol=0)
+    gy = torch.tensor(np.random.default_rng(3).normal(size=y.shape), dtype=torch.float64)
+    gx, gw = torch.autograd.grad(y, [x, w], gy)
+    gr = mo._round_bf16(gy)
+    np.testing.assert_allclose(gx.numpy(), torch.einsum("oc,bot->bct", wr, gr).numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(gw.numpy(), torch.einsum("bot,bct->oc", gr, xr).numpy(), rtol=0, atol=0)
+    assert float((xr - x.detach()).abs().max()) > 0          # the rounding is real
