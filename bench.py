@@ -136,6 +136,8 @@ def parse_args():
                     help="multi-GPU parity mode: BatchNorm statistics exchanged over RCCL (default: local-BN throughput mode)")
     ap.add_argument("--pointwise-bf16", action="store_true",
                     help="BASELINE configs[4]: bf16-operand MFMA for the 1x1 contractions (not the headline configuration)")
+    ap.add_argument("--force-generic", action="store_true",
+                    help="run the default mixednet on the generic conv/BN graph kernels (what unusual MixedNet shapes fall back to)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true", help="skip the (untimed-for-value) validation-throughput leg")
@@ -251,6 +253,12 @@ def main():
             pk = [b.tout * b.cout for b in lay.blocks]
             step_bytes = 4 * (2 * T_FRAMES * 40 + 4 * sum(pk) + 2 * sum(pk[:-1]))
             kernel_elems = {"assemble": T_FRAMES * 40 * 3 // 2}
+        elif args.force_generic:
+            from microwakeword_amd.layout import GraphMixedNetLayout
+            model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream, seed=42,
+                          max_batch=B, layout=GraphMixedNetLayout(synthetic.DEFAULT_MIXEDNET_FLAGS, T_FRAMES), name="mixednet (generic)")
+            model.engine.set_grad_mask(model.layout.grad_mask())
+            kernel_elems, step_bytes = {"assemble": KERNEL_ELEMS["assemble"]}, BYTES_PER_WINDOW_STEP
         else:
             model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                           seed=42, max_batch=B)

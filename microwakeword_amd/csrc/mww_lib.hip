@@ -629,7 +629,7 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds)
 }
 
 // (filters, input channels) pairs with a fused weight-gradient + data-gradient launch; others use two launches
-#define MWW_G_BWD_PAIRS(X) X(30, 24) X(10, 10) X(10, 30) X(30, 10) X(48, 10) X(16, 16) X(16, 48) X(24, 16) X(16, 24) X(36, 24) X(12, 36)
+#define MWW_G_BWD_PAIRS(X) X(30, 24) X(10, 10) X(10, 30) X(30, 10) X(48, 10) X(16, 16) X(16, 48) X(24, 16) X(16, 24) X(36, 24) X(12, 36) X(48, 32) X(48, 48) X(64, 32) X(64, 64)
 
 bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, int grid, size_t lds) {
 #define X(NCO, NCI)                                                                                            \
