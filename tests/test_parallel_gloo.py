@@ -144,7 +144,7 @@ def test_sharding_partitions_every_provider_and_splits_rng_streams():
 # Two ranks, each running the PRODUCT kernels (host-emulated, tests/hipemu) on half of a global batch with
 # sync_bn=True, against the single-process oracle on the whole batch: W ranks x B/W windows must
 # reproduce the single-device train step (loss normalisation, BN statistics, gradients, Adam, moving stats).
-def _sync_worker(rank, world, port, out_dir, emu_path, kind):
+def _sync_worker(rank, world, port, out_dir, emu_path, kind, sync=True):
     import ctypes as C
 
     import engine_checks as ec
@@ -168,7 +168,7 @@ def _sync_worker(rank, world, port, out_dir, emu_path, kind):
 
     g = wrap(eng.device_ptr(native.BUF_GRADS), eng.n_params)
     p = wrap(eng.device_ptr(native.BUF_PARAMS), eng.n_params)
-    dp = DataParallel(eng, g, p, None, sync_bn=True, wrap=wrap)
+    dp = DataParallel(eng, g, p, None, sync_bn=sync, wrap=wrap)
     assert dp.world == world
     eng.set_batch(z["x"][rank * Bl:(rank + 1) * Bl])
     eng.set_targets(z["y"][rank * Bl:(rank + 1) * Bl], z["w"][rank * Bl:(rank + 1) * Bl])
@@ -230,3 +230,48 @@ def test_sync_bn_two_ranks_equal_single_device_step(tmp_path, kind):
     well = np.abs(gref) > 1e-4 * scale
     assert np.abs(outs[0]["params"] - p_ref)[well].max() <= 0.05 * 1e-3
     assert np.abs(outs[0]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+
+
+def test_local_bn_two_ranks_with_product_kernels(tmp_path):
+    """Throughput mode (what bench.py measures at N > 1): each rank normalises over its own half batch, the flat
+    gradients are summed by the collective and Adam consumes the average.  Product kernels (host-emulated) on
+    both ranks against two single-rank oracle passes averaged by hand."""
+    import conftest
+    import engine_checks as ec
+    from microwakeword_amd.layout import MixedNetLayout
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W, Bl = 2, 3
+    rng = np.random.default_rng(3)
+    x = ec.synth_x(rng, W * Bl, T)
+    y = (rng.random(W * Bl) < 0.5).astype(np.float32)
+    w = rng.choice([0.5, 1.0, 2.0], size=W * Bl).astype(np.float32)
+    np.savez(tmp_path / "inputs.npz", x=x, y=y, w=w, keep=np.zeros(1))
+    mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "mixednet", False), nprocs=W, join=True)
+    outs = [np.load(tmp_path / ("out%d.npz" % r)) for r in range(W)]
+    np.testing.assert_array_equal(outs[0]["grads"], outs[1]["grads"])      # the reduced gradient
+    np.testing.assert_array_equal(outs[0]["params"], outs[1]["params"])    # hence identical weights
+    assert np.abs(outs[0]["state"] - outs[1]["state"]).max() > 0           # but rank-local BN moving statistics
+    lay = MixedNetLayout(ec.DEF, T)
+    gsum, states = 0.0, []
+    for r in range(W):
+        om = ec.perturbed_oracle(T)
+        sl = slice(r * Bl, (r + 1) * Bl)
+        _, _, grads, new_stats = om.loss_and_grads(x[sl], y[sl], w[sl])
+        gsum = gsum + ec.oracle_grads_native_order(lay, om, grads).astype(np.float64)
+        om.train_step(x[sl], y[sl], w[sl], 1e-3)
+        states.append(lay.pack(om.get_weights())[1])
+    g = outs[0]["grads"].astype(np.float64)
+    assert np.linalg.norm(g - gsum) <= 2e-3 * np.linalg.norm(gsum)
+    for r in range(W):
+        assert np.abs(outs[r]["state"] - states[r]).max() <= 1e-5 * max(1.0, np.abs(states[r]).max())
+    # Adam on the average: one Keras-Adam step from the common initial weights
+    om = ec.perturbed_oracle(T)
+    p0 = lay.pack(om.get_weights())[0].astype(np.float64)
+    gavg = gsum / W
+    m, v = 0.1 * gavg, 0.001 * gavg * gavg
+    alpha = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    p1 = p0 - alpha * m / (np.sqrt(v) + 1e-7)
+    well = np.abs(gavg) > 1e-4 * np.abs(gavg).max()
+    assert np.abs(outs[0]["params"] - p1)[well].max() <= 0.05 * 1e-3
