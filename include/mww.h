@@ -1,9 +1,10 @@
 /* mww.h — C ABI of libmww_hip.so: the MI355X-native (gfx950) train-step engine for
- * microWakeWord's MixedNet classifier.
+ * microWakeWord's MixedNet and Inception classifiers.
  *
  * The reference (kahrendt/microWakeWord) has no FFI layer: its hot path is duck-typed Python
  * (microwakeword/train.py:249-299) calling numpy batch assembly (microwakeword/data.py:497-597)
- * and Keras `train_on_batch` on the graph built by microwakeword/mixednet.py:278-386.  This
+ * and Keras `train_on_batch` on the graph built by microwakeword/mixednet.py:278-386 or
+ * microwakeword/inception.py:232-340.  This
  * header is the boundary a maintainer would bind (ctypes / cffi / pybind — see INTEGRATION.md):
  * plain pointers and sizes, no torch / Python types.  Each entry point names the reference
  * interface it replaces.
@@ -27,7 +28,7 @@ extern "C" {
 #define MWW_OK 0
 #define MWW_ERR_INVALID -1      /* bad argument / unsupported configuration */
 #define MWW_ERR_HIP -2          /* a HIP runtime call failed */
-#define MWW_ERR_UNSUPPORTED -3  /* model shape has no compiled kernel instantiation */
+#define MWW_ERR_UNSUPPORTED -3  /* model shape has no compiled kernel instantiation (mww_create: fall back to mww_create_convnet) */
 #define MWW_ERR_STATE -4        /* call sequence error (e.g. train step before a batch) */
 
 #define MWW_MAX_BLOCKS 8
@@ -36,7 +37,10 @@ extern "C" {
 
 typedef struct mww_ctx mww_ctx;
 
-/* ---- model: replaces mixednet.model(flags, shape, batch_size) (mixednet.py:278-386).
+/* ---- model: replaces mixednet.model(flags, shape, batch_size) (mixednet.py:278-386) with the specialised
+ * MFMA block kernels.  Covers conv1 -> ReLU -> n x [MixConv + 1x1 + BN + ReLU] -> Flatten -> Dense for the
+ * (filters, kernel size) shapes instantiated in csrc/mww_lib.hip; every other flag combination (repeat_in_block,
+ * residual_connection, spatial_attention, pooled, other widths ...) is expressed as a mww_convnet_desc below.
  * `block_kernel[i]` is the aligned depthwise length of block i (= the LAST listed MixConv kernel
  * size, mixednet.py:227); smaller MixConv groups are expressed by the host as zero leading taps
  * plus a gradient mask (mww_set_grad_mask), SURVEY §A.2.
