@@ -689,3 +689,59 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
     assert np.median(l2s) <= 2e-5
     eng.close()
     return max(l2s)
+
+
+# ------------------------------------------------------------------------------------------ data fuzz
+def random_data_case(seed):
+    """A random feature-set + augmentation policy: 2-3 providers, uint16 or float32 stores, every training
+    truncation strategy, fixed_right_cutoffs, mask sizes 0..12 and counts 0..3, short and long samples."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.choice([60, 194]))
+    dtype = np.uint16 if rng.random() < 0.6 else np.float32
+    provs = []
+    for pi in range(int(rng.integers(2, 4))):
+        n = int(rng.integers(5, 30))
+        lens = rng.integers(max(8, T - 40), T + 120, size=n)
+        if dtype == np.uint16:
+            store = [rng.integers(0, 667, size=(int(l), 40), dtype=np.uint16) for l in lens]
+        else:
+            store = [(rng.random((int(l), 40), dtype=np.float32) * np.float32(26.0)) for l in lens]
+        strat = str(rng.choice(["truncate_start", "truncate_end", "random", "fixed_right_cutoff"]))
+        cut = [int(c) for c in rng.integers(0, 8, size=int(rng.integers(1, 3)))] if strat == "fixed_right_cutoff" else [0]
+        provs.append(dict(store=store, truth=bool(pi == 0 or rng.random() < 0.3), sampling_weight=float(rng.choice([0.5, 1.0, 2.0, 10.0])),
+                          penalty_weight=float(rng.choice([0.5, 1.0, 1.5])), truncation_strategy=strat, fixed_right_cutoffs=cut))
+    policy = dict(freq_mix_prob=0.0, time_mask_max_size=int(rng.choice([0, 1, 5, 12])), time_mask_count=int(rng.integers(0, 4)),
+                  freq_mask_max_size=int(rng.choice([0, 1, 5, 12])), freq_mask_count=int(rng.integers(0, 4)))
+    # a cutoff larger than the spare frames raises in the reference: keep the lengths compatible
+    for p in provs:
+        if p["truncation_strategy"] == "fixed_right_cutoff":
+            p["store"] = [s if (s.shape[0] <= T or s.shape[0] - T >= max(p["fixed_right_cutoffs"])) else s[:T] for s in p["store"]]
+    return T, provs, policy, int(rng.integers(4, 40)), str(rng.choice(["default", "default", "truncate_start", "random"]))
+
+
+def check_data_fuzz(lib, cases=12, first=0):
+    """Engine (host sampler + HIP assembly) against the oracle on random feature sets, policies and strategies:
+    identical windows, masks, labels, weights, shuffle order and RNG tails."""
+    for case in range(first, first + cases):
+        T, provs, policy, B, strategy = random_data_case(case)
+        _, eng = make_engine(lib, T, B) if T == 194 else (None, native.Engine(lib=lib, **MixedNetLayout(DEF, T).engine_args(B)))
+        cfg = {"stride": 1, "window_step_ms": 10, "features": [
+            dict(type="mmap", stores={"training": [p["store"]]}, truth=p["truth"], sampling_weight=p["sampling_weight"],
+                 penalty_weight=p["penalty_weight"], truncation_strategy=p["truncation_strategy"],
+                 fixed_right_cutoffs=p["fixed_right_cutoffs"]) for p in provs]}
+        random.seed(case)
+        np.random.seed(case)
+        fh = FeatureHandler(cfg, engine=eng)
+        got = [fh.get_data("training", B, T, strategy, policy) for _ in range(2)]
+        tail = (random.random(), np.random.random())
+        random.seed(case)
+        np.random.seed(case)
+        op = [do.index_provider({"training": [p["store"]]}, p["truth"], p["sampling_weight"], p["penalty_weight"],
+                                p["truncation_strategy"], 1, 0.01, p["fixed_right_cutoffs"]) for p in provs]
+        for (x, y, w) in got:
+            xo, yo, wo, _, _ = do.get_data(op, "training", B, T, strategy, policy)
+            np.testing.assert_array_equal(x, xo, err_msg="case %d" % case)
+            np.testing.assert_array_equal(y, yo)
+            np.testing.assert_array_equal(w, wo)
+        assert tail == (random.random(), np.random.random()), case
+        eng.close()

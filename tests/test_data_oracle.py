@@ -131,3 +131,41 @@ def test_live_reference_agrees_on_benchmark_store():
     np.testing.assert_array_equal(x, rx)
     np.testing.assert_array_equal(y, ry)
     np.testing.assert_array_equal(w, rw)
+
+
+@pytest.mark.reference
+def test_live_reference_fuzz():
+    """Random feature sets, policies and truncation strategies (the cases of engine_checks.random_data_case, which the
+    HIP path is tested on): the oracle and the reference's own data.py produce identical batches and leave both RNG
+    streams in the same place.  Container only (needs /root/reference)."""
+    from oracle import ref_data_shim as shim
+
+    if not shim.available():
+        pytest.skip("reference tree not present")
+    import tempfile
+
+    import engine_checks as ec
+    from microwakeword_amd.ragged import write_ragged_store
+    ref = shim.load_reference_data_module()
+    for case in range(40):
+        Tc, provs, policy, B, strategy = ec.random_data_case(case)
+        with tempfile.TemporaryDirectory() as tmp:
+            feats = []
+            for i, p in enumerate(provs):
+                write_ragged_store(os.path.join(tmp, "p%d" % i, "training", "a_mmap"), p["store"])
+                feats.append(dict(type="mmap", features_dir=os.path.join(tmp, "p%d" % i), truth=p["truth"], sampling_weight=p["sampling_weight"],
+                                  penalty_weight=p["penalty_weight"], truncation_strategy=p["truncation_strategy"],
+                                  fixed_right_cutoffs=p["fixed_right_cutoffs"]))
+            random.seed(case); np.random.seed(case)
+            fh = ref.FeatureHandler({"stride": 1, "window_step_ms": 10, "features": feats})
+            want = [fh.get_data("training", B, Tc, strategy, policy) for _ in range(2)]
+            tail = (random.random(), np.random.random())
+        random.seed(case); np.random.seed(case)
+        op = [do.index_provider({"training": [p["store"]]}, p["truth"], p["sampling_weight"], p["penalty_weight"],
+                                p["truncation_strategy"], 1, 0.01, p["fixed_right_cutoffs"]) for p in provs]
+        for rx, ry, rw in want:
+            x, y, w, _, _ = do.get_data(op, "training", B, Tc, strategy, policy)
+            np.testing.assert_array_equal(x, rx, err_msg="case %d" % case)
+            np.testing.assert_array_equal(y, ry)
+            np.testing.assert_array_equal(w, rw)
+        assert tail == (random.random(), np.random.random()), case

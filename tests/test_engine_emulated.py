@@ -182,3 +182,7 @@ def test_cli_end_to_end_from_disk(emu_lib, tmp_path, monkeypatch):
     assert set(out2) == set(out)
     z = np.load(run / "restore" / "ckpt.opt.npz")
     assert int(z["step"]) == 8                                        # 4 restored + 4 new optimizer steps
+
+
+def test_data_path_fuzz(emu_lib):
+    ec.check_data_fuzz(emu_lib, cases=10)

@@ -257,3 +257,8 @@ def test_long_run_stays_finite(lib):
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses   # it memorises the fixed batch
     assert np.all(np.isfinite(eng.get_params())) and np.all(np.isfinite(eng.get_bn_state()))
     eng.close()
+
+
+def test_data_path_fuzz(lib):
+    """Random feature sets / policies / truncation strategies: sampler + HIP assembly bit-exact against the oracle."""
+    ec.check_data_fuzz(lib, cases=40)
