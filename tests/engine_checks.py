@@ -745,3 +745,42 @@ def check_data_fuzz(lib, cases=12, first=0):
             np.testing.assert_array_equal(w, wo)
         assert tail == (random.random(), np.random.random()), case
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------ topology fuzz
+def random_mixednet_flags(seed):
+    """A random MixedNet flag set inside the limits of the graph kernels."""
+    rng = np.random.default_rng(5000 + seed)
+    nb = int(rng.integers(1, 4))
+    widths = [8, 12, 16, 24, 32, 40, 48, 64]
+    pf = [int(rng.choice(widths)) for _ in range(nb)]
+    ks = []
+    for _ in range(nb):
+        n = int(rng.choice([1, 1, 2]))
+        k = sorted(int(v) for v in rng.choice([1, 3, 5, 7, 9], size=n, replace=False))
+        ks.append(k)
+    f0 = int(rng.choice([0, 8, 16, 32]))
+    flags = dict(mo.MIXEDNET_DEFAULTS, pointwise_filters=",".join(map(str, pf)) if nb > 1 else str(pf[0]),
+                 repeat_in_block=",".join(str(int(rng.integers(1, 3))) for _ in range(nb)) if nb > 1 else str(int(rng.integers(1, 3))),
+                 mixconv_kernel_sizes=",".join(str(k) for k in ks) if nb > 1 else str(ks[0]) + ",",
+                 residual_connection=",".join(str(int(rng.random() < 0.4)) for _ in range(nb)) if nb > 1 else str(int(rng.random() < 0.4)),
+                 first_conv_filters=f0, first_conv_kernel_size=int(rng.choice([3, 5])), stride=int(rng.choice([1, 1, 2, 3])) if f0 else 1,
+                 spatial_attention=int(rng.random() < 0.3), pooled=int(rng.random() < 0.3), max_pool=int(rng.random() < 0.5))
+    return flags
+
+
+def check_topology_fuzz(lib, cases=6, first=0, B=3):
+    done = 0
+    for case in range(first, first + 4 * cases):
+        flags = random_mixednet_flags(case)
+        T = 70
+        try:
+            check_graph_mixednet(lib, flags, B=B, T=T, steps=1, grid=2)
+        except ValueError as e:            # too short for this kernel stack / channel split: a legitimate refusal, draw again
+            if "too short" in str(e) or "at least 4 frames" in str(e):
+                continue
+            raise
+        done += 1
+        if done == cases:
+            return
+    raise AssertionError("too few valid random topologies")

@@ -186,3 +186,7 @@ def test_cli_end_to_end_from_disk(emu_lib, tmp_path, monkeypatch):
 
 def test_data_path_fuzz(emu_lib):
     ec.check_data_fuzz(emu_lib, cases=10)
+
+
+def test_mixednet_topology_fuzz(emu_lib):
+    ec.check_topology_fuzz(emu_lib, cases=5)

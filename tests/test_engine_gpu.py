@@ -262,3 +262,8 @@ def test_long_run_stays_finite(lib):
 def test_data_path_fuzz(lib):
     """Random feature sets / policies / truncation strategies: sampler + HIP assembly bit-exact against the oracle."""
     ec.check_data_fuzz(lib, cases=40)
+
+
+def test_mixednet_topology_fuzz(lib):
+    """Random MixedNet flag sets (widths, MixConv groups, repeats, residuals, strides, heads) on the graph kernels."""
+    ec.check_topology_fuzz(lib, cases=16, B=5)
