@@ -375,7 +375,9 @@ def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None, 
 def keras_bce(p, y):
     """Keras 3 ``binary_crossentropy(from_logits=False)``: clip to [eps, 1-eps] then the
     probability form (train.py:206)."""
-    pc = torch.clamp(p, KERAS_EPS, 1.0 - KERAS_EPS)
+    # the reference clips float32 probabilities with float32 bounds: 1 - 1e-7 is 0.99999988 there, not 0.9999999
+    lo, hi = float(np.float32(KERAS_EPS)), float(np.float32(1.0) - np.float32(KERAS_EPS))
+    pc = torch.clamp(p, lo, hi)
     return -(y * torch.log(pc) + (1.0 - y) * torch.log(1.0 - pc))
 
 
@@ -441,7 +443,7 @@ class Metrics:
         self.fp5 += float(np.sum(pos & ~y))
         self.fn5 += float(np.sum(~pos & y))
         self.lab += np.array([np.sum(~y), np.sum(y)], np.float64)
-        pcl = np.clip(p.astype(np.float64), KERAS_EPS, 1 - KERAS_EPS)
+        pcl = np.clip(p.astype(np.float64), float(np.float32(KERAS_EPS)), float(np.float32(1.0) - np.float32(KERAS_EPS)))
         self.bce_sum += float(np.sum(-(y * np.log(pcl) + (~y) * np.log(1 - pcl))))
 
     @staticmethod

@@ -657,6 +657,11 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
+        # float32 resolves 1 - p only to 6e-8: for |z| > 12 the BCE of the engine (and of the reference's float32
+        # graph) legitimately differs from a float64 evaluation by percents — such batches say nothing about parity
+        if float(om.logits(x, True)[0].abs().max()) > 12.0:
+            eng.close()
+            raise ValueError("saturated logits: unsuitable random case")
         eng.set_batch(x)
         eng.set_targets(y, w)
         eng.train_step(B, lr)
@@ -777,7 +782,7 @@ def check_topology_fuzz(lib, cases=6, first=0, B=3):
         try:
             check_graph_mixednet(lib, flags, B=B, T=T, steps=1, grid=2)
         except ValueError as e:            # too short for this kernel stack / channel split: a legitimate refusal, draw again
-            if "too short" in str(e) or "at least 4 frames" in str(e):
+            if "too short" in str(e) or "at least 4 frames" in str(e) or "saturated" in str(e):
                 continue
             raise
         done += 1

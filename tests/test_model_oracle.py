@@ -151,7 +151,10 @@ def test_loss_is_sum_over_batch_size_and_clipped():
     y = torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64)
     w = torch.tensor([1.0, 3.0, 1.0, 1.0], dtype=torch.float64)
     loss, p = mo.weighted_loss(z, y, w)
-    b = [math.log(1 + math.exp(-0.3)), math.log(1 + math.exp(-1.2)), -math.log(1e-7), -math.log(1e-7)]
+    # float32 bounds as in the reference's float32 graph: the upper clip is 1 - 1.19e-7, so a saturated wrong
+    # positive costs -log(1.19e-7), a saturated wrong negative -log(1e-7)
+    hi = float(np.float32(1.0) - np.float32(1e-7))
+    b = [math.log(1 + math.exp(-0.3)), math.log(1 + math.exp(-1.2)), -math.log(1 - hi), -math.log(float(np.float32(1e-7)))]
     assert abs(float(loss) - (b[0] + 3 * b[1] + b[2] + b[3]) / 4) < 1e-6
 
 
