@@ -657,9 +657,10 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
-        # float32 resolves 1 - p only to 6e-8: for |z| > 12 the BCE of the engine (and of the reference's float32
-        # graph) legitimately differs from a float64 evaluation by percents — such batches say nothing about parity
-        if float(om.logits(x, True)[0].abs().max()) > 12.0:
+        # float32 resolves 1 - p only to 6e-8, so the probability-form BCE of the engine (and of the reference's float32
+        # graph) is good to 6e-8 * e^|z| relative: beyond |z| ~ 6 it legitimately differs from a float64 evaluation by
+        # more than the 1e-5 asked below — such batches say nothing about parity
+        if float(om.logits(x, True)[0].abs().max()) > 6.0:
             eng.close()
             raise ValueError("saturated logits: unsuitable random case")
         eng.set_batch(x)
