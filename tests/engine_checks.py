@@ -658,11 +658,9 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         y = (rng.random(B) < 0.5).astype(np.float32)
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
         # float32 resolves 1 - p only to 6e-8, so the probability-form BCE of the engine (and of the reference's float32
-        # graph) is good to 6e-8 * e^|z| relative: beyond |z| ~ 6 it legitimately differs from a float64 evaluation by
-        # more than the 1e-5 asked below — such batches say nothing about parity
-        if float(om.logits(x, True)[0].abs().max()) > 6.0:
-            eng.close()
-            raise ValueError("saturated logits: unsuitable random case")
+        # graph) carries an absolute error of up to 6e-8 * e^|z| per window on top of ordinary rounding
+        zabs = om.logits(x, True)[0].abs().detach().numpy()
+        loss_slack = float(np.sum(w * 1.2e-7 * np.exp(np.minimum(zabs, 16.0))) / B)
         eng.set_batch(x)
         eng.set_targets(y, w)
         eng.train_step(B, lr)
@@ -671,7 +669,7 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         g = eng.get_grads()
         gref = lay.pack([grads[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)
                          for n, shape, kind in lay.keras_vars])[0]
-        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)) + loss_slack, (loss, lo, loss_slack)
         scale = max(1e-6, float(np.abs(gref).max()))
         off = 0
         for name, n in lay.segments():
@@ -783,7 +781,7 @@ def check_topology_fuzz(lib, cases=6, first=0, B=3):
         try:
             check_graph_mixednet(lib, flags, B=B, T=T, steps=1, grid=2)
         except ValueError as e:            # too short for this kernel stack / channel split: a legitimate refusal, draw again
-            if "too short" in str(e) or "at least 4 frames" in str(e) or "saturated" in str(e):
+            if "too short" in str(e) or "at least 4 frames" in str(e):
                 continue
             raise
         done += 1
