@@ -267,3 +267,44 @@ def test_data_path_fuzz(lib):
 def test_mixednet_topology_fuzz(lib):
     """Random MixedNet flag sets (widths, MixConv groups, repeats, residuals, strides, heads) on the graph kernels."""
     ec.check_topology_fuzz(lib, cases=16, B=5)
+
+
+def test_full_size_properties_batch1024(lib):
+    """Size-independent properties at BASELINE configs[1] size (B=1024, T=194), where the oracle is too slow to be the
+    checker for the backward pass: (a) the gradient is exactly linear in a power-of-two scale of the sample weights,
+    (b) the fused gradient-finish + Adam launch gives the same bits as the separate launches of the data-parallel
+    route, (c) two runs give the same bits, (d) a permutation of the batch permutes the outputs and moves no
+    statistic beyond rounding."""
+    B, T = 1024, 194
+    om = ec.perturbed_oracle(T)
+    rng = np.random.default_rng(21)
+    x = ec.synth_x(rng, B, T)
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    w = rng.choice([0.5, 1.0, 1.5], size=B).astype(np.float32)
+
+    def run(xb, yb, wb, flags=0, apply_after=False):
+        lay, eng = ec.make_engine(lib, T, B, om)
+        eng.set_batch(xb)
+        eng.set_targets(yb, wb)
+        eng.train_step(B, 1e-3, flags)
+        if apply_after:
+            eng.apply_gradients(1e-3, 1.0)
+        out = dict(g=eng.get_grads(), p=eng.get_params(), s=eng.get_bn_state(), pr=eng.read_outputs(B)[0], loss=eng.read_outputs(B)[2])
+        eng.close()
+        return out
+
+    a = run(x, y, w)
+    b = run(x, y, 2.0 * w)
+    np.testing.assert_array_equal(2.0 * a["g"], b["g"])                     # (a)
+    assert b["loss"] == pytest.approx(2.0 * a["loss"], rel=1e-6)
+    c = run(x, y, w, flags=native.STEP_NO_APPLY, apply_after=True)
+    np.testing.assert_array_equal(a["g"], c["g"])                           # (b)
+    np.testing.assert_array_equal(a["p"], c["p"])
+    d = run(x, y, w)
+    for k in ("g", "p", "s", "pr"):
+        np.testing.assert_array_equal(a[k], d[k])                           # (c)
+    perm = rng.permutation(B)
+    e = run(x[perm], y[perm], w[perm])
+    assert np.abs(e["pr"] - a["pr"][perm]).max() <= 1e-5                    # (d)
+    assert np.abs(e["s"] - a["s"]).max() <= 1e-5 * max(1.0, np.abs(a["s"]).max())
+    assert np.linalg.norm(e["g"] - a["g"]) <= 1e-4 * np.linalg.norm(a["g"])
