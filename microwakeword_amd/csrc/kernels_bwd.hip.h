@@ -369,6 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     MWW_PC_MARK(5);   // barrier 3
     // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
     if (dw_active && !(a.ablate & 4)) {
+      float* gtile = a.g_out + ((size_t)b * a.Tin + t0) * CIN;   // uniform base: the stores take a 32-bit lane offset
       {
         float da[L], dww[K];
 #pragma unroll
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           if (sl < rows_da) {
             const float raw = sP[sl * CPI + c];
             const float gg = fmaf(raw, sc_c, sh_c) > 0.f ? da[t] : 0.f;
-            a.g_out[((size_t)b * a.Tin + t0 + sl) * CIN + c] = gg;
+            gtile[sl * CIN + c] = gg;
             gs1 += gg;
             gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
           }

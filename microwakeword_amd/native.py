@@ -1,9 +1,10 @@
 """ctypes binding of ``libmww_hip.so`` (C ABI: ``include/mww.h``).
 
 There is deliberately **no CPU fallback**: if the HIP library is missing, fails to load, or no
-MI355X is visible, every entry point raises.  (The test-suite can point :class:`NativeLib` at the
-host-side kernel emulator built under ``tests/hipemu`` by passing an explicit path; product code
-never does.)
+MI355X is visible, every entry point raises.  (The library path can be overridden — explicit ``path``
+argument or the ``MWW_HIP_LIB`` environment variable, e.g. for a build in another directory; the
+test-suite uses that to load the host-side kernel emulator it builds under ``tests/hipemu`` from the same
+sources.  Nothing in this package contains or selects a CPU implementation.)
 """
 from __future__ import annotations
 
