@@ -254,6 +254,14 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
   gconv_body<NC, MODE>(a, blockIdx.x, gridDim.x);
 }
 
+// Two independent ops of the same shape ("twins": Inception's k x 1 convs of branch 2 and branch 3) as the two
+// halves of one launch: workgroups [0, nb) run op a0, [nb, 2 nb) op a1.
+template <int NC>
+__global__ __launch_bounds__(kThreads) void gconv_fwd2_kernel(GConvArgs a0, GConvArgs a1, int nb) {
+  if ((int)blockIdx.x < nb) gconv_body<NC, 0>(a0, blockIdx.x, nb);
+  else gconv_body<NC, 0>(a1, blockIdx.x - nb, nb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient: dW[j][ci][co] = sum_{b,t} act[b][t + j*dil][ci] * dp[b][t][co]
 struct GWgradArgs {
@@ -326,6 +334,16 @@ template <int NCO, int NCI>
 __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nb) {
   if ((int)blockIdx.x < nb) gconv_wgrad_body<NCO>(w, blockIdx.x, nb);
   else gconv_body<NCI, 1>(d, blockIdx.x - nb, nb);
+}
+
+// ... and of twin ops: four roles
+template <int NCO, int NCI>
+__global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GWgradArgs w0, GConvArgs d0, GWgradArgs w1, GConvArgs d1, int nb) {
+  const int role = blockIdx.x / nb, bid = blockIdx.x - role * nb;
+  if (role == 0) gconv_wgrad_body<NCO>(w0, bid, nb);
+  else if (role == 1) gconv_body<NCI, 1>(d0, bid, nb);
+  else if (role == 2) gconv_wgrad_body<NCO>(w1, bid, nb);
+  else gconv_body<NCI, 1>(d1, bid, nb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -520,9 +538,8 @@ struct GBnFwdArgs {
   int update_moving;
 };
 
-__global__ __launch_bounds__(kThreads) void gbn_fwd_finalize_kernel(GBnFwdArgs a) {
-  __shared__ double sAcc[2 * kThreads];
-  const int tid = threadIdx.x, slot = blockIdx.x;
+__device__ __forceinline__ void gbn_fwd_finalize_body(const GBnFwdArgs& a, int slot, double* sAcc) {
+  const int tid = threadIdx.x;
   const int members = a.groups > 1 ? a.C / a.groups : 1, cstride = a.groups > 1 ? a.groups : 0;
   double t1 = 0.0, t2 = 0.0;
   for (int it = tid; it < a.G * members; it += kThreads) {
@@ -548,6 +565,17 @@ __global__ __launch_bounds__(kThreads) void gbn_fwd_finalize_kernel(GBnFwdArgs a
     a.moving_mean[slot] = a.moving_mean[slot] * kBnMomentum + meanf * (1.0f - kBnMomentum);
     a.moving_var[slot] = a.moving_var[slot] * kBnMomentum + varf * (1.0f - kBnMomentum);
   }
+}
+
+__global__ __launch_bounds__(kThreads) void gbn_fwd_finalize_kernel(GBnFwdArgs a) {
+  __shared__ double sAcc[2 * kThreads];
+  gbn_fwd_finalize_body(a, blockIdx.x, sAcc);
+}
+// twin ops: slots of a0 first, then those of a1
+__global__ __launch_bounds__(kThreads) void gbn_fwd_finalize2_kernel(GBnFwdArgs a0, GBnFwdArgs a1, int n0) {
+  __shared__ double sAcc[2 * kThreads];
+  if ((int)blockIdx.x < n0) gbn_fwd_finalize_body(a0, blockIdx.x, sAcc);
+  else gbn_fwd_finalize_body(a1, blockIdx.x - n0, sAcc);
 }
 
 struct GBnEvalArgs {
@@ -576,9 +604,8 @@ struct GBnBwdArgs {
   int bias_only;             // the op has a bias instead of a BN (depthwise convolution): only dbeta = sum g is needed,
                              // the backward coefficients are the constants c1 = 1, mg = mgx = 0
 };
-__global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a) {
-  __shared__ double sAcc[2 * kThreads];
-  const int tid = threadIdx.x, slot = blockIdx.x;
+__device__ __forceinline__ void gbn_bwd_finalize_body(const GBnBwdArgs& a, int slot, double* sAcc) {
+  const int tid = threadIdx.x;
   const int members = a.groups > 1 ? a.C / a.groups : 1, cstride = a.groups > 1 ? a.groups : 0;
   double t1 = 0.0, t2 = 0.0;
   for (int it = tid; it < a.G * members; it += kThreads) {
@@ -601,6 +628,16 @@ __global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a
     a.dbeta[slot] = (float)t1 * a.dscale;
     a.dgamma[slot] = (float)t2 * a.dscale;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void gbn_bwd_finalize_kernel(GBnBwdArgs a) {
+  __shared__ double sAcc[2 * kThreads];
+  gbn_bwd_finalize_body(a, blockIdx.x, sAcc);
+}
+__global__ __launch_bounds__(kThreads) void gbn_bwd_finalize2_kernel(GBnBwdArgs a0, GBnBwdArgs a1, int n0) {
+  __shared__ double sAcc[2 * kThreads];
+  if ((int)blockIdx.x < n0) gbn_bwd_finalize_body(a0, blockIdx.x, sAcc);
+  else gbn_bwd_finalize_body(a1, blockIdx.x - n0, sAcc);
 }
 
 // ---------------------------------------------------------------------------------------------

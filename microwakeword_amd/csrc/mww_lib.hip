@@ -61,6 +61,7 @@ struct GOp {
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   int nq = 1;                 // frame subsets of the weight-gradient mapping
   bool needs_dx = false;
+  bool twin_next = false;     // op i+1 is an independent op of the same shape: the pair shares its launches
   size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
 };
 
@@ -645,6 +646,29 @@ bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const 
   return false;
 }
 
+#define MWW_G_TWIN_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
+bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, int grid, size_t lds) {
+#define X(N)                                                                                                   \
+  if (nc == N) {                                                                                               \
+    hipLaunchKernelGGL((gconv_fwd2_kernel<N>), dim3(2 * grid), dim3(kThreads), lds, c->stream, a0, a1, grid);  \
+    return true;                                                                                               \
+  }
+  MWW_G_TWIN_WIDTHS(X)
+#undef X
+  return false;
+}
+bool launch_gbwd2(mww_ctx* c, int nc, const GWgradArgs& w0, const GConvArgs& d0, const GWgradArgs& w1, const GConvArgs& d1,
+                  int grid, size_t lds) {
+#define X(N)                                                                                                   \
+  if (nc == N) {                                                                                               \
+    hipLaunchKernelGGL((gconv_bwd2_kernel<N, N>), dim3(4 * grid), dim3(kThreads), lds, c->stream, w0, d0, w1, d1, grid); \
+    return true;                                                                                               \
+  }
+  MWW_G_TWIN_WIDTHS(X)
+#undef X
+  return false;
+}
+
 float* gbn_slot(GOp& o, int i) { return o.bn + (size_t)i * o.cout; }
 
 // source i of op `oi` as the kernels see it; `backward` adds the gradient routing flags
@@ -734,22 +758,65 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       lp.end();
       continue;
     }
-    GConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_src = o.n_src;
-    for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, false);
-    a.w = c->params + o.o_w;
-    a.k = o.k;
-    a.dil = o.dil;
-    a.cin = o.cin;
-    a.stride = o.stride;
-    a.B = B;
-    a.Tin = o.tin;
-    a.Tout = o.tout;
-    a.out = o.p;
-    a.stat_part = (training && o.norm == MWW_NORM_BN) ? o.stat_part : nullptr;
+    auto fwd_args = [&](int oi) {
+      GOp& q = c->G[oi];
+      GConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n_src = q.n_src;
+      for (int s = 0; s < q.n_src; ++s) a.src[s] = g_make_src(c, oi, s, false);
+      a.w = c->params + q.o_w;
+      a.k = q.k;
+      a.dil = q.dil;
+      a.cin = q.cin;
+      a.stride = q.stride;
+      a.B = B;
+      a.Tin = q.tin;
+      a.Tout = q.tout;
+      a.out = q.p;
+      a.stat_part = (training && q.norm == MWW_NORM_BN) ? q.stat_part : nullptr;
+      return a;
+    };
+    auto fin_args = [&](int oi, const StatSource& ss) {
+      GOp& q = c->G[oi];
+      return GBnFwdArgs{ss.part, ss.G, q.cout, q.groups, ss.inv_n,
+                        c->params + q.o_gamma, c->params + q.o_beta, c->bn_state + q.o_mm, c->bn_state + q.o_mv,
+                        gbn_slot(q, BN_SCALE), gbn_slot(q, BN_SHIFT), gbn_slot(q, BN_MEAN), gbn_slot(q, BN_RSTD), update_moving ? 1 : 0};
+    };
+    const bool sync = c->hook && c->sync_bn;
+    if (o.twin_next && !sync && !c->profile_split) {
+      // twins: one convolution launch and one finalize launch for the pair
+      GOp& o2 = c->G[i + 1];
+      if (!training) {
+        GBnEvalArgs e{c->params + o2.o_gamma, c->params + o2.o_beta, c->bn_state + o2.o_mm, c->bn_state + o2.o_mv,
+                      gbn_slot(o2, BN_SCALE), gbn_slot(o2, BN_SHIFT), o2.cout, o2.groups};
+        hipLaunchKernelGGL(gbn_eval_prepare_kernel, dim3(1), dim3(kThreads), 0, c->stream, e);
+      }
+      const GConvArgs fa0 = fwd_args(i), fa1 = fwd_args(i + 1);
+      lp.begin("conv_fwd2_", i);
+      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, gg, std::max(o.lds_fwd, o2.lds_fwd));
+      lp.end();
+      if (ok) {
+        if (training) {
+          const float inv_n = 1.0f / ((float)B * (float)o.tout * (float)(o.groups > 1 ? o.cout / o.groups : 1));
+          StatSource s0{o.stat_part, gg, inv_n, 1.0f}, s1{o2.stat_part, gg, inv_n, 1.0f};
+          const GBnFwdArgs f0 = fin_args(i, s0), f1 = fin_args(i + 1, s1);
+          const int n0 = o.slots;
+          lp.begin("bn_fwd_finalize2_", i);
+          hipLaunchKernelGGL(gbn_fwd_finalize2_kernel, dim3(o.slots + o2.slots), dim3(kThreads), 0, c->stream, f0, f1, n0);
+          lp.end();
+        }
+        ++i;   // the twin is done
+        continue;
+      }
+      if (c->profile) {   // width not instantiated: nothing was launched, fall through to the single-op route
+        (void)hipEventDestroy(c->prof.back().a);
+        (void)hipEventDestroy(c->prof.back().b);
+        c->prof.pop_back();
+      }
+    }
+    const GConvArgs fa = fwd_args(i);
     lp.begin("conv_fwd", i);
-    int rc = launch_gconv<0>(c, o.cout, a, gg, o.lds_fwd);
+    int rc = launch_gconv<0>(c, o.cout, fa, gg, o.lds_fwd);
     lp.end();
     if (rc) return rc;
     if (training && o.norm == MWW_NORM_BN) {
@@ -758,9 +825,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, o.stat_part, gg, o.cout, 0,
                                1.0f / ((float)B * (float)o.tout * (float)members), &ss);
       if (rcs) return rcs;
-      GBnFwdArgs f{ss.part, ss.G, o.cout, o.groups, ss.inv_n,
-                   c->params + o.o_gamma, c->params + o.o_beta, c->bn_state + o.o_mm, c->bn_state + o.o_mv,
-                   gbn_slot(o, BN_SCALE), gbn_slot(o, BN_SHIFT), gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), update_moving ? 1 : 0};
+      const GBnFwdArgs f = fin_args(i, ss);
       lp.begin("bn_fwd_finalize", i);
       hipLaunchKernelGGL(gbn_fwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
       lp.end();
@@ -853,9 +918,81 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
+  auto bwd_fin_args = [&](int oi, const StatSource& ss) {
+    GOp& q = c->G[oi];
+    return GBnBwdArgs{ss.part, ss.G, q.cout, q.groups, ss.inv_n,
+                      c->params + q.o_gamma, gbn_slot(q, BN_RSTD), gbn_slot(q, BN_C1), gbn_slot(q, BN_MG), gbn_slot(q, BN_MGX),
+                      c->grads + q.o_gamma, c->grads + q.o_beta, ss.dscale, 0};
+  };
+  auto wgrad_args = [&](int oi) {
+    GOp& q = c->G[oi];
+    GWgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.n_src = q.n_src;
+    for (int s = 0; s < q.n_src; ++s) w.src[s] = g_make_src(c, oi, s, false);
+    w.y = g_make_bnbwd(c, q);
+    w.k = q.k;
+    w.dil = q.dil;
+    w.cin = q.cin;
+    w.stride = q.stride;
+    w.B = B;
+    w.Tin = q.tin;
+    w.Tout = q.tout;
+    w.nq = q.nq;
+    w.grad_part = q.grad_part;
+    return w;
+  };
+  auto dgrad_args = [&](int oi) {
+    GOp& q = c->G[oi];
+    GConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_src = q.n_src;
+    for (int s = 0; s < q.n_src; ++s) a.src[s] = g_make_src(c, oi, s, true);
+    a.w = c->wt + q.o_wt;
+    a.k = q.k;
+    a.dil = q.dil;
+    a.cin = q.cout;
+    a.stride = 1;
+    a.B = B;
+    a.Tin = q.tout;
+    a.Tout = q.tin;
+    a.y = g_make_bnbwd(c, q);
+    return a;
+  };
+  auto add_segment = [&](int oi) {
+    GOp& q = c->G[oi];
+    GradSegment s;
+    s.part = q.grad_part;
+    s.G = gg * q.nq;
+    s.stride = q.k * q.cin * q.cout;
+    s.n = s.stride;
+    s.dst = (int)q.o_w;
+    ga.seg[ga.nseg++] = s;
+  };
+  const bool sync = c->hook && c->sync_bn;
   for (int i = n - 1; i >= 0; --i) {
     GOp& o = c->G[i];
     const int members = o.groups > 1 ? o.cout / o.groups : 1;
+    if (i > 0 && c->G[i - 1].twin_next && !sync && !c->profile_split) {
+      // twins (i-1, i): one finalize launch and one four-role backward launch for the pair
+      GOp& o1 = c->G[i - 1];
+      const float inv_n = 1.0f / ((float)B * (float)o.tout * (float)members);
+      StatSource s0{o.gstat_part, gg, inv_n, 1.0f}, s1{o1.gstat_part, gg, inv_n, 1.0f};
+      const GBnBwdArgs bf0 = bwd_fin_args(i, s0), bf1 = bwd_fin_args(i - 1, s1);
+      const GWgradArgs w0 = wgrad_args(i), w1 = wgrad_args(i - 1);
+      const GConvArgs d0 = dgrad_args(i), d1 = dgrad_args(i - 1);
+      const int n0 = o.slots;
+      lp.begin("conv_bwd2_", i);
+      hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
+      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, gg,
+                                   std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)));
+      lp.end();
+      if (!ok) return fail(MWW_ERR_UNSUPPORTED, "twin ops without a fused backward instantiation");
+      add_segment(i);
+      add_segment(i - 1);
+      --i;
+      continue;
+    }
     if (!o.adders.empty()) {
       GResGatherArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -1340,6 +1477,23 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   }
   for (int i = 0; i + 1 < d.n_ops; ++i)
     if (n_consumers[i] == 0 && ops[i].adders.empty()) return fail(MWW_ERR_INVALID, "op " + std::to_string(i) + " has no consumer");
+  // twins: consecutive, mutually independent convolutions of one shape (Inception's second-level k x 1 convs of
+  // branch 2 and branch 3) share their forward, finalize and backward launches
+  auto twin_width = [](int n) {
+#define X(N) if (n == N) return true;
+    MWW_G_TWIN_WIDTHS(X)
+#undef X
+    return false;
+  };
+  for (int i = 0; i + 2 < d.n_ops; ++i) {
+    GOp &a = ops[i], &b = ops[i + 1];
+    const bool same = a.kind == MWW_OP_CONV && b.kind == MWW_OP_CONV && a.k == b.k && a.dil == b.dil && a.cin == b.cin && a.cout == b.cout &&
+                      a.groups == b.groups && a.norm == MWW_NORM_BN && b.norm == MWW_NORM_BN && a.act == b.act && a.stride == 1 &&
+                      b.stride == 1 && a.tin == b.tin && a.n_src == 1 && b.n_src == 1 && a.src[0] >= 0 && b.src[0] >= 0 &&
+                      b.src[0] != i && a.res_src < 0 && b.res_src < 0 && a.adders.empty() && b.adders.empty() && a.cin == a.cout &&
+                      twin_width(a.cout);
+    if (same && (i == 0 || !ops[i - 1].twin_next)) a.twin_next = true;
+  }
   // gradient routing: per producer, the slices its consumers read must be identical or disjoint and cover
   // every channel; in the backward pass (descending op index) the first consumer of a slice stores, later
   // ones accumulate and the last one also emits the BN statistics partials of that slice
