@@ -788,3 +788,41 @@ def check_topology_fuzz(lib, cases=6, first=0, B=3):
         if done == cases:
             return
     raise AssertionError("too few valid random topologies")
+
+
+# ------------------------------------------------------------------------------------------ frozen oracle outputs
+def check_against_frozen_oracle(lib, golden_dir):
+    """The engine against the committed fixture tests/golden/model_oracle_golden.npz (outputs of the oracle frozen by
+    tests/golden/make_golden_model.py): eval / train probabilities and the loss of the default MixedNet, the notebook
+    topology and the default Inception on the fixture's inputs."""
+    import importlib.util
+    from microwakeword_amd.layout import InceptionLayout
+    spec = importlib.util.spec_from_file_location("make_golden_model", os.path.join(golden_dir, "make_golden_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(golden_dir, "model_oracle_golden.npz"))
+    for name in ("mixednet_default", "mixednet_notebook", "inception_default"):
+        kind, flags, T = mod.CASES[name]
+        om = mo.OracleModel(kind, flags, T, seed=42)          # only its initial weights are used (numpy, no forward)
+        lay = MixedNetLayout(flags, T) if kind == "mixednet" else InceptionLayout(flags, T)
+        eng = native.Engine(lib=lib, **lay.engine_args(4))
+        eng.set_grad_mask(lay.grad_mask())
+        p, s = lay.pack(om.get_weights())
+        eng.set_params(p)
+        eng.set_bn_state(s)
+        rng = np.random.default_rng(7)
+        x = (rng.integers(0, 667, size=(4, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
+        y = np.array([1, 0, 0, 1], np.float32)
+        w = np.array([1.0, 0.5, 2.0, 1.0], np.float32)
+        eng.set_batch(x)
+        eng.forward(4, training=False)
+        assert np.abs(eng.read_outputs(4, want_loss=False)[0] - gold[name + "/p_eval"]).max() <= FWD_TOL, name
+        if kind == "inception":
+            n = lay.t_last * lay.c_last
+            eng.set_dropout_mask((rng.random((4, n)) >= flags["dropout"]).astype(np.float32))
+        eng.set_targets(y, w)
+        eng.train_step(4, 1e-3, flags=native.STEP_NO_APPLY)
+        pr, _, loss = eng.read_outputs(4)
+        assert np.abs(pr - gold[name + "/p_train"]).max() <= FWD_TOL, name
+        assert abs(loss - float(gold[name + "/loss"])) <= 1e-5 * max(1.0, abs(float(gold[name + "/loss"]))), name
+        eng.close()

@@ -190,3 +190,7 @@ def test_data_path_fuzz(emu_lib):
 
 def test_mixednet_topology_fuzz(emu_lib):
     ec.check_topology_fuzz(emu_lib, cases=5)
+
+
+def test_against_frozen_oracle_outputs(emu_lib, golden_dir):
+    ec.check_against_frozen_oracle(emu_lib, golden_dir)

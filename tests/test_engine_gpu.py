@@ -308,3 +308,8 @@ def test_full_size_properties_batch1024(lib):
     assert np.abs(e["pr"] - a["pr"][perm]).max() <= 1e-5                    # (d)
     assert np.abs(e["s"] - a["s"]).max() <= 1e-5 * max(1.0, np.abs(a["s"]).max())
     assert np.linalg.norm(e["g"] - a["g"]) <= 1e-4 * np.linalg.norm(a["g"])
+
+
+def test_against_frozen_oracle_outputs(lib, golden_dir):
+    """Committed fixture route: tests/golden/model_oracle_golden.npz."""
+    ec.check_against_frozen_oracle(lib, golden_dir)

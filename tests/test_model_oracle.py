@@ -239,3 +239,19 @@ def test_bf16_pointwise_function_gradients_use_rounded_operands():
     np.testing.assert_allclose(gx.numpy(), torch.einsum("oc,bot->bct", wr, gr).numpy(), rtol=0, atol=0)
     np.testing.assert_allclose(gw.numpy(), torch.einsum("bot,bct->oc", gr, xr).numpy(), rtol=0, atol=0)
     assert float((xr - x.detach()).abs().max()) > 0          # the rounding is real
+
+
+def test_oracle_outputs_frozen():
+    """Regression guard: the restatement still produces the numbers frozen in tests/golden/model_oracle_golden.npz
+    (made by tests/golden/make_golden_model.py from this same oracle — not a reference pin, see its docstring)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_model", os.path.join(here, "golden", "make_golden_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(here, "golden", "model_oracle_golden.npz"))
+    for name, (kind, flags, T) in mod.CASES.items():
+        got = mod.run(kind, flags, T)
+        for k, v in got.items():
+            np.testing.assert_allclose(v, gold["%s/%s" % (name, k)], rtol=1e-9, atol=1e-12, err_msg="%s/%s" % (name, k))
