@@ -287,6 +287,10 @@ def main():
             eng.set_option("pointwise_bf16", 1)
         if os.environ.get("MWW_BENCH_SIDE_STREAM") is not None:
             eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
+        if os.environ.get("MWW_BENCH_BN_INLINE") is not None:
+            eng.set_option("bn_inline", int(os.environ["MWW_BENCH_BN_INLINE"]))
+        if os.environ.get("MWW_BENCH_ASM_OVERLAP") is not None:
+            eng.set_option("assemble_overlap", int(os.environ["MWW_BENCH_ASM_OVERLAP"]))
         if args.graphs and not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY

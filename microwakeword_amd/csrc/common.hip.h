@@ -117,4 +117,116 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- BN statistics hand-over without a finalize launch (DESIGN §4 "statistics hand-over") ---------------
+// Producer: every workgroup adds its partial sums to one of kStatRows replicated fp64 accumulator rows with
+// memory-side atomics (no fence, no ticket: the kernel boundary publishes them).  First consumer: every
+// workgroup sums the kStatRows rows in its prologue and folds them exactly like bn_*_finalize_kernel does;
+// workgroup 0 also writes the folded arrays / moving statistics / dgamma, dbeta for the later kernels of the
+// step.  The accumulators are double-buffered by launch parity: a producer clears the rows its next-but-one
+// launch will add to.  fp64 sums of fp32 partials are exact unless the partials span more than 2^29 in
+// magnitude, so the result does not depend on the arrival order in practice (see DESIGN).
+constexpr int kStatRows = 8;
+
+struct StatAcc {
+  double* acc;     // [kStatRows][2C] rows this launch adds to (null: write the per-workgroup partial row instead)
+  double* clear;   // the other parity's rows
+};
+
+// called by threads tid < C2 with their column's per-workgroup sum
+__device__ __forceinline__ void publish_stat(const StatAcc& s, float* row, int C2, int tid, float v) {
+  if (s.acc) {
+    unsafeAtomicAdd(s.acc + (size_t)(blockIdx.x % kStatRows) * C2 + tid, (double)v);
+    if (blockIdx.x < kStatRows) s.clear[(size_t)blockIdx.x * C2 + tid] = 0.0;
+  } else {
+    row[tid] = v;
+  }
+}
+
+struct BnFoldArgs {      // forward statistics of a BN layer, folded by the first kernel that consumes them
+  const double* acc;     // [kStatRows][2][C] sums of x, x^2 (null: scale / shift were written by a finalize / eval-prepare launch)
+  float inv_n;           // 1 / (B*T)
+  int update_moving;
+  const float* gamma;
+  const float* beta;
+  float* moving_mean;
+  float* moving_var;
+  float* scale;          // published by workgroup 0 (same arrays bn_fwd_finalize_kernel writes)
+  float* shift;
+  float* mean;
+  float* rstd;
+};
+
+// one thread per channel; same arithmetic as bn_fwd_finalize_kernel
+__device__ __forceinline__ void bn_fold_channel(const BnFoldArgs& f, int C, int ch, float& sc, float& sh, float& meanf, float& rstd) {
+  double s1 = 0.0, s2 = 0.0;
+  double v1[kStatRows], v2[kStatRows];
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    v1[j] = f.acc[(size_t)j * 2 * C + ch];
+    v2[j] = f.acc[(size_t)j * 2 * C + C + ch];
+  }
+  const float gam = f.gamma[ch], bet = f.beta[ch];
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    s1 += v1[j];
+    s2 += v2[j];
+  }
+  const double m = s1 * (double)f.inv_n;
+  double var = s2 * (double)f.inv_n - m * m;   // biased batch variance (Keras BN)
+  if (var < 0.0) var = 0.0;
+  meanf = (float)m;
+  const float varf = (float)var;
+  rstd = 1.0f / sqrtf(varf + kBnEps);
+  sc = gam * rstd;
+  sh = bet - meanf * sc;
+  if (blockIdx.x == 0) {
+    f.scale[ch] = sc;
+    f.shift[ch] = sh;
+    f.mean[ch] = meanf;
+    f.rstd[ch] = rstd;
+    if (f.update_moving) {
+      f.moving_mean[ch] = f.moving_mean[ch] * kBnMomentum + meanf * (1.0f - kBnMomentum);
+      f.moving_var[ch] = f.moving_var[ch] * kBnMomentum + varf * (1.0f - kBnMomentum);
+    }
+  }
+}
+
+struct BnGradFoldArgs {  // backward statistics (sum g, sum g*xhat) of a BN layer, folded by the first consumer
+  const double* acc;     // [kStatRows][2][C] (null: c1 / mg / mgx were written by a finalize launch)
+  float inv_n;
+  float dscale;
+  const float* gamma;
+  float* c1;             // published by workgroup 0 (same arrays bn_bwd_finalize_kernel writes)
+  float* mg;
+  float* mgx;
+  float* dgamma;
+  float* dbeta;
+};
+
+__device__ __forceinline__ void bn_grad_fold_channel(const BnGradFoldArgs& f, int C, int ch, float rstd, float& c1, float& mg, float& mgx) {
+  double s1 = 0.0, s2 = 0.0;
+  double v1[kStatRows], v2[kStatRows];
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    v1[j] = f.acc[(size_t)j * 2 * C + ch];
+    v2[j] = f.acc[(size_t)j * 2 * C + C + ch];
+  }
+  const float gam = f.gamma[ch];
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    s1 += v1[j];
+    s2 += v2[j];
+  }
+  c1 = gam * rstd;
+  mg = (float)(s1 * (double)f.inv_n);
+  mgx = (float)(s2 * (double)f.inv_n);
+  if (blockIdx.x == 0) {
+    f.dbeta[ch] = (float)s1 * f.dscale;
+    f.dgamma[ch] = (float)s2 * f.dscale;
+    f.c1[ch] = c1;
+    f.mg[ch] = mg;
+    f.mgx[ch] = mgx;
+  }
+}
+
 }  // namespace mww

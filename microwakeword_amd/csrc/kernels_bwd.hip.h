@@ -45,6 +45,8 @@ struct BwdBlockArgs {
   int B, Tin, Tout;
   int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid); bit 16: phase clocks
   unsigned long long* phase_clk;   // [gridDim.x][8]
+  StatAcc gacc;           // (sum g, sum g*xhat) of g_{k-1} go to the accumulator rows instead of gstat_part when set
+  BnGradFoldArgs gfold;   // gfold.acc set: k_c1 / k_mg / k_mgx are folded here from the producer's accumulator rows
 };
 
 // dp tile: rows [t0, t0+TT) of (p_k, g_k) are fetched into registers early (issue) and turned into
@@ -290,11 +292,20 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   MWW_PC_DECL
 
   for (int i = tid; i < COUT; i += kThreads) {
+    const float krs = a.k_rstd[i];
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
     sKp[0 * COUT + i] = a.k_mean[i];
-    sKp[1 * COUT + i] = a.k_rstd[i];
-    sKp[2 * COUT + i] = a.k_c1[i];
-    sKp[3 * COUT + i] = a.k_mg[i];
-    sKp[4 * COUT + i] = a.k_mgx[i];
+    sKp[1 * COUT + i] = krs;
+    sKp[2 * COUT + i] = c1;
+    sKp[3 * COUT + i] = mg;
+    sKp[4 * COUT + i] = mgx;
     sKp[5 * COUT + i] = LAST ? a.k_scale[i] : 0.f;
     sKp[6 * COUT + i] = LAST ? a.k_shift[i] : 0.f;
   }
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     float v = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) v += smem[j * 2 * CIN + tid];
-    a.gstat_part[(size_t)blockIdx.x * 2 * CIN + tid] = v;
+    publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * CIN, 2 * CIN, tid, v);
   }
 }
 
@@ -429,6 +440,7 @@ struct BwdFirstArgs {
   const float* pw_w;      // [C1][COUT]
   float* grad_part;       // [gridDim.x][K1*40*C1 + K*C1 + C1 + C1*COUT]
   int B, T, Tout;         // a0 frames Ta = (T-K1)/S+1 ; Tout = Ta-(K-1)
+  BnGradFoldArgs gfold;   // gfold.acc set: k_c1 / k_mg / k_mgx are folded here from the producer's accumulator rows
 };
 
 template <int K1, int C1, int COUT, int K, int S, bool BF>
@@ -499,11 +511,20 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   if (nitems > 0) issue(0);
 
   for (int i = tid; i < COUT; i += kThreads) {
+    const float krs = a.k_rstd[i];
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
     sKp[0 * COUT + i] = a.k_mean[i];
-    sKp[1 * COUT + i] = a.k_rstd[i];
-    sKp[2 * COUT + i] = a.k_c1[i];
-    sKp[3 * COUT + i] = a.k_mg[i];
-    sKp[4 * COUT + i] = a.k_mgx[i];
+    sKp[1 * COUT + i] = krs;
+    sKp[2 * COUT + i] = c1;
+    sKp[3 * COUT + i] = mg;
+    sKp[4 * COUT + i] = mgx;
     sKp[5 * COUT + i] = 0.f;
     sKp[6 * COUT + i] = 0.f;
   }

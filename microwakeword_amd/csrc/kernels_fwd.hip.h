@@ -24,6 +24,7 @@ struct FwdFirstArgs {
   float* stat_part;      // [gridDim.x][2][COUT]
   int B, T, Tout;        // Tout = (T - K1)/S + 1 - (K-1)
   int ablate;            // profiling only: bit0 skip depthwise, bit1 skip MFMA, bit2 skip stores (results invalid)
+  StatAcc sacc;          // statistics go to the accumulator rows instead of stat_part when set
 };
 
 struct FwdBlockArgs {
@@ -38,6 +39,8 @@ struct FwdBlockArgs {
   int B, Tin, Tout;      // Tout = Tin - (K-1)
   int ablate;            // profiling only (see FwdFirstArgs); bit 16: per-phase clocks of thread 0 -> phase_clk
   unsigned long long* phase_clk;   // [gridDim.x][8]
+  StatAcc sacc;          // statistics go to the accumulator rows instead of stat_part when set
+  BnFoldArgs fold;       // fold.acc set: in_scale / in_shift are computed here from the producer's accumulator rows
 };
 
 // depthwise conv over one (channel, chunk): out[t] = bias + sum_i w[i]*src[t+i], t in [0,L)
@@ -173,7 +176,7 @@ __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* 
 
 template <int NT, int COUT>
 __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)[NT], float* sRed, float* dst,
-                                                    int tid, int wave, int r16, int g) {
+                                                    int tid, int wave, int r16, int g, const StatAcc& sacc) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     s1[nt] = sum_over_groups(s1[nt]);
@@ -188,7 +191,7 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += sRed[w * 2 * COUT + tid];
-    dst[tid] = v;
+    publish_stat(sacc, dst, 2 * COUT, tid, v);
   }
 }
 
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
     __syncthreads();
   }
-  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
+  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,8 +338,15 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   const bool dw_active = chunk < NCH;
 
   if (tid < CIN) {
-    sScale[tid] = a.in_scale[tid];
-    sShift[tid] = a.in_shift[tid];
+    float sc, sh, mu, rs;
+    if (a.fold.acc) {
+      bn_fold_channel(a.fold, CIN, tid, sc, sh, mu, rs);
+    } else {
+      sc = a.in_scale[tid];
+      sh = a.in_shift[tid];
+    }
+    sScale[tid] = sc;
+    sShift[tid] = sh;
   }
   for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) sA[i] = 0.f;
 
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     MWW_PC_MARK(7);   // barrier 3
   }
   MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);
-  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g);
+  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ struct HeadArgs {
   int B, T;
   float inv_b;
   int training;
+  BnFoldArgs fold;         // fold.acc set: BN_L's scale / shift / mean / rstd are folded here from the accumulator rows
 };
 
 template <int C, int JMAX>
@@ -52,7 +53,18 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   const int q = tid % Q, rg = tid / Q;
   const bool active = rg < NRG;
   float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, rs = sc;
-  if (active) {
+  if (a.fold.acc) {
+    float* sFold = sStat;   // [4][C], free until the first window's partials
+    if (tid < C) bn_fold_channel(a.fold, C, tid, sFold[tid], sFold[C + tid], sFold[2 * C + tid], sFold[3 * C + tid]);
+    __syncthreads();
+    if (active) {
+      sc = *reinterpret_cast<const float4*>(sFold + q * 4);
+      sh = *reinterpret_cast<const float4*>(sFold + C + q * 4);
+      mu = *reinterpret_cast<const float4*>(sFold + 2 * C + q * 4);
+      rs = *reinterpret_cast<const float4*>(sFold + 3 * C + q * 4);
+    }
+    __syncthreads();
+  } else if (active) {
     sc = *reinterpret_cast<const float4*>(a.scale + q * 4);
     sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
     if (a.training) {

@@ -46,6 +46,12 @@ struct Layer {
   float* grad_part = nullptr;  // [grid_bwd][params of the block (+ conv1 for block 0)]
   int grad_part_stride = 0;
   float* bn = nullptr;         // 9 x cout: scale, shift, mean, rstd, c1, mg, mgx, (spare x2)
+  // statistics hand-over without finalize launches (common.hip.h): [parity][kStatRows][2][cout] for the forward
+  // sums (x, x^2) and the backward sums (g, g*xhat); *_cur = rows the latest producer launch added to
+  double* facc[2] = {nullptr, nullptr};
+  double* gacc[2] = {nullptr, nullptr};
+  double* facc_cur = nullptr;
+  double* gacc_cur = nullptr;
 };
 
 // one conv -> BN/SSN -> ReLU op of a mww_convnet_desc graph (kernels_graph.hip.h)
@@ -137,6 +143,15 @@ struct mww_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  // "assemble_overlap" option: the batch assembly of step k+1 runs on its own stream next to the gradient
+  // reduction / Adam launches of step k (tiny launch-bound kernels), never next to the block kernels
+  hipStream_t asm_stream = nullptr;
+  hipEvent_t ev_xfree = nullptr, ev_asm = nullptr;
+  bool asm_overlap = false, xfree_valid = false;
+  // "bn_inline" option (default on): BN statistics travel through replicated fp64 accumulator rows and are folded by
+  // their first consumer instead of by a finalize launch (off with sync-BN: the sums must be exchanged in between)
+  bool bn_inline = true;
+  int fpar = 0, gpar = 0;   // accumulator parity of the next training forward / backward
   bool tail_pending = false, tail_metrics = false;   // dense gradient (+ metrics) ride in the first backward launch
   void* store[MWW_MAX_STORES] = {};
   int store_dtype[MWW_MAX_STORES] = {};
@@ -152,7 +167,7 @@ struct mww_ctx {
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
   // cached graphs keyed by (B, flags)
-  struct GraphEntry { int B, flags, mail; hipGraphExec_t exec; };
+  struct GraphEntry { int B, flags, mail, par; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
 };
 
@@ -374,12 +389,37 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       lp.end();
     }
   }
+  // statistics of BN_i: accumulator rows folded by the next kernel, or partial rows + a finalize launch
+  const bool inl = training && c->bn_inline && !(c->hook && c->sync_bn);
+  auto fold_of = [&](Layer& pl) {
+    BnFoldArgs f;
+    memset(&f, 0, sizeof(f));
+    if (!inl) return f;
+    f.acc = pl.facc_cur;
+    f.inv_n = 1.0f / ((float)B * (float)pl.tout);
+    f.update_moving = update_moving ? 1 : 0;
+    f.gamma = c->params + pl.o_gamma;
+    f.beta = c->params + pl.o_beta;
+    f.moving_mean = c->bn_state + pl.o_mm;
+    f.moving_var = c->bn_state + pl.o_mv;
+    f.scale = bn_slot(pl, BN_SCALE);
+    f.shift = bn_slot(pl, BN_SHIFT);
+    f.mean = bn_slot(pl, BN_MEAN);
+    f.rstd = bn_slot(pl, BN_RSTD);
+    return f;
+  };
   for (int i = 0; i < nb; ++i) {
     Layer& l = c->L[i];
     const int grid = std::min(B, c->grid_fwd);
+    StatAcc sacc{nullptr, nullptr};
+    if (inl) {
+      sacc.acc = l.facc[c->fpar];
+      sacc.clear = l.facc[c->fpar ^ 1];
+      l.facc_cur = sacc.acc;
+    }
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
-                     l.p, l.stat_part, B, d.frames, l.tout, 0};
+                     l.p, l.stat_part, B, d.frames, l.tout, 0, sacc};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
@@ -387,13 +427,14 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     } else {
       Layer& pl = c->L[i - 1];
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * 8};
+                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * 8,
+                     sacc, fold_of(pl)};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
       if (rc) return rc;
     }
-    if (training) {
+    if (training && !inl) {
       StatSource ss;
       int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, l.stat_part, grid, l.cout, 0, 1.0f / ((float)B * (float)l.tout), &ss);
       if (rcs) return rcs;
@@ -426,6 +467,8 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.T = ll.tout;
   h.inv_b = 1.0f / (float)B;
   h.training = loss ? 1 : 0;
+  h.fold = fold_of(ll);
+  if (inl) c->fpar ^= 1;
   const int q = ll.cout / 4, nrg = kThreads / q;
   lp.begin("head");
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
@@ -449,6 +492,11 @@ int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam)
   Launcher lp{c};
   int rcj = join_side(c);
   if (rcj) return rcj;
+  if (c->asm_overlap && !c->use_graphs && !c->profile) {
+    // x, y and the sample weights were last read by the launches above: the next batch may be assembled from here on
+    HIPCHK(hipEventRecord(c->ev_xfree, c->stream));
+    c->xfree_valid = true;
+  }
   const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
   const int ndchunks = (B + dchunk - 1) / dchunk;
   {
@@ -498,17 +546,38 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   const int nb = d.n_blocks;
   const int gbwd = std::min(B, c->grid_bwd);
   const int ghead = std::min(B, c->grid_head);
+  const bool inl = c->bn_inline && !(c->hook && c->sync_bn);
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
-    StatSource ss;
-    int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, l.gstat_part, last ? ghead : gbwd, l.cout, 1,
-                             1.0f / ((float)B * (float)l.tout), &ss);
-    if (rcs) return rcs;
+    // BN_i's backward sums: the last block's come from the head kernel's partial rows (folded by head_tail);
+    // the others arrive in accumulator rows and are folded by this block's backward kernel
+    const bool fold_here = inl && !last;
+    StatSource ss{nullptr, 0, 0.f, 1.0f};
+    if (!fold_here) {
+      int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, l.gstat_part, last ? ghead : gbwd, l.cout, 1,
+                               1.0f / ((float)B * (float)l.tout), &ss);
+      if (rcs) return rcs;
+    }
     BnBwdFinalizeArgs f{ss.part, ss.G, l.cout, ss.inv_n,
                         c->params + l.o_gamma, bn_slot(l, BN_RSTD), bn_slot(l, BN_C1), bn_slot(l, BN_MG),
                         bn_slot(l, BN_MGX), c->grads + l.o_gamma, c->grads + l.o_beta, ss.dscale};
-    if (last && c->tail_pending) {
+    BnGradFoldArgs gf;
+    memset(&gf, 0, sizeof(gf));
+    if (fold_here) {
+      gf.acc = l.gacc_cur;
+      gf.inv_n = 1.0f / ((float)B * (float)l.tout);
+      gf.dscale = 1.0f;
+      gf.gamma = c->params + l.o_gamma;
+      gf.c1 = bn_slot(l, BN_C1);
+      gf.mg = bn_slot(l, BN_MG);
+      gf.mgx = bn_slot(l, BN_MGX);
+      gf.dgamma = c->grads + l.o_gamma;
+      gf.dbeta = c->grads + l.o_beta;
+    }
+    if (fold_here) {
+      // no launch
+    } else if (last && c->tail_pending) {
       c->tail_pending = false;
       const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
       HeadTailArgs ht;
@@ -558,6 +627,13 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.Tout = l.tout;
       a.ablate = c->ablate;
       a.phase_clk = c->phase_clk + (size_t)(2 * i + 1) * 2048 * 8;
+      a.gacc = StatAcc{nullptr, nullptr};
+      if (inl) {
+        a.gacc.acc = pl.gacc[c->gpar];
+        a.gacc.clear = pl.gacc[c->gpar ^ 1];
+        pl.gacc_cur = a.gacc.acc;
+      }
+      a.gfold = gf;
       lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
@@ -566,13 +642,14 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       if (last) return fail(MWW_ERR_UNSUPPORTED, "single-block models are not supported");
       BwdFirstArgs a{c->x, c->params + c->o_conv1, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout};
+                     c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf};
       lp.begin("bwd_block", i);
       int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, gbwd);
       lp.end();
       if (rc) return rc;
     }
   }
+  if (inl) c->gpar ^= 1;
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
   int ns = 0;
@@ -1252,6 +1329,9 @@ int alloc_common(mww_ctx* c) {
   H(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   H(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   H(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  H(hipStreamCreateWithFlags(&c->asm_stream, hipStreamNonBlocking));
+  H(hipEventCreateWithFlags(&c->ev_xfree, hipEventDisableTiming));
+  H(hipEventCreateWithFlags(&c->ev_asm, hipEventDisableTiming));
 #undef A
 #undef H
   return MWW_OK;
@@ -1352,6 +1432,10 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     A(dev_alloc(&l.g, mb * l.tout * l.cout));
     A(dev_alloc(&l.stat_part, (size_t)gmax_f * 2 * l.cout));
     A(dev_alloc(&l.gstat_part, (size_t)std::max(gmax_b, gmax_h) * 2 * l.cout));
+    for (int par = 0; par < 2; ++par) {
+      A(dev_alloc(&l.facc[par], (size_t)kStatRows * 2 * l.cout));
+      A(dev_alloc(&l.gacc[par], (size_t)kStatRows * 2 * l.cout));
+    }
     l.grad_part_stride = (l.k + 1) * l.cin + l.cin * l.cout;
     if (i == 0) l.grad_part_stride += d.conv1_kernel * MWW_FEATURE_BINS * d.conv1_filters;
     A(dev_alloc(&l.grad_part, (size_t)gmax_b * l.grad_part_stride));
@@ -1643,7 +1727,7 @@ void mww_destroy(mww_ctx* c) {
                   c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk};
   for (void* p : flat) if (p) (void)hipFree(p);
   for (auto& l : c->L) {
-    void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn};
+    void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn, l.facc[0], l.facc[1], l.gacc[0], l.gacc[1]};
     for (void* p : lp) if (p) (void)hipFree(p);
   }
   for (auto& o : c->G) {
@@ -1666,6 +1750,9 @@ void mww_destroy(mww_ctx* c) {
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   }
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->asm_stream) { (void)hipStreamSynchronize(c->asm_stream); (void)hipStreamDestroy(c->asm_stream); }
+  if (c->ev_xfree) (void)hipEventDestroy(c->ev_xfree);
+  if (c->ev_asm) (void)hipEventDestroy(c->ev_asm);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1784,10 +1871,19 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
   a.T = T;
   a.ntm = ntm;
   a.nfm = nfm;
-  Launcher lp{c};
-  lp.begin("assemble");
-  hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->stream, a);
-  lp.end();
+  if (c->xfree_valid && c->asm_overlap && !c->profile) {
+    c->xfree_valid = false;
+    HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_copy[c->mail_cur], 0));
+    HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_xfree, 0));
+    hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->asm_stream, a);
+    HIPCHK(hipEventRecord(c->ev_asm, c->asm_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_asm, 0));
+  } else {
+    Launcher lp{c};
+    lp.begin("assemble");
+    hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->stream, a);
+    lp.end();
+  }
   HIPCHK(hipGetLastError());
   c->have_batch = B;
   return MWW_OK;
@@ -1796,6 +1892,7 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
 int mww_set_batch(mww_ctx* c, const float* hx, int B) {
   if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   HIPCHK(hipSetDevice(c->device));
+  c->xfree_valid = false;
   int rc = copy_in(c, c->x, hx, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
   if (!rc) c->have_batch = B;
   return rc;
@@ -1842,9 +1939,16 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
   }
   if (c->use_graphs && !c->profile && !c->hook) {   // the exchange hook enqueues foreign work: no capture
     const int mail = (apply || gen_dropout) ? c->mail_cur : -1;   // only the Adam / dropout nodes read the mailbox
+    // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
+    const bool flips = !c->generic && c->bn_inline;
+    const int par = flips ? (4 | c->fpar | (c->gpar << 1)) : 0;
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
-      if (g.B == B && g.flags == flags && g.mail == mail) exec = g.exec;
+      if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
+    if (exec && flips) {
+      c->fpar ^= 1;
+      c->gpar ^= 1;
+    }
     if (!exec) {
       hipGraph_t graph;
       HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1854,7 +1958,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
       if (e != hipSuccess) return fail(MWW_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
       HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       HIPCHK(hipGraphDestroy(graph));
-      c->graphs.push_back({B, flags, mail, exec});
+      c->graphs.push_back({B, flags, mail, par, exec});
     }
     HIPCHK(hipGraphLaunch(exec, c->stream));
     return mail_commit(c);
@@ -1882,6 +1986,7 @@ int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
   if (c->have_batch < B) return fail(MWW_ERR_STATE, "forward needs a batch of at least B rows");
   if (update_metrics && c->have_targets < B) return fail(MWW_ERR_STATE, "metric update needs targets");
   HIPCHK(hipSetDevice(c->device));
+  c->xfree_valid = false;   // this forward reads x on the main stream: the next assembly must queue behind it
   int rc = flush_targets(c);
   if (rc) return rc;
   rc = enqueue_forward(c, B, training != 0, false, false, update_metrics != 0);
@@ -1991,6 +2096,8 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   }
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
+  else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
+  else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "profile_split")) c->profile_split = v != 0;
   else if (!strcmp(name, "pointwise_bf16")) {
     if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");

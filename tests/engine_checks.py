@@ -826,3 +826,79 @@ def check_against_frozen_oracle(lib, golden_dir):
         assert np.abs(pr - gold[name + "/p_train"]).max() <= FWD_TOL, name
         assert abs(loss - float(gold[name + "/loss"])) <= 1e-5 * max(1.0, abs(float(gold[name + "/loss"]))), name
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------ overlapped assembly
+def check_assemble_overlap(lib, B=8, T=60, steps=5):
+    """"assemble_overlap" (the next batch is gathered on its own stream next to the previous step's gradient
+    reduction / Adam launches) changes the schedule only: parameters after a few steps, with an evaluation forward
+    and a host-provided batch in between, are bit-identical to the serial schedule."""
+    from microwakeword_amd import mixednet
+    policy = dict(time_mask_max_size=4, time_mask_count=2, freq_mask_max_size=4, freq_mask_count=2)
+    results = []
+    for overlap in (0, 1):
+        random.seed(3)
+        np.random.seed(3)
+        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=11, max_batch=B)
+        eng = model.engine
+        eng.set_option("assemble_overlap", overlap)
+        fh = FeatureHandler(learnable_config(T=T), engine=eng)
+        probs = []
+        for k in range(steps):
+            fh.next_training_batch_on_device(B, T, "default", policy)
+            eng.train_step(B, 1e-2)
+            if k == 1:   # an evaluation pass reads x on the main stream between two steps
+                fh.next_training_batch_on_device(B, T, "default", policy)
+                eng.forward(B, training=False)
+                probs.append(eng.read_outputs(B, want_loss=False)[0].copy())
+            if k == 2:   # a host batch overwrites x between two steps
+                eng.set_batch(np.full((B, T, 40), 0.5, np.float32))
+                eng.set_targets(np.ones(B, np.float32), np.ones(B, np.float32))
+                eng.train_step(B, 1e-2)
+        probs.append(eng.read_outputs(B)[0].copy())
+        results.append((eng.get_params().copy(), probs, eng.get_batch(B).copy()))
+        eng.close()
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    np.testing.assert_array_equal(results[0][2], results[1][2])
+    for a, b in zip(results[0][1], results[1][1]):
+        np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ statistics hand-over
+def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
+    """"bn_inline" (BN sums in replicated fp64 accumulator rows, folded by their first consumer) against the
+    finalize-launch path: same arithmetic on the same sums, so parameters, moving statistics and outputs agree to
+    fp32 rounding of a differently ordered fp64 sum (identical in practice; tolerance 1e-6 relative).  Also
+    through captured graphs (the accumulator parity is part of the graph key) and with a training-mode forward
+    between steps (flips the forward parity only)."""
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 667, size=(steps + 1, B, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
+    y = (rng.random((steps + 1, B)) < 0.4).astype(np.float32)
+    w = np.ones(B, np.float32)
+    om = mo.OracleModel("mixednet", flags, T, seed=42)
+    lay = MixedNetLayout(flags, T)
+    p0, s0 = lay.pack(om.get_weights())
+    outs = []
+    for inline, graphs in ((0, 0), (1, 0), (1, 1)):
+        eng = native.Engine(lib=lib, **lay.engine_args(B))
+        eng.set_grad_mask(lay.grad_mask())
+        eng.set_params(p0)
+        eng.set_bn_state(s0)
+        eng.set_option("bn_inline", inline)
+        eng.set_option("graphs", graphs)
+        probs = []
+        for k in range(steps):
+            eng.set_batch(x[k])
+            eng.set_targets(y[k], w)
+            eng.train_step(B, 1e-2)
+            probs.append(eng.read_outputs(B)[0].copy())
+            if k == 0:
+                eng.set_batch(x[steps])
+                eng.forward(B, training=True)
+                probs.append(eng.read_outputs(B, want_loss=False)[0].copy())
+        outs.append((eng.get_params().copy(), eng.get_bn_state().copy(), np.concatenate(probs), eng.get_grads().copy()))
+        eng.close()
+    ref = outs[0]
+    for got in outs[1:]:
+        for a, b in zip(ref, got):
+            np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)

@@ -136,6 +136,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline double unsafeAtomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline float __ldg(const float* p) { return *p; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }

@@ -194,3 +194,11 @@ def test_mixednet_topology_fuzz(emu_lib):
 
 def test_against_frozen_oracle_outputs(emu_lib, golden_dir):
     ec.check_against_frozen_oracle(emu_lib, golden_dir)
+
+
+def test_assemble_overlap_is_schedule_only(emu_lib):
+    ec.check_assemble_overlap(emu_lib)
+
+
+def test_bn_inline_matches_finalize(emu_lib):
+    ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)

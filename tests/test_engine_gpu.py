@@ -313,3 +313,12 @@ def test_full_size_properties_batch1024(lib):
 def test_against_frozen_oracle_outputs(lib, golden_dir):
     """Committed fixture route: tests/golden/model_oracle_golden.npz."""
     ec.check_against_frozen_oracle(lib, golden_dir)
+
+
+def test_assemble_overlap_is_schedule_only(lib):
+    ec.check_assemble_overlap(lib, B=64, T=194, steps=6)
+
+
+def test_bn_inline_matches_finalize(lib):
+    ec.check_bn_inline_matches_finalize(lib, B=96, T=194, steps=4)
+    ec.check_bn_inline_matches_finalize(lib, B=5, T=194, steps=2)   # fewer workgroups than accumulator rows
