@@ -289,6 +289,10 @@ def main():
             eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
         if os.environ.get("MWW_BENCH_BN_INLINE") is not None:
             eng.set_option("bn_inline", int(os.environ["MWW_BENCH_BN_INLINE"]))
+        if os.environ.get("MWW_BENCH_FUSED_INPUT") is not None:
+            eng.set_option("fused_input", int(os.environ["MWW_BENCH_FUSED_INPUT"]))
+        if os.environ.get("MWW_BENCH_ASM_SPLIT") is not None:
+            eng.set_option("assemble_split", int(os.environ["MWW_BENCH_ASM_SPLIT"]))
         if os.environ.get("MWW_BENCH_ASM_OVERLAP") is not None:
             eng.set_option("assemble_overlap", int(os.environ["MWW_BENCH_ASM_OVERLAP"]))
         if args.graphs and not args.no_graphs:

@@ -100,6 +100,17 @@ struct PhaseClock {
   }
 };
 
+// workgroup-uniform values read from LDS / memory: move them to scalar registers
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uniform_i64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  return reinterpret_cast<const void*>((uintptr_t)uniform_i64((long long)(uintptr_t)p));
+}
+
 // sum over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48)
 __device__ __forceinline__ float sum_over_groups(float v) {
   v += __shfl_xor(v, 16);

@@ -441,6 +441,7 @@ struct BwdFirstArgs {
   float* grad_part;       // [gridDim.x][K1*40*C1 + K*C1 + C1 + C1*COUT]
   int B, T, Tout;         // a0 frames Ta = (T-K1)/S+1 ; Tout = Ta-(K-1)
   BnGradFoldArgs gfold;   // gfold.acc set: k_c1 / k_mg / k_mgx are folded here from the producer's accumulator rows
+  XGather xg;             // xg.win set: x rows are gathered from the feature stores (see kernels_fwd.hip.h)
 };
 
 template <int K1, int C1, int COUT, int K, int S, bool BF>
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   static_assert(4 % NT1 == 0 && TT >= K - 1, "shape");
 
   __shared__ __attribute__((aligned(16))) float sX[XR * PX];
+  __shared__ XShared sXg;
   __shared__ __attribute__((aligned(16))) float smem[OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
@@ -483,18 +485,12 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   const int ntiles = (Ta + TT - 1) / TT;
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int nitems = nsamp * ntiles;
-  float4 pre_x[NLDX];
+  XStage<XR, PX> xs;
   DpStage<COUT, false> dps;
   auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvx = ((min(RA, Ta - t0) - 1) * S + K1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + (size_t)t0 * S) * FBINS);
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      pre_x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvx) pre_x[j] = src[i];
-    }
+    const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nrx = (min(RA, Ta - t0) - 1) * S + K1;
+    xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrx, tid);
     const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
     const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
     dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
@@ -508,6 +504,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     okm[mi] = m < M1;
     offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
   }
+  if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
   if (nitems > 0) issue(0);
 
   for (int i = tid; i < COUT; i += kThreads) {
@@ -571,15 +568,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     const int rows_da = min(TT, Ta - t0);
     const int rows_a = min(RA, Ta - t0);          // a0 rows that exist in this tile
     // ---- P0: commit x (odd pitch), dp; roll the du ring
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      if (i < XR * FBINS / 4) {
-        const int r = i / (FBINS / 4), f0 = (i - r * (FBINS / 4)) * 4;
-        float* d = sX + r * PX + f0;
-        d[0] = pre_x[j].x; d[1] = pre_x[j].y; d[2] = pre_x[j].z; d[3] = pre_x[j].w;
-      }
-    }
+    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
     dps.commit(sDP, sKp, 0.f, nrows_new * (COUT / 4), tid);
     carry_du<K, CPI>(sDU, t0 == 0, tid);
     __syncthreads();

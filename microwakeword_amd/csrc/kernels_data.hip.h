@@ -22,27 +22,30 @@ struct AssembleArgs {
   float* y_dst;
   float* sw_dst;
   int n_targets;
+  int split;               // workgroups per window (each gathers a contiguous share of the window's rows)
 };
 
 constexpr int kMaxMasks = 16;
 
 __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
   __shared__ __attribute__((aligned(16))) int sMask[kMaxMasks * 2];
-  const int j = blockIdx.x;
+  const int j = blockIdx.x / a.split, part = blockIdx.x - j * a.split;
   const int tid = threadIdx.x;
   const int nm = a.ntm + a.nfm;
   const mww_window w = a.win[j];   // issued together with the mask loads: one memory round trip, not two
   if (tid < nm * 2) sMask[tid] = a.masks[(size_t)j * nm * 2 + tid];
-  if (j < a.n_targets && tid == 64) a.y_dst[j] = a.y_src[j];
-  if (j < a.n_targets && tid == 128) a.sw_dst[j] = a.sw_src[j];
+  if (part == 0 && j < a.n_targets && tid == 64) a.y_dst[j] = a.y_src[j];
+  if (part == 0 && j < a.n_targets && tid == 128) a.sw_dst[j] = a.sw_src[j];
   __syncthreads();
   const int dtype = a.dtype[w.store];
   const unsigned short* s16 = reinterpret_cast<const unsigned short*>(a.store[w.store]);
   const float* s32 = reinterpret_cast<const float*>(a.store[w.store]);
   float* dst = a.x + (size_t)j * a.T * FBINS;
   constexpr int Q = FBINS / 4;
-  constexpr int U = 8;   // float4 groups in flight per thread: all loads of a batch (the whole 194-frame window) are issued before the first store
-  for (int i0 = tid; i0 < a.T * Q; i0 += kThreads * U) {
+  constexpr int U = 4;   // float4 groups in flight per thread: all loads of a workgroup's share are issued before the first store
+  const int n_all = a.T * Q, share = (n_all + a.split - 1) / a.split;
+  const int i_end = min(n_all, (part + 1) * share);
+  for (int i0 = part * share + tid; i0 < i_end; i0 += kThreads * U) {
     float4 v[U];
     int tt[U], qq[U];
 #pragma unroll
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
       qq[u] = q;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int r = t - w.pad_rows;
-      if (i < a.T * Q && r >= 0 && r < w.copy_rows) {
+      if (i < i_end && r >= 0 && r < w.copy_rows) {
         const size_t e = (size_t)w.src_elem + (size_t)r * FBINS + q * 4;
         if (dtype == MWW_DTYPE_U16) {
           const ushort4 u16 = *reinterpret_cast<const ushort4*>(s16 + e);
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(AssembleArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * kThreads;
-      if (i >= a.T * Q) continue;
+      if (i >= i_end) continue;
       const int t = tt[u], q = qq[u];
       bool row_masked = false;
       for (int m = 0; m < a.ntm; ++m) {

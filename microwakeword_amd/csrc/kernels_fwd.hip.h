@@ -11,8 +11,173 @@
 //   (classifier head and loss: kernels_head.hip.h)
 #pragma once
 #include "common.hip.h"
+#include "../../include/mww.h"
 
 namespace mww {
+
+// ---- first-block input straight from the feature stores ("fused_input") ---------------------------------
+// With XGather::win set, fwd_first_kernel / bwd_first_kernel do what assemble_kernel does (reference
+// microwakeword/data.py:74-118 pad / truncate, :268-269 uint16 scaling, :32-71 SpecAugment zeroing) while
+// staging their x rows: the window descriptors and masks of the workgroup's samples are fetched once in
+// the prologue (descriptors to LDS, masks as row / column bitmaps), each staged float4 group is gathered
+// from its store (uint16: 8 bytes instead of 16) and converted + masked on its way into LDS.  The x buffer
+// is then neither written nor read: 93 KB less HBM traffic per window and one launch less per step.
+constexpr int kXMaxSamples = 8;   // windows per workgroup the gather mode keeps descriptors for
+constexpr int kXRowWords = 8;     // row bitmap: up to 256 frames
+constexpr int kXMaxMasks = 8;     // SpecAugment masks per window in gather mode (more: the batch is materialised)
+
+struct XGather {
+  const mww_window* win;   // [B] (null: dense float32 x)
+  const int* masks;        // [B][ntm + nfm][2]
+  const void* store[MWW_MAX_STORES];
+  int dtype[MWW_MAX_STORES];
+  int ntm, nfm, T;
+};
+
+struct XShared {
+  const void* base[kXMaxSamples];
+  long long src_elem[kXMaxSamples];
+  int pad_rows[kXMaxSamples], copy_rows[kXMaxSamples], dtype[kXMaxSamples];
+  unsigned rowbits[kXMaxSamples][kXRowWords];
+  unsigned colbits[kXMaxSamples][2];
+};
+
+__device__ __forceinline__ unsigned bits_of_range(int start, int width, int word) {
+  const int lo = max(start, 32 * word) - 32 * word, hi = min(start + width, 32 * word + 32) - 32 * word;
+  if (hi <= lo) return 0u;
+  const unsigned run = (hi - lo >= 32) ? 0xffffffffu : ((1u << (hi - lo)) - 1u);
+  return run << lo;
+}
+
+// prologue (all threads; ends with a barrier): descriptors, store bases and mask bitmaps of this workgroup's samples
+__device__ __forceinline__ void xgather_setup(const XGather& g, XShared& sh, int nsamp, int tid) {
+  if (tid < nsamp) {
+    const mww_window w = g.win[blockIdx.x + tid * gridDim.x];
+    const void* base = g.store[0];
+    int dt = g.dtype[0];
+#pragma unroll
+    for (int i = 1; i < MWW_MAX_STORES; ++i)
+      if (w.store == i) {
+        base = g.store[i];
+        dt = g.dtype[i];
+      }
+    sh.base[tid] = base;
+    sh.dtype[tid] = dt;
+    sh.src_elem[tid] = w.src_elem;
+    sh.pad_rows[tid] = w.pad_rows;
+    sh.copy_rows[tid] = w.copy_rows;
+  }
+  constexpr int WPS = kXRowWords + 2;   // bitmap words per sample
+  if (tid < nsamp * WPS) {
+    const int s = tid / WPS, word = tid - s * WPS;
+    const int nm = g.ntm + g.nfm;
+    const int* mk = g.masks + (size_t)(blockIdx.x + s * gridDim.x) * nm * 2;
+    // all (start, width) pairs are fetched before the first one is used: one memory round trip
+    int mv[2 * kXMaxMasks];
+#pragma unroll
+    for (int m = 0; m < 2 * kXMaxMasks; ++m) mv[m] = (m < 2 * nm) ? mk[m] : 0;
+    const bool row = word < kXRowWords;
+    const int w = row ? word : word - kXRowWords;
+    unsigned bits = 0u;
+#pragma unroll
+    for (int m = 0; m < kXMaxMasks; ++m)
+      if (m < nm && (m < g.ntm) == row) bits |= bits_of_range(mv[2 * m], mv[2 * m + 1], w);
+    if (row) sh.rowbits[s][w] = bits;
+    else sh.colbits[s][w] = bits;
+  }
+  __syncthreads();
+}
+
+// register stage of the x rows of one (sample, tile) item.  Thread -> (row group rq = tid / 10, float4 column
+// q = tid % 10) for tid < 250; pass j handles row rq + 25 j: every per-pass address is a compile-time offset
+// from a per-thread base, in HBM (float4 index tid + 250 j of the tile) and in LDS (odd row pitch PX).
+// issue() fetches rows [row0, row0 + nrows) of the sample (dense) or gathers them (store rows row0 - pad_rows ...);
+// commit() writes them to LDS, converting / masking in gather mode.
+template <int XROWS, int PX>
+struct XStage {
+  static constexpr int QX = FBINS / 4, RPP = kThreads / QX, ACT = RPP * QX, NJ = (XROWS + RPP - 1) / RPP;
+  float4 pre[NJ];
+
+  // `tid` is laundered in both methods: the per-lane row / offset arithmetic is a handful of VALU ops per tile,
+  // hoisted out of the tile loop it would cost long-lived registers in kernels that have none to spare
+  __device__ __forceinline__ void issue(const float* x, const XGather& g, const XShared& sh, int s, int b, int T, int row0,
+                                        int nrows, int tid) {
+    asm volatile("" : "+v"(tid));
+    const int rq = tid / QX;
+    const bool act = tid < ACT;
+    if (g.win == nullptr) {
+      const float4* src = reinterpret_cast<const float4*>(x + ((size_t)b * T + row0) * FBINS) + tid;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act && rq + RPP * j < nrows) pre[j] = src[ACT * j];
+      }
+      return;
+    }
+    // the descriptor is workgroup-uniform: keep it in scalar registers, address the rows with 32-bit lane offsets
+    const int pad = uniform_int(sh.pad_rows[s]), copy = uniform_int(sh.copy_rows[s]);
+    const bool u16 = uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+    const long long e0 = uniform_i64(sh.src_elem[s]) + (long long)(row0 - pad) * FBINS;
+    const char* base = reinterpret_cast<const char*>(uniform_ptr(sh.base[s])) + e0 * (u16 ? 2 : 4);
+    const int r_lo = pad - row0, r_hi = min(pad + copy - row0, nrows);   // rows [r_lo, r_hi) of the tile exist in the store
+    if (u16) {
+      const uint2* src = reinterpret_cast<const uint2*>(base) + tid;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = rq + RPP * j;
+        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act && r >= r_lo && r < r_hi) {
+          const uint2 raw = src[ACT * j];
+          pre[j].x = __uint_as_float(raw.x);
+          pre[j].y = __uint_as_float(raw.y);
+        }
+      }
+    } else {
+      const float4* src = reinterpret_cast<const float4*>(base) + tid;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = rq + RPP * j;
+        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act && r >= r_lo && r < r_hi) pre[j] = src[ACT * j];
+      }
+    }
+  }
+
+  __device__ __forceinline__ void commit(float* sX, const XGather& g, const XShared& sh, int s, int row0, int tid) const {
+    asm volatile("" : "+v"(tid));
+    const int rq = tid / QX, q = tid - rq * QX;
+    if (tid >= ACT) return;
+    const bool gather = g.win != nullptr;
+    const bool u16 = gather && uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+    unsigned cm = 0u;
+    if (gather) cm = (sh.colbits[s][(4 * q) >> 5] >> ((4 * q) & 31)) & 0xfu;
+    float* dst = sX + rq * PX + q * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int r = rq + RPP * j;
+      if (r < XROWS) {
+        float4 v = pre[j];
+        if (u16) {
+          const unsigned lo = __float_as_uint(v.x), hi = __float_as_uint(v.y);
+          v.x = (float)(lo & 0xffffu) * 0.0390625f;   // data.py:268-269
+          v.y = (float)(lo >> 16) * 0.0390625f;
+          v.z = (float)(hi & 0xffffu) * 0.0390625f;
+          v.w = (float)(hi >> 16) * 0.0390625f;
+        }
+        if (gather) {
+          const int t = row0 + r;
+          const unsigned m4 = (t < g.T && ((sh.rowbits[s][t >> 5] >> (t & 31)) & 1u)) ? 0xfu : cm;
+          if (m4 & 1u) v.x = 0.f;
+          if (m4 & 2u) v.y = 0.f;
+          if (m4 & 4u) v.z = 0.f;
+          if (m4 & 8u) v.w = 0.f;
+        }
+        float* d = dst + RPP * j * PX;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+  }
+};
 
 struct FwdFirstArgs {
   const float* x;        // [B][T][40]
@@ -25,6 +190,7 @@ struct FwdFirstArgs {
   int B, T, Tout;        // Tout = (T - K1)/S + 1 - (K-1)
   int ablate;            // profiling only: bit0 skip depthwise, bit1 skip MFMA, bit2 skip stores (results invalid)
   StatAcc sacc;          // statistics go to the accumulator rows instead of stat_part when set
+  XGather xg;            // xg.win set: x rows are gathered from the feature stores (x is not read)
 };
 
 struct FwdBlockArgs {
@@ -216,6 +382,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   __shared__ __attribute__((aligned(16))) float sA[RAP * CP1];
   __shared__ __attribute__((aligned(16))) float sU[TTP * CP1];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
+  __shared__ XShared sXg;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % C1, chunk = tid / C1;
@@ -227,19 +394,14 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   const int ntiles = (a.Tout + TT - 1) / TT;
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int nitems = nsamp * ntiles;
-  float4 pre[NLDX];
+  XStage<XR, PX> xs;
   auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvalid = ((min(TT, a.Tout - t0) + K - 2) * S + K1) * FBINS / 4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + ((size_t)b * a.T + (size_t)t0 * S) * FBINS);
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvalid) pre[j] = src[i];
-    }
+    const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nrows = (min(TT, a.Tout - t0) + K - 2) * S + K1;
+    xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrows, tid);
   };
-  if (nitems > 0) issue(0);
+  const bool gather = a.xg.win != nullptr;
+  if (!gather && nitems > 0) issue(0);
 
   // register-resident weights
   const int nt1 = wave % NT1;
@@ -261,6 +423,10 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+  if (gather) {   // after the weight loads were issued: their latency covers the descriptor round trip
+    xgather_setup(a.xg, sXg, nsamp, tid);
+    if (nitems > 0) issue(0);
+  }
 
 #pragma unroll
   for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
@@ -272,15 +438,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
     // commit the staged x rows (zero filled past the valid ones) with an odd row pitch
-#pragma unroll
-    for (int j = 0; j < NLDX; ++j) {
-      const int i = tid + j * kThreads;
-      if (i < XR * FBINS / 4) {
-        const int r = i / (FBINS / 4), f0 = (i - r * (FBINS / 4)) * 4;
-        float* d = sX + r * PX + f0;
-        d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
-      }
-    }
+    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
     __syncthreads();
     if (it + 1 < nitems) issue(it + 1);
     // first conv as im2col GEMM: A[row][k] = x[row + k/40][k%40]

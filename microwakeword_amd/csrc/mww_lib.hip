@@ -148,6 +148,16 @@ struct mww_ctx {
   hipStream_t asm_stream = nullptr;
   hipEvent_t ev_xfree = nullptr, ev_asm = nullptr;
   bool asm_overlap = false, xfree_valid = false;
+  int asm_split = 2;        // workgroups per window of the assembly kernel ("assemble_split" option)
+  // "fused_input" option (default on, specialised MixedNet kernels only): mww_assemble_batch only uploads the window
+  // descriptors; the first block's forward / backward kernels gather their rows from the stores themselves
+  // (kernels_fwd.hip.h XGather).  x is materialised (assemble_kernel) only for a reader that needs it.
+  bool fused_input = true;
+  bool x_lazy = false;
+  int lazy_slot = -1;
+  AssembleArgs lazy_a;
+  const float* y_cur = nullptr;   // labels / sample weights the kernels read: the y / sw buffers, or the rows that
+  const float* sw_cur = nullptr;  // travelled in the mailbox of a descriptor-only batch
   // "bn_inline" option (default on): BN statistics travel through replicated fp64 accumulator rows and are folded by
   // their first consumer instead of by a finalize launch (off with sync-BN: the sums must be exchanged in between)
   bool bn_inline = true;
@@ -295,6 +305,47 @@ enum { BN_SCALE = 0, BN_SHIFT, BN_MEAN, BN_RSTD, BN_C1, BN_MG, BN_MGX };
 // ---------------------------------------------------------------------------------- sequences
 const float* mail_hyper(mww_ctx* c) { return reinterpret_cast<const float*>(c->mail_dev[c->mail_cur] + c->mail_off_hyper); }
 
+// labels / weights read in place from the mailbox of a descriptor-only batch -> the y / sw buffers (before that
+// mailbox slot can be rewritten)
+int bring_targets(mww_ctx* c) {
+  if (c->y_cur == c->y) return MWW_OK;
+  const size_t n = (size_t)c->lazy_a.B * sizeof(float);
+  HIPCHK(hipMemcpyAsync(c->y, c->y_cur, n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->sw, c->sw_cur, n, hipMemcpyDeviceToDevice, c->stream));
+  c->y_cur = c->y;
+  c->sw_cur = c->sw;
+  return MWW_OK;
+}
+
+// descriptor-only batch -> x, for readers outside the first block's kernels
+int materialise_x(mww_ctx* c) {
+  int rc = bring_targets(c);
+  if (rc || !c->x_lazy) return rc;
+  AssembleArgs a = c->lazy_a;
+  a.n_targets = 0;
+  Launcher lp{c};
+  lp.begin("assemble");
+  hipLaunchKernelGGL(assemble_kernel, dim3(a.B * a.split), dim3(kThreads), 0, c->stream, a);
+  lp.end();
+  HIPCHK(hipGetLastError());
+  c->x_lazy = false;
+  return MWW_OK;
+}
+
+XGather x_gather(mww_ctx* c) {
+  XGather g;
+  memset(&g, 0, sizeof(g));
+  if (!c->x_lazy) return g;
+  const AssembleArgs& a = c->lazy_a;
+  g.win = a.win;
+  g.masks = a.masks;
+  for (int i = 0; i < MWW_MAX_STORES; ++i) { g.store[i] = a.store[i]; g.dtype[i] = a.dtype[i]; }
+  g.ntm = a.ntm;
+  g.nfm = a.nfm;
+  g.T = a.T;
+  return g;
+}
+
 int join_side(mww_ctx* c) {
   if (c->side_pending) {
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -316,7 +367,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
       HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
     if (metrics) {
-      MetricsArgs ma{c->prob, c->y, c->metrics, B};
+      MetricsArgs ma{c->prob, c->y_cur, c->metrics, B};
       lp.begin("metrics");
       hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
       lp.end();
@@ -419,7 +470,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     }
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
-                     l.p, l.stat_part, B, d.frames, l.tout, 0, sacc};
+                     l.p, l.stat_part, B, d.frames, l.tout, 0, sacc, x_gather(c)};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
@@ -456,8 +507,8 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.rstd = bn_slot(ll, BN_RSTD);
   h.wd = c->params + c->o_dense_w;
   h.bd = c->params + c->o_dense_b;
-  h.y = (loss || metrics) ? c->y : nullptr;
-  h.sw = c->sw;
+  h.y = (loss || metrics) ? c->y_cur : nullptr;
+  h.sw = c->sw_cur;
   h.z = c->z;
   h.prob = c->prob;
   h.dz = c->dz;
@@ -584,7 +635,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       ht.fin = f;
       ht.dense = DenseGradArgs{l.p, bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
                                c->c_last, c->dwd_stride, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
-      ht.met = MetricsArgs{c->prob, c->y, c->metrics, B};
+      ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
       ht.n_fin = l.cout;
       ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
       ht.ndy = (B + dchunk - 1) / dchunk;
@@ -642,7 +693,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       if (last) return fail(MWW_ERR_UNSUPPORTED, "single-block models are not supported");
       BwdFirstArgs a{c->x, c->params + c->o_conv1, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf};
+                     c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf, x_gather(c)};
       lp.begin("bwd_block", i);
       int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, gbwd);
       lp.end();
@@ -927,8 +978,8 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   h.rstd = gbn_slot(lo, BN_RSTD);
   h.wd = c->params + c->o_dense_w;
   h.bd = c->params + c->o_dense_b;
-  h.y = (loss || metrics) ? c->y : nullptr;
-  h.sw = c->sw;
+  h.y = (loss || metrics) ? c->y_cur : nullptr;
+  h.sw = c->sw_cur;
   h.keep = drop ? c->keep : nullptr;
   h.z = c->z;
   h.prob = c->prob;
@@ -1243,6 +1294,8 @@ int flush_targets(mww_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->y, m + c->mail_off_y, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->sw, m + c->mail_off_sw, n, hipMemcpyHostToDevice, c->stream));
     c->targets_in_mail = 0;
+    c->y_cur = c->y;
+    c->sw_cur = c->sw;
   }
   return MWW_OK;
 }
@@ -1303,6 +1356,8 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->x, mb * d.frames * MWW_FEATURE_BINS));
   A(dev_alloc(&c->y, mb));
   A(dev_alloc(&c->sw, mb));
+  c->y_cur = c->y;
+  c->sw_cur = c->sw;
   A(dev_alloc(&c->z, mb));
   A(dev_alloc(&c->prob, mb));
   A(dev_alloc(&c->dz, mb));
@@ -1871,17 +1926,47 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
   a.T = T;
   a.ntm = ntm;
   a.nfm = nfm;
+  a.split = c->asm_split;
+  {
+    const int per_fwd = (B + std::min(B, c->grid_fwd) - 1) / std::min(B, c->grid_fwd);
+    const int per_bwd = (B + std::min(B, c->grid_bwd) - 1) / std::min(B, c->grid_bwd);
+    if (c->fused_input && !c->generic && T <= 32 * kXRowWords && nm <= kXMaxMasks && per_fwd <= kXMaxSamples && per_bwd <= kXMaxSamples) {
+      // descriptor-only batch: the first block's kernels gather from the stores (the labels / weights that
+      // arrived in this mailbox are read in place)
+      if (a.n_targets) {
+        c->y_cur = a.y_src;
+        c->sw_cur = a.sw_src;
+      } else {
+        int rcx = bring_targets(c);   // labels of an earlier descriptor-only batch stay valid past their mailbox slot
+        if (rcx) return rcx;
+      }
+      c->lazy_a = a;
+      c->x_lazy = true;
+      c->lazy_slot = c->mail_cur;
+      c->xfree_valid = false;
+      c->have_batch = B;
+      return MWW_OK;
+    }
+    if (a.n_targets) {   // the assembly kernel below brings this batch's labels / weights into y / sw
+      c->y_cur = c->y;
+      c->sw_cur = c->sw;
+    } else {
+      int rcx = bring_targets(c);
+      if (rcx) return rcx;
+    }
+    c->x_lazy = false;
+  }
   if (c->xfree_valid && c->asm_overlap && !c->profile) {
     c->xfree_valid = false;
     HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_copy[c->mail_cur], 0));
     HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_xfree, 0));
-    hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->asm_stream, a);
+    hipLaunchKernelGGL(assemble_kernel, dim3(B * a.split), dim3(kThreads), 0, c->asm_stream, a);
     HIPCHK(hipEventRecord(c->ev_asm, c->asm_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_asm, 0));
   } else {
     Launcher lp{c};
     lp.begin("assemble");
-    hipLaunchKernelGGL(assemble_kernel, dim3(B), dim3(kThreads), 0, c->stream, a);
+    hipLaunchKernelGGL(assemble_kernel, dim3(B * a.split), dim3(kThreads), 0, c->stream, a);
     lp.end();
   }
   HIPCHK(hipGetLastError());
@@ -1893,12 +1978,18 @@ int mww_set_batch(mww_ctx* c, const float* hx, int B) {
   if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   HIPCHK(hipSetDevice(c->device));
   c->xfree_valid = false;
-  int rc = copy_in(c, c->x, hx, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
+  int rc = bring_targets(c);
+  if (rc) return rc;
+  c->x_lazy = false;
+  rc = copy_in(c, c->x, hx, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
   if (!rc) c->have_batch = B;
   return rc;
 }
 int mww_get_batch(mww_ctx* c, float* hx, int B) {
   if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = materialise_x(c);
+  if (rc) return rc;
   return copy_out(c, hx, c->x, (size_t)B * c->d.frames * MWW_FEATURE_BINS * sizeof(float));
 }
 
@@ -1921,6 +2012,10 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
   HIPCHK(hipSetDevice(c->device));
   int rc = flush_targets(c);
   if (rc) return rc;
+  if (c->lazy_slot != c->mail_cur) {   // a descriptor-only batch is gathered in place only while its mailbox slot is current
+    rc = materialise_x(c);
+    if (rc) return rc;
+  }
   const bool apply = !(flags & MWW_STEP_NO_APPLY);
   if (apply) {
     c->step += 1;
@@ -1938,10 +2033,11 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     c->dropout_counter += 1;
   }
   if (c->use_graphs && !c->profile && !c->hook) {   // the exchange hook enqueues foreign work: no capture
-    const int mail = (apply || gen_dropout) ? c->mail_cur : -1;   // only the Adam / dropout nodes read the mailbox
+    // only the Adam / dropout nodes and the gather of a descriptor-only batch read the mailbox
+    const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = !c->generic && c->bn_inline;
-    const int par = flips ? (4 | c->fpar | (c->gpar << 1)) : 0;
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -1989,6 +2085,10 @@ int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
   c->xfree_valid = false;   // this forward reads x on the main stream: the next assembly must queue behind it
   int rc = flush_targets(c);
   if (rc) return rc;
+  if (c->lazy_slot != c->mail_cur) {
+    rc = materialise_x(c);
+    if (rc) return rc;
+  }
   rc = enqueue_forward(c, B, training != 0, false, false, update_metrics != 0);
   if (rc) return rc;
   rc = join_side(c);
@@ -2062,7 +2162,11 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
     else if ((k = gidx("bn")) >= 0) { src = c->G[k].bn; n = (int64_t)9 * c->G[k].cout; }
     else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
     else if (!strcmp(name, "keep")) { src = c->keep; n = (int64_t)B * c->t_last * c->c_last; }
-    else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
+    else if (!strcmp(name, "x")) {
+      if (materialise_x(c)) return -1;
+      src = c->x;
+      n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS;
+    }
     else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
     if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");
     int rcg = copy_out(c, host, src, (size_t)n * sizeof(float));
@@ -2098,6 +2202,11 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
   else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
+  else if (!strcmp(name, "fused_input")) {
+    c->fused_input = v != 0;
+    if (!v) { int rc = materialise_x(c); if (rc) return rc; }
+  }
+  else if (!strcmp(name, "assemble_split")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "assemble_split out of range"); c->asm_split = (int)v; }
   else if (!strcmp(name, "profile_split")) c->profile_split = v != 0;
   else if (!strcmp(name, "pointwise_bf16")) {
     if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");

@@ -902,3 +902,51 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
     for got in outs[1:]:
         for a, b in zip(ref, got):
             np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ fused input
+def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", kind="mixednet"):
+    """"fused_input" (descriptor-only batches: the first block's kernels gather, scale and mask their rows straight from
+    the feature stores) against the materialised x: the gathered values are the same floats, so parameters, outputs and
+    the batch read back afterwards are bit-identical.  Covers a second step on the same batch (the descriptors' mailbox
+    slot is no longer current: x is materialised), an evaluation forward, and labels set after the batch."""
+    from microwakeword_amd import mixednet
+    policy = dict(time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)
+    cfg = learnable_config(T=T)
+    if dtype == "f32":
+        for prov in cfg["features"]:
+            for mode, sets in prov["stores"].items():
+                prov["stores"][mode] = [[(s.astype(np.float32) * SCALE).astype(np.float32) for s in group] for group in sets]
+    results = []
+    for fused in (0, 1):
+        random.seed(4)
+        np.random.seed(4)
+        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=13, max_batch=B)
+        eng = model.engine
+        eng.set_option("fused_input", fused)
+        fh = FeatureHandler(cfg, engine=eng)
+        seen = []
+        for k in range(steps):
+            fh.next_training_batch_on_device(B, T, "default", policy)
+            eng.train_step(B, 1e-2)
+            seen.append(eng.read_outputs(B)[0].copy())
+            if k == 0:   # same batch again: its mailbox slot has moved on
+                eng.train_step(B, 1e-2)
+                seen.append(eng.read_outputs(B)[0].copy())
+            if k == 1:   # evaluation forward on a fresh batch, then the batch itself
+                fh.next_training_batch_on_device(B, T, "default", policy)
+                eng.forward(B, training=False, update_metrics=True)
+                seen.append(eng.read_outputs(B, want_loss=False)[0].copy())
+                seen.append(eng.get_batch(B).copy())
+            if k == 2:   # labels replaced after the batch was described
+                eng.set_targets(np.ones(B, np.float32), np.full(B, 0.5, np.float32))
+                eng.train_step(B, 1e-2)
+                seen.append(eng.read_outputs(B)[0].copy())
+        m = native.metrics_from_raw(eng.metrics_raw())
+        seen.append(np.concatenate([np.asarray(m["tp"], np.float64), np.asarray(m["fp"], np.float64), np.asarray(m["fn"], np.float64)]))
+        results.append((eng.get_params().copy(), eng.get_bn_state().copy(), seen))
+        eng.close()
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    np.testing.assert_array_equal(results[0][1], results[1][1])
+    for a, b in zip(results[0][2], results[1][2]):
+        np.testing.assert_array_equal(a, b)

@@ -138,6 +138,10 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline double unsafeAtomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline float __ldg(const float* p) { return *p; }
+static inline int hipemu_rfl(int v) { return v; }
+#define __builtin_amdgcn_readfirstlane hipemu_rfl
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float fmaxf_emu(float a, float b) { return a > b ? a : b; }

@@ -202,3 +202,8 @@ def test_assemble_overlap_is_schedule_only(emu_lib):
 
 def test_bn_inline_matches_finalize(emu_lib):
     ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)
+
+
+@pytest.mark.parametrize("dtype", ["u16", "f32"])
+def test_fused_input_is_bit_identical(emu_lib, dtype):
+    ec.check_fused_input(emu_lib, dtype=dtype)

@@ -322,3 +322,9 @@ def test_assemble_overlap_is_schedule_only(lib):
 def test_bn_inline_matches_finalize(lib):
     ec.check_bn_inline_matches_finalize(lib, B=96, T=194, steps=4)
     ec.check_bn_inline_matches_finalize(lib, B=5, T=194, steps=2)   # fewer workgroups than accumulator rows
+
+
+@pytest.mark.parametrize("dtype", ["u16", "f32"])
+def test_fused_input_is_bit_identical(lib, dtype):
+    ec.check_fused_input(lib, B=64, T=194, steps=4, dtype=dtype)
+    ec.check_fused_input(lib, B=5, T=100, steps=3, dtype=dtype)
