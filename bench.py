@@ -35,9 +35,13 @@ BYTES_PER_WINDOW_STEP = 793216  # fp32 algorithmic bytes per wind
 # per-kernel share of the §8(d) element accounting (elements per window, fp32 => x4 bytes); DESIGN.md §5
 P_ELEMS = {1: 188 * 48, 2: 180 * 48, 3: 168 * 48, 4: 148 * 48}
 X_ELEMS = 194 * 40
+# The first block's kernels gather their rows straight from the uint16 feature stores ("fused_input", the default):
+# x costs 2 B/elem there and no assembly kernel runs; with MWW_BENCH_FUSED_INPUT=0 the assembly kernel writes fp32 x.
+FUSED_INPUT = os.environ.get("MWW_BENCH_FUSED_INPUT", "1") != "0"
+X_READ = X_ELEMS // 2 if FUSED_INPUT else X_ELEMS   # in 4-byte units
 KERNEL_ELEMS = {
     "assemble": X_ELEMS // 2 + X_ELEMS,  # uint16 source read (2 B/elem) + fp32 write, in 4-byte units
-    "fwd_block1": X_ELEMS + P_ELEMS[1],
+    "fwd_block1": X_READ + P_ELEMS[1],
     "fwd_block2": P_ELEMS[1] + P_ELEMS[2],
     "fwd_block3": P_ELEMS[2] + P_ELEMS[3],
     "fwd_block4": P_ELEMS[3] + P_ELEMS[4],
@@ -45,7 +49,7 @@ KERNEL_ELEMS = {
     "bwd_block4": P_ELEMS[3] + P_ELEMS[4] + P_ELEMS[3],              # R p3, R p4, W g3
     "bwd_block3": P_ELEMS[2] + P_ELEMS[3] + P_ELEMS[3] + P_ELEMS[2],  # R p2, R p3, R g3, W g2
     "bwd_block2": P_ELEMS[1] + P_ELEMS[2] + P_ELEMS[2] + P_ELEMS[1],
-    "bwd_block1": X_ELEMS + P_ELEMS[1] + P_ELEMS[1],                  # R x, R p1, R g1
+    "bwd_block1": X_READ + P_ELEMS[1] + P_ELEMS[1],                   # R x, R p1, R g1
 }
 
 
@@ -96,13 +100,13 @@ def inception_kernel_elems(layout):
 
 
 def pmc_traffic(kernel, model):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round1_k_*:
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round1_m_*:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run of `bench.py --no-graphs`), corrected
     as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE (KB) counts half the bytes of wide coalesced
     reads -> x2; WRITE_SIZE (KB) as reported.  Returns (bytes, source) or (None, None).  The counters cannot be
     read from inside this process; the figure belongs to the kernel binary profiled at the end of the round."""
     import re
-    path = os.path.join(ROOT, "profiles", "round1_k_kernel_stats_and_pmc.txt")
+    path = os.path.join(ROOT, "profiles", "round1_m_kernel_stats_and_pmc.txt")
     if model != "mixednet" or not os.path.isfile(path):
         return None, None
     want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
@@ -120,7 +124,7 @@ def pmc_traffic(kernel, model):
             write = float(m.group(1)) if m else write
     if fetch is None or write is None:
         return None, None
-    return int(2 * fetch * 1024 + write * 1024), "profiles/round1_k_kernel_stats_and_pmc.txt (FETCH_SIZE x2 + WRITE_SIZE, KB)"
+    return int(2 * fetch * 1024 + write * 1024), "profiles/round1_m_kernel_stats_and_pmc.txt (FETCH_SIZE x2 + WRITE_SIZE, KB)"
 
 
 def parse_args():

@@ -149,8 +149,18 @@ struct XStage {
     if (tid >= ACT) return;
     const bool gather = g.win != nullptr;
     const bool u16 = gather && uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
-    unsigned cm = 0u;
-    if (gather) cm = (sh.colbits[s][(4 * q) >> 5] >> ((4 * q) & 31)) & 0xfu;
+    // mask words of this thread's rows are fetched together (one LDS round trip), then applied without branches
+    unsigned cm = 0u, rb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rb[j] = 0u;
+    if (gather) {
+      cm = (sh.colbits[s][(4 * q) >> 5] >> ((4 * q) & 31)) & 0xfu;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int t = min(row0 + rq + RPP * j, g.T - 1);   // rows past the window are zero already
+        rb[j] = sh.rowbits[s][t >> 5] >> (t & 31);
+      }
+    }
     float* dst = sX + rq * PX + q * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -165,12 +175,11 @@ struct XStage {
           v.w = (float)(hi >> 16) * 0.0390625f;
         }
         if (gather) {
-          const int t = row0 + r;
-          const unsigned m4 = (t < g.T && ((sh.rowbits[s][t >> 5] >> (t & 31)) & 1u)) ? 0xfu : cm;
-          if (m4 & 1u) v.x = 0.f;
-          if (m4 & 2u) v.y = 0.f;
-          if (m4 & 4u) v.z = 0.f;
-          if (m4 & 8u) v.w = 0.f;
+          const unsigned m4 = (rb[j] & 1u) ? 0xfu : cm;
+          v.x = (m4 & 1u) ? 0.f : v.x;
+          v.y = (m4 & 2u) ? 0.f : v.y;
+          v.z = (m4 & 4u) ? 0.f : v.z;
+          v.w = (m4 & 8u) ? 0.f : v.w;
         }
         float* d = dst + RPP * j * PX;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
