@@ -167,7 +167,9 @@ typedef struct {
   int64_t src_elem;   /* element offset of the first copied frame inside the store */
 } mww_window;
 /* masks: [B][n_time_masks + n_freq_masks][2] = (start, width); time masks first.
- * Writes x[B][T][40] float32 into the context's batch buffer. */
+ * Defines x[B][T][40] float32 of the context's batch buffer.  With the "fused_input" option (default for the
+ * specialised MixedNet kernels) only the descriptors are uploaded and the first block's kernels read the stores;
+ * the buffer itself is filled when a reader outside those kernels needs it (mww_get_batch, mww_debug_read "x"). */
 int mww_assemble_batch(mww_ctx* ctx, const mww_window* windows, const int32_t* masks, int B, int n_time_masks,
                        int n_freq_masks);
 /* ready-made batch: the `x` argument of Keras train_on_batch / evaluate (train.py:295-299,50-58) */
@@ -232,7 +234,13 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
 
 /* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head", "grid_graph",
  * "dropout_seed", "pointwise_bf16" (0 = exact fp32 MFMA, the default; 1 = the MixedNet 1x1 convolutions and
- * their two backward contractions take bf16-rounded operands with fp32 accumulation — BASELINE configs[4]) */
+ * their two backward contractions take bf16-rounded operands with fp32 accumulation — BASELINE configs[4]),
+ * "fused_input" (default 1, specialised MixedNet kernels: mww_assemble_batch uploads descriptors only and the first
+ * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
+ * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of
+ * by finalize launches; forced off by the sync-BN exchange hook), "assemble_split" (workgroups per window of the
+ * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's
+ * gradient reduction — measured slower), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing of the last N steps measured with HIP events on the context's stream:
