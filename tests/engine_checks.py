@@ -905,7 +905,7 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
 
 
 # ------------------------------------------------------------------------------------------ fused input
-def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", kind="mixednet"):
+def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", graphs=False):
     """"fused_input" (descriptor-only batches: the first block's kernels gather, scale and mask their rows straight from
     the feature stores) against the materialised x: the gathered values are the same floats, so parameters, outputs and
     the batch read back afterwards are bit-identical.  Covers a second step on the same batch (the descriptors' mailbox
@@ -924,6 +924,7 @@ def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", kind="mixednet"):
         model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=13, max_batch=B)
         eng = model.engine
         eng.set_option("fused_input", fused)
+        eng.set_option("graphs", 1 if (graphs and fused) else 0)   # captured steps bake the mailbox slot of the descriptors
         fh = FeatureHandler(cfg, engine=eng)
         seen = []
         for k in range(steps):

@@ -207,3 +207,7 @@ def test_bn_inline_matches_finalize(emu_lib):
 @pytest.mark.parametrize("dtype", ["u16", "f32"])
 def test_fused_input_is_bit_identical(emu_lib, dtype):
     ec.check_fused_input(emu_lib, dtype=dtype)
+
+
+def test_fused_input_through_captured_graphs(emu_lib):
+    ec.check_fused_input(emu_lib, steps=12, graphs=True)   # more steps than mailbox slots: every slot's graph is replayed

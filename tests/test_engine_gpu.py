@@ -328,3 +328,7 @@ def test_bn_inline_matches_finalize(lib):
 def test_fused_input_is_bit_identical(lib, dtype):
     ec.check_fused_input(lib, B=64, T=194, steps=4, dtype=dtype)
     ec.check_fused_input(lib, B=5, T=100, steps=3, dtype=dtype)
+
+
+def test_fused_input_through_captured_graphs(lib):
+    ec.check_fused_input(lib, B=64, T=194, steps=20, graphs=True)

@@ -17,6 +17,9 @@ echo "== bench inception"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; tail -c 400 $OUT/bench_inception.json | head -c 400; echo
 echo "== bench bf16-operand"
 timeout 900 python bench.py --pointwise-bf16 --no-cpu-baseline --no-validation > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; head -c 300 $OUT/bench_bf16.json; echo
+echo "== collective path forced on one GPU (RCCL world of one): local-BN, sync-BN"
+MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation --profile-steps 0 2> $OUT/bench_dp.err | tee $OUT/bench_dp.json | head -c 300; echo
+MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --sync-bn --no-cpu-baseline --no-validation --profile-steps 0 2> $OUT/bench_dp_sync.err | tee $OUT/bench_dp_sync.json | head -c 300; echo
 echo "== rocprofv3"
 export TMPDIR=/tmp
 B="python $R/bench.py --steps 6 --warmup 2 --no-graphs --no-cpu-baseline --no-validation --profile-steps 0"
