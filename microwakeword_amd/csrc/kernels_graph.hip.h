@@ -274,6 +274,8 @@ struct GWgradArgs {
   float* grad_part;     // [grid * nq][k*cin*NC]
 };
 
+constexpr int kGWgChunk = 4;   // output channels per pass of the in-workgroup reduction over the frame subsets
+
 template <int NC>
 __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
@@ -315,8 +317,32 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       }
     }
   }
-  if (active) {
-    float* dst = a.grad_part + ((size_t)bid * nq + q) * ((size_t)tasks * NC) + (size_t)task * NC;
+  // sum over the frame subsets inside the workgroup (fixed order), kGWgChunk output channels at a time through
+  // LDS: one partial row per workgroup instead of nq of them (the rows are what grad_reduce_kernel has to read)
+  if (nq > 1) {
+    float* sQ = g_smem;   // [nq][tasks][kGWgChunk]
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += kGWgChunk) {
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int u = 0; u < kGWgChunk; ++u)
+          if (c0 + u < NC) sQ[(q * tasks + task) * kGWgChunk + u] = acc[c0 + u];
+      }
+      __syncthreads();
+      if (active && q == 0) {
+#pragma unroll
+        for (int u = 0; u < kGWgChunk; ++u)
+          if (c0 + u < NC) {
+            float v = 0.f;
+            for (int qq = 0; qq < nq; ++qq) v += sQ[(qq * tasks + task) * kGWgChunk + u];
+            acc[c0 + u] = v;
+          }
+      }
+    }
+  }
+  if (active && q == 0) {
+    float* dst = a.grad_part + (size_t)bid * ((size_t)tasks * NC) + (size_t)task * NC;
 #pragma unroll
     for (int co = 0; co < NC; ++co) dst[co] = acc[co];
   }
@@ -658,7 +684,24 @@ struct GHeadArgs {
   int training;
   const float *rp, *rscale, *rshift;   // residual branch of the last op (see GSrc), or null
   int rT, rdrop;
+  // keep_gen set: this step's dropout mask is generated here (and written to keep_gen for the dense-weight gradient)
+  float* keep_gen;
+  unsigned long long seed;
+  const unsigned* counter;   // [2] low / high word of this step's counter (mapped mailbox)
+  float rate;
 };
+
+// Dropout keep value of element e in step `step`: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).
+// (Keras draws its mask from a stateful generator that is not reproducible across frameworks; the parity tests
+// inject an explicit mask instead.)
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long step, unsigned long long e, float rate) {
+  unsigned long long h = seed * 0x9E3779B97F4A7C15ull + step * 0xD1B54A32D192ED03ull + e;
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 27; h *= 0x94D049BB133111EBull;
+  h ^= h >> 31;
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+  return u >= rate ? 1.0f / (1.0f - rate) : 0.f;
+}
 
 __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   __shared__ float sRed[8];
@@ -677,14 +720,24 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     const float* pb = a.p + (size_t)b * n;
     const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
     const float* rb = a.rp ? a.rp + ((size_t)b * a.rT + a.rdrop) * C : nullptr;
+    float* kgen = a.keep_gen ? a.keep_gen + (size_t)b * n : nullptr;
     float dot = 0.f;
     if (active) {
+      const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
       for (int t = rg; t < a.T; t += nrg) {
         const int i = t * C + c;
         const float act = fmaxf(fmaf(pb[i], sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f), 0.f);
-        dot = fmaf(kb ? act * kb[i] : act, a.wd[i], dot);
+        float kv = 1.f;
+        if (kgen) {
+          kv = dropout_keep(a.seed, step, (unsigned long long)b * n + i, a.rate);
+          kgen[i] = kv;   // read back by this thread in the backward part below and by the dense-weight gradient
+        } else if (kb) {
+          kv = kb[i];
+        }
+        dot = fmaf((kgen || kb) ? act * kv : act, a.wd[i], dot);
       }
     }
+    if (kgen) kb = kgen;
     dot = wave_sum(dot);
     if (lane == 0) sRed[wave] = dot;
     __syncthreads();
@@ -910,9 +963,7 @@ __global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
   }
 }
 
-// Dropout keep-mask of one step: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).
-// (Keras draws its mask from a stateful generator that is not reproducible across frameworks; the
-// parity tests inject an explicit mask instead.)
+// Dropout keep-mask of one step as its own launch (the attention / pooled heads; ghead_kernel generates it inline)
 struct DropoutMaskArgs {
   float* keep;
   long long n;
@@ -924,12 +975,7 @@ __global__ __launch_bounds__(kThreads) void dropout_mask_kernel(DropoutMaskArgs 
   const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (e >= a.n) return;
   const unsigned long long step = ((unsigned long long)a.counter[1] << 32) | a.counter[0];
-  unsigned long long h = a.seed * 0x9E3779B97F4A7C15ull + step * 0xD1B54A32D192ED03ull + (unsigned long long)e;
-  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
-  h ^= h >> 27; h *= 0x94D049BB133111EBull;
-  h ^= h >> 31;
-  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
-  a.keep[e] = u >= a.rate ? 1.0f / (1.0f - a.rate) : 0.f;
+  a.keep[e] = dropout_keep(a.seed, step, (unsigned long long)e, a.rate);
 }
 
 }  // namespace mww

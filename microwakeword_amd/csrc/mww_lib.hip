@@ -366,7 +366,8 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
       HIPCHK(hipEventRecord(c->ev_fork, c->stream));
       HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
-    if (metrics) {
+    const bool one_launch = metrics && loss && inline_side;   // both pieces as roles of one launch (head_tail_kernel without a finalize role)
+    if (metrics && !one_launch) {
       MetricsArgs ma{c->prob, c->y_cur, c->metrics, B};
       lp.begin("metrics");
       hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
@@ -385,9 +386,23 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
         dg.rT = rr.tout;
         dg.rdrop = c->G.back().res_drop;
       }
-      lp.begin("dense_grad");
-      hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
-      lp.end();
+      if (one_launch) {
+        HeadTailArgs ht;
+        memset(&ht, 0, sizeof(ht));
+        ht.dense = dg;
+        ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
+        ht.n_fin = 0;
+        ht.ndx = (dg.n + 1 + kThreads - 1) / kThreads;
+        ht.ndy = ndchunks;
+        ht.do_metrics = 1;
+        lp.begin("dense_grad+metrics");
+        hipLaunchKernelGGL(head_tail_kernel, dim3(ht.ndx * ht.ndy + 1), dim3(kThreads), 0, ss, ht);
+        lp.end();
+      } else {
+        lp.begin("dense_grad");
+        hipLaunchKernelGGL(dense_grad_kernel, dim3((dg.n + 1 + kThreads - 1) / kThreads, ndchunks), dim3(kThreads), 0, ss, dg);
+        lp.end();
+      }
     }
     if (!inline_side) {
       HIPCHK(hipEventRecord(c->ev_join, c->side));
@@ -961,7 +976,8 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   }
   GOp& lo = c->G[n - 1];
   const bool drop = loss && c->dropout > 0.f;   // Dropout is active in the train step only (Keras training=True)
-  if (drop && !c->keep_explicit) {
+  const bool gen_inline = drop && !c->keep_explicit && !c->head2;   // ghead_kernel draws the mask itself
+  if (drop && !c->keep_explicit && !gen_inline) {
     const long long ne = (long long)B * c->t_last * c->c_last;
     DropoutMaskArgs dm{c->keep, ne, c->dropout_seed, reinterpret_cast<const unsigned*>(mail_hyper(c)) + 2, c->dropout};
     lp.begin("dropout_mask");
@@ -980,7 +996,13 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   h.bd = c->params + c->o_dense_b;
   h.y = (loss || metrics) ? c->y_cur : nullptr;
   h.sw = c->sw_cur;
-  h.keep = drop ? c->keep : nullptr;
+  h.keep = (drop && !gen_inline) ? c->keep : nullptr;
+  if (gen_inline) {
+    h.keep_gen = c->keep;
+    h.seed = c->dropout_seed;
+    h.counter = reinterpret_cast<const unsigned*>(mail_hyper(c)) + 2;
+    h.rate = c->dropout;
+  }
   h.z = c->z;
   h.prob = c->prob;
   h.dz = c->dz;
@@ -1091,7 +1113,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     GOp& q = c->G[oi];
     GradSegment s;
     s.part = q.grad_part;
-    s.G = gg * q.nq;
+    s.G = gg;
     s.stride = q.k * q.cin * q.cout;
     s.n = s.stride;
     s.dst = (int)q.o_w;
@@ -1234,7 +1256,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     GradSegment s;
     s.part = o.grad_part;
-    s.G = gg * o.nq;
+    s.G = gg;
     s.stride = o.k * o.cin * o.cout;
     s.n = s.stride;
     s.dst = (int)o.o_w;
@@ -1584,6 +1606,7 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
       o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
       o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
+      o.lds_wg = std::max(o.lds_wg, (size_t)kThreads * kGWgChunk * sizeof(float));   // scratch of the reduction over the frame subsets
       if (!o.needs_dx) o.lds_dx = 0;
     }
     if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > kMaxDynLds) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the LDS tile");
@@ -1717,7 +1740,7 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     A(dev_alloc(&o.g, mb * o.tout * o.cout));
     A(dev_alloc(&o.stat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
-    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.nq * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));
+    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));
     A(dev_alloc(&o.bn, (size_t)9 * o.cout));
     if (o.norm == MWW_NORM_BN) bn.push_back(BnSlots{o.o_gamma, o.o_beta, o.o_mv, o.slots});
     else if (o.norm == MWW_NORM_BIAS) bn.push_back(BnSlots{o.o_beta, o.o_beta, -1, o.cout});   // bias gradient is written directly too
