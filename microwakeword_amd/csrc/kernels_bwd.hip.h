@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           if (sl < rows_da) {
             const float raw = sP[sl * CPI + c];
             const float gg = fmaf(raw, sc_c, sh_c) > 0.f ? da[t] : 0.f;
-            gtile[sl * CIN + c] = gg;
+            store_stream(gtile + sl * CIN + c, gg);
             gs1 += gg;
             gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
           }

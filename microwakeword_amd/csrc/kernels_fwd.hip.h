@@ -329,7 +329,7 @@ __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = acc[nt][r];
-        out_rows[(size_t)(row0 + g * 4 + r) * COUT + nt * 16 + r16] = v;
+        store_stream(out_rows + (size_t)(row0 + g * 4 + r) * COUT + nt * 16 + r16, v);
         s1[nt] += v;
         s2[nt] = fmaf(v, v, s2[nt]);
       }
@@ -341,7 +341,7 @@ __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* 
         const int row = row0 + g * 4 + r;
         const float v = acc[nt][r];
         if (row < rows_valid) {
-          out_rows[(size_t)row * COUT + nt * 16 + r16] = v;
+          store_stream(out_rows + (size_t)row * COUT + nt * 16 + r16, v);
           s1[nt] += v;
           s2[nt] = fmaf(v, v, s2[nt]);
         }
