@@ -951,3 +951,45 @@ def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", graphs=False):
     np.testing.assert_array_equal(results[0][1], results[1][1])
     for a, b in zip(results[0][2], results[1][2]):
         np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ gather fuzz
+def check_gather_fuzz(lib, cases=8, first=0, notebook=False):
+    """The gather stage inside the first block's kernels (fused_input) against the materialised x on random feature
+    sets / policies / strategies (random_data_case: ragged lengths around T, uint16 and float32 stores, 0..3 masks of
+    0..12 frames / bins per kind): evaluation outputs and the flat gradient of a train step are bit-identical."""
+    flags = NOTEBOOK if notebook else DEF
+    for case in range(first, first + cases):
+        T, provs, policy, B, strategy = random_data_case(case)
+        if notebook:
+            T = 204
+        cfg = {"stride": 1, "window_step_ms": 10, "features": [
+            dict(type="mmap", stores={"training": [p["store"]]}, truth=p["truth"], sampling_weight=p["sampling_weight"],
+                 penalty_weight=p["penalty_weight"], truncation_strategy=p["truncation_strategy"],
+                 fixed_right_cutoffs=p["fixed_right_cutoffs"]) for p in provs]}
+        lay = MixedNetLayout(flags, T)
+        om = mo.OracleModel("mixednet", flags, T, seed=case)
+        p0, s0 = lay.pack(om.get_weights())
+        outs = []
+        for fused in (0, 1):
+            random.seed(case)
+            np.random.seed(case)
+            eng = native.Engine(lib=lib, **lay.engine_args(B))
+            eng.set_grad_mask(lay.grad_mask())
+            eng.set_params(p0)
+            eng.set_bn_state(s0)
+            eng.set_option("fused_input", fused)
+            fh = FeatureHandler(cfg, engine=eng)
+            got = []
+            for _ in range(2):
+                fh.next_training_batch_on_device(B, T, strategy, policy)
+                eng.forward(B, training=False)
+                got.append(eng.read_outputs(B, want_loss=False)[0].copy())
+                fh.next_training_batch_on_device(B, T, strategy, policy)
+                eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
+                got.append(eng.get_grads().copy())
+                got.append(eng.read_outputs(B)[0].copy())
+            outs.append(got)
+            eng.close()
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b, err_msg="case %d" % case)

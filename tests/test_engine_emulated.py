@@ -211,3 +211,8 @@ def test_fused_input_is_bit_identical(emu_lib, dtype):
 
 def test_fused_input_through_captured_graphs(emu_lib):
     ec.check_fused_input(emu_lib, B=4, steps=9, graphs=True)   # more steps than mailbox slots (8): a slot's graph is replayed
+
+
+def test_gather_fuzz(emu_lib):
+    ec.check_gather_fuzz(emu_lib, cases=1, first=11)   # the short-window cases of the fuzz (the GPU suite runs 46)
+    ec.check_gather_fuzz(emu_lib, cases=1, first=5)

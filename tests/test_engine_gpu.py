@@ -332,3 +332,8 @@ def test_fused_input_is_bit_identical(lib, dtype):
 
 def test_fused_input_through_captured_graphs(lib):
     ec.check_fused_input(lib, B=64, T=194, steps=20, graphs=True)
+
+
+def test_gather_fuzz(lib):
+    ec.check_gather_fuzz(lib, cases=150)
+    ec.check_gather_fuzz(lib, cases=20, first=200, notebook=True)
