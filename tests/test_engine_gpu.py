@@ -322,6 +322,8 @@ def test_assemble_overlap_is_schedule_only(lib):
 def test_bn_inline_matches_finalize(lib):
     ec.check_bn_inline_matches_finalize(lib, B=96, T=194, steps=4)
     ec.check_bn_inline_matches_finalize(lib, B=5, T=194, steps=2)   # fewer workgroups than accumulator rows
+    ec.check_bn_inline_matches_finalize(lib, B=1024, T=194, steps=3)
+    ec.check_bn_inline_matches_finalize(lib, B=33, T=204, steps=3, flags=ec.NOTEBOOK)
 
 
 @pytest.mark.parametrize("dtype", ["u16", "f32"])
