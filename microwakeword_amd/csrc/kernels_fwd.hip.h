@@ -1,10 +1,12 @@
 // Forward kernels of the MixedNet train step (reference graph: microwakeword/mixednet.py:307-386).
 //
-//   fwd_first_kernel : x -> Conv2D(K1x1, valid, no bias) -> ReLU -> DepthwiseConv(Kx1)+bias
-//                        -> 1x1 Conv -> p_1 (pre-BN) + per-workgroup (sum, sum^2) partials
+//   fwd_first_kernel : x (dense, or gathered from the feature stores: XGather / XStage below) -> Conv2D(K1x1, valid,
+//                      no bias) -> ReLU -> DepthwiseConv(Kx1)+bias -> 1x1 Conv -> p_1 (pre-BN) + (sum, sum^2) of p_1
 //                      (mixednet.py:317-331 then :209-211 and :349-351; no BN in between, so one kernel)
-//   fwd_block_kernel : p_{k-1} -> [BN_{k-1} + ReLU on load] -> Depthwise(Kx1)+bias -> 1x1 -> p_k + partials
+//   fwd_block_kernel : p_{k-1} -> [BN_{k-1} + ReLU on load] -> Depthwise(Kx1)+bias -> 1x1 -> p_k + its sums
 //                      (mixednet.py:352,360 of block k-1, then :209-211,:349-351 of block k)
+//   The sums leave a kernel either as fp64 atomic adds to replicated accumulator rows, folded by the next kernel's
+//   prologue (common.hip.h "BN statistics hand-over"; the default), or as per-workgroup partial rows for
 //   bn_fwd_finalize_kernel : partials -> batch mean / biased variance -> folded scale/shift,
 //                      saved mean/rstd for backward, Keras moving-average update
 //   bn_eval_prepare_kernel : moving stats -> folded scale/shift (inference)
