@@ -238,7 +238,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * "fused_input" (default 1, specialised MixedNet kernels: mww_assemble_batch uploads descriptors only and the first
  * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
  * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of
- * by finalize launches; forced off by the sync-BN exchange hook), "assemble_split" (workgroups per window of the
+ * by finalize launches; forced off by the sync-BN exchange hook), "tail_roles" (default 1, with bn_inline: the dense-weight
+ * gradient and the metric update ride in the gradient-reduction launch), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's
  * gradient reduction — measured slower), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);

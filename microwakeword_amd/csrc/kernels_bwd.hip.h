@@ -702,7 +702,7 @@ struct GradReduceArgs {
 };
 
 // grid = (ceil(maxn/256), nseg, kGradSplit)
-__global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a) {
+__device__ __forceinline__ void grad_reduce_body(const GradReduceArgs& a) {
   const GradSegment s = a.seg[blockIdx.y];
   const int e = blockIdx.x * kThreads + threadIdx.x;
   if (e >= s.n) return;
@@ -720,6 +720,8 @@ __global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a)
   }
   a.stage[(size_t)js * a.P + s.dst + e] = acc;
 }
+
+__global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a) { grad_reduce_body(a); }
 
 // flat gradient = mask * sum of the staged slices (BN gamma/beta slots are written by
 // bn_bwd_finalize_kernel and flagged by direct[p] != 0)

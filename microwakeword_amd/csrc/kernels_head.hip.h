@@ -39,6 +39,7 @@ struct HeadArgs {
   float inv_b;
   int training;
   BnFoldArgs fold;         // fold.acc set: BN_L's scale / shift / mean / rstd are folded here from the accumulator rows
+  StatAcc gacc;            // gacc.acc set: the (sum g, sum g*xhat) partials go to accumulator rows instead of gstat_part
 };
 
 template <int C, int JMAX>
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
     if (tid < 2 * C) {
       float v = 0.f;
       for (int r = 0; r < NRG; ++r) v += sStat[r * 2 * C + tid];
-      a.gstat_part[(size_t)blockIdx.x * 2 * C + tid] = v;
+      publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * C, 2 * C, tid, v);
     }
   }
 }

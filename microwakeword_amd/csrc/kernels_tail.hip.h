@@ -34,4 +34,31 @@ __global__ __launch_bounds__(kThreads) void head_tail_kernel(HeadTailArgs a) {
   }
 }
 
+// MixedNet train step with the statistics hand-over: the dense-weight gradient and the metric update have no
+// consumer before the gradient finish, so they ride in the gradient-reduction launch as extra z-slices of its grid
+// (slices [0, kGradSplit) reduce the weight-gradient partials; the blocks of the slices above are numbered linearly:
+// ndx * kGradSplit dense-gradient tiles, then one metric workgroup).  The dense tiles write their batch-chunk sums
+// straight into the staging slices the finish kernel adds up (chunk by = slice by), so no partial rows and no segment.
+struct GradReduceTailArgs {
+  DenseGradArgs dense;   // part = stage + offset of the dense kernel, stride = P, chunk = ceil(B / kGradSplit)
+  MetricsArgs met;
+  int ndx;
+  int do_metrics;
+};
+
+__global__ __launch_bounds__(kThreads) void grad_reduce_tail_kernel(GradReduceArgs a, GradReduceTailArgs t) {
+  __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
+  __shared__ unsigned sH101[2][101];
+  __shared__ unsigned sH200[2][200];
+  __shared__ unsigned sCnt[8];
+  if ((int)blockIdx.z < kGradSplit) {
+    grad_reduce_body(a);
+    return;
+  }
+  const int id = (((int)blockIdx.z - kGradSplit) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+  const int n_dense = t.ndx * kGradSplit;
+  if (id < n_dense) dense_grad_body(t.dense, id % t.ndx, id / t.ndx, threadIdx.x);
+  else if (id == n_dense && t.do_metrics) metrics_body<kThreads>(t.met, sH101, sH200, sCnt, sAcc, threadIdx.x);
+}
+
 }  // namespace mww

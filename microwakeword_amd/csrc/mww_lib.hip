@@ -163,6 +163,8 @@ struct mww_ctx {
   bool bn_inline = true;
   int fpar = 0, gpar = 0;   // accumulator parity of the next training forward / backward
   bool tail_pending = false, tail_metrics = false;   // dense gradient (+ metrics) ride in the first backward launch
+  bool tail_in_reduce = false;   // ... or, with the statistics hand-over, in the gradient-reduction launch ("tail_roles" option)
+  bool tail_roles = true;
   void* store[MWW_MAX_STORES] = {};
   int store_dtype[MWW_MAX_STORES] = {};
   int64_t store_elems[MWW_MAX_STORES] = {};
@@ -535,11 +537,25 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.training = loss ? 1 : 0;
   h.fold = fold_of(ll);
   if (inl) c->fpar ^= 1;
+  // train step with the statistics hand-over: BN_L's backward sums go to accumulator rows (folded by the last block's
+  // backward kernel) and the dense-weight gradient / metric update ride in the gradient-reduction launch
+  const bool tail_late = loss && inl && c->tail_roles;
+  h.gacc = StatAcc{nullptr, nullptr};
+  if (tail_late) {
+    h.gacc.acc = ll.gacc[c->gpar];
+    h.gacc.clear = ll.gacc[c->gpar ^ 1];
+    ll.gacc_cur = h.gacc.acc;
+  }
   const int q = ll.cout / 4, nrg = kThreads / q;
   lp.begin("head");
   int rc = launch_head(c, ll.cout, (ll.tout + nrg - 1) / nrg, h, ghead);
   lp.end();
   if (rc) return rc;
+  if (tail_late) {
+    c->tail_in_reduce = true;
+    c->tail_metrics = metrics;
+    return MWW_OK;
+  }
   if (loss && !(c->hook && c->sync_bn)) {
     // train step: the dense-weight gradient and the metric update share the launch of the last block's
     // BN-backward finalize (head_tail_kernel, first thing in enqueue_backward)
@@ -565,7 +581,9 @@ int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam)
   }
   const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
   const int ndchunks = (B + dchunk - 1) / dchunk;
-  {
+  const bool tail_here = c->tail_in_reduce;
+  c->tail_in_reduce = false;
+  if (!tail_here) {
     GradSegment s;
     s.part = c->dwd_part;
     s.G = ndchunks;
@@ -578,10 +596,28 @@ int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam)
   for (int i = 0; i < ga.nseg; ++i) maxn = std::max(maxn, ga.seg[i].n);
   ga.stage = c->stage;
   ga.P = (int)c->P;
-  lp.begin("grad_reduce");
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ga.nseg, kGradSplit), dim3(kThreads), 0,
-                     c->stream, ga);
-  lp.end();
+  if (tail_here) {
+    static_assert(kDenseChunks == kGradSplit, "the dense-gradient chunks are the staging slices");
+    Layer& ll = c->L[c->d.n_blocks - 1];
+    GradReduceTailArgs t;
+    memset(&t, 0, sizeof(t));
+    t.dense = DenseGradArgs{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->stage + c->o_dense_w, B, c->t_last * c->c_last,
+                            c->c_last, (int)c->P, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    t.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
+    t.ndx = (t.dense.n + 1 + kThreads - 1) / kThreads;
+    t.do_metrics = c->tail_metrics ? 1 : 0;
+    const int gx = (maxn + kThreads - 1) / kThreads, gy = ga.nseg;
+    const int n_role = t.ndx * kGradSplit + t.do_metrics;
+    const int gz = kGradSplit + (n_role + gx * gy - 1) / (gx * gy);
+    lp.begin("grad_reduce+tail");
+    hipLaunchKernelGGL(grad_reduce_tail_kernel, dim3(gx, gy, gz), dim3(kThreads), 0, c->stream, ga, t);
+    lp.end();
+  } else {
+    lp.begin("grad_reduce");
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ga.nseg, kGradSplit), dim3(kThreads), 0,
+                       c->stream, ga);
+    lp.end();
+  }
   GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
   if (fuse_adam && c->hook && c->reduce_grads) {
     // complete data-parallel step: local gradient -> sum over the ranks -> Adam on the average
@@ -618,7 +654,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     const bool last = (i == nb - 1);
     // BN_i's backward sums: the last block's come from the head kernel's partial rows (folded by head_tail);
     // the others arrive in accumulator rows and are folded by this block's backward kernel
-    const bool fold_here = inl && !last;
+    const bool fold_here = inl && (!last || c->tail_in_reduce);
     StatSource ss{nullptr, 0, 0.f, 1.0f};
     if (!fold_here) {
       int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, l.gstat_part, last ? ghead : gbwd, l.cout, 1,
@@ -2060,7 +2096,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = !c->generic && c->bn_inline;
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2225,6 +2261,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
   else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
+  else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;
   else if (!strcmp(name, "fused_input")) {
     c->fused_input = v != 0;
     if (!v) { int rc = materialise_x(c); if (rc) return rc; }

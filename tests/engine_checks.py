@@ -879,12 +879,13 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
     lay = MixedNetLayout(flags, T)
     p0, s0 = lay.pack(om.get_weights())
     outs = []
-    for inline, graphs in ((0, 0), (1, 0), (1, 1)):
+    for inline, graphs, tail in ((0, 0, 0), (1, 0, 0), (1, 0, 1), (1, 1, 1)):
         eng = native.Engine(lib=lib, **lay.engine_args(B))
         eng.set_grad_mask(lay.grad_mask())
         eng.set_params(p0)
         eng.set_bn_state(s0)
         eng.set_option("bn_inline", inline)
+        eng.set_option("tail_roles", tail)   # dense-weight gradient + metrics inside the gradient-reduction launch
         eng.set_option("graphs", graphs)
         probs = []
         for k in range(steps):
@@ -896,7 +897,9 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
                 eng.set_batch(x[steps])
                 eng.forward(B, training=True)
                 probs.append(eng.read_outputs(B, want_loss=False)[0].copy())
-        outs.append((eng.get_params().copy(), eng.get_bn_state().copy(), np.concatenate(probs), eng.get_grads().copy()))
+        m = native.metrics_from_raw(eng.metrics_raw())
+        counts = np.concatenate([np.asarray(m[k], np.float64).ravel() for k in ("tp", "fp", "fn", "tn")])
+        outs.append((eng.get_params().copy(), eng.get_bn_state().copy(), np.concatenate(probs), eng.get_grads().copy(), counts))
         eng.close()
     ref = outs[0]
     for got in outs[1:]:
