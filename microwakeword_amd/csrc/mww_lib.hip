@@ -1690,7 +1690,10 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
                       b.stride == 1 && a.tin == b.tin && a.n_src == 1 && b.n_src == 1 && a.src[0] >= 0 && b.src[0] >= 0 &&
                       b.src[0] != i && a.res_src < 0 && b.res_src < 0 && a.adders.empty() && b.adders.empty() && a.cin == a.cout &&
                       twin_width(a.cout);
-    if (same && (i == 0 || !ops[i - 1].twin_next)) a.twin_next = true;
+    // twins run concurrently inside one launch: they must not route gradient into the same channels of one producer
+    // (store vs accumulate would race; e.g. the unfused 1x1 branch heads of an Inception block with sub-spectral groups)
+    const bool shared = a.src[0] == b.src[0] && a.sc0[0] < b.sc0[0] + b.cin && b.sc0[0] < a.sc0[0] + a.cin;
+    if (same && !shared && (i == 0 || !ops[i - 1].twin_next)) a.twin_next = true;
   }
   // gradient routing: per producer, the slices its consumers read must be identical or disjoint and cover
   // every channel; in the backward pass (descending op index) the first consumer of a slice stores, later

@@ -417,7 +417,10 @@ def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graph
             off += n
             seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
             l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
-            assert l2 <= 1e-4, (s, name, l2)
+            # dense.bias and the BN / sub-spectral gamma, beta gradients are signed sums that may nearly cancel (and have as
+            # few as 1-4 entries): float32 summation noise reaches a few 1e-4 of their norm in ~1 % of random topologies
+            loose = name == "dense.bias" or name.endswith((".bn.gamma", ".bn.beta"))
+            assert l2 <= (1e-3 if loose else 1e-4), (s, name, l2)
             assert np.abs(a - r).max() <= 1e-3 * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
             l2s.append(l2)
         om.train_step(x, y, w, lr, dropout_mask=keep, relu_masks=masks)
@@ -1007,3 +1010,33 @@ def check_gather_fuzz(lib, cases=8, first=0, notebook=False):
             eng.close()
         for a, b in zip(*outs):
             np.testing.assert_array_equal(a, b, err_msg="case %d" % case)
+
+
+# ------------------------------------------------------------------------------------------ inception topology fuzz
+def random_inception_flags(seed):
+    """A random Inception flag set inside the widths the graph kernels instantiate: 1-2 stem layers, 1-3 blocks,
+    kernel sizes 3/5/7, dilation 1/2, sub-spectral groups that divide the filters, dropout 0.1..0.4."""
+    rng = np.random.default_rng(9000 + seed)
+    ns, nb = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+
+    def groups_for(f):
+        return int(rng.choice([g for g in (1, 1, 2, 4) if f % g == 0]))
+
+    stem_f = [int(rng.choice([8, 16, 24, 32])) for _ in range(ns)]
+    f1 = [int(rng.choice([8, 10, 12, 16])) for _ in range(nb)]
+    f2 = [int(rng.choice([8, 10, 12, 16, 20, 24])) for _ in range(nb)]
+    return dict(cnn1_filters=",".join(map(str, stem_f)), cnn1_kernel_sizes=",".join(str(int(rng.choice([3, 5]))) for _ in range(ns)),
+                cnn1_subspectral_groups=",".join(str(groups_for(f)) for f in stem_f),
+                cnn2_filters1=",".join(map(str, f1)), cnn2_filters2=",".join(map(str, f2)),
+                cnn2_kernel_sizes=",".join(str(int(rng.choice([3, 5, 7]))) for _ in range(nb)),
+                cnn2_subspectral_groups=",".join(str(int(rng.choice([g for g in (1, 1, 2) if a % g == 0 and b % g == 0]))) for a, b in zip(f1, f2)),
+                cnn2_dilation=",".join(str(int(rng.choice([1, 1, 2]))) for _ in range(nb)), dropout=float(rng.choice([0.1, 0.2, 0.4])))
+
+
+def check_inception_topology_fuzz(lib, cases=4, first=0, B=3, T=150):
+    for case in range(first, first + cases):
+        flags = random_inception_flags(case)
+        try:
+            check_inception_train_steps(lib, B=B, T=T, steps=1, grid=2, flags=flags)
+        except AssertionError as e:
+            raise AssertionError("case %d %s: %s" % (case, flags, e))

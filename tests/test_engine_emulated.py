@@ -216,3 +216,7 @@ def test_fused_input_through_captured_graphs(emu_lib):
 def test_gather_fuzz(emu_lib):
     ec.check_gather_fuzz(emu_lib, cases=1, first=11)   # the short-window cases of the fuzz (the GPU suite runs 46)
     ec.check_gather_fuzz(emu_lib, cases=1, first=5)
+
+
+def test_inception_topology_fuzz(emu_lib):
+    ec.check_inception_topology_fuzz(emu_lib, cases=1, first=76, B=2, T=70)   # unfused heads with sub-spectral groups

@@ -339,3 +339,9 @@ def test_fused_input_through_captured_graphs(lib):
 def test_gather_fuzz(lib):
     ec.check_gather_fuzz(lib, cases=150)
     ec.check_gather_fuzz(lib, cases=20, first=200, notebook=True)
+
+
+def test_inception_topology_fuzz(lib):
+    """Random Inception flag sets (stem layers, blocks, kernel sizes, dilation, sub-spectral groups, dropout).  Found the
+    twin-launch race of unfused branch heads that share a producer (fixed in mww_create_convnet's twin rule)."""
+    ec.check_inception_topology_fuzz(lib, cases=60)
