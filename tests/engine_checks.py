@@ -200,7 +200,7 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
     # decisions are read back, checked to differ from the oracle's only at near-zero values, and imposed
     # on the oracle (as in the Inception check): what is compared are identical graphs.
     lowp = bool(flags.get("pw_bf16"))
-    loss_tol, l2_tol, el_tol, med_tol = (1e-3, 2e-2, 6e-2, 6e-3) if lowp else (1e-5, 1e-3, 5e-3, 2e-5)
+    loss_tol, l2_tol, el_tol, med_tol = (1e-3, 2e-2, 6e-2, 6e-3) if lowp else (1e-5, 1e-4, 1e-3, 2e-5)
     for s in range(steps):
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
@@ -209,20 +209,23 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         eng.set_targets(y, w)
         eng.train_step(B, lr)
         pr, z, loss = eng.read_outputs(B)
-        masks = None
-        if lowp:
-            taps, masks, flips = {}, {}, 0
-            om.logits(x, True, taps=taps)
-            for k, b in enumerate(lay.blocks):
-                pk = eng.debug_read("p%d" % (k + 1), B, B * b.tout * b.cout).reshape(B, b.tout, b.cout).astype(np.float64)
-                bn = eng.debug_read("bn%d" % (k + 1), B, 9 * b.cout).reshape(9, b.cout).astype(np.float64)
-                m = (pk * bn[0] + bn[1]) > 0
-                ref = taps["b%d.r0.bn_out" % k].detach().numpy()
-                diff = m != (ref > 0)
-                flips += int(diff.sum())
-                assert np.abs(ref[diff]).max(initial=0.0) <= 2e-2 * max(1.0, np.abs(ref).max()), (k, np.abs(ref[diff]).max())
-                masks["b%d.r0" % k] = np.ascontiguousarray(m.transpose(0, 2, 1))
-            assert flips <= 2e-3 * sum(B * b.tout * b.cout for b in lay.blocks), flips
+        # The engine's own ReLU decisions at the BN outputs are read back, checked to differ from the float64 oracle's only
+        # where the oracle's value is within rounding of zero, and imposed on the oracle: the gradients compared below are
+        # those of identical graphs.  (One flipped unit moves every upstream gradient by ~1/sqrt(units): a random sweep over
+        # (frames, batch) sizes hit such a unit in 13 % of the cases, each time with |value| < 2e-7.)
+        taps, masks, flips = {}, {}, 0
+        om.logits(x, True, taps=taps)
+        for k, b in enumerate(lay.blocks):
+            pk = eng.debug_read("p%d" % (k + 1), B, B * b.tout * b.cout).reshape(B, b.tout, b.cout).astype(np.float64)
+            bn = eng.debug_read("bn%d" % (k + 1), B, 9 * b.cout).reshape(9, b.cout).astype(np.float64)
+            m = (pk * bn[0] + bn[1]) > 0
+            ref = taps["b%d.r0.bn_out" % k].detach().numpy()
+            diff = m != (ref > 0)
+            flips += int(diff.sum())
+            assert np.abs(ref[diff]).max(initial=0.0) <= (2e-2 if lowp else 2e-5) * max(1.0, np.abs(ref).max()), (k, np.abs(ref[diff]).max())
+            masks["b%d.r0" % k] = np.ascontiguousarray(m.transpose(0, 2, 1))
+        n_units = sum(B * b.tout * b.cout for b in lay.blocks)
+        assert flips <= (2e-3 * n_units if lowp else max(8, 2e-5 * n_units)), flips
         lo, po, grads, _ = om.loss_and_grads(x, y, w, relu_masks=masks)
         g = eng.get_grads()
         gref = oracle_grads_native_order(lay, om, grads)
@@ -247,8 +250,10 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
                 # relative L2 error of the tensor and a looser one on any single element.
                 seg_scale = max(float(np.abs(r).max()), 1e-3 * scale)
                 l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
-                # measured: 1e-6 typical; 2e-4..4e-4 on the rare step where one activation flips (B=6)
-                assert l2 <= l2_tol, (s, name, l2)
+                # measured: 1e-6 typical.  The BN gamma / beta and dense-bias gradients are short signed sums that may nearly
+                # cancel: float32 summation noise reaches a few 1e-4 of their norm in ~1 % of random cases
+                loose = name == "dense.bias" or name.endswith((".bn.gamma", ".bn.beta"))
+                assert l2 <= (max(l2_tol, 1e-3) if loose else l2_tol), (s, name, l2)
                 assert np.abs(a - r).max() <= el_tol * seg_scale, (s, name, np.abs(a - r).max(), seg_scale)
                 worst["grad"] = max(worst.get("grad", 0), l2)
                 worst.setdefault("l2s", []).append(l2)
@@ -1040,3 +1045,23 @@ def check_inception_topology_fuzz(lib, cases=4, first=0, B=3, T=150):
             check_inception_train_steps(lib, B=B, T=T, steps=1, grid=2, flags=flags)
         except AssertionError as e:
             raise AssertionError("case %d %s: %s" % (case, flags, e))
+
+
+# ------------------------------------------------------------------------------------------ shape fuzz
+def check_shape_fuzz(lib, cases=10, first=0):
+    """Random (frames, batch, grid) sizes through the specialised MixedNet kernels, default and notebook topologies
+    (partial time tiles, fewer windows than workgroups and the reverse, windows per workgroup 1..48)."""
+    for case in range(first, first + cases):
+        rng = np.random.default_rng(7000 + case)
+        nb = rng.random() < 0.35
+        flags = NOTEBOOK if nb else DEF
+        T = int(rng.integers(110, 300)) if nb else int(rng.integers(52, 300))
+        B = int(rng.integers(1, 48))
+        grid = int(rng.choice([0, 1, 2, 3, 5, 8]))
+        try:
+            check_train_steps(lib, B=B, T=T, steps=1, grid=grid, flags=flags)
+        except ValueError as e:
+            if "too short" not in str(e):
+                raise
+        except AssertionError as e:
+            raise AssertionError("case %d (notebook=%s, T=%d, B=%d, grid=%d): %s" % (case, nb, T, B, grid, e))

