@@ -62,14 +62,58 @@ __host__ __device__ constexpr int chunk_len(int c) { return (TT + nchunks(c) - 1
 __host__ __device__ constexpr int tile_rows_padded(int c) { return nchunks(c) * chunk_len(c); }
 __host__ __device__ constexpr int halo_rows_padded(int c, int k) { return tile_rows_padded(c) + k - 1; }
 
+// ---- bounds-checked tile access through buffer resources ------------------------------------------------
+// A (sample, time tile) slice of a tensor is addressed through a buffer resource whose num_records is the slice's
+// valid byte count: loads past it return 0 and stores past it are dropped by the address unit.  The tile loops
+// therefore carry no per-lane bounds branches.  That is not cosmetic: a conditional load (`v = 0; if (ok) v = *p`)
+// reaches its consumer through a phi whose copies the register allocator places right behind the load, and the
+// wait-count pass then drains the whole memory queue there (`s_waitcnt vmcnt(0)` in the middle of the prefetch,
+// seen in the round-1 ISA of every block kernel) - the "register prefetch" of the next tile became a synchronous
+// load.  Straight-line buffer loads keep every wait at the point of first use with an exact count.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// base must be workgroup-uniform (the descriptor lives in scalar registers); bytes <= 0 makes every access a no-op
+__device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
+  // the count is pinned to a scalar register: clamps like max(0, min(n, TT)) are otherwise selected as v_med3_i32
+  // and a descriptor with a vector-register word is applied through a waterfall loop
+  const int n = __builtin_amdgcn_readfirstlane(bytes > 0 ? bytes : 0);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, n, 0x00020000);
+}
+__device__ __forceinline__ float4 tile_load4(BufRsrc r, int byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ uint2 tile_load2(BufRsrc r, int byte_off) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  uint2 o;
+  o.x = v.x;
+  o.y = v.y;
+  return o;
+}
+__device__ __forceinline__ float tile_load1(BufRsrc r, int byte_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void tile_store1(BufRsrc r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+}
+// lane offset that is out of range for every resource (lanes that take no part in an access)
+constexpr int kOobOffset = 0x40000000;
+
 // keep a value (and the loads that produce it) from sinking below this point: used to retire the
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
-// profiling only (build with -DMWW_PHASE_CLOCKS, see tools/phase_clocks.py): per-phase shader-clock
-// accounting of one thread, enabled at run time by the "ablate" bit 16.  Compiled out by default
-// because the counters cost ~17 VGPRs.
-#ifdef MWW_PHASE_CLOCKS
+// profiling only (build with -DMWW_PROFILE, see tools/phase_clocks.py): phase ablation by the "ablate" option bits
+// (results invalid) and per-phase shader-clock accounting of one thread ("ablate" bit 16).  Compiled out of the
+// shipped library: the default build neither reads `ablate` nor carries the ~17 VGPRs of the counters.
+#ifdef MWW_PROFILE
+#define MWW_ABLATE(a, bits) ((a).ablate & (bits))
+#else
+#define MWW_ABLATE(a, bits) 0
+#endif
+#ifdef MWW_PROFILE
 #define MWW_PC_DECL PhaseClock pc;
 #define MWW_PC_START(en) pc.start(en)
 #define MWW_PC_MARK(i) pc.mark(i)
@@ -158,7 +202,9 @@ struct StatAcc {
 __device__ __forceinline__ void publish_stat(const StatAcc& s, float* row, int C2, int tid, float v) {
   if (s.acc) {
     unsafeAtomicAdd(s.acc + (size_t)(blockIdx.x % kStatRows) * C2 + tid, (double)v);
-    if (blockIdx.x < kStatRows) s.clear[(size_t)blockIdx.x * C2 + tid] = 0.0;
+    // every row of the other parity is cleared whatever the grid size (a launch with fewer than kStatRows workgroups
+    // must not leave rows of an earlier, larger launch behind: the consumers always sum all kStatRows rows)
+    for (int r = blockIdx.x; r < kStatRows; r += gridDim.x) s.clear[(size_t)r * C2 + tid] = 0.0;
   } else {
     row[tid] = v;
   }

@@ -57,16 +57,13 @@ struct DpStage {
   static constexpr int QO = COUT / 4, CPO = pitch(COUT), N = (TT * QO + kThreads - 1) / kThreads;
   float4 pk[N], gg[N];
 
+  // both slices hold nvalid float4s; float4s past them come back as zeros
   __device__ __forceinline__ void issue(const float* pk_base, const float* g_base, int nvalid, int tid) {
+    const BufRsrc rp = tile_rsrc(pk_base, nvalid * 16), rg = tile_rsrc(g_base, nvalid * 16);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const int i = tid + j * kThreads;
-      pk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      gg[j] = pk[j];
-      if (i < nvalid) {
-        pk[j] = reinterpret_cast<const float4*>(pk_base)[i];
-        gg[j] = reinterpret_cast<const float4*>(g_base)[i];
-      }
+      pk[j] = tile_load4(rp, (tid + j * kThreads) * 16);
+      gg[j] = tile_load4(rg, (tid + j * kThreads) * 16);
     }
   }
 
@@ -276,17 +273,13 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nvp = min(RA, a.Tin - t0) * QI;
-    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
+    const BufRsrc src = tile_rsrc(a.in + ((size_t)b * a.Tin + t0) * CIN, nvp * 16);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int i = tid + j * kThreads;
-      pre_p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvp) pre_p[j] = src[i];
-    }
+    for (int j = 0; j < NP; ++j) pre_p[j] = tile_load4(src, (tid + j * kThreads) * 16);
     const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
     const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
     dps.issue(a.pk + koff, LAST ? a.wd + (size_t)t0 * COUT : a.gk + koff, nvk, tid);
-    if (LAST) pre_dz = a.dz[b];
+    if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
   };
   if (nitems > 0) issue(0);
   MWW_PC_DECL
@@ -338,7 +331,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
-  MWW_PC_START((a.ablate & 16) && tid == 0);
+  MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
@@ -355,11 +348,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
     carry_du<K, CPI>(sDU, t0 == 0, tid);
     MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
-    if (dw_active && !(a.ablate & 1)) {
+    if (dw_active && !MWW_ABLATE(a, 1)) {
       float o[L], dww[K];
 #pragma unroll
       for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
@@ -371,38 +364,42 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       }
     }
     MWW_PC_MARK(2);   // issue + P1 (u recompute)
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-    if (!(a.ablate & 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    if (!MWW_ABLATE(a, 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
     MWW_PC_MARK(4);   // MFMA (dW_pw, du)
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(5);   // barrier 3
-    // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}
-    if (dw_active && !(a.ablate & 4)) {
-      float* gtile = a.g_out + ((size_t)b * a.Tin + t0) * CIN;   // uniform base: the stores take a 32-bit lane offset
+    // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}.  No divergent branch around the global stores (the
+    // wait-count pass would have to assume the skipped path at the next commit): the lanes past the last chunk shadow
+    // it, their stores are out of range and their sums are dropped by the epilogue.
+    if (!MWW_ABLATE(a, 4)) {
+      const int cch = dw_active ? chunk : NCH - 1;
+      // the tile's slice of g_{k-1}: rows past rows_da are dropped by the address unit
+      const BufRsrc gtile = tile_rsrc(a.g_out + ((size_t)b * a.Tin + t0) * CIN, rows_da * CIN * 4);
+      const int goff = (dw_active ? 0 : kOobOffset) + (cch * L * CIN + c) * 4;
       {
         float da[L], dww[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-        depthwise_input_grad_chunk<K, L, CPI>(sDU, chunk, c, dww, da);
+        depthwise_input_grad_chunk<K, L, CPI>(sDU, cch, c, dww, da);
 #pragma unroll
         for (int t = 0; t < L; ++t) {
-          const int sl = chunk * L + t;
-          if (sl < rows_da) {
-            const float raw = sP[sl * CPI + c];
-            const float gg = fmaf(raw, sc_c, sh_c) > 0.f ? da[t] : 0.f;
-            store_stream(gtile + sl * CIN + c, gg);
-            gs1 += gg;
-            gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
-          }
+          const int sl = cch * L + t;
+          const float raw = sP[sl * CPI + c];
+          // (row TT of the last chunk belongs to the next tile: its da is still partial)
+          const float gg = (sl < rows_da && fmaf(raw, sc_c, sh_c) > 0.f) ? da[t] : 0.f;
+          tile_store1(gtile, goff + t * CIN * 4, gg);
+          gs1 += gg;
+          gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
         }
       }
-      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb,
+      depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
                                              [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
     }
     MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(7);   // barrier 4
   }
   MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);

@@ -101,47 +101,30 @@ struct XStage {
   float4 pre[NJ];
 
   // `tid` is laundered in both methods: the per-lane row / offset arithmetic is a handful of VALU ops per tile,
-  // hoisted out of the tile loop it would cost long-lived registers in kernels that have none to spare
+  // hoisted out of the tile loop it would cost long-lived registers in kernels that have none to spare.
+  // One straight-line path for dense x and for both store dtypes (no conditional loads, see common.hip.h): the rows
+  // [r_lo, r_hi) of the tile that exist in the source are one contiguous slice; it is read through two descriptors in
+  // 8-byte halves of a float4 group (uint16 stores: a group IS 8 bytes and the second descriptor is empty), lanes in
+  // front of the slice wrap to huge unsigned offsets and, like those behind it, get zeros.
   __device__ __forceinline__ void issue(const float* x, const XGather& g, const XShared& sh, int s, int b, int T, int row0,
                                         int nrows, int tid) {
     asm volatile("" : "+v"(tid));
-    const int rq = tid / QX;
-    const bool act = tid < ACT;
-    if (g.win == nullptr) {
-      const float4* src = reinterpret_cast<const float4*>(x + ((size_t)b * T + row0) * FBINS) + tid;
+    const bool gather = g.win != nullptr;
+    // the descriptor is workgroup-uniform: keep it in scalar registers
+    const int pad = gather ? uniform_int(sh.pad_rows[s]) : 0, copy = gather ? uniform_int(sh.copy_rows[s]) : T;
+    const bool u16 = gather && uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+    const int gb = u16 ? 8 : 16;                                         // bytes of one float4 group in the source
+    const int r_lo = max(pad - row0, 0), r_hi = min(pad + copy - row0, nrows);
+    const char* base = gather ? reinterpret_cast<const char*>(uniform_ptr(sh.base[s])) + uniform_i64(sh.src_elem[s]) * (u16 ? 2 : 4)
+                              : reinterpret_cast<const char*>(x + (size_t)b * T * FBINS);
+    base += (long long)(row0 - pad + r_lo) * (QX * gb);
+    const int nbytes = (r_hi - r_lo) * (QX * gb);
+    const BufRsrc lo = tile_rsrc(base, nbytes), hi = tile_rsrc(base + 8, u16 ? 0 : nbytes - 8);
+    const int off0 = tid < ACT ? (tid - r_lo * QX) * gb : kOobOffset;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act && rq + RPP * j < nrows) pre[j] = src[ACT * j];
-      }
-      return;
-    }
-    // the descriptor is workgroup-uniform: keep it in scalar registers, address the rows with 32-bit lane offsets
-    const int pad = uniform_int(sh.pad_rows[s]), copy = uniform_int(sh.copy_rows[s]);
-    const bool u16 = uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
-    const long long e0 = uniform_i64(sh.src_elem[s]) + (long long)(row0 - pad) * FBINS;
-    const char* base = reinterpret_cast<const char*>(uniform_ptr(sh.base[s])) + e0 * (u16 ? 2 : 4);
-    const int r_lo = pad - row0, r_hi = min(pad + copy - row0, nrows);   // rows [r_lo, r_hi) of the tile exist in the store
-    if (u16) {
-      const uint2* src = reinterpret_cast<const uint2*>(base) + tid;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int r = rq + RPP * j;
-        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act && r >= r_lo && r < r_hi) {
-          const uint2 raw = src[ACT * j];
-          pre[j].x = __uint_as_float(raw.x);
-          pre[j].y = __uint_as_float(raw.y);
-        }
-      }
-    } else {
-      const float4* src = reinterpret_cast<const float4*>(base) + tid;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int r = rq + RPP * j;
-        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act && r >= r_lo && r < r_hi) pre[j] = src[ACT * j];
-      }
+    for (int j = 0; j < NJ; ++j) {
+      const uint2 a = tile_load2(lo, off0 + ACT * j * gb), c = tile_load2(hi, off0 + ACT * j * gb);
+      pre[j] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(c.x), __uint_as_float(c.y));
     }
   }
 
@@ -321,34 +304,22 @@ struct PwWeights<CIN, NT, true> {
   }
 };
 
-// store a 16 x (NT*16) accumulator tile to global rows and accumulate per-channel sum / sum^2
+// store a 16 x (NT*16) accumulator tile to the (sample, tile) slice `out` of the output tensor (rows past the slice
+// are dropped by the address unit) and accumulate per-channel sum / sum^2.  Rows past the slice hold exact zeros (their
+// u rows are zero), so the sums need no mask either.
 template <int NT, int COUT>
-__device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], float* out_rows, int row0, int rows_valid,
-                                                 int r16, int g, float (&s1)[NT], float (&s2)[NT]) {
-  if (rows_valid >= row0 + 16) {   // wave-uniform: the whole 16-row tile is inside the sample
+__device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], BufRsrc out, int row0, int r16, int g,
+                                                 float (&s1)[NT], float (&s2)[NT]) {
+  const int off = ((row0 + g * 4) * COUT + r16) * 4;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[nt][r];
-        store_stream(out_rows + (size_t)(row0 + g * 4 + r) * COUT + nt * 16 + r16, v);
-        s1[nt] += v;
-        s2[nt] = fmaf(v, v, s2[nt]);
-      }
-  } else {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + g * 4 + r;
-        const float v = acc[nt][r];
-        if (row < rows_valid) {
-          store_stream(out_rows + (size_t)row * COUT + nt * 16 + r16, v);
-          s1[nt] += v;
-          s2[nt] = fmaf(v, v, s2[nt]);
-        }
-      }
-  }
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[nt][r];
+      tile_store1(out, off + (r * COUT + nt * 16) * 4, v);
+      s1[nt] += v;
+      s2[nt] = fmaf(v, v, s2[nt]);
+    }
 }
 
 template <int NT, int COUT>
@@ -479,7 +450,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     // pointwise
     f32x4 acc[NT];
     pw.tile(sU, CP1, wave * 16, r16, g, acc);
-    store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
+    store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
     __syncthreads();
   }
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
@@ -524,17 +495,14 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   const int nitems = nsamp * ntiles;
   constexpr int NLD = (RA * Q + kThreads - 1) / kThreads;
   float4 pre[NLD];
-  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at offset 4*i
+  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at byte 16*i of the tile's slice;
+  // float4s past the valid rows come back as zeros
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
-    const float4* src = reinterpret_cast<const float4*>(a.in + ((size_t)b * a.Tin + t0) * CIN);
+    const BufRsrc src = tile_rsrc(a.in + ((size_t)b * a.Tin + t0) * CIN, nvalid * 16);
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int i = tid + j * kThreads;
-      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < nvalid) pre[j] = src[i];
-    }
+    for (int j = 0; j < NLD; ++j) pre[j] = tile_load4(src, (tid + j * kThreads) * 16);
   };
   if (nitems > 0) issue(0);
   MWW_PC_DECL
@@ -559,7 +527,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   pin(dwb);
   __syncthreads();
 
-  MWW_PC_START((a.ablate & 16) && tid == 0);
+  MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int rows_out = min(TT, a.Tout - t0);
@@ -581,11 +549,11 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
       }
     }
     MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     MWW_PC_MARK(2);   // prefetch issue
-    if (dw_active && !(a.ablate & 1)) {
+    if (dw_active && !MWW_ABLATE(a, 1)) {
       float o[L];
       dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
@@ -595,15 +563,15 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
       }
     }
     MWW_PC_MARK(3);   // depthwise
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(4);   // barrier 2
     f32x4 acc[NT];
-    if (!(a.ablate & 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
+    if (!MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
     else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
     MWW_PC_MARK(5);   // pointwise MFMA
-    if (!(a.ablate & 4)) store_tile_stats<NT, COUT>(acc, a.out + ((size_t)b * a.Tout + t0) * COUT, wave * 16, rows_out, r16, g, s1, s2);
+    store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
     MWW_PC_MARK(6);   // stores + stats
-    if (!(a.ablate & 8)) __syncthreads();
+    if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(7);   // barrier 3
   }
   MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);

@@ -131,6 +131,41 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x16bf16(hipemu_s16x4 a, hipemu_s16x4
 static inline unsigned long long hipemu_memtime() { return 0ull; }
 #define __builtin_amdgcn_s_memtime hipemu_memtime
 
+// buffer resources (common.hip.h "bounds-checked tile access"): base + byte count; loads past the count
+// return 0, stores past it are dropped — the semantics of a raw (stride 0) gfx9 buffer descriptor
+struct hipemu_rsrc { char* base; long long bytes; };
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_rsrc hipemu_make_rsrc(void* p, short, int bytes, int) { return {static_cast<char*>(p), bytes}; }
+static inline hipemu_u32x4 hipemu_buf_load128(hipemu_rsrc r, int off, int soff, int) {
+  hipemu_u32x4 v = {0u, 0u, 0u, 0u};
+  const long long o = (long long)(unsigned)off + (unsigned)soff;
+  if (o + 16 <= r.bytes) std::memcpy(&v, r.base + o, 16);
+  return v;
+}
+static inline hipemu_u32x2 hipemu_buf_load64(hipemu_rsrc r, int off, int soff, int) {
+  hipemu_u32x2 v = {0u, 0u};
+  const long long o = (long long)(unsigned)off + (unsigned)soff;
+  if (o + 8 <= r.bytes) std::memcpy(&v, r.base + o, 8);
+  return v;
+}
+static inline unsigned hipemu_buf_load32(hipemu_rsrc r, int off, int soff, int) {
+  unsigned v = 0u;
+  const long long o = (long long)(unsigned)off + (unsigned)soff;
+  if (o + 4 <= r.bytes) std::memcpy(&v, r.base + o, 4);
+  return v;
+}
+static inline void hipemu_buf_store32(unsigned v, hipemu_rsrc r, int off, int soff, int) {
+  const long long o = (long long)(unsigned)off + (unsigned)soff;
+  if (o + 4 <= r.bytes) std::memcpy(r.base + o, &v, 4);
+}
+#define __amdgpu_buffer_rsrc_t hipemu_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buf_load128
+#define __builtin_amdgcn_raw_buffer_load_b64 hipemu_buf_load64
+#define __builtin_amdgcn_raw_buffer_load_b32 hipemu_buf_load32
+#define __builtin_amdgcn_raw_buffer_store_b32 hipemu_buf_store32
+
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

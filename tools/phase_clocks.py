@@ -11,7 +11,7 @@ from microwakeword_amd.model import Model
 import subprocess
 from microwakeword_amd import native
 LIB = "/tmp/libmww_hip_phaseclk.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PHASE_CLOCKS",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PROFILE",
                 "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
                 os.path.join(ROOT, "microwakeword_amd", "csrc", "sampler.cpp"), "-o", LIB], check=True)
 B, T = 1024, 194
