@@ -114,12 +114,14 @@ __device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
 template <int CIN, int COUT, int K, bool BF>
 __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const float* sDP, float* sDU, int wave, int r16,
                                                         int g, const float* sWt,
-                                                        f32x4 (&dwacc)[CIN / 16][COUT / 16]) {
+                                                        f32x4 (&dwacc)[CIN / 16][COUT / 16], bool live) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT), MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
   f32x4 du[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) du[mt] = zero4();
-  if constexpr (!BF) {
+  if (!live) {
+    // (wave-uniform) this wave's 16 rows lie past the sample: dp = 0 there, so dW gains nothing and du = 0
+  } else if constexpr (!BF) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int row = wave * 16 + kk * 4 + g;
@@ -352,22 +354,28 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
+    // (chunks / row tiles past the sample's last row only write their zero rows, see fwd_block_kernel)
     if (dw_active && !MWW_ABLATE(a, 1)) {
-      float o[L], dww[K];
+      if (chunk * L < nrows_new) {
+        float o[L], dww[K];
 #pragma unroll
-      for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-      dw_chunk<K, L, false, true>(sP, CPI, chunk * L, c, dww, dwb, o, sc_c, sh_c);
+        for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
+        dw_chunk<K, L, false, true>(sP, CPI, chunk * L, c, dww, dwb, o, sc_c, sh_c);
 #pragma unroll
-      for (int t = 0; t < L; ++t) {
-        const int tl = chunk * L + t;
-        sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
       }
     }
     MWW_PC_MARK(2);   // issue + P1 (u recompute)
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-    if (!MWW_ABLATE(a, 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    if (!MWW_ABLATE(a, 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc, wave * 16 < nrows_new);
     MWW_PC_MARK(4);   // MFMA (dW_pw, du)
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(5);   // barrier 3
@@ -380,10 +388,16 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       const BufRsrc gtile = tile_rsrc(a.g_out + ((size_t)b * a.Tin + t0) * CIN, rows_da * CIN * 4);
       const int goff = (dw_active ? 0 : kOobOffset) + (cch * L * CIN + c) * 4;
       {
-        float da[L], dww[K];
+        float da[L];
+        if (cch * L < rows_da) {   // chunks past the sample's last row: da = 0, nothing to compute
+          float dww[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-        depthwise_input_grad_chunk<K, L, CPI>(sDU, cch, c, dww, da);
+          for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
+          depthwise_input_grad_chunk<K, L, CPI>(sDU, cch, c, dww, da);
+        } else {
+#pragma unroll
+          for (int t = 0; t < L; ++t) da[t] = 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int sl = cch * L + t;
@@ -395,8 +409,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
         }
       }
-      depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
-                                             [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
+      if (cch * L < nrows_new)   // du = 0 past the sample's last output row
+        depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
+                                               [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
     }
     MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
     if (!MWW_ABLATE(a, 8)) __syncthreads();
@@ -419,12 +434,14 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------
-// First block: the block input is relu(conv1(x)) (no BN), recomputed from x; instead of an
-// input gradient tensor the kernel produces the first-conv weight gradient
-//   dW1[j*40+f][c1] += sum_s x[s+j][f] * g0[s][c1]      (im2col^T x g0 on MFMA)
+// First block: the block input a0 = relu(conv1(x)) has no BN in front and is read back from the tensor fwd_first_kernel
+// stored (49 KB/window of traffic instead of recomputing the K1*40-deep im2col GEMM, which was 40 % of this kernel's
+// MFMA work and made it the longest launch of the step); instead of an input gradient tensor the kernel produces the
+// first-conv weight gradient
+//   dW1[j*40+f][c1] += sum_s x[s*S+j][f] * g0[s][c1]      (im2col^T x g0 on MFMA)
 struct BwdFirstArgs {
   const float* x;         // [B][T][40]
-  const float* w1;        // [K1*40][C1]
+  const float* a0;        // relu(conv1(x)) [B][Ta][C1]
   const float* pk;        // p_1 [B][Tout][COUT]
   const float* gk;        // g_1 [B][Tout][COUT]
   const float* k_mean;
@@ -446,22 +463,20 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   constexpr int CIN = C1;
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
-  constexpr int RT1 = (RA + 15) / 16;
-  constexpr int XR = (RT1 * 16 - 1) * S + K1;
-  constexpr int KS1 = K1 * FBINS / 4;
+  constexpr int XR = (TT - 1) * S + K1;          // x rows the dW1 contraction of one tile reads
   constexpr int NT1 = C1 / 16;
   constexpr int M1 = K1 * FBINS;                 // rows of W1
   constexpr int MT1 = (M1 + 15) / 16;            // m-tiles of dW1
   constexpr int MPW = (MT1 + 3) / 4;             // m-tiles per wave
   constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
   constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
+  constexpr int QI = CIN / 4;
   constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
   constexpr int OFF_A = 0, OFF_DP = OFF_A + RAP * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TTP * CPI;
   constexpr int OFF_G0 = OFF_DU + RAP * CPI, OFF_END = OFF_G0 + TTP * CPI;
   constexpr int PX = FBINS + 1;                  // odd pitch of the staged x rows (see fwd_first_kernel)
-  constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
-  static_assert(4 % NT1 == 0 && TT >= K - 1, "shape");
+  static_assert(TT >= K - 1, "shape");
 
   __shared__ __attribute__((aligned(16))) float sX[XR * PX];
   __shared__ XShared sXg;
@@ -484,15 +499,20 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   const int nitems = nsamp * ntiles;
   XStage<XR, PX> xs;
   DpStage<COUT, false> dps;
+  constexpr int NA = (RA * QI + kThreads - 1) / kThreads;
+  float4 pre_a[NA];
   auto issue = [&](int it) {
     const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nrx = (min(RA, Ta - t0) - 1) * S + K1;
+    const int nrx = (min(TT, Ta - t0) - 1) * S + K1;
     xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrx, tid);
+    const BufRsrc ra = tile_rsrc(a.a0 + ((size_t)b * Ta + t0) * CIN, min(RA, Ta - t0) * QI * 16);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) pre_a[j] = tile_load4(ra, (tid + j * kThreads) * 16);
     const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
     const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
     dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
   };
-  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s+j][f]
+  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s*S+j][f]
   int offm[MPW];
   bool okm[MPW];
 #pragma unroll
@@ -522,10 +542,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     sKp[5 * COUT + i] = 0.f;
     sKp[6 * COUT + i] = 0.f;
   }
-  const int nt1 = wave % NT1;
-  float w1frag[KS1];
-#pragma unroll
-  for (int kk = 0; kk < KS1; ++kk) w1frag[kk] = a.w1[(kk * 4 + g) * C1 + nt1 * 16 + r16];
   for (int i = tid; i < CIN * COUT; i += kThreads) {
     const int ci = i / COUT, co = i - ci * COUT;
     sWt[co * CPI + ci] = a.pw_w[i];
@@ -542,8 +558,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     accw[i] = 0.f;
   }
   if (dw_active) dwb = a.dw_b[c];
-#pragma unroll
-  for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
@@ -563,38 +577,37 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     const int t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));
     const int rows_da = min(TT, Ta - t0);
-    const int rows_a = min(RA, Ta - t0);          // a0 rows that exist in this tile
-    // ---- P0: commit x (odd pitch), dp; roll the du ring
+    // ---- P0: commit x (odd pitch), a0 rows [t0, t0+RA) (zero past the sample), dp; roll the du ring
     xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < RA * QI) {
+        const int r = i / QI, q = i - r * QI;
+        *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = pre_a[j];
+      }
+    }
     dps.commit(sDP, sKp, 0.f, nrows_new * (COUT / 4), tid);
     carry_du<K, CPI>(sDU, t0 == 0, tid);
     __syncthreads();
     if (it + 1 < nitems) issue(it + 1);
-    // ---- recompute a0 = relu(conv1(x)) for local rows [0, RA)
-    for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
-      f32x4 acc = zero4();
-      const float* xr = sX + (rt * 16 + r16) * S * PX + g;
-#pragma unroll
-      for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + g * 4 + r;
-        if (row < RA) sA[row * CPI + nt1 * 16 + r16] = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
-      }
-    }
-    __syncthreads();
     // ---- P1: u = depthwise(a0) + bias
     if (dw_active) {
-      float o[L];
-      dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
+      if (chunk * L < nrows_new) {
+        float o[L];
+        dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
-      for (int t = 0; t < L; ++t) {
-        const int tl = chunk * L + t;
-        sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
       }
     }
     __syncthreads();
-    pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc);
+    pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc, wave * 16 < nrows_new);
     __syncthreads();
     // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
     if (dw_active) {
@@ -607,10 +620,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
           sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
         }
       }
-      depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return sA[row * CPI + c]; });
+      if (chunk * L < nrows_new)
+        depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return sA[row * CPI + c]; });
     }
     __syncthreads();
-    // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s + m/40][m%40], B[k=s][n] = g0[s][n]
+    // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s*S + m/40][m%40], B[k=s][n] = g0[s][n]
 #pragma unroll
     for (int kk = 0; kk < TT / 4; ++kk) {
       const int s = kk * 4 + g;

@@ -185,6 +185,7 @@ struct FwdFirstArgs {
   int ablate;            // profiling only: bit0 skip depthwise, bit1 skip MFMA, bit2 skip stores (results invalid)
   StatAcc sacc;          // statistics go to the accumulator rows instead of stat_part when set
   XGather xg;            // xg.win set: x rows are gathered from the feature stores (x is not read)
+  float* a0;             // relu(conv1(x)) [B][Ta][C1] kept for bwd_first_kernel (null: not stored, e.g. inference)
 };
 
 struct FwdBlockArgs {
@@ -309,8 +310,9 @@ struct PwWeights<CIN, NT, true> {
 // u rows are zero), so the sums need no mask either.
 template <int NT, int COUT>
 __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], BufRsrc out, int row0, int r16, int g,
-                                                 float (&s1)[NT], float (&s2)[NT]) {
-  const int off = ((row0 + g * 4) * COUT + r16) * 4;
+                                                 float (&s1)[NT], float (&s2)[NT], int row_base = 0) {
+  // row_base < 0 (rows in front of the slice) gives negative = huge unsigned offsets: dropped like the rows behind it
+  const int off = ((row_base + row0 + g * 4) * COUT + r16) * 4;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -344,21 +346,26 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiles follow the first conv's output a0 = relu(conv1(x)): tile i computes a0 rows [64 i, 64 i + 64) exactly once
+// (four 16-row MFMA tiles, no halo recompute: the im2col GEMM with K = K1*40 is the most expensive contraction of the
+// network), keeps them in an LDS ring behind the K-1 rows carried over from the previous tile, and stores them to
+// HBM for bwd_first_kernel.  The depthwise / pointwise part of the tile then produces the output rows
+// [64 i - (K-1), 64 i + 64 - (K-1)) that those ring rows complete.
 template <int K1, int C1, int COUT, int K, int S, bool BF>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
   constexpr int CP1 = pitch(C1);
-  constexpr int RA = TT + K - 1;               // a0 rows per tile
-  constexpr int RT1 = (RA + 15) / 16;          // MFMA row tiles of the first conv
-  constexpr int XR = (RT1 * 16 - 1) * S + K1;  // x rows staged (zero filled past the valid ones); S = first-conv time stride
+  constexpr int RA = TT + K - 1;               // ring rows: K-1 carried + TT new
+  constexpr int RT1 = TT / 16;                 // MFMA row tiles of the first conv
+  constexpr int XR = (TT - 1) * S + K1;        // x rows staged (zero filled past the valid ones); S = first-conv time stride
   constexpr int KS1 = K1 * FBINS / 4;          // k-steps of the im2col GEMM
   constexpr int NT1 = C1 / 16;
   constexpr int KS = C1 / 4, NT = COUT / 16;
   constexpr int NCH = nchunks(C1), L = chunk_len(C1);
   constexpr int RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
   constexpr int PX = FBINS + 1;                // odd LDS pitch of the staged x rows: conflict-free MFMA operand reads
-  constexpr int NLDX = (XR * FBINS / 4 + kThreads - 1) / kThreads;
   static_assert(4 % NT1 == 0, "first-conv filters must be 16, 32 or 64");
   static_assert((K1 * FBINS) % 4 == 0 && C1 % 16 == 0 && COUT % 16 == 0, "shape");
+  static_assert(TT >= K - 1, "carry rows must not overlap");
 
   __shared__ __attribute__((aligned(16))) float sX[XR * PX];
   __shared__ __attribute__((aligned(16))) float sA[RAP * CP1];
@@ -369,17 +376,18 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % C1, chunk = tid / C1;
   const bool dw_active = chunk < NCH;
-  for (int i = RA * CP1 + tid; i < RAP * CP1; i += kThreads) sA[i] = 0.f;
+  for (int i = RA * CP1 + tid; i < RAP * CP1; i += kThreads) sA[i] = 0.f;   // rows only the padded windows touch
 
   // work items = (sample, time tile); the next item's rows are fetched into registers while the
   // current one is computed (global->register early, register->LDS late)
-  const int ntiles = (a.Tout + TT - 1) / TT;
+  const int Ta = (a.T - K1) / S + 1;
+  const int ntiles = (Ta + TT - 1) / TT;
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int nitems = nsamp * ntiles;
   XStage<XR, PX> xs;
   auto issue = [&](int it) {
     const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nrows = (min(TT, a.Tout - t0) + K - 2) * S + K1;
+    const int nrows = (min(TT, Ta - t0) - 1) * S + K1;
     xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrows, tid);
   };
   const bool gather = a.xg.win != nullptr;
@@ -418,39 +426,54 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   pin(dwb);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int rows_out = min(TT, a.Tout - t0);
-    // commit the staged x rows (zero filled past the valid ones) with an odd row pitch
+    const int rows_a = min(TT, Ta - t0);                    // a0 rows this tile computes
+    const int tu0 = t0 - (K - 1);                           // output row of ring row 0
+    const int r_lo = t0 == 0 ? K - 1 : 0, r_hi = min(TT, a.Tout - tu0);   // tile rows [r_lo, r_hi) are output rows
+    // commit the staged x rows (zero filled past the valid ones) with an odd row pitch; roll the a0 ring
     xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
+    for (int i = tid; i < (K - 1) * CP1; i += kThreads) sA[i] = t0 == 0 ? 0.f : sA[TT * CP1 + i];
     __syncthreads();
     if (it + 1 < nitems) issue(it + 1);
-    // first conv as im2col GEMM: A[row][k] = x[row + k/40][k%40]
-    for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
-      f32x4 acc = zero4();
-      const float* xr = sX + (rt * 16 + r16) * S * PX + g;
+    // first conv as im2col GEMM: A[row][k] = x[row*S + k/40][k%40]; a0 rows past the sample are zero
+    {
+      const BufRsrc a0s = tile_rsrc(a.a0 ? a.a0 + (size_t)b * Ta * C1 : nullptr, a.a0 ? Ta * C1 * 4 : 0);
+      for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
+        f32x4 acc = zero4();
+        const float* xr = sX + (rt * 16 + r16) * S * PX + g;
 #pragma unroll
-      for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
+        for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + g * 4 + r;
-        if (row < RA) sA[row * CP1 + nt1 * 16 + r16] = fmaxf(acc[r], 0.f);
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + g * 4 + r;
+          const float v = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
+          sA[(K - 1 + row) * CP1 + nt1 * 16 + r16] = v;
+          tile_store1(a0s, ((t0 + row) * C1 + nt1 * 16 + r16) * 4, v);
+        }
       }
     }
     __syncthreads();
-    // depthwise
+    // depthwise over the ring: tile row r is output row tu0 + r
     if (dw_active) {
-      float o[L];
-      dw_chunk<K, L>(sA, CP1, chunk * L, c, dww, dwb, o);
+      if (chunk * L < r_hi && chunk * L + L > r_lo) {
+        float o[L];
+        dw_chunk<K, L>(sA, CP1, chunk * L, c, dww, dwb, o);
 #pragma unroll
-      for (int t = 0; t < L; ++t) {
-        const int tl = chunk * L + t;
-        sU[tl * CP1 + c] = (tl < rows_out) ? o[t] : 0.f;
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          sU[tl * CP1 + c] = (tl >= r_lo && tl < r_hi) ? o[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CP1 + c] = 0.f;
       }
     }
     __syncthreads();
     // pointwise
-    f32x4 acc[NT];
-    pw.tile(sU, CP1, wave * 16, r16, g, acc);
-    store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
+    if (wave * 16 < r_hi && wave * 16 + 16 > r_lo) {   // wave-uniform
+      f32x4 acc[NT];
+      pw.tile(sU, CP1, wave * 16, r16, g, acc);
+      store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + (size_t)b * a.Tout * COUT, a.Tout * COUT * 4), wave * 16, r16, g, s1, s2, tu0);
+    }
     __syncthreads();
   }
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
@@ -553,23 +576,32 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     MWW_PC_MARK(2);   // prefetch issue
+    // chunks / row tiles past the sample's last row (short last tile) only write their zero rows: the issue slots
+    // they would burn go to the other workgroups of the CU
     if (dw_active && !MWW_ABLATE(a, 1)) {
-      float o[L];
-      dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
+      if (chunk * L < rows_out) {
+        float o[L];
+        dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
 #pragma unroll
-      for (int t = 0; t < L; ++t) {
-        const int tl = chunk * L + t;
-        sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
       }
     }
     MWW_PC_MARK(3);   // depthwise
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(4);   // barrier 2
-    f32x4 acc[NT];
-    if (!MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
-    else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
-    MWW_PC_MARK(5);   // pointwise MFMA
-    store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
+    if (wave * 16 < rows_out) {   // wave-uniform
+      f32x4 acc[NT];
+      if (!MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
+      else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+      MWW_PC_MARK(5);   // pointwise MFMA
+      store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
+    }
     MWW_PC_MARK(6);   // stores + stats
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(7);   // barrier 3

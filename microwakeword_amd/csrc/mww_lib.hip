@@ -120,6 +120,7 @@ struct mww_ctx {
   unsigned char* direct = nullptr;
   float* bn_state = nullptr;
   float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
+  float* a0 = nullptr;     // relu(conv1(x)) [max_batch][Ta][conv1_filters]: written by the training forward, read by bwd_first_kernel
   float* dwd_part = nullptr;
   MetricState* metrics = nullptr;
   // "mailboxes": pinned host memory mapped into the device address space.  The host writes one
@@ -487,7 +488,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     }
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
-                     l.p, l.stat_part, B, d.frames, l.tout, 0, sacc, x_gather(c)};
+                     l.p, l.stat_part, B, d.frames, l.tout, 0, sacc, x_gather(c), training ? c->a0 : nullptr};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
@@ -742,7 +743,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       if (rc) return rc;
     } else {
       if (last) return fail(MWW_ERR_UNSUPPORTED, "single-block models are not supported");
-      BwdFirstArgs a{c->x, c->params + c->o_conv1, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
+      BwdFirstArgs a{c->x, c->a0, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf, x_gather(c)};
       lp.begin("bwd_block", i);
@@ -1539,6 +1540,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   int rc = 0;
 #define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
   A(alloc_common(c));
+  A(dev_alloc(&c->a0, mb * c->L[0].tin * d.conv1_filters));
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
@@ -1841,7 +1843,7 @@ void mww_destroy(mww_ctx* c) {
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
-                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk};
+                  c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk, c->a0};
   for (void* p : flat) if (p) (void)hipFree(p);
   for (auto& l : c->L) {
     void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn, l.facc[0], l.facc[1], l.gacc[0], l.gacc[1]};

@@ -10,11 +10,12 @@ from microwakeword_amd.model import Model
 
 import subprocess
 from microwakeword_amd import native
-LIB = "/tmp/libmww_hip_phaseclk.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PROFILE",
-                "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
-                os.path.join(ROOT, "microwakeword_amd", "csrc", "sampler.cpp"), "-o", LIB], check=True)
-B, T = 1024, 194
+LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_hip_prof.so")   # tools/build_prof.sh (-DMWW_PROFILE), built in the container
+if not os.path.isfile(LIB):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PROFILE",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
+                    os.path.join(ROOT, "microwakeword_amd", "csrc", "sampler.cpp"), "-o", LIB], check=True)
+B, T = int(os.environ.get("PC_B", "1024")), 194
 model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T, 40), B, seed=42, max_batch=B, lib=native.NativeLib(LIB))
 eng = model.engine
 cfg, _ = synthetic.benchmark_config(1024, 1234)
@@ -32,7 +33,7 @@ BWD = ["commit+wait", "barrier1", "issue+P1", "barrier2", "mfma", "barrier3", "P
 for k in (2, 3, 4):
     for tag, names, grid in (("f", FWD, 1024), ("b", BWD, 512)):
         raw = eng.debug_read("clk%s%d" % (tag, k), 1, 2048 * 8 * 2)
-        clk = raw.view(np.uint64).reshape(2048, 8)[:grid].astype(np.float64)
+        clk = raw.view(np.uint64).reshape(2048, 8)[:min(grid, B)].astype(np.float64)
         tot = clk.sum(1)
         print("layer %d %s: total cycles/WG mean %.0f (min %.0f max %.0f)" % (k, "fwd" if tag == "f" else "bwd", tot.mean(), tot.min(), tot.max()))
         print("   " + "  ".join("%s=%.0f(%.0f%%)" % (n, v, 100 * v / tot.mean()) for n, v in zip(names, clk.mean(0))))
