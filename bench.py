@@ -2,13 +2,15 @@
 """bench.py — spectrogram-windows/sec of the MixedNet train step on N MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 8                      # launches its own 8 ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of synthetic ragged spectrograms already
 resident in HBM: exact-RNG window/mask draw (host C++, continuing the reference's MT19937 streams)
 -> HIP batch assembly (gather + pad/truncate + uint16->f32 + SpecAugment) -> forward (batch-stat BN)
--> weighted Keras BCE -> backward -> gradient assembly [-> RCCL all-reduce] -> Adam, + metric update.
+-> weighted Keras BCE -> backward -> gradient assembly [-> two-bucket RCCL all-reduce overlapped with the backward
+tail] -> Adam, + metric update.
 Workload = BASELINE configs[1]: default mixednet (argparse defaults + residual_connection "0,0,0,0"),
 T=194, batch 1024 per GPU, fp32; weak scaling (per-GPU batch fixed).
 
@@ -55,13 +57,14 @@ KERNEL_ELEMS = {
 
 # exact-fp32 MFMA flops per window of the default MixedNet's GEMM-shaped phases: first conv as
 # im2col GEMM, the 1x1 convolutions; the backward kernels run the 1x1 twice (weight + data gradient) and
-# bwd_block1 recomputes the first conv and forms its weight gradient
+# bwd_block1 forms the first conv's weight gradient (its input relu(conv1(x)) is read back, not recomputed: every
+# flop counted here is a useful one)
 FP32_MFMA_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CONV1_FLOPS, PW_FLOPS = 1474560, {1: 577536, 2: 829440, 3: 774144, 4: 681984}
 KERNEL_MFMA_FLOPS = {
     "fwd_block1": CONV1_FLOPS + PW_FLOPS[1], "fwd_block2": PW_FLOPS[2], "fwd_block3": PW_FLOPS[3], "fwd_block4": PW_FLOPS[4],
     "bwd_block4": 2 * PW_FLOPS[4], "bwd_block3": 2 * PW_FLOPS[3], "bwd_block2": 2 * PW_FLOPS[2],
-    "bwd_block1": 2 * CONV1_FLOPS + 2 * PW_FLOPS[1],
+    "bwd_block1": CONV1_FLOPS + 2 * PW_FLOPS[1],
 }
 
 
@@ -111,14 +114,19 @@ def inception_kernel_elems(layout):
     return elems
 
 
+PMC_FILE = "round2_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
+
+
 def pmc_traffic(kernel, model):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round1_m_*:
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round2_*:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run of `bench.py --no-graphs`), corrected
     as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE (KB) counts half the bytes of wide coalesced
     reads -> x2; WRITE_SIZE (KB) as reported.  Returns (bytes, source) or (None, None).  The counters cannot be
-    read from inside this process; the figure belongs to the kernel binary profiled at the end of the round."""
+    read from inside this process; the figure belongs to the kernel binary profiled at the end of the round (it includes
+    the 24.6 KB/window of a0 = relu(conv1(x)) that fwd_block1 stores and bwd_block1 reads back, which SURVEY 8(d)'s
+    algorithmic bytes do not count)."""
     import re
-    path = os.path.join(ROOT, "profiles", "round1_m_kernel_stats_and_pmc.txt")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if model != "mixednet" or not os.path.isfile(path):
         return None, None
     want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
@@ -136,7 +144,7 @@ def pmc_traffic(kernel, model):
             write = float(m.group(1)) if m else write
     if fetch is None or write is None:
         return None, None
-    return int(2 * fetch * 1024 + write * 1024), "profiles/round1_m_kernel_stats_and_pmc.txt (FETCH_SIZE x2 + WRITE_SIZE, KB)"
+    return int(2 * fetch * 1024 + write * 1024), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB)" % PMC_FILE
 
 
 def parse_args():
@@ -166,13 +174,43 @@ def parse_args():
     ap.add_argument("--grid-bwd", type=int, default=0)
     ap.add_argument("--grid-head", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: skip kernel phases (results invalid)")
+    ap.add_argument("--grad-buckets", type=int, default=2, choices=(1, 2),
+                    help="N > 1: 2 = the gradient all-reduce goes in two buckets, the first one overlapped with the backward tail (default)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
-    """CPU port of the same step (oracle loader + torch-CPU fp32 train step, all host cores), on a
-    bounded sample; rank 0 / N=1 only.  kind="port": TensorFlow is not installable here, so the
-    reference's own train.py cannot run."""
+def _reference_loader(batch, n_samples, policy):
+    """the reference's UNMODIFIED FeatureHandler.get_data (microwakeword/data.py:497-597), imported
+    through oracle/ref_data_shim over the same synthetic stores - only where /root/reference exists (the build
+    container; never on the GPU box).  Returns a zero-argument callable or None."""
+    try:
+        from oracle import ref_data_shim as shim
+        if not shim.available():
+            return None
+        import tempfile
+
+        from microwakeword_amd.ragged import write_ragged_store
+        from oracle import data_oracle as do
+        ref = shim.load_reference_data_module()
+        pos, neg = do.synthetic_stores(n_samples, 1234)
+        tmp = tempfile.mkdtemp(prefix="mww_cpu_baseline_")
+        write_ragged_store(os.path.join(tmp, "pos", "training", "a_mmap"), pos)
+        write_ragged_store(os.path.join(tmp, "neg", "training", "a_mmap"), neg)
+        config = {"stride": 1, "window_step_ms": 10, "features": [
+            dict(type="mmap", features_dir=os.path.join(tmp, "pos"), truth=True, sampling_weight=2.0, penalty_weight=1.0, truncation_strategy="truncate_start"),
+            dict(type="mmap", features_dir=os.path.join(tmp, "neg"), truth=False, sampling_weight=10.0, penalty_weight=1.0, truncation_strategy="random")]}
+        fh = ref.FeatureHandler(config)
+        return lambda B: fh.get_data("training", B, T_FRAMES, "default", policy)
+    except Exception as e:   # the baseline must never take the benchmark down
+        sys.stderr.write("[cpu_baseline] reference loader unavailable: %r\n" % (e,))
+        return None
+
+
+def cpu_baseline(batch, budget_s=24.0, model="mixednet"):
+    """The CPU train.py loop of SURVEY 8(d) on this box's host cores, on a bounded sample, rank 0 / N=1 only:
+    loader (the reference's own data.py when /root/reference is present, else the oracle's restatement of it) +
+    the torch-CPU fp32 restatement of train_on_batch, at the reference's plumbing batch (32) and at the headline
+    batch.  kind = "port": TensorFlow is not installable here, so the model half can never be the reference itself."""
     import torch
 
     from oracle import data_oracle as do
@@ -185,7 +223,7 @@ def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
     flags = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0,0,0")
     random.seed(0)
     np.random.seed(0)
-    provs = do.synthetic_providers(512, 1234)
+    n_samples = 512
     if model == "inception":
         flags = dict(mo.INCEPTION_DEFAULTS)
     elif model == "notebook":
@@ -193,32 +231,66 @@ def cpu_baseline(batch, budget_s=20.0, model="mixednet"):
         flags = dict(synthetic.NOTEBOOK_MIXEDNET_FLAGS)
     om = mo.OracleModel("inception" if model == "inception" else "mixednet", flags, T_FRAMES, seed=42, dtype=torch.float32)
     n_keep = (T_FRAMES - mo.inception_slices_dropped(flags)) * 16 if model == "inception" else 0
-
-    def keep_mask():
-        return (np.random.default_rng(0).random((batch, n_keep)) >= 0.2).astype(np.float32) if n_keep else None
-
     pol = dict(time_mask_max_size=5, time_mask_count=2, freq_mask_max_size=5, freq_mask_count=2)
-    # one untimed step (allocator / thread-pool warm-up), then timed steps until the budget is used
-    x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
-    om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask())
-    t_load = t_model = 0.0
-    n = 0
-    t_start = time.perf_counter()
-    while n < 1 or (time.perf_counter() - t_start) < budget_s * 0.6:
-        t0 = time.perf_counter()
-        x, y, w, _, _ = do.get_data(provs, "training", batch, T_FRAMES, "default", pol)
-        t1 = time.perf_counter()
-        om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask())
-        t2 = time.perf_counter()
-        t_load += t1 - t0
-        t_model += t2 - t1
-        n += 1
-        if n >= 8:
-            break
-    total = t_load + t_model
-    return {"value": round(n * batch / total, 1), "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of batch %d (oracle loader %.2fs + torch-CPU fp32 fwd/bwd/Adam %.2fs)" % (n, batch, t_load, t_model),
-            "loader_windows_per_s": round(n * batch / t_load, 1), "model_windows_per_s": round(n * batch / t_model, 1)}
+    ref_get = _reference_loader(batch, n_samples, pol)
+    provs = do.synthetic_providers(n_samples, 1234)
+
+    def load(B):
+        if ref_get is not None:
+            return ref_get(B)
+        return do.get_data(provs, "training", B, T_FRAMES, "default", pol)[:3]
+
+    def keep_mask(B):
+        return (np.random.default_rng(0).random((B, n_keep)) >= 0.2).astype(np.float32) if n_keep else None
+
+    def run(B, share, max_steps):
+        x, y, w = load(B)     # one untimed step (allocator / thread-pool warm-up)
+        om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask(B))
+        t_load = t_model = 0.0
+        n = 0
+        t_start = time.perf_counter()
+        while n < 1 or ((time.perf_counter() - t_start) < share and n < max_steps):
+            t0 = time.perf_counter()
+            x, y, w = load(B)
+            t1 = time.perf_counter()
+            om.train_step(x, y, w, 1e-3, dropout_mask=keep_mask(B))
+            t2 = time.perf_counter()
+            t_load += t1 - t0
+            t_model += t2 - t1
+            n += 1
+        return {"steps": n, "windows_per_s": round(n * B / (t_load + t_model), 1), "loader_windows_per_s": round(n * B / t_load, 1),
+                "model_windows_per_s": round(n * B / t_model, 1), "loader_s": round(t_load, 3), "model_s": round(t_model, 3)}
+
+    small = run(32, 0.15 * budget_s, 40)
+    big = small if batch == 32 else run(batch, 0.45 * budget_s, 8)
+    return {"value": big["windows_per_s"], "unit": "windows/s", "cores": cores, "kind": "port",
+            "loader": "reference data.py (unmodified, via oracle/ref_data_shim)" if ref_get is not None else "oracle/data_oracle.py (restatement; /root/reference is not on this box)",
+            "model": "oracle/model_oracle.py torch-CPU fp32 fwd/bwd/Keras-Adam",
+            "sample": "%d train steps of batch %d (loader %.2fs + model %.2fs) and %d of batch 32, %d torch threads of %d host threads"
+                      % (big["steps"], batch, big["loader_s"], big["model_s"], small["steps"], cores, os.cpu_count() or 1),
+            "loader_windows_per_s": big["loader_windows_per_s"], "model_windows_per_s": big["model_windows_per_s"],
+            "by_batch": {"32": small, str(batch): big}}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: become the launcher (one rank per GPU over RCCL)."""
+    import socket
+    import subprocess
+
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus:
+        raise SystemExit("--gpus %d but only %d GPU(s) are visible; refusing to report a smaller job under that label" % (args.gpus, ndev))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -227,7 +299,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch
     import torch.distributed as dist
@@ -249,6 +323,9 @@ def main():
         real_stdout = os.dup(1)
         os.dup2(2, 1)
     if world > 1 or force_dp:
+        # 88 KB of gradient per step: one channel moves it as fast as many and takes fewer CUs from the backward kernels
+        # the first bucket overlaps (override with NCCL_MAX_NCHANNELS)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -292,8 +369,10 @@ def main():
             shard_feature_handler(fh, rank, world, seed=0)
         else:
             fh.use_private_rng()
-        dp = DataParallel.for_engine(eng, device, sync_bn=args.sync_bn and (world > 1 or force_dp))
-        dp.broadcast_parameters(0)
+        dp = None
+        if world > 1 or force_dp:
+            dp = DataParallel.for_engine(eng, device, sync_bn=args.sync_bn, grad_buckets=args.grad_buckets)
+            dp.broadcast_parameters(0)
         for opt, v in (("grid_fwd", args.grid_fwd), ("grid_bwd", args.grid_bwd), ("grid_head", args.grid_head)):
             if v:
                 eng.set_option(opt, v)
@@ -390,12 +469,15 @@ def main():
             eng.set_option("profile", 1)
             for _ in range(args.profile_steps):
                 fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
-                if dp.sync_bn:
-                    dp.train_step(B, lr)
-                    continue
-                eng.train_step(B, lr, native.STEP_NO_APPLY if (world > 1 or force_dp) else 0)
-                if world > 1 or force_dp:
-                    eng.apply_gradients(lr, 1.0)
+                if dp is not None and world == 1:
+                    dp.train_step(B, lr)          # forced-DP on one GPU: the exchanges are degenerate but present
+                elif dp is not None:
+                    # the other ranks are past their timed loop: no collective may be issued from here on
+                    eng.set_allreduce_hook(None)
+                    dp = None
+                    eng.train_step(B, lr)
+                else:
+                    eng.train_step(B, lr)
             for name, ms in eng.profile_read():
                 prof.setdefault(name, []).append(ms)
             eng.set_option("profile", 0)
@@ -418,15 +500,21 @@ def main():
         dominant, dom_bytes, achieved = "train_step(all kernels)", step_bytes * B, value / world * step_bytes
         kern[dominant] = 1e3 * elapsed / args.steps
     traffic, traffic_src = pmc_traffic(dominant, args.model) if B == 1024 and not args.pointwise_bf16 else (None, None)
-    # governing roofline of the dominant kernel: the larger of its HBM time and its fp32-MFMA time at the spec peaks
+    # roofline of the dominant kernel.  SURVEY 8(d) names HBM as the governing roofline of the train step; a kernel whose
+    # exact-fp32 MFMA time at the spec peak exceeds its HBM time at the spec peak is priced against the MFMA peak
+    # instead - and BOTH fractions are always reported, with the flops counted (useful ones only: nothing is recomputed
+    # on MFMA since bwd_block1 reads relu(conv1(x)) back)
+    hbm_frac = achieved / HBM_PEAK
     roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK, 4)}
+            "frac": round(hbm_frac, 4), "hbm_achieved_GBps": round(achieved / 1e9, 1), "hbm_frac": round(hbm_frac, 4)}
     mfma_flops = KERNEL_MFMA_FLOPS.get(dominant, 0) * B if (args.model == "mixednet" and not args.force_generic and not args.pointwise_bf16) else 0
-    if mfma_flops and mfma_flops / FP32_MFMA_PEAK > dom_bytes / HBM_PEAK:
+    if mfma_flops:
         tf = mfma_flops / (kern[dominant] * 1e-3)
-        roof = {"bound": "mfma", "kernel": dominant, "achieved": round(tf / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(tf / FP32_MFMA_PEAK, 4), "algorithmic_flops_per_launch": mfma_flops,
-                "hbm_achieved_GBps": round(achieved / 1e9, 1), "hbm_frac": round(achieved / HBM_PEAK, 4)}
+        roof.update({"mfma_achieved_TFLOPs": round(tf / 1e12, 2), "mfma_peak_TFLOPs": FP32_MFMA_PEAK / 1e12, "mfma_frac": round(tf / FP32_MFMA_PEAK, 4),
+                     "useful_mfma_flops_per_launch": mfma_flops})
+        if mfma_flops / FP32_MFMA_PEAK > dom_bytes / HBM_PEAK:
+            roof.update({"bound": "mfma", "achieved": round(tf / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": round(tf / FP32_MFMA_PEAK, 4)})
     out = {
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -442,6 +530,7 @@ def main():
         "roofline": {**roof, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,
+                     "step_frac_note": "whole step, per GPU: windows/s x SURVEY 8(d) algorithmic bytes per window / 8.0 TB/s",
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "final_loss": round(float(last_loss), 5),
     }

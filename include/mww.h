@@ -189,17 +189,29 @@ int mww_apply_gradients(mww_ctx* ctx, float learning_rate, float grad_scale);
 
 /* ---- data-parallel exchange.  The caller owns the communicator (RCCL through
  * torch.distributed, one process per GPU); the library calls back whenever a buffer has to be summed
- * over the ranks.  The callback must ENQUEUE an in-place sum all-reduce of device_buf[0..n) on the
- * context's stream (no host synchronisation needed) and return 0.
+ * over the ranks.  The callback must ENQUEUE an in-place sum all-reduce of device_buf[0..n) (no host
+ * synchronisation needed) and return 0.  `flags` says how the exchange is ordered:
+ *   MWW_EXCHANGE_IN_ORDER  the reduced values are read by the next launch on the context's stream: the all-reduce has to
+ *                          be complete, in stream order, when the callback's work is reached (e.g. a blocking-in-stream
+ *                          dist.all_reduce issued while the context's stream is the current stream);
+ *   MWW_EXCHANGE_DEFERRED  a finished gradient bucket: the all-reduce may run on the communicator's own stream next to
+ *                          the backward kernels that follow (SURVEY §8e "two buckets ... overlaps the remaining backward
+ *                          blocks"); it only has to be complete when the next MWW_EXCHANGE_FLUSH call returns its work;
+ *   MWW_EXCHANGE_FLUSH     device_buf = NULL, n = 0: order the context's stream after every deferred exchange.
  *   sync_bn = 1: BatchNorm statistics are exchanged in every train step — per BN layer one all-reduce of
  *                (sum x, sum x^2) in the forward and one of (sum g, sum g*xhat) in the backward — so the W
  *                ranks normalise over the GLOBAL batch exactly like the single-device reference ("parity
  *                mode"; 2 x layers tiny all-reduces on the critical path, no hipGraph replay).
  *   sync_bn = 0: local-batch statistics ("throughput mode").
  *   reduce_grads = 1: mww_train_step also all-reduces the flat gradient through the callback and applies
- *                Adam to the rank average, i.e. it is the complete data-parallel step.
+ *                Adam to the rank average, i.e. it is the complete data-parallel step.  With the specialised MixedNet
+ *                kernels and option "grad_buckets" 2 (default) the gradient goes in two buckets: [dense + the last two
+ *                blocks] as soon as their backward kernels are enqueued (deferred), the rest after the first block's.
  * fn = NULL removes the hook. */
-typedef int (*mww_allreduce_fn)(void* user, float* device_buf, int64_t n);
+#define MWW_EXCHANGE_IN_ORDER 0
+#define MWW_EXCHANGE_DEFERRED 1
+#define MWW_EXCHANGE_FLUSH 2
+typedef int (*mww_allreduce_fn)(void* user, float* device_buf, int64_t n, int flags);
 int mww_set_allreduce_hook(mww_ctx* ctx, mww_allreduce_fn fn, void* user, int world_size, int sync_bn, int reduce_grads);
 
 /* ---- inference forward on the current batch: replaces model(x, training=...) /
@@ -239,7 +251,9 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
  * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of
  * by finalize launches; forced off by the sync-BN exchange hook), "tail_roles" (default 1, with bn_inline: the dense-weight
- * gradient and the metric update ride in the gradient-reduction launch), "assemble_split" (workgroups per window of the
+ * gradient and the metric update ride in the gradient-assembly launch), "bce_from_logits" (default 1: the loss is the
+ * logits form Keras 3 evaluates for a sigmoid output, 0: clipped probability form), "grad_buckets" (data-parallel step: 2 =
+ * overlapped two-bucket gradient exchange, 1 = one exchange after the backward pass), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's
  * gradient reduction — measured slower), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);

@@ -25,6 +25,22 @@ constexpr float kBnEps = 1e-3f;
 constexpr float kBnMomentum = 0.99f;
 constexpr float kKerasEps = 1e-7f;
 
+// Loss of train.py:206, BinaryCrossentropy(from_logits=False) on a Dense(1, activation="sigmoid") output.  Keras 3
+// (the reference needs TF >= 2.16) caches the logits on the sigmoid output (`_keras_logits`, keras/src/activations) and
+// the TensorFlow backend's binary_crossentropy evaluates tf.nn.sigmoid_cross_entropy_with_logits on them: no clipping,
+// dL/dz = p - y everywhere - the default here.  The probability form with the [1e-7, 1-1e-7] clip (zero
+// gradient for saturated samples) is what a graph without the cached logits computes: option "bce_from_logits" 0.
+constexpr int kHeadTraining = 1, kHeadClippedLoss = 2;   // bits of the head kernels' `training` argument
+__device__ __forceinline__ float bce_value(float z, float pr, float yy, bool clipped_form) {
+  if (!clipped_form) return fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
+  const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
+  return -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
+}
+__device__ __forceinline__ float bce_dz(float pr, float yy, bool clipped_form) {
+  if (clipped_form && ((pr < kKerasEps) || (pr > 1.0f - kKerasEps))) return 0.f;
+  return pr - yy;
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

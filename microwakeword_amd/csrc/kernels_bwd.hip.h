@@ -695,7 +695,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalize
 }
 
 // ------------------------------------------------------------------------------------------
-// Gradient assembly: sum the per-workgroup partials of every segment in a fixed order.
+// Gradient assembly: the per-workgroup partial rows of every segment are summed in a fixed order by
+// grad_final_kernel (kernels_tail.hip.h); the host lists the segments of a step here.
 struct GradSegment {
   const float* part;   // [G][stride]
   int G;
@@ -703,64 +704,11 @@ struct GradSegment {
   int n;               // parameters in this segment
   int dst;             // offset in the flat gradient
 };
-constexpr int kMaxSegments = 50;
-constexpr int kGradSplit = 32;   // second-level split of the partial index
-struct GradReduceArgs {
+constexpr int kMaxSegments = 112;
+struct GradReduceArgs {   // host-side list (not a kernel argument)
   GradSegment seg[kMaxSegments];
   int nseg;
-  float* stage;        // [kGradSplit][P]
-  int P;
 };
-
-// grid = (ceil(maxn/256), nseg, kGradSplit)
-__device__ __forceinline__ void grad_reduce_body(const GradReduceArgs& a) {
-  const GradSegment s = a.seg[blockIdx.y];
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= s.n) return;
-  const int js = blockIdx.z;
-  const int per = (s.G + kGradSplit - 1) / kGradSplit;
-  const int j0 = js * per, j1 = min(s.G, j0 + per);
-  // issue every load of a 16-partial group before the first add: one memory round trip per group
-  float acc = 0.f;
-  for (int jb = j0; jb < j1; jb += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (jb + u < j1) ? s.part[(size_t)(jb + u) * s.stride + e] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];
-  }
-  a.stage[(size_t)js * a.P + s.dst + e] = acc;
-}
-
-__global__ __launch_bounds__(kThreads) void grad_reduce_kernel(GradReduceArgs a) { grad_reduce_body(a); }
-
-// flat gradient = mask * sum of the staged slices (BN gamma/beta slots are written by
-// bn_bwd_finalize_kernel and flagged by direct[p] != 0)
-struct GradFinishArgs {
-  const float* stage;      // [kGradSplit][P]
-  const float* mask;       // [P] 1 = trainable tap, 0 = structural zero (MixConv padding)
-  const unsigned char* direct;  // [P] 1 = already final in grad[]
-  float* grad;             // [P]
-  int P;
-  float scale;             // 1/world_size folded here when gradients are averaged after all-reduce (1 otherwise)
-};
-
-__global__ __launch_bounds__(kThreads) void grad_finish_kernel(GradFinishArgs a) {
-  const int p = blockIdx.x * kThreads + threadIdx.x;
-  if (p >= a.P) return;
-  float v;
-  if (a.direct[p]) {
-    v = a.grad[p];
-  } else {
-    float t[kGradSplit];
-#pragma unroll
-    for (int j = 0; j < kGradSplit; ++j) t[j] = a.stage[(size_t)j * a.P + p];
-    v = 0.f;
-#pragma unroll
-    for (int j = 0; j < kGradSplit; ++j) v += t[j];
-  }
-  a.grad[p] = v * a.mask[p] * a.scale;
-}
 
 // Keras Adam: alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host per step.
 struct AdamArgs {
@@ -778,34 +726,6 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs a) {
   if (p >= a.P) return;
   const float alpha = a.hyper[0];
   const float gg = a.grad[p] * a.hyper[1];
-  float m = a.m[p], v = a.v[p];
-  m += (gg - m) * (1.0f - a.beta1);
-  v += (gg * gg - v) * (1.0f - a.beta2);
-  a.m[p] = m;
-  a.v[p] = v;
-  a.param[p] -= alpha * m / (sqrtf(v) + a.eps);
-}
-
-// single-GPU step: gradient finish and Adam in one pass (the flat gradient is still written for
-// mww_get_grads / tests)
-__global__ __launch_bounds__(kThreads) void grad_finish_adam_kernel(GradFinishArgs f, AdamArgs a) {
-  const int p = blockIdx.x * kThreads + threadIdx.x;
-  if (p >= f.P) return;
-  float g;
-  if (f.direct[p]) {
-    g = f.grad[p];
-  } else {
-    float t[kGradSplit];
-#pragma unroll
-    for (int j = 0; j < kGradSplit; ++j) t[j] = f.stage[(size_t)j * f.P + p];
-    g = 0.f;
-#pragma unroll
-    for (int j = 0; j < kGradSplit; ++j) g += t[j];
-  }
-  g = g * f.mask[p] * f.scale;
-  f.grad[p] = g;
-  const float alpha = a.hyper[0];
-  const float gg = g * a.hyper[1];
   float m = a.m[p], v = a.v[p];
   m += (gg - m) * (1.0f - a.beta1);
   v += (gg * gg - v) * (1.0f - a.beta2);

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const bool active = rg < nrg;
   const int n = a.T * C;
   const float sc = active ? a.scale[c] : 0.f, sh = active ? a.shift[c] : 0.f;
-  const float mu = (active && a.training) ? a.mean[c] : 0.f, rs = (active && a.training) ? a.rstd[c] : 0.f;
+  const float mu = (active && (a.training & kHeadTraining)) ? a.mean[c] : 0.f, rs = (active && (a.training & kHeadTraining)) ? a.rstd[c] : 0.f;
   const float rsc = (active && a.rp) ? a.rscale[c] : 0.f, rsh = (active && a.rp) ? a.rshift[c] : 0.f;
   const float bias = a.bd[0];
   float g1 = 0.f, g2 = 0.f;
@@ -749,20 +749,19 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       float dzz = 0.f;
       if (a.y != nullptr) {
         const float yy = a.y[b];
-        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
-        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
-        if (a.training) {
+        const bool clipped_form = (a.training & kHeadClippedLoss) != 0;
+        const float bce = bce_value(zz, pr, yy, clipped_form);
+        if (a.training & kHeadTraining) {
           const float w = a.sw[b];
           a.loss_part[b] = w * bce * a.inv_b;
-          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
-          dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
+          dzz = w * bce_dz(pr, yy, clipped_form) * a.inv_b;
           a.dz[b] = dzz;
         }
       }
       sBcast[0] = dzz;
     }
     __syncthreads();
-    if (a.training && active) {
+    if ((a.training & kHeadTraining) && active) {
       const float dzz = sBcast[0];
       float* gb = a.g + (size_t)b * n;
       for (int t = rg; t < a.T; t += nrg) {
@@ -776,7 +775,7 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       }
     }
   }
-  if (a.training) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
+  if (a.training & kHeadTraining) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -820,7 +819,7 @@ __global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
   const int nrg = kThreads / C, c = tid % C, rg = tid / C;
   const bool active = rg < nrg;
   const float sc = active ? h.scale[c] : 0.f, sh = active ? h.shift[c] : 0.f;
-  const float mu = (active && h.training) ? h.mean[c] : 0.f, rs = (active && h.training) ? h.rstd[c] : 0.f;
+  const float mu = (active && (h.training & kHeadTraining)) ? h.mean[c] : 0.f, rs = (active && (h.training & kHeadTraining)) ? h.rstd[c] : 0.f;
   const float rsc = (active && h.rp) ? h.rscale[c] : 0.f, rsh = (active && h.rp) ? h.rshift[c] : 0.f;
   float w8[8];
 #pragma unroll
@@ -879,13 +878,13 @@ __global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
         sV[tid] = acc;
         sArgT[tid] = arg;
         dot = acc * h.wd[tid];
-        if (h.training) a.hact[(size_t)b * nd + tid] = acc;
+        if (h.training & kHeadTraining) a.hact[(size_t)b * nd + tid] = acc;
       }
     } else if (active) {
       for (int t = rg; t < To; t += nrg) {
         const float v = sA[(t + Toff) * PA + c] * (att ? sS[t] : 1.f);
         dot = fmaf(v, h.wd[t * C + c], dot);
-        if (h.training) a.hact[(size_t)b * nd + t * C + c] = v;
+        if (h.training & kHeadTraining) a.hact[(size_t)b * nd + t * C + c] = v;
       }
     }
     dot = wave_sum(dot);
@@ -899,20 +898,19 @@ __global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
       float dzz = 0.f;
       if (h.y != nullptr) {
         const float yy = h.y[b];
-        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
-        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
-        if (h.training) {
+        const bool clipped_form = (h.training & kHeadClippedLoss) != 0;
+        const float bce = bce_value(zz, pr, yy, clipped_form);
+        if (h.training & kHeadTraining) {
           const float w = h.sw[b];
           h.loss_part[b] = w * bce * h.inv_b;
-          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
-          dzz = clipped ? 0.f : w * (pr - yy) * h.inv_b;
+          dzz = w * bce_dz(pr, yy, clipped_form) * h.inv_b;
           h.dz[b] = dzz;
         }
       }
       sBcast[0] = dzz;
     }
     __syncthreads();
-    if (!h.training) continue;
+    if (!(h.training & kHeadTraining)) continue;
     const float dzz = sBcast[0];
     if (att) {
       for (int t = tid; t < To; t += kThreads) {
@@ -957,7 +955,7 @@ __global__ __launch_bounds__(kThreads) void ghead_att_kernel(GHead2Args a) {
       }
     }
   }
-  if (h.training) {
+  if (h.training & kHeadTraining) {
     write_channel_partials(g1, g2, C, sStat, h.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
     if (att && tid < 8) a.watt_part[(size_t)blockIdx.x * 8 + tid] = wacc;
   }

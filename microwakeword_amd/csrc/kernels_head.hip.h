@@ -37,7 +37,7 @@ struct HeadArgs {
   float* gstat_part;       // [gridDim.x][2][C]   sum g, sum g*xhat of the BN_L input gradient
   int B, T;
   float inv_b;
-  int training;
+  int training;            // kHeadTraining | kHeadClippedLoss
   BnFoldArgs fold;         // fold.acc set: BN_L's scale / shift / mean / rstd are folded here from the accumulator rows
   StatAcc gacc;            // gacc.acc set: the (sum g, sum g*xhat) partials go to accumulator rows instead of gstat_part
 };
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   } else if (active) {
     sc = *reinterpret_cast<const float4*>(a.scale + q * 4);
     sh = *reinterpret_cast<const float4*>(a.shift + q * 4);
-    if (a.training) {
+    if (a.training & kHeadTraining) {
       mu = *reinterpret_cast<const float4*>(a.mean + q * 4);
       rs = *reinterpret_cast<const float4*>(a.rstd + q * 4);
     }
@@ -108,21 +108,19 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
       float dzz = 0.f;
       if (a.y != nullptr) {
         const float yy = a.y[b];
-        // Keras binary_crossentropy(from_logits=False): clip to [eps, 1-eps], probability form
-        const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
-        const float bce = -(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc));
-        if (a.training) {
+        const bool clipped_form = (a.training & kHeadClippedLoss) != 0;
+        const float bce = bce_value(zz, pr, yy, clipped_form);
+        if (a.training & kHeadTraining) {
           const float w = a.sw[b];
           a.loss_part[b] = w * bce * a.inv_b;
-          const bool clipped = (pr < kKerasEps) || (pr > 1.0f - kKerasEps);
-          dzz = clipped ? 0.f : w * (pr - yy) * a.inv_b;
+          dzz = w * bce_dz(pr, yy, clipped_form) * a.inv_b;
           a.dz[b] = dzz;
         }
       }
       sBcast[0] = dzz;
     }
     __syncthreads();
-    if (a.training) {
+    if (a.training & kHeadTraining) {
       const float dzz = sBcast[0];
 #pragma unroll
       for (int j = 0; j < JMAX; ++j) {
@@ -140,7 +138,7 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
     }
     // sRed / sBcast are rewritten only after the next window's first barrier
   }
-  if (a.training) {
+  if (a.training & kHeadTraining) {
     if (active) {
       *reinterpret_cast<float4*>(sStat + (rg * 2 + 0) * C + q * 4) = g1;
       *reinterpret_cast<float4*>(sStat + (rg * 2 + 1) * C + q * 4) = g2;
@@ -161,6 +159,7 @@ struct MetricsArgs {
   const float* y;      // [B]
   MetricState* m;
   int B;
+  const float* z;      // [B] logits for the loss metric (null: probability form with the Keras clip)
 };
 
 template <int NT>
@@ -178,7 +177,7 @@ __device__ __forceinline__ void metrics_body(const MetricsArgs& a, unsigned (*sH
     const int b101 = (int)ceilf(p01 * 100.0f) - 1;
     int b200 = (int)ceilf(p01 * 199.0f) - 1;
     if (b200 < 0) b200 = 0;                       // AUC thresholds carry epsilon ends
-    if (b101 >= 0) atomicAdd(&sH101[lab][b101], 1u);
+    if (b101 >= 0) atomicAdd(&sH101[lab][b101], 1u);   // p == 0 exceeds no threshold (0.0 included): strict '>' of train.py's metrics
     atomicAdd(&sH200[lab][b200], 1u);
     const bool ppos = pr > 0.5f;
     atomicAdd(&sCnt[0], 1u);
@@ -187,8 +186,7 @@ __device__ __forceinline__ void metrics_body(const MetricsArgs& a, unsigned (*sH
     if (ppos && !lab) atomicAdd(&sCnt[3], 1u);
     if (!ppos && lab) atomicAdd(&sCnt[4], 1u);
     atomicAdd(&sCnt[lab ? 5 : 6], 1u);
-    const float pc = fminf(fmaxf(pr, kKerasEps), 1.0f - kKerasEps);
-    bce += (double)(-(yy * logf(pc) + (1.0f - yy) * logf(1.0f - pc)));
+    bce += (double)bce_value(a.z ? a.z[b] : 0.f, pr, yy, a.z == nullptr);
   }
   sBce[tid] = bce;
   __syncthreads();

@@ -34,31 +34,119 @@ __global__ __launch_bounds__(kThreads) void head_tail_kernel(HeadTailArgs a) {
   }
 }
 
-// MixedNet train step with the statistics hand-over: the dense-weight gradient and the metric update have no
-// consumer before the gradient finish, so they ride in the gradient-reduction launch as extra z-slices of its grid
-// (slices [0, kGradSplit) reduce the weight-gradient partials; the blocks of the slices above are numbered linearly:
-// ndx * kGradSplit dense-gradient tiles, then one metric workgroup).  The dense tiles write their batch-chunk sums
-// straight into the staging slices the finish kernel adds up (chunk by = slice by), so no partial rows and no segment.
-struct GradReduceTailArgs {
-  DenseGradArgs dense;   // part = stage + offset of the dense kernel, stride = P, chunk = ceil(B / kGradSplit)
+// ---- gradient assembly (+ Adam) in one launch -------------------------------------------------------------------
+// Every workgroup owns kFinalCols consecutive parameters of one segment and finishes them completely: its 256 threads
+// are kFinalSlices row slices x kFinalCols parameters; a thread sums its slice of the segment's rows in a fixed order
+// (16 loads in flight, 128-byte coalesced), the slices are added in a fixed order through LDS => bit-reproducible
+// gradients; then the structural mask and the gradient scale and - in the single-device step - Keras Adam (SURVEY
+// A.6) are applied in place.  (Round 1 used a two-level reduction through a [32][P] staging buffer in three
+// launches: partial sums, finish + Adam; each tiny launch costs ~6 us on the stream.)
+// Rows of a segment:  kind 0  the per-workgroup partial rows a backward kernel wrote;
+//                     kind 1  the dense kernel's gradient, one row per window: dz_b * relu(bn(p_L[b, e])) and, as the
+//                             last element, the bias gradient sum_b dz_b (second read of p_L);
+//                     kind 2  values that are already final in grad[] (BN gamma / beta, written by the folding kernels);
+//                     kind 3  parameters nothing contributes to (gradient 0).
+// One more workgroup updates the metric counters (train.py:209-221) - they have no consumer on the device.
+constexpr int kFinalCols = 32, kFinalSlices = kThreads / kFinalCols;
+constexpr int kMaxFinalSegments = 56;
+enum { kSegPartials = 0, kSegDense = 1, kSegDirect = 2, kSegZero = 3 };
+struct FinalSegment {
+  const float* part;   // [G][stride] (kind 0)
+  int G, stride, n, dst, kind;
+  int block0;          // first workgroup of this segment
+};
+struct GradFinalArgs {
+  FinalSegment seg[kMaxFinalSegments];
+  int nseg, nblocks;       // nblocks = workgroups of all segments (the metric workgroup, if any, follows)
+  DenseGradArgs dense;     // kind 1: p, scale, shift, dz, B, n, C, keep, residual (part / stride / chunk unused)
   MetricsArgs met;
-  int ndx;
   int do_metrics;
+  const float* mask;       // [P] 1 = trainable tap, 0 = structural zero (MixConv padding)
+  float* grad;             // [P]
+  float scale;
+  AdamArgs adam;
+  int apply_adam;
 };
 
-__global__ __launch_bounds__(kThreads) void grad_reduce_tail_kernel(GradReduceArgs a, GradReduceTailArgs t) {
+__global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ unsigned sH101[2][101];
   __shared__ unsigned sH200[2][200];
   __shared__ unsigned sCnt[8];
-  if ((int)blockIdx.z < kGradSplit) {
-    grad_reduce_body(a);
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  if (bid >= a.nblocks) {
+    if (a.do_metrics) metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-thread BCE partials
     return;
   }
-  const int id = (((int)blockIdx.z - kGradSplit) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
-  const int n_dense = t.ndx * kGradSplit;
-  if (id < n_dense) dense_grad_body(t.dense, id % t.ndx, id / t.ndx, threadIdx.x);
-  else if (id == n_dense && t.do_metrics) metrics_body<kThreads>(t.met, sH101, sH200, sCnt, sAcc, threadIdx.x);
+  int si = 0;
+  for (int i = 1; i < a.nseg; ++i)
+    if (bid >= a.seg[i].block0) si = i;
+  const FinalSegment s = a.seg[si];
+  const int pl = tid % kFinalCols, sl = tid / kFinalCols;
+  const int e = (bid - s.block0) * kFinalCols + pl;
+  const bool in = e < s.n;
+  float acc = 0.f;
+  if (s.kind == kSegPartials) {
+    const int per = (s.G + kFinalSlices - 1) / kFinalSlices;
+    const int j0 = sl * per, j1 = min(s.G, j0 + per);
+    for (int jb = j0; jb < j1; jb += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (in && jb + u < j1) ? s.part[(size_t)(jb + u) * s.stride + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+  } else if (s.kind == kSegDense) {
+    const DenseGradArgs& d = a.dense;
+    const int per = (d.B + kFinalSlices - 1) / kFinalSlices;
+    const int b0 = sl * per, b1 = min(d.B, b0 + per);
+    if (in && e < d.n) {
+      const int c = e % d.C;
+      const float sc = d.scale[c], sh = d.shift[c];
+      const float rsc = d.rp ? d.rscale[c] : 0.f, rsh = d.rp ? d.rshift[c] : 0.f;
+      const size_t roff = d.rp ? (size_t)d.rdrop * d.C + e : 0, rstride = (size_t)d.rT * d.C;
+      constexpr int U = 32;   // rows in flight per thread: the chain over a slice's B/8 windows is B/256 round trips long
+      for (int bb = b0; bb < b1; bb += U) {
+        float v[U], dz[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool ok = bb + u < b1;
+          v[u] = ok ? d.p[(size_t)(bb + u) * d.n + e] : 0.f;
+          dz[u] = ok ? d.dz[bb + u] : 0.f;
+          r[u] = (ok && d.rp) ? fmaf(d.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
+          if (ok && d.keep) dz[u] *= d.keep[(size_t)(bb + u) * d.n + e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fmaf(dz[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), acc);
+      }
+    } else if (in) {   // e == d.n: the dense bias
+      for (int b = b0; b < b1; ++b) acc += d.dz[b];
+    }
+  } else if (s.kind == kSegDirect) {
+    if (in && sl == 0) acc = a.grad[s.dst + e];
+  }
+  float* sSum = reinterpret_cast<float*>(sAcc);
+  sSum[tid] = acc;
+  __syncthreads();
+  if (sl == 0 && in) {
+    float g = 0.f;
+#pragma unroll
+    for (int j = 0; j < kFinalSlices; ++j) g += sSum[j * kFinalCols + pl];
+    const int p = s.dst + e;
+    g = g * a.mask[p] * a.scale;
+    a.grad[p] = g;
+    if (a.apply_adam) {
+      const AdamArgs& ad = a.adam;
+      const float alpha = ad.hyper[0];
+      const float gg = g * ad.hyper[1];
+      float m = ad.m[p], v = ad.v[p];
+      m += (gg - m) * (1.0f - ad.beta1);
+      v += (gg * gg - v) * (1.0f - ad.beta2);
+      ad.m[p] = m;
+      ad.v[p] = v;
+      ad.param[p] -= alpha * m / (sqrtf(v) + ad.eps);
+    }
+  }
 }
 
 }  // namespace mww

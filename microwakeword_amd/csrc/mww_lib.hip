@@ -116,8 +116,11 @@ struct mww_ctx {
   bool sync_bn = false, reduce_grads = false;
   float* sync_buf = nullptr;        // [layers][fwd 2C | bwd 2C] statistics sums being exchanged
   std::vector<int64_t> sync_off;    // offset of layer i in sync_buf
-  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr, *stage = nullptr;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr;
   unsigned char* direct = nullptr;
+  std::vector<unsigned char> direct_host;   // host copy: which parameters' gradients are written directly by a folding kernel
+  bool exchange_pending = false;            // a deferred bucket exchange is in flight (data-parallel step)
+  int grad_buckets = 2;                     // data-parallel step: gradient exchanged in this many buckets ("grad_buckets" option)
   float* bn_state = nullptr;
   float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
   float* a0 = nullptr;     // relu(conv1(x)) [max_batch][Ta][conv1_filters]: written by the training forward, read by bwd_first_kernel
@@ -176,6 +179,7 @@ struct mww_ctx {
   bool use_side = false;  // "side_stream" option: metric update + dense-weight gradient on a second stream (measured: co-running
                           // kernels displace workgroups of the occupancy-tuned block kernels; serial is 8 us/step faster)
   bool pw_bf16 = false;   // 1x1 contractions with bf16 operands (mww_set_option "pointwise_bf16")
+  bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
@@ -371,7 +375,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
     }
     const bool one_launch = metrics && loss && inline_side;   // both pieces as roles of one launch (head_tail_kernel without a finalize role)
     if (metrics && !one_launch) {
-      MetricsArgs ma{c->prob, c->y_cur, c->metrics, B};
+      MetricsArgs ma{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
       lp.begin("metrics");
       hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
       lp.end();
@@ -393,7 +397,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
         HeadTailArgs ht;
         memset(&ht, 0, sizeof(ht));
         ht.dense = dg;
-        ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
+        ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
         ht.n_fin = 0;
         ht.ndx = (dg.n + 1 + kThreads - 1) / kThreads;
         ht.ndy = ndchunks;
@@ -432,7 +436,7 @@ int exchange_stats(mww_ctx* c, Launcher& lp, const char* what, int layer, const 
   lp.begin(what, layer);
   hipLaunchKernelGGL(stat_collapse_kernel, dim3(C), dim3(kThreads), 0, c->stream, a);
   lp.end();
-  if (c->hook(c->hook_user, buf, 2 * C) != 0) return fail(MWW_ERR_STATE, "all-reduce hook failed");
+  if (c->hook(c->hook_user, buf, 2 * C, MWW_EXCHANGE_IN_ORDER) != 0) return fail(MWW_ERR_STATE, "all-reduce hook failed");
   out->part = buf;
   out->G = 1;
   out->inv_n = local_inv_n / (float)c->world;
@@ -535,7 +539,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   h.B = B;
   h.T = ll.tout;
   h.inv_b = 1.0f / (float)B;
-  h.training = loss ? 1 : 0;
+  h.training = (loss ? kHeadTraining : 0) | (c->bce_clipped ? kHeadClippedLoss : 0);
   h.fold = fold_of(ll);
   if (inl) c->fpar ^= 1;
   // train step with the statistics hand-over: BN_L's backward sums go to accumulator rows (folded by the last block's
@@ -571,75 +575,131 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
 // from the side stream), structural mask, optionally fused with the Adam update
 int enqueue_adam(mww_ctx* c);
 
-int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam) {
+// Gradient assembly of the parameter range [lo, hi): one grad_final_kernel launch (kernels_tail.hip.h) finishes every
+// parameter of the range - fixed-order sums of the partial rows listed in `ga` (and of the rows the dense / metric
+// roles produce when they ride along), the values the folding kernels already wrote (BN gamma / beta), zeros for
+// parameters nothing contributes to - and applies the mask, and Adam when `apply_adam`.
+int assemble_range(mww_ctx* c, int B, const GradReduceArgs& ga, int64_t lo, int64_t hi, bool tail_dense, bool metrics, bool apply_adam) {
   Launcher lp{c};
+  std::vector<FinalSegment> segs;
+  for (int i = 0; i < ga.nseg; ++i) {
+    const GradSegment& g = ga.seg[i];
+    if (g.dst < lo || g.dst >= hi) continue;
+    if (g.dst + g.n > hi) return fail(MWW_ERR_STATE, "gradient segment straddles a bucket boundary");
+    segs.push_back(FinalSegment{g.part, g.G, g.stride, g.n, g.dst, kSegPartials, 0});
+  }
+  GradFinalArgs a;
+  memset(&a, 0, sizeof(a));
+  if (tail_dense && c->o_dense_w >= lo && c->o_dense_w < hi) {
+    Layer& ll = c->L[c->d.n_blocks - 1];
+    a.dense = DenseGradArgs{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, nullptr, B, c->t_last * c->c_last,
+                            c->c_last, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    segs.push_back(FinalSegment{nullptr, B, 0, c->t_last * c->c_last + 1, (int)c->o_dense_w, kSegDense, 0});
+  }
+  std::sort(segs.begin(), segs.end(), [](const FinalSegment& x, const FinalSegment& y) { return x.dst < y.dst; });
+  // the gaps between the segments: runs of parameters that are final in grad[] already ("direct") or untouched
+  std::vector<FinalSegment> all;
+  int64_t cur = lo;
+  auto fill = [&](int64_t upto) {
+    while (cur < upto) {
+      const bool dir = c->direct_host[(size_t)cur] != 0;
+      int64_t e = cur;
+      while (e < upto && (c->direct_host[(size_t)e] != 0) == dir) ++e;
+      all.push_back(FinalSegment{nullptr, 1, 0, (int)(e - cur), (int)cur, dir ? kSegDirect : kSegZero, 0});
+      cur = e;
+    }
+  };
+  for (const FinalSegment& sgm : segs) {
+    if (sgm.dst < cur) return fail(MWW_ERR_STATE, "overlapping gradient segments");
+    fill(sgm.dst);
+    all.push_back(sgm);
+    cur = sgm.dst + sgm.n;
+  }
+  fill(hi);
+  a.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
+  a.mask = c->mask;
+  a.grad = c->grads;
+  a.scale = 1.0f;
+  a.adam = AdamArgs{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
+  a.apply_adam = apply_adam ? 1 : 0;
+  for (size_t first = 0; first < all.size() || (metrics && first == 0); first += kMaxFinalSegments) {
+    const int n = (int)std::min<size_t>(kMaxFinalSegments, all.size() - first);
+    int nb = 0;
+    for (int i = 0; i < n; ++i) {
+      a.seg[i] = all[first + i];
+      a.seg[i].block0 = nb;
+      nb += (a.seg[i].n + kFinalCols - 1) / kFinalCols;
+    }
+    a.nseg = n;
+    a.nblocks = nb;
+    a.do_metrics = (metrics && first == 0) ? 1 : 0;
+    if (nb + a.do_metrics == 0) break;
+    lp.begin(apply_adam ? "grad_final+adam" : "grad_final");
+    hipLaunchKernelGGL(grad_final_kernel, dim3(nb + a.do_metrics), dim3(kThreads), 0, c->stream, a);
+    lp.end();
+    if (all.empty()) break;
+  }
+  return MWW_OK;
+}
+
+// gradient exchange of a finished range through the caller's hook (data-parallel step)
+int exchange_range(mww_ctx* c, int64_t lo, int64_t hi, int flags) {
+  if (c->hook(c->hook_user, flags == MWW_EXCHANGE_FLUSH ? nullptr : c->grads + lo, flags == MWW_EXCHANGE_FLUSH ? 0 : hi - lo, flags) != 0)
+    return fail(MWW_ERR_STATE, "all-reduce hook failed");
+  return MWW_OK;
+}
+
+int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam, int64_t lo = 0, int64_t hi = -1, bool last_range = true) {
+  if (hi < 0) hi = c->P;
   int rcj = join_side(c);
   if (rcj) return rcj;
-  if (c->asm_overlap && !c->use_graphs && !c->profile) {
+  if (last_range && c->asm_overlap && !c->use_graphs && !c->profile) {
     // x, y and the sample weights were last read by the launches above: the next batch may be assembled from here on
     HIPCHK(hipEventRecord(c->ev_xfree, c->stream));
     c->xfree_valid = true;
   }
-  const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
-  const int ndchunks = (B + dchunk - 1) / dchunk;
-  const bool tail_here = c->tail_in_reduce;
-  c->tail_in_reduce = false;
-  if (!tail_here) {
+  const bool tail_here = c->tail_in_reduce && c->o_dense_w >= lo && c->o_dense_w < hi;
+  if (tail_here) c->tail_in_reduce = false;
+  if (!tail_here && c->o_dense_w >= lo && c->o_dense_w < hi) {
+    // the dense-weight gradient came as batch-chunk rows from dense_grad_kernel / head_tail_kernel
+    const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
     GradSegment s;
     s.part = c->dwd_part;
-    s.G = ndchunks;
+    s.G = (B + dchunk - 1) / dchunk;
     s.stride = c->dwd_stride;
     s.n = c->t_last * c->c_last + 1;
     s.dst = (int)c->o_dense_w;
     ga.seg[ga.nseg++] = s;
   }
-  int maxn = 0;
-  for (int i = 0; i < ga.nseg; ++i) maxn = std::max(maxn, ga.seg[i].n);
-  ga.stage = c->stage;
-  ga.P = (int)c->P;
-  if (tail_here) {
-    static_assert(kDenseChunks == kGradSplit, "the dense-gradient chunks are the staging slices");
-    Layer& ll = c->L[c->d.n_blocks - 1];
-    GradReduceTailArgs t;
-    memset(&t, 0, sizeof(t));
-    t.dense = DenseGradArgs{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, c->stage + c->o_dense_w, B, c->t_last * c->c_last,
-                            c->c_last, (int)c->P, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    t.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
-    t.ndx = (t.dense.n + 1 + kThreads - 1) / kThreads;
-    t.do_metrics = c->tail_metrics ? 1 : 0;
-    const int gx = (maxn + kThreads - 1) / kThreads, gy = ga.nseg;
-    const int n_role = t.ndx * kGradSplit + t.do_metrics;
-    const int gz = kGradSplit + (n_role + gx * gy - 1) / (gx * gy);
-    lp.begin("grad_reduce+tail");
-    hipLaunchKernelGGL(grad_reduce_tail_kernel, dim3(gx, gy, gz), dim3(kThreads), 0, c->stream, ga, t);
-    lp.end();
-  } else {
-    lp.begin("grad_reduce");
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((maxn + kThreads - 1) / kThreads, ga.nseg, kGradSplit), dim3(kThreads), 0,
-                       c->stream, ga);
-    lp.end();
+  const bool exchange = fuse_adam && c->hook && c->reduce_grads;
+  // single device: Adam rides in the assembly launch; data-parallel: local gradient -> sum over the ranks (the 1/W
+  // factor travels as the gradient scale next to the step size, see mww_train_step) -> Adam on the average
+  int rc = assemble_range(c, B, ga, lo, hi, tail_here, tail_here && c->tail_metrics, fuse_adam && !exchange);
+  if (rc || !exchange) return rc;
+  rc = exchange_range(c, lo, hi, last_range ? MWW_EXCHANGE_IN_ORDER : MWW_EXCHANGE_DEFERRED);
+  if (!last_range) c->exchange_pending = true;
+  if (rc || !last_range) return rc;
+  if (c->exchange_pending) {
+    rc = exchange_range(c, 0, 0, MWW_EXCHANGE_FLUSH);
+    c->exchange_pending = false;
+    if (rc) return rc;
   }
-  GradFinishArgs gf{c->stage, c->mask, c->direct, c->grads, (int)c->P, 1.0f};
-  if (fuse_adam && c->hook && c->reduce_grads) {
-    // complete data-parallel step: local gradient -> sum over the ranks -> Adam on the average
-    // (the 1/W factor travels as the gradient scale next to the step size, see mww_train_step)
-    lp.begin("grad_finish");
-    hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
-    lp.end();
-    if (c->hook(c->hook_user, c->grads, c->P) != 0) return fail(MWW_ERR_STATE, "all-reduce hook failed");
-    return enqueue_adam(c);
+  return enqueue_adam(c);
+}
+
+// the weight-gradient partial rows of blocks [b0, b1)
+void block_segments(mww_ctx* c, int gbwd, int b0, int b1, GradReduceArgs* ga) {
+  memset(ga, 0, sizeof(*ga));
+  for (int i = b0; i < b1; ++i) {
+    Layer& l = c->L[i];
+    GradSegment s;
+    s.part = l.grad_part;
+    s.G = gbwd;
+    s.stride = l.grad_part_stride;
+    s.n = l.grad_part_stride;
+    s.dst = (int)(i == 0 ? c->o_conv1 : l.o_dw_w);
+    ga->seg[ga->nseg++] = s;
   }
-  if (fuse_adam) {
-    AdamArgs aa{c->params, c->grads, c->adam_m, c->adam_v, mail_hyper(c), (int)c->P, 0.9f, 0.999f, 1e-7f};
-    lp.begin("grad_finish_adam");
-    hipLaunchKernelGGL(grad_finish_adam_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf, aa);
-    lp.end();
-    return MWW_OK;
-  }
-  lp.begin("grad_finish");
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(((int)c->P + kThreads - 1) / kThreads), dim3(kThreads), 0, c->stream, gf);
-  lp.end();
-  return MWW_OK;
 }
 
 int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
@@ -650,6 +710,12 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   const int gbwd = std::min(B, c->grid_bwd);
   const int ghead = std::min(B, c->grid_head);
   const bool inl = c->bn_inline && !(c->hook && c->sync_bn);
+  // data-parallel step: the gradient of [blocks >= split, dense] (a contiguous tail of the flat vector) is final once
+  // block `split`'s backward kernel is enqueued; it is assembled and handed to the exchange hook there, so that the
+  // all-reduce runs next to the remaining backward kernels.  Needs the statistics hand-over (the BN
+  // gamma / beta gradients of a block are then written by that block's own backward kernel).
+  const int split = nb >= 3 ? nb - 2 : 0;
+  const bool bucketed = fuse_adam && c->hook && c->reduce_grads && !c->sync_bn && inl && c->tail_in_reduce && c->grad_buckets == 2 && split > 0;
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -687,7 +753,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       ht.fin = f;
       ht.dense = DenseGradArgs{l.p, bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
                                c->c_last, c->dwd_stride, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
-      ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B};
+      ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
       ht.n_fin = l.cout;
       ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
       ht.ndy = (B + dchunk - 1) / dchunk;
@@ -741,6 +807,12 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
       if (rc) return rc;
+      if (bucketed && i == split) {
+        GradReduceArgs gb;
+        block_segments(c, gbwd, split, nb, &gb);
+        rc = enqueue_grad_assembly(c, B, gb, fuse_adam, l.o_dw_w, c->P, false);
+        if (rc) return rc;
+      }
     } else {
       if (last) return fail(MWW_ERR_UNSUPPORTED, "single-block models are not supported");
       BwdFirstArgs a{c->x, c->a0, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
@@ -754,20 +826,8 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   }
   if (inl) c->gpar ^= 1;
   GradReduceArgs ga;
-  memset(&ga, 0, sizeof(ga));
-  int ns = 0;
-  for (int i = 0; i < nb; ++i) {
-    Layer& l = c->L[i];
-    GradSegment s;
-    s.part = l.grad_part;
-    s.G = gbwd;
-    s.stride = l.grad_part_stride;
-    s.n = l.grad_part_stride;
-    s.dst = (int)(i == 0 ? c->o_conv1 : l.o_dw_w);
-    ga.seg[ns++] = s;
-  }
-  ga.nseg = ns;
-  return enqueue_grad_assembly(c, B, ga, fuse_adam);
+  block_segments(c, gbwd, 0, bucketed ? split : nb, &ga);
+  return enqueue_grad_assembly(c, B, ga, fuse_adam, 0, bucketed ? c->L[split].o_dw_w : c->P, true);
 }
 
 // ---------------------------------------------------------------------------------- conv/BN graphs
@@ -1050,7 +1110,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   h.T = lo.tout;
   h.C = lo.cout;
   h.inv_b = 1.0f / (float)B;
-  h.training = loss ? 1 : 0;
+  h.training = (loss ? kHeadTraining : 0) | (c->bce_clipped ? kHeadClippedLoss : 0);
   if (lo.res_src >= 0) {
     GOp& rr = c->G[lo.res_src];
     h.rp = rr.p;
@@ -1393,6 +1453,7 @@ int init_defaults(mww_ctx* c, const std::vector<BnSlots>& bn) {
     }
   HIPCHK(hipMemcpy(c->mask, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(c->direct, dir.data(), dir.size(), hipMemcpyHostToDevice));
+  c->direct_host = dir;
   HIPCHK(hipMemcpy(c->bn_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   return MWW_OK;
 }
@@ -1410,7 +1471,6 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->adam_v, c->P));
   A(dev_alloc(&c->mask, c->P));
   A(dev_alloc(&c->direct, c->P));
-  A(dev_alloc(&c->stage, (size_t)kGradSplit * c->P));
   A(dev_alloc(&c->bn_state, c->S));
   A(dev_alloc(&c->x, mb * d.frames * MWW_FEATURE_BINS));
   A(dev_alloc(&c->y, mb));
@@ -1842,7 +1902,7 @@ void mww_destroy(mww_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->stage, c->bn_state, c->x, c->y, c->sw,
+  void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->bn_state, c->x, c->y, c->sw,
                   c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk, c->a0};
   for (void* p : flat) if (p) (void)hipFree(p);
   for (auto& l : c->L) {
@@ -2267,6 +2327,8 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;
+  else if (!strcmp(name, "bce_from_logits")) c->bce_clipped = v == 0;
+  else if (!strcmp(name, "grad_buckets")) { if (v < 1 || v > 2) return fail(MWW_ERR_INVALID, "grad_buckets must be 1 or 2"); c->grad_buckets = (int)v; }
   else if (!strcmp(name, "fused_input")) {
     c->fused_input = v != 0;
     if (!v) { int rc = materialise_x(c); if (rc) return rc; }

@@ -76,7 +76,8 @@ class SamplerDesc(C.Structure):
                 ("cutoff_offsets", C.POINTER(C.c_int32)), ("cutoffs", C.POINTER(C.c_int32))]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)   # mww_allreduce_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)   # mww_allreduce_fn
+EXCHANGE_IN_ORDER, EXCHANGE_DEFERRED, EXCHANGE_FLUSH = 0, 1, 2
 
 
 class NativeError(RuntimeError):
@@ -342,16 +343,17 @@ class Engine:
         self.nl.check(self.nl.lib.mww_set_dropout_mask(self.h, k.ctypes.data_as(C.c_void_p), k.shape[0]))
 
     def set_allreduce_hook(self, fn, world_size=1, sync_bn=False, reduce_grads=False):
-        """``fn(device_ptr: int, n: int) -> None`` must enqueue an in-place sum all-reduce of ``n`` floats
-        at ``device_ptr`` on this engine's stream (see ``parallel.DataParallel``); ``None`` removes it."""
+        """``fn(device_ptr: int, n: int, flags: int) -> None`` must enqueue an in-place sum all-reduce of ``n``
+        floats at ``device_ptr`` ordered as ``flags`` says (``EXCHANGE_IN_ORDER`` / ``_DEFERRED`` / ``_FLUSH``,
+        include/mww.h; see ``parallel.DataParallel``); ``None`` removes it."""
         if fn is None:
             self._hook = ALLREDUCE_FN(0)
             self.nl.check(self.nl.lib.mww_set_allreduce_hook(self.h, self._hook, None, 1, 0, 0))
             return
 
-        def tramp(_user, ptr, n):
+        def tramp(_user, ptr, n, flags):
             try:
-                fn(int(ptr), int(n))
+                fn(int(ptr or 0), int(n), int(flags))
                 return 0
             except Exception:   # a Python exception must not unwind through the C frames
                 import traceback

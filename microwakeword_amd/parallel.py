@@ -1,6 +1,7 @@
 """Data-parallel training over the GPUs of one node: one process per GPU, ``torch.distributed``
 (backend "nccl" == RCCL over xGMI) for the single exchange step of the path — an all-reduce(sum)
-of the flat 22 177-float gradient (88.7 KB: latency-bound, one collective, no bucketing).
+of the flat 22 177-float gradient (88.7 KB: latency-bound), issued in two buckets so that the first one
+([dense + blocks 4, 3], 54.5 KB) overlaps the backward kernels of blocks 2 and 1.
 
 The reference has no distributed code at all (SURVEY §2 "Parallelism strategies: none"); this is
 new work defined by SURVEY §8(e):
@@ -52,10 +53,18 @@ def shard_feature_handler(handler, rank: int, world: int, seed: int):
 
 class DataParallel:
     """Wraps one engine per rank.  ``grad_view`` / ``param_view`` are torch tensors aliasing the
-    engine's flat gradient / parameter vectors (device memory on the GPU path)."""
+    engine's flat gradient / parameter vectors (device memory on the GPU path).
+
+    With ``wrap`` (the normal case: ``for_engine``) the engine drives the exchange through
+    ``mww_set_allreduce_hook``: ``engine.train_step`` is the complete data-parallel step.  In throughput
+    mode (local BatchNorm) the specialised MixedNet kernels hand the gradient over in TWO buckets - [dense +
+    the last two blocks] right after those blocks' backward kernels are enqueued, as a *deferred* exchange
+    that RCCL runs on its own stream next to the remaining backward kernels, and the rest after the first
+    block's backward - then Adam consumes grad/W.  Without ``wrap`` (engines that only expose
+    NO_APPLY + apply, e.g. the test stub) the single all-reduce is issued from here."""
 
     def __init__(self, engine, grad_view: torch.Tensor, param_view: torch.Tensor, state_view: Optional[torch.Tensor] = None,
-                 group=None, sync_bn: bool = False, wrap=None):
+                 group=None, sync_bn: bool = False, wrap=None, grad_buckets: int = 2):
         """``wrap(ptr, n) -> tensor`` turns a device address handed out by the engine into a tensor the
         process group can reduce in place (defaults to a zero-copy view of HBM on the engine's device)."""
         self.engine = engine
@@ -66,27 +75,43 @@ class DataParallel:
         self.sync_bn = bool(sync_bn)
         self._wrap = wrap
         self._views = {}
-        if self.sync_bn:
-            if wrap is None:
-                raise ValueError("sync_bn needs a wrap(ptr, n) function")
-            # the engine calls back for every BN layer (and for the gradient): the complete DP step
-            engine.set_allreduce_hook(self._allreduce, self.world, sync_bn=True, reduce_grads=True)
+        self._pending = []
+        self.exchanges = []   # (n, flags) of the hook calls of the last step (tests / diagnostics)
+        if self.sync_bn and wrap is None:
+            raise ValueError("sync_bn needs a wrap(ptr, n) function")
+        self.engine_driven = wrap is not None
+        if self.engine_driven:
+            # the engine calls back for every BN layer (sync-BN) and for the gradient buckets: the complete DP step
+            engine.set_allreduce_hook(self._allreduce, self.world, sync_bn=self.sync_bn, reduce_grads=True)
+            engine.set_option("grad_buckets", int(grad_buckets))
 
     @classmethod
-    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False):
+    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False, grad_buckets: int = 2):
         g = wrap_device_floats(engine.device_ptr(native.BUF_GRADS), engine.n_params, device)
         p = wrap_device_floats(engine.device_ptr(native.BUF_PARAMS), engine.n_params, device)
         s = wrap_device_floats(engine.device_ptr(native.BUF_BN_STATE), engine.n_state, device)
-        return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=lambda ptr, n: wrap_device_floats(ptr, n, device))
+        return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=lambda ptr, n: wrap_device_floats(ptr, n, device),
+                   grad_buckets=grad_buckets)
 
-    def _allreduce(self, ptr: int, n: int):
-        """Hook target: enqueue sum-all-reduce of n floats at ptr (views are cached per buffer).  With
-        the engine created on torch's current stream the collective is ordered with its kernels."""
+    def _allreduce(self, ptr: int, n: int, flags: int = native.EXCHANGE_IN_ORDER):
+        """Hook target (include/mww.h mww_allreduce_fn).  The engine lives on torch's current stream, so an in-order
+        exchange is a plain ``dist.all_reduce`` (the NCCL backend orders it after, and the current stream behind, the
+        collective); a deferred bucket is issued ``async_op`` - it starts once the kernels enqueued so far are done and
+        runs on the communicator's stream - and its ``wait()`` is what the flush call enqueues."""
+        self.exchanges.append((int(n), int(flags)))
+        if flags == native.EXCHANGE_FLUSH:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            return
         t = self._views.get((ptr, n))
         if t is None:
             t = self._views[(ptr, n)] = self._wrap(ptr, n)
         if dist.is_initialized():
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if flags == native.EXCHANGE_DEFERRED:
+                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_parameters(self, src=0):
         if dist.is_initialized():
@@ -96,14 +121,12 @@ class DataParallel:
                 dist.broadcast(self.state_view, src=src, group=self.group)
 
     def train_step(self, B, lr, flags=0, prefetch=None):
-        """Local forward/backward, gradient all-reduce, Adam on the averaged gradient.
-
-        ``prefetch`` (optional callable) is run between launching the all-reduce and waiting for it: the
-        train loop passes the assembly of the NEXT batch, whose gather kernel then runs on the compute
-        stream while RCCL moves the 88 KB gradient on its own stream (the step's backward has finished
-        with the batch buffers by then, so the single set of buffers suffices)."""
-        if self.sync_bn:
-            self.engine.train_step(B, lr, flags)   # statistics and gradient exchanges happen inside, via the hook
+        """Local forward/backward, gradient all-reduce (overlapped with the backward tail when the engine drives
+        it), Adam on the averaged gradient.  ``prefetch`` (optional callable, e.g. the draw of the next batch) runs
+        after the step has been enqueued."""
+        self.exchanges = []
+        if self.engine_driven:
+            self.engine.train_step(B, lr, flags)   # statistics / gradient exchanges happen inside, via the hook
             if prefetch is not None:
                 prefetch()
             return

@@ -376,18 +376,30 @@ def inception_logits(flags, tensors, x, training, dropout_mask=None, taps=None, 
 # ----------------------------------------------------------------------------- loss / Adam / metrics
 
 def keras_bce(p, y):
-    """Keras 3 ``binary_crossentropy(from_logits=False)``: clip to [eps, 1-eps] then the
-    probability form (train.py:206)."""
+    """Probability form of Keras 3 ``binary_crossentropy(from_logits=False)``: clip to [eps, 1-eps]
+    (train.py:206 WITHOUT the cached logits; ``BCE_FROM_LOGITS = False``)."""
     # the reference clips float32 probabilities with float32 bounds: 1 - 1e-7 is 0.99999988 there, not 0.9999999
     lo, hi = float(np.float32(KERAS_EPS)), float(np.float32(1.0) - np.float32(KERAS_EPS))
     pc = torch.clamp(p, lo, hi)
     return -(y * torch.log(pc) + (1.0 - y) * torch.log(1.0 - pc))
 
 
+def keras_bce_logits(z, y):
+    """What train.py:206 runs under Keras 3 + TensorFlow: ``activations.sigmoid`` caches its input on the
+    output tensor (``_keras_logits``), the TF backend's ``binary_crossentropy`` finds it (``_get_logits``) and
+    evaluates ``tf.nn.sigmoid_cross_entropy_with_logits``: max(z,0) - z*y + log1p(exp(-|z|)), no clipping,
+    gradient sigmoid(z) - y everywhere."""
+    return torch.clamp(z, min=0.0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))
+
+
+BCE_FROM_LOGITS = True   # the engine's default ("bce_from_logits" option); tests flip both together
+
+
 def weighted_loss(z, y, w):
     """sum_over_batch_size reduction: sum(w_i * bce_i) / B (NOT / sum(w))."""
     p = torch.sigmoid(z)
-    return (keras_bce(p, y) * w).sum() / z.shape[0], p
+    bce = keras_bce_logits(z, y) if BCE_FROM_LOGITS else keras_bce(p, y)
+    return (bce * w).sum() / z.shape[0], p
 
 
 class KerasAdam:
@@ -428,7 +440,8 @@ class Metrics:
         self.bce_sum = 0.0
         self.lab = np.zeros(2, np.float64)
 
-    def update(self, p, y):
+    def update(self, p, y, z=None):
+        """z: the logits behind p (loss metric in the logits form); None: probability form with the Keras clip."""
         p = np.asarray(p, np.float32).reshape(-1)
         y = np.asarray(y).reshape(-1) > 0.5
         pc = np.clip(p, np.float32(0.0), np.float32(1.0))
@@ -446,8 +459,12 @@ class Metrics:
         self.fp5 += float(np.sum(pos & ~y))
         self.fn5 += float(np.sum(~pos & y))
         self.lab += np.array([np.sum(~y), np.sum(y)], np.float64)
-        pcl = np.clip(p.astype(np.float64), float(np.float32(KERAS_EPS)), float(np.float32(1.0) - np.float32(KERAS_EPS)))
-        self.bce_sum += float(np.sum(-(y * np.log(pcl) + (~y) * np.log(1 - pcl))))
+        if z is not None and BCE_FROM_LOGITS:
+            zz = np.asarray(z, np.float64).reshape(-1)
+            self.bce_sum += float(np.sum(np.maximum(zz, 0.0) - zz * y + np.log1p(np.exp(-np.abs(zz)))))
+        else:
+            pcl = np.clip(p.astype(np.float64), float(np.float32(KERAS_EPS)), float(np.float32(1.0) - np.float32(KERAS_EPS)))
+            self.bce_sum += float(np.sum(-(y * np.log(pcl) + (~y) * np.log(1 - pcl))))
 
     @staticmethod
     def _div(a, b):
@@ -511,9 +528,12 @@ class OracleModel:
         return inception_logits(self.flags, tensors, x, training, dm, taps, rm)
 
     def predict(self, x, training=False):
+        return self.predict_with_logits(x, training)[0]
+
+    def predict_with_logits(self, x, training=False):
         with torch.no_grad():
             z, _ = self.logits(x, training)
-        return torch.sigmoid(z).numpy()
+        return torch.sigmoid(z).numpy(), z.numpy()
 
     def loss_and_grads(self, x, y, w, dropout_mask=None, relu_masks=None):
         """-> (loss, probs, {name: grad}, new_moving_stats) for one batch, training mode."""
@@ -524,6 +544,7 @@ class OracleModel:
         loss, p = weighted_loss(z, yt, wt)
         names = [v.name for v in self.vars if v.trainable]
         grads = torch.autograd.grad(loss, [t[n] for n in names])
+        self.last_logits = z.detach().numpy()
         return float(loss.detach()), p.detach().numpy(), dict(zip(names, grads)), new_stats
 
     def train_step(self, x, y, w, lr, dropout_mask=None, relu_masks=None):
@@ -540,5 +561,5 @@ class OracleModel:
         for v in self.vars:
             if v.name in new_stats:
                 v.value = new_stats[v.name].numpy().astype(np.float32)
-        self.metrics.update(p, y)
+        self.metrics.update(p, y, self.last_logits)
         return loss, p

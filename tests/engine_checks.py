@@ -292,6 +292,88 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
     return worst
 
 
+def check_saturated_logits_loss(lib, B=8, T=194):
+    """Saturated logits (|z| ~ 40): the default loss is the logits form Keras 3 + TensorFlow evaluates for
+    train.py:206 (no clip: the loss grows like |z| and dL/dz = w (p - y) / B stays alive); option
+    "bce_from_logits" 0 switches the engine to the clipped probability form (loss capped near 16, zero gradient).
+    Both are compared with the oracle's restatement of the same form."""
+    for logits_form in (True, False):
+        om = perturbed_oracle(T)
+        ws = om.get_weights()
+        names = [v.name for v in om.vars]
+        ws[names.index("dense.bias")] = np.float32([40.0])
+        om.set_weights(ws)
+        lay, eng = make_engine(lib, T, B, om)
+        if not logits_form:
+            eng.set_option("bce_from_logits", 0)
+        rng = np.random.default_rng(11)
+        x = synth_x(rng, B, T)
+        y = (np.arange(B) % 2).astype(np.float32)
+        w = (1.0 + 0.5 * rng.random(B)).astype(np.float32)
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+        eng.metrics_reset()
+        eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
+        pr, z, loss = eng.read_outputs(B)
+        assert z.min() > 20.0                      # every sample saturated towards 1
+        old = mo.BCE_FROM_LOGITS
+        mo.BCE_FROM_LOGITS = logits_form
+        try:
+            lo, po, grads, _ = om.loss_and_grads(x, y, w)
+            met = mo.Metrics()
+            met.update(po, y, om.last_logits)
+        finally:
+            mo.BCE_FROM_LOGITS = old
+        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (logits_form, loss, lo)
+        if logits_form:
+            assert lo > 0.4 * 30.0                # the wrong (y = 0) half pays ~|z| each, weights >= 1
+        else:
+            assert lo < 0.5 * 1.5 * 16.2           # ... or at most -log(1.19e-7) = 15.9 each
+        g = eng.get_grads()
+        gref = oracle_grads_native_order(lay, om, grads)
+        scale = float(np.abs(gref).max())
+        if logits_form:
+            assert scale > 1e-3                    # the gradient is alive
+            assert np.abs(g - gref).max() <= 2e-3 * scale, np.abs(g - gref).max() / scale
+        else:
+            assert scale < 1e-6 and np.abs(g).max() < 1e-6   # dead zone of the clip
+        m = native.metrics_from_raw(eng.metrics_raw())
+        assert abs(m["loss"] - met.result()["loss"]) <= 1e-5 * max(1.0, met.result()["loss"]), (logits_form, m["loss"], met.result()["loss"])
+        eng.close()
+
+
+def check_variable_batch_sizes(lib, T=194, sizes=(16, 4, 4, 1, 16), graphs=False):
+    """train_on_batch with a different batch size per call (fewer windows than statistics accumulator rows after a
+    larger batch): every step has to match a fresh engine that starts from the same weights.  Regression test for
+    stale rows in the BN statistics hand-over (common.hip.h publish_stat)."""
+    om = perturbed_oracle(T)
+    rng = np.random.default_rng(3)
+    lay, eng = make_engine(lib, T, max(sizes), om)
+    if graphs:
+        eng.set_option("graphs", 1)
+    for B in sizes:
+        x = synth_x(rng, B, T)
+        y = (rng.random(B) < 0.5).astype(np.float32)
+        w = np.ones(B, np.float32)
+        p0, s0 = eng.get_params(), eng.get_bn_state()
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+        eng.train_step(B, 1e-3)
+        loss = eng.read_outputs(B)[2]
+        g = eng.get_grads()
+        lay2, fresh = make_engine(lib, T, max(sizes), om)
+        fresh.set_params(p0)
+        fresh.set_bn_state(s0)
+        fresh.set_batch(x)
+        fresh.set_targets(y, w)
+        fresh.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
+        assert abs(loss - fresh.read_outputs(B)[2]) <= 1e-6 * max(1.0, abs(loss)), (B, loss, fresh.read_outputs(B)[2])
+        gf = fresh.get_grads()
+        assert np.abs(g - gf).max() <= 1e-6 * max(1e-6, np.abs(gf).max()), (B, np.abs(g - gf).max())
+        fresh.close()
+    eng.close()
+
+
 def check_training_reduces_loss(lib, B=8, T=194, steps=8):
     om = mo.OracleModel("mixednet", DEF, T, seed=3, dtype=torch.float32)
     lay, eng = make_engine(lib, T, B, om)
@@ -527,8 +609,8 @@ def check_validation_on_device(lib, gold, tag="u16"):
     xv, yv, _ = fh.get_data("validation", 16, T, "truncate_start")
     xa, ya, _ = fh.get_data("validation_ambient", 16, T, "split")
     met = mo.Metrics()
-    met.update(om.predict(xv), yv)
-    met.update(om.predict(xa), ya)
+    met.update(*om.predict_with_logits(xv)[:1], yv, om.predict_with_logits(xv)[1])
+    met.update(*om.predict_with_logits(xa)[:1], ya, om.predict_with_logits(xa)[1])
     r = met.result()
     for k in ("tp", "fp", "tn", "fn"):
         np.testing.assert_array_equal(fast_counts[k], r[k])

@@ -37,6 +37,15 @@ def test_train_steps(emu_lib):
     ec.check_train_steps(emu_lib, B=5, T=194, steps=2, grid=2)
 
 
+def test_saturated_logits_loss_forms(emu_lib):
+    ec.check_saturated_logits_loss(emu_lib, B=4, T=60)
+
+
+def test_variable_batch_sizes_do_not_leave_stale_statistics(emu_lib):
+    ec.check_variable_batch_sizes(emu_lib, T=60, sizes=(10, 3, 3, 1, 10))
+    ec.check_variable_batch_sizes(emu_lib, T=60, sizes=(9, 2, 2), graphs=True)
+
+
 def test_train_steps_other_lengths(emu_lib):
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4)
     ec.check_train_steps(emu_lib, B=2, T=60, steps=1, grid=1, graphs=True)

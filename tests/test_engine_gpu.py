@@ -70,6 +70,15 @@ def test_train_step_batch64_multi_tile_grid(lib):
     ec.check_train_steps(lib, B=64, T=194, steps=1, grid=16)
 
 
+def test_saturated_logits_loss_forms(lib):
+    ec.check_saturated_logits_loss(lib, B=8, T=194)
+
+
+def test_variable_batch_sizes_do_not_leave_stale_statistics(lib):
+    ec.check_variable_batch_sizes(lib, T=194, sizes=(16, 4, 4, 1, 16))
+    ec.check_variable_batch_sizes(lib, T=194, sizes=(16, 4, 4), graphs=True)
+
+
 def test_training_reduces_loss(lib):
     ec.check_training_reduces_loss(lib)
 

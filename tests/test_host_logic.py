@@ -235,7 +235,8 @@ def test_inception_flags_layout_and_oracle_order(tmp_path):
 
 
 def test_package_and_bench_main_path_never_import_the_oracle():
-    """oracle/ is test infrastructure: the package must not reference it, bench.py only inside cpu_baseline()."""
+    """oracle/ is test infrastructure: the package must not reference it, bench.py only inside the cpu_baseline leg
+    (cpu_baseline() and the _reference_loader() it calls)."""
     import ast
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "microwakeword_amd")
@@ -250,5 +251,5 @@ def test_package_and_bench_main_path_never_import_the_oracle():
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         for node in ast.walk(fn):
             if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
-                assert fn.name == "cpu_baseline", fn.name
+                assert fn.name in ("cpu_baseline", "_reference_loader"), fn.name   # the baseline leg and its loader helper
     assert synthetic.DEFAULT_INCEPTION_FLAGS == mo.INCEPTION_DEFAULTS

@@ -146,7 +146,23 @@ def test_keras_adam_first_steps():
     assert abs(float(q[0]) - torch_style) > 1e-6
 
 
-def test_loss_is_sum_over_batch_size_and_clipped():
+def test_loss_logits_form_is_sum_over_batch_size_and_unclipped():
+    """Keras 3 + TF: the cached logits of the sigmoid output are used, so saturated wrong samples cost |z| (not
+    -log(1e-7)) and keep their gradient."""
+    z = torch.tensor([0.3, -1.2, 40.0, -40.0], dtype=torch.float64, requires_grad=True)
+    y = torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64)
+    w = torch.tensor([1.0, 3.0, 1.0, 1.0], dtype=torch.float64)
+    assert mo.BCE_FROM_LOGITS
+    loss, p = mo.weighted_loss(z, y, w)
+    b = [math.log(1 + math.exp(-0.3)), math.log(1 + math.exp(-1.2)), 40.0, 40.0]
+    assert abs(float(loss.detach()) - (b[0] + 3 * b[1] + b[2] + b[3]) / 4) < 1e-9
+    (gz,) = torch.autograd.grad(loss, z)
+    np.testing.assert_allclose(gz.numpy(), (w * (torch.sigmoid(z.detach()) - y) / 4).numpy(), atol=1e-15)
+    assert abs(float(gz[2]) - 0.25) < 1e-12 and abs(float(gz[3]) + 0.25) < 1e-12   # no dead zone
+
+
+def test_loss_probability_form_is_clipped(monkeypatch):
+    monkeypatch.setattr(mo, "BCE_FROM_LOGITS", False)
     z = torch.tensor([0.3, -1.2, 40.0, -40.0], dtype=torch.float64)
     y = torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64)
     w = torch.tensor([1.0, 3.0, 1.0, 1.0], dtype=torch.float64)

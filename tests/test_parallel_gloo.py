@@ -144,7 +144,7 @@ def test_sharding_partitions_every_provider_and_splits_rng_streams():
 # Two ranks, each running the PRODUCT kernels (host-emulated, tests/hipemu) on half of a global batch with
 # sync_bn=True, against the single-process oracle on the whole batch: W ranks x B/W windows must
 # reproduce the single-device train step (loss normalisation, BN statistics, gradients, Adam, moving stats).
-def _sync_worker(rank, world, port, out_dir, emu_path, kind, sync=True):
+def _sync_worker(rank, world, port, out_dir, emu_path, kind, sync=True, buckets=2, tag="out"):
     import ctypes as C
 
     import engine_checks as ec
@@ -168,14 +168,14 @@ def _sync_worker(rank, world, port, out_dir, emu_path, kind, sync=True):
 
     g = wrap(eng.device_ptr(native.BUF_GRADS), eng.n_params)
     p = wrap(eng.device_ptr(native.BUF_PARAMS), eng.n_params)
-    dp = DataParallel(eng, g, p, None, sync_bn=sync, wrap=wrap)
+    dp = DataParallel(eng, g, p, None, sync_bn=sync, wrap=wrap, grad_buckets=buckets)
     assert dp.world == world
     eng.set_batch(z["x"][rank * Bl:(rank + 1) * Bl])
     eng.set_targets(z["y"][rank * Bl:(rank + 1) * Bl], z["w"][rank * Bl:(rank + 1) * Bl])
     dp.train_step(Bl, 1e-3)
     pr, _, loss = eng.read_outputs(Bl)
-    np.savez(os.path.join(out_dir, "out%d.npz" % rank), grads=eng.get_grads(), params=eng.get_params(), state=eng.get_bn_state(),
-             probs=pr, loss=loss)
+    np.savez(os.path.join(out_dir, "%s%d.npz" % (tag, rank)), grads=eng.get_grads(), params=eng.get_params(), state=eng.get_bn_state(),
+             probs=pr, loss=loss, exchanges=np.asarray(dp.exchanges, np.int64))
     eng.close()
     dist.destroy_process_group()
 
@@ -250,10 +250,24 @@ def test_local_bn_two_ranks_with_product_kernels(tmp_path):
     np.savez(tmp_path / "inputs.npz", x=x, y=y, w=w, keep=np.zeros(1))
     mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "mixednet", False), nprocs=W, join=True)
     outs = [np.load(tmp_path / ("out%d.npz" % r)) for r in range(W)]
+    # the gradient went in two buckets: [blocks 3, 4 + dense] deferred - it overlaps the backward kernels of
+    # blocks 2 and 1 -, then the rest in stream order, then the flush that orders Adam behind the deferred bucket
+    lay = MixedNetLayout(ec.DEF, T)
+    from microwakeword_amd import native
+    ex = outs[0]["exchanges"].tolist()
+    n_tail = lay.n_params - lay.blocks[2].o_dw_w if hasattr(lay.blocks[2], "o_dw_w") else None
+    assert [f for _, f in ex] == [native.EXCHANGE_DEFERRED, native.EXCHANGE_IN_ORDER, native.EXCHANGE_FLUSH], ex
+    assert ex[0][0] + ex[1][0] == lay.n_params and ex[2][0] == 0 and min(ex[0][0], ex[1][0]) > 0, ex
+    assert n_tail is None or ex[0][0] == n_tail
+    # ... and the overlapped schedule is bit-identical to the single exchange after the backward pass
+    mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "mixednet", False, 1, "one"), nprocs=W, join=True)
+    ones = [np.load(tmp_path / ("one%d.npz" % r)) for r in range(W)]
+    assert [f for _, f in ones[0]["exchanges"].tolist()] == [native.EXCHANGE_IN_ORDER]
+    for k in ("grads", "params", "state"):
+        np.testing.assert_array_equal(outs[0][k], ones[0][k])
     np.testing.assert_array_equal(outs[0]["grads"], outs[1]["grads"])      # the reduced gradient
     np.testing.assert_array_equal(outs[0]["params"], outs[1]["params"])    # hence identical weights
     assert np.abs(outs[0]["state"] - outs[1]["state"]).max() > 0           # but rank-local BN moving statistics
-    lay = MixedNetLayout(ec.DEF, T)
     gsum, states = 0.0, []
     for r in range(W):
         om = ec.perturbed_oracle(T)
