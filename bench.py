@@ -434,6 +434,7 @@ def main():
         for _ in range(args.steps):
             one_step()
         ev1.record(stream)
+        host_enqueue = time.perf_counter() - t0   # the host's share: sampler + launches (+ exchange hooks); it must stay below the GPU's
         fence()
         elapsed = time.perf_counter() - t0
         gpu_ms = ev0.elapsed_time(ev1)
@@ -532,7 +533,7 @@ def main():
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,
                      "step_frac_note": "whole step, per GPU: windows/s x SURVEY 8(d) algorithmic bytes per window / 8.0 TB/s",
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
-        "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "final_loss": round(float(last_loss), 5),
+        "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4), "final_loss": round(float(last_loss), 5),
     }
     if validation is not None:
         out["validation"] = validation

@@ -97,30 +97,44 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
       for (int u = 0; u < 16; ++u) acc += v[u];
     }
   } else if (s.kind == kSegDense) {
+    // same arithmetic as dense_grad_kernel's batch chunks summed as partial rows (the path without the ride-along role):
+    // an fma chain per chunk of d.chunk windows, the chunk sums added in order => bit-identical gradients either way
     const DenseGradArgs& d = a.dense;
-    const int per = (d.B + kFinalSlices - 1) / kFinalSlices;
-    const int b0 = sl * per, b1 = min(d.B, b0 + per);
+    const int nchunk = (d.B + d.chunk - 1) / d.chunk;
+    const int per = (nchunk + kFinalSlices - 1) / kFinalSlices;
+    const int c0 = sl * per, c1 = min(nchunk, c0 + per);
     if (in && e < d.n) {
       const int c = e % d.C;
       const float sc = d.scale[c], sh = d.shift[c];
       const float rsc = d.rp ? d.rscale[c] : 0.f, rsh = d.rp ? d.rshift[c] : 0.f;
       const size_t roff = d.rp ? (size_t)d.rdrop * d.C + e : 0, rstride = (size_t)d.rT * d.C;
-      constexpr int U = 32;   // rows in flight per thread: the chain over a slice's B/8 windows is B/256 round trips long
-      for (int bb = b0; bb < b1; bb += U) {
-        float v[U], dz[U], r[U];
+      constexpr int U = 32;   // rows in flight per thread (a chunk of the headline batch is one round trip)
+      for (int ci = c0; ci < c1; ++ci) {
+        const int b0 = ci * d.chunk, b1 = min(d.B, b0 + d.chunk);
+        float sub = 0.f;
+        for (int bb = b0; bb < b1; bb += U) {
+          float v[U], dz[U], r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool ok = bb + u < b1;
-          v[u] = ok ? d.p[(size_t)(bb + u) * d.n + e] : 0.f;
-          dz[u] = ok ? d.dz[bb + u] : 0.f;
-          r[u] = (ok && d.rp) ? fmaf(d.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
-          if (ok && d.keep) dz[u] *= d.keep[(size_t)(bb + u) * d.n + e];
+          for (int u = 0; u < U; ++u) {
+            const bool ok = bb + u < b1;
+            v[u] = ok ? d.p[(size_t)(bb + u) * d.n + e] : 0.f;
+            dz[u] = ok ? d.dz[bb + u] : 0.f;
+            r[u] = (ok && d.rp) ? fmaf(d.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
+            if (ok && d.keep) dz[u] *= d.keep[(size_t)(bb + u) * d.n + e];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (bb + u < b1) sub = fmaf(dz[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), sub);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = fmaf(dz[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), acc);
+        acc += sub;
       }
     } else if (in) {   // e == d.n: the dense bias
-      for (int b = b0; b < b1; ++b) acc += d.dz[b];
+      for (int ci = c0; ci < c1; ++ci) {
+        const int b0 = ci * d.chunk, b1 = min(d.B, b0 + d.chunk);
+        float sub = 0.f;
+        for (int b = b0; b < b1; ++b) sub += d.dz[b];
+        acc += sub;
+      }
     }
   } else if (s.kind == kSegDirect) {
     if (in && sl == 0) acc = a.grad[s.dst + e];
