@@ -46,6 +46,10 @@ def test_variable_batch_sizes_do_not_leave_stale_statistics(emu_lib):
     ec.check_variable_batch_sizes(emu_lib, T=60, sizes=(9, 2, 2), graphs=True)
 
 
+def test_gradients_without_imposed_relu_masks(emu_lib):
+    ec.check_gradients_unimposed(emu_lib, B=6, T=130, bound=1e-2)
+
+
 def test_train_steps_other_lengths(emu_lib):
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4)
     ec.check_train_steps(emu_lib, B=2, T=60, steps=1, grid=1, graphs=True)

@@ -79,6 +79,20 @@ def test_variable_batch_sizes_do_not_leave_stale_statistics(lib):
     ec.check_variable_batch_sizes(lib, T=194, sizes=(16, 4, 4), graphs=True)
 
 
+def test_train_step_at_the_baseline_size_vs_float64_oracle(lib):
+    """BASELINE configs[1] size (B = 1024, T = 194: two windows per backward workgroup, every accumulator row contended):
+    loss, probabilities, the whole flat gradient per tensor (L2 <= 1e-4), the Adam-updated weights, the BN moving
+    statistics and the metric counters against one float64 oracle step (~20 s of CPU)."""
+    worst = ec.check_train_steps(lib, B=1024, T=194, steps=1, grid=0)
+    assert worst["l2_max"] <= 1e-4
+    # ... and the same gradients without imposing the engine's ReLU decisions on the oracle
+    assert ec.check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2) <= 1e-2
+
+
+def test_inception_train_step_batch1024_vs_float64_oracle(lib):
+    ec.check_inception_train_steps(lib, B=1024, T=194, steps=1, grid=0)
+
+
 def test_training_reduces_loss(lib):
     ec.check_training_reduces_loss(lib)
 
