@@ -230,12 +230,9 @@ class Model:
             self.set_weights([z[k] for k in keys])
             return
         if os.path.isfile(path):
-            try:
-                import h5py  # noqa: F401
-            except ImportError:
-                raise RuntimeError("%s is a Keras .weights.h5 file and h5py is not installed; convert it with "
-                                   "tools/keras_weights_to_npz.py on a machine that has it" % path) from None
-            raise NotImplementedError("reading Keras .weights.h5 directly is not implemented yet")
+            raise RuntimeError("%s is a Keras .weights.h5 checkpoint (train.py:336-338,448-451).  This package keeps the same variables in "
+                               "the same order as an .npz twin; convert on the machine that has TensorFlow with "
+                               "tools/keras_weights_to_npz.py (and back, for the reference's TFLite export, with tools/npz_to_keras_weights.py)" % path)
         raise FileNotFoundError(path)
 
     def save_optimizer_state(self, path):

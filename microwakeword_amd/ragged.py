@@ -9,8 +9,11 @@ layout implemented below is the one recalled from mmap_ninja 0.7 (a ``data/`` nu
 holding every sample concatenated flat, plus ``starts/``, ``ends/``, ``shapes/``,
 ``flattened_shapes/`` numpy-memmap dirs; each numpy-memmap dir = ``data.ninja`` raw bytes +
 ``dtype.ninja`` + ``shape.ninja`` + ``order.ninja`` text files).  **It has not been verified
-against a folder written by the real library** — if ``mmap_ninja`` is importable it is used
-instead, and a store that does not parse raises ``ValueError`` rather than guessing.
+against a folder written by the real library** (no wheel, no network here).  Therefore, in this order:
+if ``mmap_ninja`` is importable it is used; a ``flat_export.npz`` next to the store (written on a machine
+that has the library by ``tools/export_ragged_to_flat.py``) is the verified interchange; only then the
+recalled layout is tried, and it is accepted only if every file, dtype, order and offset invariant of that
+layout holds — anything else raises ``ValueError`` instead of guessing.
 
 The GPU path never touches these files per step: :func:`flatten_store` turns a store into the
 three flat arrays (``data``, ``starts``, ``lens``) that are uploaded once into HBM.
@@ -45,6 +48,34 @@ def _open_np_dir(d: Path) -> np.ndarray:
     if int(np.prod(shape)) == 0:
         return np.zeros(shape, dtype)
     return np.memmap(d / "data.ninja", dtype=dtype, mode="r", shape=shape)
+
+
+FLAT_EXPORT = "flat_export.npz"   # {data, starts, lens}: see tools/export_ragged_to_flat.py
+
+
+def _check_invariants(path, data, starts, ends, shapes, flat_shapes):
+    """Everything the layout implies; any violation means "this is not the format I think it is"."""
+    def bad(msg):
+        raise ValueError("unrecognised ragged store layout: %s: %s (install mmap_ninja, or export the store with "
+                         "tools/export_ragged_to_flat.py where it is installed)" % (path, msg))
+    if data.ndim != 1 or data.dtype not in (np.dtype(np.uint16), np.dtype(np.float32)):
+        bad("data must be a flat uint16 / float32 array, got %s %s" % (data.dtype, data.shape))
+    if starts.ndim != 1 or starts.shape != ends.shape or starts.dtype.kind not in "iu" or ends.dtype.kind not in "iu":
+        bad("starts / ends must be integer vectors of one length")
+    n = starts.shape[0]
+    if n == 0:
+        bad("empty store")
+    st, en = starts.astype(np.int64), ends.astype(np.int64)
+    if st[0] != 0 or np.any(en <= st) or np.any(st[1:] != en[:-1]) or en[-1] != data.shape[0]:
+        bad("samples must tile the data array without gaps (starts[0] = 0, starts[i+1] = ends[i], ends[-1] = len(data))")
+    if np.any((en - st) % FEATURE_BINS):
+        bad("every sample must hold whole [T, %d] frames" % FEATURE_BINS)
+    if shapes is not None:
+        if shapes.dtype.kind not in "iu" or flat_shapes.dtype.kind not in "iu" or shapes.shape != (2 * n,) or flat_shapes.shape != (n,):
+            bad("shapes / flattened_shapes must list one [T, %d] shape per sample" % FEATURE_BINS)
+        sh = shapes.astype(np.int64).reshape(n, 2)
+        if np.any(flat_shapes.astype(np.int64) != 2 * np.arange(n)) or np.any(sh[:, 1] != FEATURE_BINS) or np.any(sh[:, 0] * FEATURE_BINS != en - st):
+            bad("shapes do not match the start / end offsets")
 
 
 def write_ragged_store(path: str, samples: Iterable[np.ndarray]) -> None:
@@ -84,12 +115,29 @@ class RaggedStoreReader:
                 self._real = RaggedMmap(p)
         except Exception:
             self._real = None
-        if self._real is None:
+        if self._real is None and (p / FLAT_EXPORT).is_file():
+            # the verified interchange: written on a machine that has the real mmap_ninja by tools/export_ragged_to_flat.py
+            z = np.load(p / FLAT_EXPORT)
+            self.data = z["data"]
+            self.starts = np.asarray(z["starts"], np.int64)
+            self.ends = self.starts + np.asarray(z["lens"], np.int64) * FEATURE_BINS
+            _check_invariants(self.path, self.data, self.starts, self.ends, None, None)
+        elif self._real is None:
+            # recalled (unverified) mmap_ninja layout: accepted only if EVERY invariant of that layout holds, so a folder
+            # written by a different library version fails here, loudly, instead of yielding shifted spectrograms
+            for sub in ("data", "starts", "ends", "shapes", "flattened_shapes"):
+                for f in ("data.ninja", "dtype.ninja", "shape.ninja", "order.ninja"):
+                    if not (p / sub / f).is_file():
+                        raise ValueError("unrecognised ragged store layout: %s lacks %s/%s (install mmap_ninja, or export the store "
+                                         "with tools/export_ragged_to_flat.py where it is installed)" % (p, sub, f))
+                if (p / sub / "order.ninja").read_text().strip() != "C":
+                    raise ValueError("unrecognised ragged store layout: %s/%s is not C-ordered" % (p, sub))
             self.data = _open_np_dir(p / "data")
-            self.starts = np.asarray(_open_np_dir(p / "starts"), np.int64)
-            self.ends = np.asarray(_open_np_dir(p / "ends"), np.int64)
-            if self.starts.shape != self.ends.shape or self.data.ndim != 1:
-                raise ValueError("unrecognised ragged store layout: %s" % p)
+            self.starts = np.asarray(_open_np_dir(p / "starts"))
+            self.ends = np.asarray(_open_np_dir(p / "ends"))
+            _check_invariants(self.path, self.data, self.starts, self.ends, np.asarray(_open_np_dir(p / "shapes")),
+                              np.asarray(_open_np_dir(p / "flattened_shapes")))
+            self.starts, self.ends = self.starts.astype(np.int64), self.ends.astype(np.int64)
 
     def __len__(self) -> int:
         return len(self._real) if self._real is not None else int(self.starts.shape[0])

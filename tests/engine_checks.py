@@ -525,7 +525,8 @@ def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graph
                 flips += int(diff.sum())
                 assert np.abs(ref[diff]).max(initial=0.0) <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(ref[diff]).max())
                 masks[name] = np.ascontiguousarray(m.transpose(0, 2, 1))
-        assert flips <= 8, flips
+        n_units = sum(B * op["tout"] * op["filters"] for op in lay.ops)
+        assert flips <= max(8, 2e-5 * n_units), (flips, n_units)   # 21 of 5e7 units at B = 1024, each within 2e-5 of zero
         lo, po, grads, _ = om.loss_and_grads(x, y, w, dropout_mask=keep, relu_masks=masks)
         g = eng.get_grads()
         gref = lay.pack([grads[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)

@@ -253,3 +253,44 @@ def test_package_and_bench_main_path_never_import_the_oracle():
             if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
                 assert fn.name in ("cpu_baseline", "_reference_loader"), fn.name   # the baseline leg and its loader helper
     assert synthetic.DEFAULT_INCEPTION_FLAGS == mo.INCEPTION_DEFAULTS
+
+
+def test_ragged_store_reader_refuses_anything_but_the_exact_layout(tmp_path):
+    """microwakeword_amd/ragged.py: the recalled mmap_ninja layout is accepted only if every invariant holds; the
+    flat export written by tools/export_ragged_to_flat.py (on a machine with the real library) takes precedence."""
+    import shutil
+
+    from microwakeword_amd.ragged import FLAT_EXPORT, RaggedStoreReader, flatten_store, write_ragged_store
+    rng = np.random.default_rng(0)
+    samples = [rng.integers(0, 667, size=(t, 40)).astype(np.uint16) for t in (150, 7, 400)]
+    d = tmp_path / "a_mmap"
+    write_ragged_store(str(d), samples)
+    r = RaggedStoreReader(str(d))
+    assert len(r) == 3 and r.dtype == np.uint16
+    for i, s in enumerate(samples):
+        np.testing.assert_array_equal(r[i], s)
+    flat, starts, lens = flatten_store(r)
+    assert lens.tolist() == [150, 7, 400] and starts.tolist() == [0, 6000, 6280] and flat.size == 557 * 40
+
+    def broken(name, mutate):
+        b = tmp_path / name
+        shutil.copytree(d, b)
+        mutate(b)
+        with pytest.raises(ValueError, match="unrecognised ragged store layout"):
+            RaggedStoreReader(str(b))
+
+    broken("no_shapes", lambda b: shutil.rmtree(b / "shapes"))
+    broken("fortran", lambda b: (b / "data" / "order.ninja").write_text("F"))
+    broken("gap", lambda b: np.array([0, 6000, 6400], np.int64).tofile(b / "starts" / "data.ninja"))
+    broken("short_data", lambda b: ((b / "data" / "shape.ninja").write_text("22000"), np.zeros(22000, np.uint16).tofile(b / "data" / "data.ninja")))
+    broken("wrong_bins", lambda b: np.array([150, 41, 7, 40, 400, 40], np.int64).tofile(b / "shapes" / "data.ninja"))
+    broken("float64", lambda b: ((b / "data" / "dtype.ninja").write_text("float64"), np.zeros(22280, np.float64).tofile(b / "data" / "data.ninja")))
+
+    # the verified interchange wins over whatever else is in the directory
+    e = tmp_path / "b_mmap"
+    e.mkdir()
+    sizes = np.array([150, 7, 400]) * 40
+    np.savez(e / FLAT_EXPORT, data=np.concatenate([s.reshape(-1) for s in samples]), starts=np.cumsum(sizes) - sizes, lens=np.array([150, 7, 400], np.int32))
+    r2 = RaggedStoreReader(str(e))
+    for i, s in enumerate(samples):
+        np.testing.assert_array_equal(r2[i], s)
