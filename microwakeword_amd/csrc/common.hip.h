@@ -117,6 +117,14 @@ __device__ __forceinline__ void tile_store1(BufRsrc r, int byte_off, float v) {
 // lane offset that is out of range for every resource (lanes that take no part in an access)
 constexpr int kOobOffset = 0x40000000;
 
+// scheduling hint for a VALU phase that starts with a window of LDS reads: put every DS read of the region in front of
+// its VALU work (the default schedule interleaves "two reads, wait, four VALU" to save registers, which exposes one LDS
+// round trip per pair at two waves per SIMD)
+__device__ __forceinline__ void lds_reads_first() {
+  __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);   // DS reads
+  __builtin_amdgcn_sched_group_barrier(0x002, 2048, 0);  // then VALU
+}
+
 // keep a value (and the loads that produce it) from sinking below this point: used to retire the
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
@@ -134,15 +142,19 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 #define MWW_PC_START(en) pc.start(en)
 #define MWW_PC_MARK(i) pc.mark(i)
 #define MWW_PC_DUMP(p) do { if (p) pc.dump(p); } while (0)
+#define MWW_PC_AT(i) pc.at(i)
 #else
+#define MWW_PC_AT(i) ((void)0)
 #define MWW_PC_DECL
 #define MWW_PC_START(en) ((void)0)
 #define MWW_PC_MARK(i) ((void)0)
 #define MWW_PC_DUMP(p) ((void)0)
 #endif
+constexpr int kClkSlots = 12;   // per workgroup: 8 phase accumulators + entry / loop start / loop end / exit timestamps
 struct PhaseClock {
-  unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp[4] = {0, 0, 0, 0};
   bool on = false;
+  __device__ __forceinline__ void at(int i) { stamp[i] = __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void start(bool enable) {
     on = enable;
     if (on) last = __builtin_amdgcn_s_memtime();
@@ -155,8 +167,10 @@ struct PhaseClock {
     }
   }
   __device__ __forceinline__ void dump(unsigned long long* dst) const {
-    if (on)
+    if (on) {
       for (int i = 0; i < 8; ++i) dst[i] = acc[i];
+      for (int i = 0; i < 4; ++i) dst[8 + i] = stamp[i];
+    }
   }
 };
 
@@ -250,6 +264,13 @@ __device__ __forceinline__ void bn_fold_channel(const BnFoldArgs& f, int C, int 
     v2[j] = f.acc[(size_t)j * 2 * C + C + ch];
   }
   const float gam = f.gamma[ch], bet = f.beta[ch];
+  // workgroup 0 also updates the moving statistics: their old values travel with the sums (a load behind the stores
+  // below would be a second, dependent round trip that only this workgroup pays - and the launch ends with it)
+  float mm_old = 0.f, mv_old = 0.f;
+  if (blockIdx.x == 0 && f.update_moving) {
+    mm_old = f.moving_mean[ch];
+    mv_old = f.moving_var[ch];
+  }
 #pragma unroll
   for (int j = 0; j < kStatRows; ++j) {
     s1 += v1[j];
@@ -269,8 +290,8 @@ __device__ __forceinline__ void bn_fold_channel(const BnFoldArgs& f, int C, int 
     f.mean[ch] = meanf;
     f.rstd[ch] = rstd;
     if (f.update_moving) {
-      f.moving_mean[ch] = f.moving_mean[ch] * kBnMomentum + meanf * (1.0f - kBnMomentum);
-      f.moving_var[ch] = f.moving_var[ch] * kBnMomentum + varf * (1.0f - kBnMomentum);
+      f.moving_mean[ch] = mm_old * kBnMomentum + meanf * (1.0f - kBnMomentum);
+      f.moving_var[ch] = mv_old * kBnMomentum + varf * (1.0f - kBnMomentum);
     }
   }
 }

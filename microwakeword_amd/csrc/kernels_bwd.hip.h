@@ -102,6 +102,36 @@ struct DpStage {
   }
 };
 
+// Weight staging of the backward kernels, in two halves so that the prologue is ONE memory round trip deep: load()
+// issues every global load of the thread (W_pw for the transposed LDS copy, the depthwise taps), the BN fold that
+// follows issues its own, and store() writes LDS once everything has arrived.  (Rolled loops with a load and an LDS
+// write per iteration cost one L2 round trip per element - nine in a row for W_pw^T: the round-2 timeline showed a
+// 6 us prologue per backward kernel.)
+template <int CIN, int COUT, int KD>
+struct WeightStage {
+  static constexpr int CPI = pitch(CIN), NW = (CIN * COUT + kThreads - 1) / kThreads, ND = KD > 0 ? (KD * CIN + kThreads - 1) / kThreads : 1;
+  float w[NW], d[ND];
+  __device__ __forceinline__ void load(const float* pw_w, const float* dw_w, int tid) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = (tid + j * kThreads < CIN * COUT) ? pw_w[tid + j * kThreads] : 0.f;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) d[j] = (KD > 0 && tid + j * kThreads < KD * CIN) ? dw_w[tid + j * kThreads] : 0.f;
+  }
+  // sWt [COUT][pitch(CIN)] = W_pw^T; sDW [KD][CIN] (KD = 0: the taps stay in registers, nothing to stage)
+  __device__ __forceinline__ void store(float* sWt, float* sDW, int tid) const {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < CIN * COUT) sWt[(i % COUT) * CPI + i / COUT] = w[j];
+    }
+    if (KD > 0) {
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        if (tid + j * kThreads < KD * CIN) sDW[tid + j * kThreads] = d[j];
+    }
+  }
+};
+
 // carry the last K-1 rows of du to the front of the ring (or clear them at the start of a sample)
 template <int K, int CPI>
 __device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
@@ -223,16 +253,19 @@ __device__ __forceinline__ void depthwise_input_grad_chunk(const float* sDU, int
 template <int K, int L, int CPI, typename ActFn>
 __device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, int chunk, int c, float (&accw)[K],
                                                             float& accb, ActFn a_at) {
-  float win[L + K - 1];
+  // every LDS read of the phase is issued before the first FMA (read -> wait -> use per element exposes one LDS
+  // round trip per output row: the round-2 ISA of this phase was a chain of lgkmcnt(0) waits)
+  float win[L + K - 1], du[L];
+#pragma unroll
+  for (int t = 0; t < L; ++t) du[t] = sDU[(K - 1 + chunk * L + t) * CPI + c];   // ring rows past the tile are allocated and zero
 #pragma unroll
   for (int j = 0; j < L + K - 1; ++j) win[j] = a_at(chunk * L + j);
+  lds_reads_first();
 #pragma unroll
   for (int t = 0; t < L; ++t) {
-    const int tl = chunk * L + t;
-    const float du = sDU[(K - 1 + tl) * CPI + c];   // ring rows past the tile are allocated and zero
-    accb += du;
+    accb += du[t];
 #pragma unroll
-    for (int i = 0; i < K; ++i) accw[i] = fmaf(du, win[t + i], accw[i]);
+    for (int i = 0; i < K; ++i) accw[i] = fmaf(du[t], win[t + i], accw[i]);
   }
 }
 
@@ -262,6 +295,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % CIN, chunk = tid / CIN;
   const bool dw_active = chunk < NCH;
+  MWW_PC_DECL
+  MWW_PC_AT(0);   // kernel entry
 
   // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
   // current one is computed
@@ -284,35 +319,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
   };
   if (nitems > 0) issue(0);
-  MWW_PC_DECL
 
-  for (int i = tid; i < COUT; i += kThreads) {
-    const float krs = a.k_rstd[i];
-    float c1, mg, mgx;
-    if (a.gfold.acc) {
-      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
-    } else {
-      c1 = a.k_c1[i];
-      mg = a.k_mg[i];
-      mgx = a.k_mgx[i];
-    }
-    sKp[0 * COUT + i] = a.k_mean[i];
-    sKp[1 * COUT + i] = krs;
-    sKp[2 * COUT + i] = c1;
-    sKp[3 * COUT + i] = mg;
-    sKp[4 * COUT + i] = mgx;
-    sKp[5 * COUT + i] = LAST ? a.k_scale[i] : 0.f;
-    sKp[6 * COUT + i] = LAST ? a.k_shift[i] : 0.f;
-  }
-  for (int i = tid; i < CIN * COUT; i += kThreads) {
-    const int ci = i / COUT, co = i - ci * COUT;
-    sWt[co * CPI + ci] = a.pw_w[i];
-  }
-  for (int i = tid; i < K * CIN; i += kThreads) sDW[i] = a.dw_w[i];
-  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {   // rows only the padded windows touch
-    sP[i] = 0.f;
-    sDU[i] = 0.f;
-  }
+  // every global load of the prologue first ...
+  WeightStage<CIN, COUT, K> wst;
+  wst.load(a.pw_w, a.dw_w, tid);
   float accw[K];
   float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
   float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
@@ -325,6 +335,32 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     mu_c = a.in_mean[c];
     rs_c = a.in_rstd[c];
   }
+  // ... then BN_k's backward coefficients (their loads are the last ones issued: when they have arrived, all have)
+  for (int i = tid; i < COUT; i += kThreads) {
+    const float krs = a.k_rstd[i];
+    const float kmean = a.k_mean[i];
+    const float ksc = LAST ? a.k_scale[i] : 0.f, ksh = LAST ? a.k_shift[i] : 0.f;
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
+    sKp[0 * COUT + i] = kmean;
+    sKp[1 * COUT + i] = krs;
+    sKp[2 * COUT + i] = c1;
+    sKp[3 * COUT + i] = mg;
+    sKp[4 * COUT + i] = mgx;
+    sKp[5 * COUT + i] = ksc;
+    sKp[6 * COUT + i] = ksh;
+  }
+  wst.store(sWt, sDW, tid);
+  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {   // rows only the padded windows touch
+    sP[i] = 0.f;
+    sDU[i] = 0.f;
+  }
   f32x4 dwacc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -333,6 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
   __syncthreads();
 
+  MWW_PC_AT(1);   // prologue done
   MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
@@ -388,7 +425,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       const BufRsrc gtile = tile_rsrc(a.g_out + ((size_t)b * a.Tin + t0) * CIN, rows_da * CIN * 4);
       const int goff = (dw_active ? 0 : kOobOffset) + (cch * L * CIN + c) * 4;
       {
-        float da[L];
+        float da[L], raw[L];
+#pragma unroll
+        for (int t = 0; t < L; ++t) raw[t] = sP[(cch * L + t) * CPI + c];   // in flight under the da FMAs
         if (cch * L < rows_da) {   // chunks past the sample's last row: da = 0, nothing to compute
           float dww[K];
 #pragma unroll
@@ -401,12 +440,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int sl = cch * L + t;
-          const float raw = sP[sl * CPI + c];
           // (row TT of the last chunk belongs to the next tile: its da is still partial)
-          const float gg = (sl < rows_da && fmaf(raw, sc_c, sh_c) > 0.f) ? da[t] : 0.f;
+          const float gg = (sl < rows_da && fmaf(raw[t], sc_c, sh_c) > 0.f) ? da[t] : 0.f;
           tile_store1(gtile, goff + t * CIN * 4, gg);
           gs1 += gg;
-          gs2 = fmaf(gg, (raw - mu_c) * rs_c, gs2);
+          gs2 = fmaf(gg, (raw[t] - mu_c) * rs_c, gs2);
         }
       }
       if (cch * L < nrows_new)   // du = 0 past the sample's last output row
@@ -417,7 +455,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(7);   // barrier 4
   }
-  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);
+  MWW_PC_AT(2);   // tile loop done
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
   write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
   if (dw_active) {
@@ -431,6 +469,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     for (int j = 0; j < NCH; ++j) v += smem[j * 2 * CIN + tid];
     publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * CIN, 2 * CIN, tid, v);
   }
+  MWW_PC_AT(3);   // epilogue done
+  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * kClkSlots : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,32 +564,9 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
   if (nitems > 0) issue(0);
 
-  for (int i = tid; i < COUT; i += kThreads) {
-    const float krs = a.k_rstd[i];
-    float c1, mg, mgx;
-    if (a.gfold.acc) {
-      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
-    } else {
-      c1 = a.k_c1[i];
-      mg = a.k_mg[i];
-      mgx = a.k_mgx[i];
-    }
-    sKp[0 * COUT + i] = a.k_mean[i];
-    sKp[1 * COUT + i] = krs;
-    sKp[2 * COUT + i] = c1;
-    sKp[3 * COUT + i] = mg;
-    sKp[4 * COUT + i] = mgx;
-    sKp[5 * COUT + i] = 0.f;
-    sKp[6 * COUT + i] = 0.f;
-  }
-  for (int i = tid; i < CIN * COUT; i += kThreads) {
-    const int ci = i / COUT, co = i - ci * COUT;
-    sWt[co * CPI + ci] = a.pw_w[i];
-  }
-  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {
-    sA[i] = 0.f;
-    sDU[i] = 0.f;
-  }
+  // every global load of the prologue first (see WeightStage) ...
+  WeightStage<CIN, COUT, 0> wst;
+  wst.load(a.pw_w, nullptr, tid);
   float dww[K], accw[K];
   float accb = 0.f, dwb = 0.f;
 #pragma unroll
@@ -558,6 +575,31 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     accw[i] = 0.f;
   }
   if (dw_active) dwb = a.dw_b[c];
+  // ... then BN_1's backward coefficients
+  for (int i = tid; i < COUT; i += kThreads) {
+    const float krs = a.k_rstd[i];
+    const float kmean = a.k_mean[i];
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
+    sKp[0 * COUT + i] = kmean;
+    sKp[1 * COUT + i] = krs;
+    sKp[2 * COUT + i] = c1;
+    sKp[3 * COUT + i] = mg;
+    sKp[4 * COUT + i] = mgx;
+    sKp[5 * COUT + i] = 0.f;
+    sKp[6 * COUT + i] = 0.f;
+  }
+  wst.store(sWt, nullptr, tid);
+  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {
+    sA[i] = 0.f;
+    sDU[i] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);

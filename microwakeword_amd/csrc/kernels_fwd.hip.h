@@ -218,6 +218,7 @@ __device__ __forceinline__ void dw_chunk(const float* src, int src_pitch, int ro
     if (ACT) v = fmaxf(fmaf(v, sc, sh), 0.f);
     win[j] = v;
   }
+  lds_reads_first();
 #pragma unroll
   for (int t = 0; t < L; ++t) {
     float acc = bias;
@@ -469,9 +470,12 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     }
     __syncthreads();
     // pointwise
-    if (wave * 16 < r_hi && wave * 16 + 16 > r_lo) {   // wave-uniform
+    {
       f32x4 acc[NT];
-      pw.tile(sU, CP1, wave * 16, r16, g, acc);
+      if (wave * 16 < r_hi && wave * 16 + 16 > r_lo) pw.tile(sU, CP1, wave * 16, r16, g, acc);   // wave-uniform
+      else
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
       store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + (size_t)b * a.Tout * COUT, a.Tout * COUT * 4), wave * 16, r16, g, s1, s2, tu0);
     }
     __syncthreads();
@@ -495,22 +499,13 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ __attribute__((aligned(16))) float sScale[CIN];
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
+  MWW_PC_DECL
+  MWW_PC_AT(0);   // kernel entry
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int c = tid % CIN, chunk = tid / CIN;
   const bool dw_active = chunk < NCH;
 
-  if (tid < CIN) {
-    float sc, sh, mu, rs;
-    if (a.fold.acc) {
-      bn_fold_channel(a.fold, CIN, tid, sc, sh, mu, rs);
-    } else {
-      sc = a.in_scale[tid];
-      sh = a.in_shift[tid];
-    }
-    sScale[tid] = sc;
-    sShift[tid] = sh;
-  }
   for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) sA[i] = 0.f;
 
   const int ntiles = (a.Tout + TT - 1) / TT;
@@ -528,7 +523,6 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     for (int j = 0; j < NLD; ++j) pre[j] = tile_load4(src, (tid + j * kThreads) * 16);
   };
   if (nitems > 0) issue(0);
-  MWW_PC_DECL
   PwWeights<CIN, NT, BF> pw;
   pw.load(a.pw_w, COUT, g, r16);
   float dww[K];
@@ -544,12 +538,28 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+  // BN_{k-1}: folded after the tile / weight loads were issued, so that the prologue is one memory round trip deep
+  // (fold first cost a second, dependent one: 2.4k + 3.5-7k cycles per workgroup in the round-2 timeline)
+  if (tid < CIN) {
+    float sc, sh, mu, rs;
+    if (a.fold.acc) {
+      bn_fold_channel(a.fold, CIN, tid, sc, sh, mu, rs);
+    } else {
+      sc = a.in_scale[tid];
+      sh = a.in_shift[tid];
+    }
+    sScale[tid] = sc;
+    sShift[tid] = sh;
+  }
+  MWW_PC_AT(1);   // statistics folded (thread 0 is one of the folding threads)
   pw.retire();
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
+  MWW_PC_AT(2);   // weights (and the first tile's rows) have arrived
   __syncthreads();
 
+  MWW_PC_AT(3);   // prologue done
   MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
@@ -595,10 +605,14 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     MWW_PC_MARK(3);   // depthwise
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(4);   // barrier 2
-    if (wave * 16 < rows_out) {   // wave-uniform
+    {
+      // (the stores stay unconditional - a dead wave's are dropped by the address unit - so that the wait-count pass
+      // sees the same memory-op sequence on every path and the next commit waits for the prefetched rows only)
       f32x4 acc[NT];
-      if (!MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);
-      else for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+      if (wave * 16 < rows_out && !MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);   // wave-uniform
+      else
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
       MWW_PC_MARK(5);   // pointwise MFMA
       store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
     }
@@ -606,8 +620,8 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
     if (!MWW_ABLATE(a, 8)) __syncthreads();
     MWW_PC_MARK(7);   // barrier 3
   }
-  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * 8 : nullptr);
   write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
+  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * kClkSlots : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -500,7 +500,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     } else {
       Layer& pl = c->L[i - 1];
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
-                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * 8,
+                     c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * kClkSlots,
                      sacc, fold_of(pl)};
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
@@ -795,7 +795,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.Tin = l.tin;
       a.Tout = l.tout;
       a.ablate = c->ablate;
-      a.phase_clk = c->phase_clk + (size_t)(2 * i + 1) * 2048 * 8;
+      a.phase_clk = c->phase_clk + (size_t)(2 * i + 1) * 2048 * kClkSlots;
       a.gacc = StatAcc{nullptr, nullptr};
       if (inl) {
         a.gacc.acc = pl.gacc[c->gpar];
@@ -1483,7 +1483,7 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->loss_part, mb));
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
-  A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * 8));
+  A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * kClkSlots));
   c->mail_off_masks = mb * sizeof(mww_window);
   c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
   c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
@@ -2304,8 +2304,8 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
     // phase clocks of layer k (1-based) as raw 64-bit counters viewed as floats: 2048 x 8 x 2 words
     const int kk = atoi(name + 4);
     if (kk < 1 || kk > nb) return fail(MWW_ERR_INVALID, "bad layer");
-    src = reinterpret_cast<const float*>(c->phase_clk + (size_t)(2 * (kk - 1) + (name[3] == 'b' ? 1 : 0)) * 2048 * 8);
-    n = 2048 * 8 * 2;
+    src = reinterpret_cast<const float*>(c->phase_clk + (size_t)(2 * (kk - 1) + (name[3] == 'b' ? 1 : 0)) * 2048 * kClkSlots);
+    n = 2048 * kClkSlots * 2;
   }
   else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
   else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);

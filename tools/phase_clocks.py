@@ -30,10 +30,18 @@ for _ in range(3):
 eng.synchronize()
 FWD = ["commit+wait", "barrier1", "issue", "depthwise", "barrier2", "mfma", "stores", "barrier3"]
 BWD = ["commit+wait", "barrier1", "issue+P1", "barrier2", "mfma", "barrier3", "P4", "barrier4"]
+S = 12   # kClkSlots
 for k in (2, 3, 4):
     for tag, names, grid in (("f", FWD, 1024), ("b", BWD, 512)):
-        raw = eng.debug_read("clk%s%d" % (tag, k), 1, 2048 * 8 * 2)
-        clk = raw.view(np.uint64).reshape(2048, 8)[:min(grid, B)].astype(np.float64)
+        raw = eng.debug_read("clk%s%d" % (tag, k), 1, 2048 * S * 2)
+        rec = raw.view(np.uint64).reshape(2048, S)[:min(grid, B)].astype(np.float64)
+        clk, st = rec[:, :8], rec[:, 8:]
         tot = clk.sum(1)
         print("layer %d %s: total cycles/WG mean %.0f (min %.0f max %.0f)" % (k, "fwd" if tag == "f" else "bwd", tot.mean(), tot.min(), tot.max()))
         print("   " + "  ".join("%s=%.0f(%.0f%%)" % (n, v, 100 * v / tot.mean()) for n, v in zip(names, clk.mean(0))))
+        if tag == "f":
+            d = [(st[:, i + 1] - st[:, i]) for i in range(3)]
+            print("   fwd prologue per WG (cycles, mean/max): entry->fold %.0f/%.0f  fold->weights %.0f/%.0f  weights->barrier %.0f/%.0f" %
+                  (d[0].mean(), d[0].max(), d[1].mean(), d[1].max(), d[2].mean(), d[2].max()))
+        else:
+            print("   per WG: prologue %.0f  loop %.0f  epilogue %.0f cycles" % ((st[:, 1] - st[:, 0]).mean(), (st[:, 2] - st[:, 1]).mean(), (st[:, 3] - st[:, 2]).mean()))
