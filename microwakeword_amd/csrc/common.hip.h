@@ -125,6 +125,25 @@ __device__ __forceinline__ void lds_reads_first() {
   __builtin_amdgcn_sched_group_barrier(0x002, 2048, 0);  // then VALU
 }
 
+// The workgroups that share a CU are not served equally: the SIMD arbiter prefers the oldest wave, so the workgroup
+// dispatched first (blockIdx < 256 on the 256-CU part) ran its tile loop 14-16 % faster than the one dispatched into
+// the same CU after it (round-2 timeline: 76.8k vs 89.3k cycles in bwd_block), and the launch lasts as long as the
+// slowest.  Rotating the wave priority per work item - co-resident workgroups differ in (blockIdx >> 8) - gives each
+// its turn in front: the two halves of the backward grids then finish together (-1...-2 us per backward launch).  The
+// forward kernels (four workgroups per CU) measured no gain for K = 9 / 13 and +3 us for K = 21: not used there.
+__device__ __forceinline__ void rotate_priority(int item, int levels) {
+  const int p = ((int)(blockIdx.x >> 8) + item) & (levels - 1);
+  if (levels == 2) {
+    if (p) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  } else {
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
+}
+
 // keep a value (and the loads that produce it) from sinking below this point: used to retire the
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }

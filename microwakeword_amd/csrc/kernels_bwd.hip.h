@@ -372,6 +372,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   MWW_PC_AT(1);   // prologue done
   MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
+    rotate_priority(it, 2);
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
     const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   __syncthreads();
 
   for (int it = 0; it < nitems; ++it) {
+    rotate_priority(it, 2);
     const int t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));
     const int rows_da = min(TT, Ta - t0);

@@ -166,6 +166,8 @@ static inline void hipemu_buf_store32(unsigned v, hipemu_rsrc r, int off, int so
 #define __builtin_amdgcn_raw_buffer_load_b32 hipemu_buf_load32
 #define __builtin_amdgcn_raw_buffer_store_b32 hipemu_buf_store32
 
+static inline void hipemu_setprio(int) {}
+#define __builtin_amdgcn_s_setprio hipemu_setprio
 static inline void hipemu_sched_group_barrier(int, int, int) {}
 #define __builtin_amdgcn_sched_group_barrier hipemu_sched_group_barrier
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

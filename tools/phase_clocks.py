@@ -45,3 +45,14 @@ for k in (2, 3, 4):
                   (d[0].mean(), d[0].max(), d[1].mean(), d[1].max(), d[2].mean(), d[2].max()))
         else:
             print("   per WG: prologue %.0f  loop %.0f  epilogue %.0f cycles" % ((st[:, 1] - st[:, 0]).mean(), (st[:, 2] - st[:, 1]).mean(), (st[:, 3] - st[:, 2]).mean()))
+
+# ---- who is slow?  loop time per workgroup grouped by XCD (blockIdx % 8) and by dispatch round-robin position
+for k in (2, 4):
+    raw = eng.debug_read("clkb%d" % k, 1, 2048 * S * 2)
+    rec = raw.view(np.uint64).reshape(2048, S)[:min(512, B)].astype(np.float64)
+    tot = rec[:, :8].sum(1)
+    print("layer %d bwd loop cycles by XCD:" % k, [int(tot[x::8].mean()) for x in range(8)], " spread within XCD0: min %d max %d" % (tot[0::8].min(), tot[0::8].max()))
+    half = len(tot) // 2
+    print("   first half of the grid (first WG on each CU?) mean %d, second half mean %d" % (tot[:half].mean(), tot[half:].mean()))
+    order = np.argsort(tot)
+    print("   slowest 16 blockIdx:", order[-16:].tolist(), " fastest 16:", order[:16].tolist())
