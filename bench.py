@@ -338,7 +338,7 @@ def main():
             model = inception.model(dict(synthetic.DEFAULT_INCEPTION_FLAGS), (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                                     seed=42, max_batch=B)
             kernel_elems = inception_kernel_elems(model.layout)
-            step_bytes = 4 * sum(v for k, v in kernel_elems.items() if not k.startswith("conv_bwd"))
+            step_bytes = 1222208   # algorithmic bytes per window of the default Inception train step (fp32, T = 194)
         elif args.model == "notebook":
             from microwakeword_amd import mixednet
             T_FRAMES = 204

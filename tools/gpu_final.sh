@@ -17,9 +17,12 @@ echo "== bench inception"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; tail -c 400 $OUT/bench_inception.json | head -c 400; echo
 echo "== bench bf16-operand"
 timeout 900 python bench.py --pointwise-bf16 --no-cpu-baseline --no-validation > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; head -c 300 $OUT/bench_bf16.json; echo
-echo "== collective path forced on one GPU (RCCL world of one): local-BN, sync-BN"
-MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation --profile-steps 0 2> $OUT/bench_dp.err | tee $OUT/bench_dp.json | head -c 300; echo
-MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --sync-bn --no-cpu-baseline --no-validation --profile-steps 0 2> $OUT/bench_dp_sync.err | tee $OUT/bench_dp_sync.json | head -c 300; echo
+echo "== collective path forced on one GPU (RCCL world of one): local-BN with two buckets / one bucket, sync-BN"
+MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation 2> $OUT/bench_dp.err | tee $OUT/bench_dp.json | head -c 300; echo
+MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation --grad-buckets 1 2> $OUT/bench_dp1.err | tee $OUT/bench_dp1.json | head -c 300; echo
+MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --sync-bn --no-cpu-baseline --no-validation 2> $OUT/bench_dp_sync.err | tee $OUT/bench_dp_sync.json | head -c 300; echo
+echo "== batch sweep"
+for b in 256 512 2048 4096; do timeout 300 python bench.py --batch $b --steps 100 --warmup 10 --no-cpu-baseline --no-validation --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch $b', d['value'], d['ms_per_step'], d['roofline']['step_frac'])" | tee -a $OUT/batch_sweep.txt; done
 echo "== rocprofv3"
 export TMPDIR=/tmp
 B="python $R/bench.py --steps 6 --warmup 2 --no-graphs --no-cpu-baseline --no-validation --profile-steps 0"
