@@ -29,6 +29,7 @@
 namespace mww {
 
 constexpr int kGMaxSrc = 3;
+constexpr int kGB = 8;   // rows a thread keeps in flight in the staging / epilogue loops
 enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8, GSRC_LINEAR = 16 };   // LINEAR: affine only, no ReLU
 
 struct GSrc {
@@ -77,10 +78,21 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
       const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
       const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
       const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.toff + s.rdrop) * C + c : nullptr;
-      for (int t = rg; t < rows; t += nrg) {
-        const float v = base[(size_t)t * s.ld];
-        const float rv = rbase ? rbase[(size_t)t * C] : 0.f;
-        sIn[t * PI + c0 + c] = fmaxf(src_affine(s, v, sc, sh, rv, rsc, rsh), lo);
+      // kGB rows per thread in flight (a rolled loop with one load and one LDS write per row is one memory round trip
+      // per row: ~rows * C / 256 of them per window and source)
+      for (int t0 = rg; t0 < rows; t0 += kGB * nrg) {
+        float v[kGB], rv[kGB];
+#pragma unroll
+        for (int u = 0; u < kGB; ++u) {
+          const int t = t0 + u * nrg;
+          v[u] = t < rows ? base[(size_t)t * s.ld] : 0.f;
+          rv[u] = (t < rows && rbase) ? rbase[(size_t)t * C] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kGB; ++u) {
+          const int t = t0 + u * nrg;
+          if (t < rows) sIn[t * PI + c0 + c] = fmaxf(src_affine(s, v[u], sc, sh, rv[u], rsc, rsh), lo);
+        }
       }
     }
     c0 += C;
@@ -92,9 +104,19 @@ __device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows
   if (rg < nrg) {
     const float mu = y.mean[c], rs = y.rstd[c], c1 = y.c1[c], mg = y.mg[c], mgx = y.mgx[c];
     const size_t base = (size_t)b * rows * C + c;
-    for (int t = rg; t < rows; t += nrg) {
-      const float g = y.g[base + (size_t)t * C], p = y.p[base + (size_t)t * C];
-      dst[t * ld + c] = c1 * (g - mg - (p - mu) * rs * mgx);
+    for (int t0 = rg; t0 < rows; t0 += kGB * nrg) {
+      float g[kGB], p[kGB];
+#pragma unroll
+      for (int u = 0; u < kGB; ++u) {
+        const int t = t0 + u * nrg;
+        g[u] = t < rows ? y.g[base + (size_t)t * C] : 0.f;
+        p[u] = t < rows ? y.p[base + (size_t)t * C] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kGB; ++u) {
+        const int t = t0 + u * nrg;
+        if (t < rows) dst[t * ld + c] = c1 * (g[u] - mg - (p[u] - mu) * rs * mgx);
+      }
     }
   }
 }
@@ -218,16 +240,31 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
             const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
             const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.rdrop) * C + c : nullptr;
             float t1 = 0.f, t2 = 0.f;
-            for (int t = rg; t < s.T; t += nrg) {
-              const size_t idx = base + (size_t)t * s.ld;
-              const float p = s.p[idx];
-              const float rv = rbase ? rbase[(size_t)t * C] : 0.f;
-              const int r = t - s.toff;
-              float gv = (r >= 0 && (linear || src_affine(s, p, sc, sh, rv, rsc, rsh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
-              if (accum) gv += s.g[idx];
-              s.g[idx] = gv;
-              t1 += gv;
-              t2 = fmaf(gv, (p - mu) * rs, t2);
+            for (int tb = rg; tb < s.T; tb += kGB * nrg) {
+              float pv[kGB], rvv[kGB], gold[kGB];
+#pragma unroll
+              for (int u = 0; u < kGB; ++u) {
+                const int t = tb + u * nrg;
+                const bool ok = t < s.T;
+                const size_t idx = base + (size_t)(ok ? t : 0) * s.ld;
+                pv[u] = ok ? s.p[idx] : 0.f;
+                rvv[u] = (ok && rbase) ? rbase[(size_t)t * C] : 0.f;
+                gold[u] = (ok && accum) ? s.g[idx] : 0.f;
+              }
+#pragma unroll
+              for (int u = 0; u < kGB; ++u) {
+                const int t = tb + u * nrg;
+                if (t < s.T) {
+                  const size_t idx = base + (size_t)t * s.ld;
+                  const float p = pv[u];
+                  const int r = t - s.toff;
+                  float gv = (r >= 0 && (linear || src_affine(s, p, sc, sh, rvv[u], rsc, rsh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
+                  if (accum) gv += gold[u];
+                  s.g[idx] = gv;
+                  t1 += gv;
+                  t2 = fmaf(gv, (p - mu) * rs, t2);
+                }
+              }
             }
             sSrcAcc[(i * 2 + 0) * kThreads + tid] += t1;
             sSrcAcc[(i * 2 + 1) * kThreads + tid] += t2;
@@ -722,19 +759,37 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     const float* rb = a.rp ? a.rp + ((size_t)b * a.rT + a.rdrop) * C : nullptr;
     float* kgen = a.keep_gen ? a.keep_gen + (size_t)b * n : nullptr;
     float dot = 0.f;
+    // rows in batches of kHB per thread: every load of a batch is issued before the first use (one load, one wait per
+    // row made this kernel a chain of ~2 T C / 256 memory round trips per window: 51 us per launch for 10 MB in round 2)
+    constexpr int kHB = 8;
     if (active) {
       const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
-      for (int t = rg; t < a.T; t += nrg) {
-        const int i = t * C + c;
-        const float act = fmaxf(fmaf(pb[i], sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f), 0.f);
-        float kv = 1.f;
-        if (kgen) {
-          kv = dropout_keep(a.seed, step, (unsigned long long)b * n + i, a.rate);
-          kgen[i] = kv;   // read back by this thread in the backward part below and by the dense-weight gradient
-        } else if (kb) {
-          kv = kb[i];
+      for (int t0 = rg; t0 < a.T; t0 += kHB * nrg) {
+        float pv[kHB], wv[kHB], rv[kHB], kv[kHB];
+#pragma unroll
+        for (int u = 0; u < kHB; ++u) {
+          const int t = t0 + u * nrg;
+          const bool ok = t < a.T;
+          const int i = ok ? t * C + c : c;
+          pv[u] = ok ? pb[i] : 0.f;
+          wv[u] = ok ? a.wd[i] : 0.f;
+          rv[u] = (ok && rb) ? rb[i] : 0.f;
+          kv[u] = (ok && kb && !kgen) ? kb[i] : 1.f;
         }
-        dot = fmaf((kgen || kb) ? act * kv : act, a.wd[i], dot);
+#pragma unroll
+        for (int u = 0; u < kHB; ++u) {
+          const int t = t0 + u * nrg;
+          if (t < a.T) {
+            const int i = t * C + c;
+            const float act = fmaxf(fmaf(pv[u], sc, sh) + (rb ? fmaf(rv[u], rsc, rsh) : 0.f), 0.f);
+            float k1 = kv[u];
+            if (kgen) {
+              k1 = dropout_keep(a.seed, step, (unsigned long long)b * n + i, a.rate);
+              kgen[i] = k1;   // read back by this thread in the backward part below and by the dense-weight gradient
+            }
+            dot = fmaf((kgen || kb) ? act * k1 : act, wv[u], dot);
+          }
+        }
       }
     }
     if (kgen) kb = kgen;
@@ -764,14 +819,31 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     if ((a.training & kHeadTraining) && active) {
       const float dzz = sBcast[0];
       float* gb = a.g + (size_t)b * n;
-      for (int t = rg; t < a.T; t += nrg) {
-        const int i = t * C + c;
-        const float raw = pb[i];
-        float gv = (fmaf(raw, sc, sh) + (rb ? fmaf(rb[i], rsc, rsh) : 0.f)) > 0.f ? dzz * a.wd[i] : 0.f;
-        if (kb) gv *= kb[i];
-        gb[i] = gv;
-        g1 += gv;
-        g2 = fmaf(gv, (raw - mu) * rs, g2);
+      for (int t0 = rg; t0 < a.T; t0 += kHB * nrg) {
+        float pv[kHB], wv[kHB], rv[kHB], kv[kHB];
+#pragma unroll
+        for (int u = 0; u < kHB; ++u) {
+          const int t = t0 + u * nrg;
+          const bool ok = t < a.T;
+          const int i = ok ? t * C + c : c;
+          pv[u] = ok ? pb[i] : 0.f;
+          wv[u] = ok ? a.wd[i] : 0.f;
+          rv[u] = (ok && rb) ? rb[i] : 0.f;
+          kv[u] = (ok && kb) ? kb[i] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kHB; ++u) {
+          const int t = t0 + u * nrg;
+          if (t < a.T) {
+            const int i = t * C + c;
+            const float raw = pv[u];
+            float gv = (fmaf(raw, sc, sh) + (rb ? fmaf(rv[u], rsc, rsh) : 0.f)) > 0.f ? dzz * wv[u] : 0.f;
+            if (kb) gv *= kv[u];
+            gb[i] = gv;
+            g1 += gv;
+            g2 = fmaf(gv, (raw - mu) * rs, g2);
+          }
+        }
       }
     }
   }

@@ -56,3 +56,10 @@ for k in (2, 4):
     print("   first half of the grid (first WG on each CU?) mean %d, second half mean %d" % (tot[:half].mean(), tot[half:].mean()))
     order = np.argsort(tot)
     print("   slowest 16 blockIdx:", order[-16:].tolist(), " fastest 16:", order[:16].tolist())
+for k in (2, 3, 4):
+    raw = eng.debug_read("clkf%d" % k, 1, 2048 * S * 2)
+    rec = raw.view(np.uint64).reshape(2048, S)[:min(1024, B)].astype(np.float64)
+    tot = rec[:, :8].sum(1)
+    q = len(tot) // 4
+    if q:
+        print("layer %d fwd loop cycles by dispatch quartile (blockIdx >> 8):" % k, [int(tot[i * q:(i + 1) * q].mean()) for i in range(4)])
