@@ -55,6 +55,18 @@ KERNEL_ELEMS = {
 }
 
 
+
+
+def kernel_elems_stored_bf16():
+    """The same accounting with p_k / g_k held as bf16 ("storage_bf16"): their elements cost 2 B, the input rows
+    keep their cost.  Returned in the 4-byte units of KERNEL_ELEMS."""
+    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ}
+    return {k: xpart.get(k, 0) + (v - xpart.get(k, 0)) / 2 for k, v in KERNEL_ELEMS.items()}
+
+
+BYTES_PER_WINDOW_STEP_BF16 = 427648   # SURVEY 8(d): bf16 p_k / g_k, fp32 input
+
+
 # exact-fp32 MFMA flops per window of the default MixedNet's GEMM-shaped phases (SURVEY §8d): first conv as
 # im2col GEMM, the 1x1 convolutions; the backward kernels run the 1x1 twice (weight + data gradient) and
 # bwd_block1 forms the first conv's weight gradient (its input relu(conv1(x)) is read back, not recomputed: every
@@ -158,6 +170,8 @@ def parse_args():
                          "MixedNet flags of the reference's training notebook (5x1 stride-3 first conv, 64 filters, MixConv groups, T=204)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="multi-GPU parity mode: BatchNorm statistics exchanged over RCCL (default: local-BN throughput mode)")
+    ap.add_argument("--storage-bf16", action="store_true",
+                    help="BASELINE configs[4], full form: p_k / g_k stored as bf16 in HBM on top of --pointwise-bf16 (fp32 accumulation and BN sums)")
     ap.add_argument("--pointwise-bf16", action="store_true",
                     help="BASELINE configs[4]: bf16-operand MFMA for the 1x1 contractions (not the headline configuration)")
     ap.add_argument("--force-generic", action="store_true",
@@ -359,6 +373,8 @@ def main():
             model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                           seed=42, max_batch=B)
             kernel_elems, step_bytes = KERNEL_ELEMS, BYTES_PER_WINDOW_STEP
+            if args.storage_bf16:
+                kernel_elems, step_bytes = kernel_elems_stored_bf16(), BYTES_PER_WINDOW_STEP_BF16
         eng = model.engine
         n_val = 4096 if (world == 1 and not force_dp and not args.no_validation) else 0
         cfg, _ = synthetic.benchmark_config(args.store_samples, 1234, n_val=n_val, n_ambient=n_val // 8)
@@ -380,6 +396,8 @@ def main():
             eng.set_option("ablate", args.ablate)
         if args.pointwise_bf16:
             eng.set_option("pointwise_bf16", 1)
+        if args.storage_bf16:
+            eng.set_option("storage_bf16", 1)
         if os.environ.get("MWW_BENCH_SIDE_STREAM") is not None:
             eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
         if os.environ.get("MWW_BENCH_TAIL_ROLES") is not None:
@@ -500,7 +518,7 @@ def main():
     else:  # --profile-steps 0 (e.g. under rocprofv3): whole-step figure only
         dominant, dom_bytes, achieved = "train_step(all kernels)", step_bytes * B, value / world * step_bytes
         kern[dominant] = 1e3 * elapsed / args.steps
-    traffic, traffic_src = pmc_traffic(dominant, args.model) if B == 1024 and not args.pointwise_bf16 else (None, None)
+    traffic, traffic_src = pmc_traffic(dominant, args.model) if B == 1024 and not (args.pointwise_bf16 or args.storage_bf16) else (None, None)
     # roofline of the dominant kernel.  SURVEY 8(d) names HBM as the governing roofline of the train step; a kernel whose
     # exact-fp32 MFMA time at the spec peak exceeds its HBM time at the spec peak is priced against the MFMA peak
     # instead - and BOTH fractions are always reported, with the flops counted (useful ones only: nothing is recomputed
@@ -508,7 +526,7 @@ def main():
     hbm_frac = achieved / HBM_PEAK
     roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(hbm_frac, 4), "hbm_achieved_GBps": round(achieved / 1e9, 1), "hbm_frac": round(hbm_frac, 4)}
-    mfma_flops = KERNEL_MFMA_FLOPS.get(dominant, 0) * B if (args.model == "mixednet" and not args.force_generic and not args.pointwise_bf16) else 0
+    mfma_flops = KERNEL_MFMA_FLOPS.get(dominant, 0) * B if (args.model == "mixednet" and not args.force_generic and not (args.pointwise_bf16 or args.storage_bf16)) else 0
     if mfma_flops:
         tf = mfma_flops / (kern[dominant] * 1e-3)
         roof.update({"mfma_achieved_TFLOPs": round(tf / 1e12, 2), "mfma_peak_TFLOPs": FP32_MFMA_PEAK / 1e12, "mfma_frac": round(tf / FP32_MFMA_PEAK, 4),
@@ -520,12 +538,14 @@ def main():
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 storage/accumulate, bf16-operand MFMA in the 1x1 contractions" if args.pointwise_bf16 else "f32",
+        "vs_baseline": None, "dtype": ("bf16 storage of p_k/g_k, bf16-operand MFMA in the 1x1 contractions, f32 accumulate / BN sums / parameters" if args.storage_bf16 else
+                                      "f32 storage/accumulate, bf16-operand MFMA in the 1x1 contractions" if args.pointwise_bf16 else "f32"),
         "data": "synthetic",
-        "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, fp32, "
+        "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, %s, "
                                "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM"
                                % (args.model, " + residual_connection 0,0,0,0" if args.model == "mixednet" else ", dropout 0.2 from the built-in generator",
-                                  B, args.store_samples),
+                                  B, "bf16 p_k/g_k + bf16 MFMA operands" if args.storage_bf16 else "bf16 MFMA operands" if args.pointwise_bf16 else "fp32",
+                                  args.store_samples),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": bool(args.graphs and not args.no_graphs),
                    "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch"},
         "roofline": {**roof, "traffic": traffic, "traffic_source": traffic_src,

@@ -247,6 +247,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
 /* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head", "grid_graph",
  * "dropout_seed", "pointwise_bf16" (0 = exact fp32 MFMA, the default; 1 = the MixedNet 1x1 convolutions and
  * their two backward contractions take bf16-rounded operands with fp32 accumulation — BASELINE configs[4]),
+ * "storage_bf16" (1 = additionally the block outputs p_k and the stashed gradients g_k live in HBM as bf16, every sum
+ * stays fp32 and is taken from the unrounded values; implies pointwise_bf16, cleared by pointwise_bf16 = 0),
  * "fused_input" (default 1, specialised MixedNet kernels: mww_assemble_batch uploads descriptors only and the first
  * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
  * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of

@@ -114,6 +114,50 @@ __device__ __forceinline__ float tile_load1(BufRsrc r, int byte_off) {
 __device__ __forceinline__ void tile_store1(BufRsrc r, int byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
 }
+// ---- bf16 storage of the block outputs p_k and the stashed gradients g_k ("storage_bf16", BASELINE configs[4]) ----
+// SB = true: the tensor holds bf16 (RNE on store, exact widening on load); arithmetic, accumulation and the BN sums
+// stay fp32.  Element / float4-group indices are the same in both modes, only the byte offsets differ.
+template <bool SB>
+__device__ __forceinline__ float4 tile_load4s(BufRsrc r, int group) {   // group = index of a 4-channel group in the slice
+  if constexpr (!SB) {
+    return tile_load4(r, group * 16);
+  } else {
+    const uint2 v = tile_load2(r, group * 8);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+  }
+}
+template <bool SB>
+__device__ __forceinline__ void tile_store1s(BufRsrc r, int elem, float v) {   // elem = element index in the slice
+  if constexpr (!SB) {
+    tile_store1(r, elem * 4, v);
+  } else {
+    const __bf16 h = (__bf16)v;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, elem * 2, 0, 0);
+  }
+}
+template <bool SB>
+__device__ __forceinline__ float load_elem(const float* base, size_t elem) {   // scalar read of a stored tensor
+  if constexpr (!SB) {
+    return base[elem];
+  } else {
+    // through the aligned dword that holds the element: 16-bit loads fill register halves one after the other
+    // (d16 / d16_hi chains wait for each other), a batch of dword loads stays independent
+    const unsigned dw = reinterpret_cast<const unsigned*>(base)[elem >> 1];
+    return __uint_as_float((elem & 1) ? (dw & 0xffff0000u) : (dw << 16));
+  }
+}
+__host__ __device__ constexpr int elem_bytes(bool sb) { return sb ? 2 : 4; }
+// the stored tensor at element offset `elem` (both modes keep fp32-sized allocations; bf16 uses the first half)
+template <bool SB>
+__device__ __forceinline__ const float* elem_ptr(const float* base, size_t elem) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + elem * (SB ? 2 : 4));
+}
+template <bool SB>
+__device__ __forceinline__ float* elem_ptr(float* base, size_t elem) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elem * (SB ? 2 : 4));
+}
+
 // lane offset that is out of range for every resource (lanes that take no part in an access)
 constexpr int kOobOffset = 0x40000000;
 

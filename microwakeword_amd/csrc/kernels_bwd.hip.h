@@ -52,18 +52,20 @@ struct BwdBlockArgs {
 // dp tile: rows [t0, t0+TT) of (p_k, g_k) are fetched into registers early (issue) and turned into
 // dp = BN_k backward of g_k while being written to LDS late (commit).  A sample's rows are
 // contiguous, so float4 i of the tile sits at offset 4*i from the tile start.
-template <int COUT, bool LAST>
+template <int COUT, bool LAST, bool SB = false>
 struct DpStage {
   static constexpr int QO = COUT / 4, CPO = pitch(COUT), N = (TT * QO + kThreads - 1) / kThreads;
   float4 pk[N], gg[N];
 
   // both slices hold nvalid float4s; float4s past them come back as zeros
+  // (LAST: g_base are rows of the dense kernel, a parameter: always fp32)
   __device__ __forceinline__ void issue(const float* pk_base, const float* g_base, int nvalid, int tid) {
-    const BufRsrc rp = tile_rsrc(pk_base, nvalid * 16), rg = tile_rsrc(g_base, nvalid * 16);
+    constexpr bool SG = SB && !LAST;
+    const BufRsrc rp = tile_rsrc(pk_base, nvalid * 4 * elem_bytes(SB)), rg = tile_rsrc(g_base, nvalid * 4 * elem_bytes(SG));
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      pk[j] = tile_load4(rp, (tid + j * kThreads) * 16);
-      gg[j] = tile_load4(rg, (tid + j * kThreads) * 16);
+      pk[j] = tile_load4s<SB>(rp, tid + j * kThreads);
+      gg[j] = tile_load4s<SG>(rg, tid + j * kThreads);
     }
   }
 
@@ -270,7 +272,7 @@ __device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, in
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int K, bool LAST, bool BF>
+template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
   constexpr int RA = TT + K - 1;
@@ -305,17 +307,17 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   const int nitems = nsamp * ntiles;
   constexpr int NP = (RA * QI + kThreads - 1) / kThreads;
   float4 pre_p[NP];
-  DpStage<COUT, LAST> dps;
+  DpStage<COUT, LAST, SB> dps;
   float pre_dz = 0.f;
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nvp = min(RA, a.Tin - t0) * QI;
-    const BufRsrc src = tile_rsrc(a.in + ((size_t)b * a.Tin + t0) * CIN, nvp * 16);
+    const BufRsrc src = tile_rsrc(elem_ptr<SB>(a.in, ((size_t)b * a.Tin + t0) * CIN), nvp * 4 * elem_bytes(SB));
 #pragma unroll
-    for (int j = 0; j < NP; ++j) pre_p[j] = tile_load4(src, (tid + j * kThreads) * 16);
+    for (int j = 0; j < NP; ++j) pre_p[j] = tile_load4s<SB>(src, tid + j * kThreads);
     const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
     const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(a.pk + koff, LAST ? a.wd + (size_t)t0 * COUT : a.gk + koff, nvk, tid);
+    dps.issue(elem_ptr<SB>(a.pk, koff), LAST ? a.wd + (size_t)t0 * COUT : elem_ptr<SB>(a.gk, koff), nvk, tid);
     if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
   };
   if (nitems > 0) issue(0);
@@ -423,8 +425,8 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
     if (!MWW_ABLATE(a, 4)) {
       const int cch = dw_active ? chunk : NCH - 1;
       // the tile's slice of g_{k-1}: rows past rows_da are dropped by the address unit
-      const BufRsrc gtile = tile_rsrc(a.g_out + ((size_t)b * a.Tin + t0) * CIN, rows_da * CIN * 4);
-      const int goff = (dw_active ? 0 : kOobOffset) + (cch * L * CIN + c) * 4;
+      const BufRsrc gtile = tile_rsrc(elem_ptr<SB>(a.g_out, ((size_t)b * a.Tin + t0) * CIN), rows_da * CIN * elem_bytes(SB));
+      const int goff = (dw_active ? 0 : kOobOffset / 4) + cch * L * CIN + c;   // element index (out of range for the shadow lanes)
       {
         float da[L], raw[L];
 #pragma unroll
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
           const int sl = cch * L + t;
           // (row TT of the last chunk belongs to the next tile: its da is still partial)
           const float gg = (sl < rows_da && fmaf(raw[t], sc_c, sh_c) > 0.f) ? da[t] : 0.f;
-          tile_store1(gtile, goff + t * CIN * 4, gg);
+          tile_store1s<SB>(gtile, goff + t * CIN, gg);
           gs1 += gg;
           gs2 = fmaf(gg, (raw[t] - mu_c) * rs_c, gs2);
         }
@@ -499,7 +501,7 @@ struct BwdFirstArgs {
   XGather xg;             // xg.win set: x rows are gathered from the feature stores (see kernels_fwd.hip.h)
 };
 
-template <int K1, int C1, int COUT, int K, int S, bool BF>
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) {
   constexpr int CIN = C1;
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int nitems = nsamp * ntiles;
   XStage<XR, PX> xs;
-  DpStage<COUT, false> dps;
+  DpStage<COUT, false, SB> dps;
   constexpr int NA = (RA * QI + kThreads - 1) / kThreads;
   float4 pre_a[NA];
   auto issue = [&](int it) {
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     for (int j = 0; j < NA; ++j) pre_a[j] = tile_load4(ra, (tid + j * kThreads) * 16);
     const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
     const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(a.pk + koff, a.gk + koff, nvk, tid);
+    dps.issue(elem_ptr<SB>(a.pk, koff), elem_ptr<SB>(a.gk, koff), nvk, tid);
   };
   // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s*S+j][f]
   int offm[MPW];

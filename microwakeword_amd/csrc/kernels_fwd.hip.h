@@ -309,17 +309,18 @@ struct PwWeights<CIN, NT, true> {
 // store a 16 x (NT*16) accumulator tile to the (sample, tile) slice `out` of the output tensor (rows past the slice
 // are dropped by the address unit) and accumulate per-channel sum / sum^2.  Rows past the slice hold exact zeros (their
 // u rows are zero), so the sums need no mask either.
-template <int NT, int COUT>
+template <int NT, int COUT, bool SB = false>
 __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], BufRsrc out, int row0, int r16, int g,
                                                  float (&s1)[NT], float (&s2)[NT], int row_base = 0) {
-  // row_base < 0 (rows in front of the slice) gives negative = huge unsigned offsets: dropped like the rows behind it
-  const int off = ((row_base + row0 + g * 4) * COUT + r16) * 4;
+  // row_base < 0 (rows in front of the slice) gives negative = huge unsigned offsets: dropped like the rows behind it.
+  // The sums are those of the fp32 values (bf16 storage rounds only what goes to HBM).
+  const int off = (row_base + row0 + g * 4) * COUT + r16;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[nt][r];
-      tile_store1(out, off + (r * COUT + nt * 16) * 4, v);
+      tile_store1s<SB>(out, off + r * COUT + nt * 16, v);
       s1[nt] += v;
       s2[nt] = fmaf(v, v, s2[nt]);
     }
@@ -352,7 +353,7 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 // network), keeps them in an LDS ring behind the K-1 rows carried over from the previous tile, and stores them to
 // HBM for bwd_first_kernel.  The depthwise / pointwise part of the tile then produces the output rows
 // [64 i - (K-1), 64 i + 64 - (K-1)) that those ring rows complete.
-template <int K1, int C1, int COUT, int K, int S, bool BF>
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
   constexpr int CP1 = pitch(C1);
   constexpr int RA = TT + K - 1;               // ring rows: K-1 carried + TT new
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
       else
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
-      store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + (size_t)b * a.Tout * COUT, a.Tout * COUT * 4), wave * 16, r16, g, s1, s2, tu0);
+      store_tile_stats<NT, COUT, SB>(acc, tile_rsrc(elem_ptr<SB>(a.out, (size_t)b * a.Tout * COUT), a.Tout * COUT * elem_bytes(SB)), wave * 16, r16, g, s1, s2, tu0);
     }
     __syncthreads();
   }
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int K, bool BF>
+template <int CIN, int COUT, int K, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
   constexpr int CPI = pitch(CIN);
   constexpr int RA = TT + K - 1;
@@ -518,9 +519,9 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   auto issue = [&](int it) {
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
-    const BufRsrc src = tile_rsrc(a.in + ((size_t)b * a.Tin + t0) * CIN, nvalid * 16);
+    const BufRsrc src = tile_rsrc(elem_ptr<SB>(a.in, ((size_t)b * a.Tin + t0) * CIN), nvalid * 4 * elem_bytes(SB));
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) pre[j] = tile_load4(src, (tid + j * kThreads) * 16);
+    for (int j = 0; j < NLD; ++j) pre[j] = tile_load4s<SB>(src, tid + j * kThreads);
   };
   if (nitems > 0) issue(0);
   PwWeights<CIN, NT, BF> pw;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
       MWW_PC_MARK(5);   // pointwise MFMA
-      store_tile_stats<NT, COUT>(acc, tile_rsrc(a.out + ((size_t)b * a.Tout + t0) * COUT, rows_out * COUT * 4), wave * 16, r16, g, s1, s2);
+      store_tile_stats<NT, COUT, SB>(acc, tile_rsrc(elem_ptr<SB>(a.out, ((size_t)b * a.Tout + t0) * COUT), rows_out * COUT * elem_bytes(SB)), wave * 16, r16, g, s1, s2);
     }
     MWW_PC_MARK(6);   // stores + stats
     if (!MWW_ABLATE(a, 8)) __syncthreads();

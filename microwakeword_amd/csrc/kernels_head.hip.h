@@ -9,6 +9,8 @@
 //   dense_grad_kernel : dW_dense[t,c] = sum_b dL/dz_b * relu(bn(p_L[b,t,c])) as a batch-chunked
 //                       reduction (fixed order) + the dense bias gradient.
 #pragma once
+#include <type_traits>
+
 #include "common.hip.h"
 
 namespace mww {
@@ -42,7 +44,7 @@ struct HeadArgs {
   StatAcc gacc;            // gacc.acc set: the (sum g, sum g*xhat) partials go to accumulator rows instead of gstat_part
 };
 
-template <int C, int JMAX>
+template <int C, int JMAX, bool SB = false>
 __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   constexpr int Q = C / 4;                 // float4 per frame
   constexpr int NRG = kThreads / Q;        // frame groups
@@ -85,7 +87,13 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
       raw[j] = make_float4(0, 0, 0, 0);
       wdv[j] = raw[j];
       if (active && t < a.T) {
-        raw[j] = *reinterpret_cast<const float4*>(a.p + ((size_t)b * a.T + t) * C + q * 4);
+        if constexpr (SB) {
+          const uint2 v = *reinterpret_cast<const uint2*>(elem_ptr<SB>(a.p, ((size_t)b * a.T + t) * C + q * 4));
+          raw[j] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                               __uint_as_float(v.y & 0xffff0000u));
+        } else {
+          raw[j] = *reinterpret_cast<const float4*>(a.p + ((size_t)b * a.T + t) * C + q * 4);
+        }
         wdv[j] = *reinterpret_cast<const float4*>(a.wd + (size_t)t * C + q * 4);
       }
     }
@@ -225,6 +233,7 @@ struct DenseGradArgs {
   const float* keep;    // [B][n] dropout keep-scale in front of the dense layer, or null
   const float *rp, *rscale, *rshift;   // residual branch added before the last ReLU ([B][rT][C], frame t + rdrop), or null
   int rT, rdrop;
+  int p_bf16;           // p is stored as bf16 ("storage_bf16")
 };
 
 __device__ __forceinline__ void dense_grad_body(const DenseGradArgs& a, int bx, int by, int tid) {
@@ -236,19 +245,39 @@ __device__ __forceinline__ void dense_grad_body(const DenseGradArgs& a, int bx, 
     const float rsc = a.rp ? a.rscale[c] : 0.f, rsh = a.rp ? a.rshift[c] : 0.f;
     const size_t roff = a.rp ? (size_t)a.rdrop * a.C + e : 0, rstride = (size_t)a.rT * a.C;
     float acc = 0.f;
-    for (int bb = b0; bb < b1; bb += 8) {
-      float v[8], d[8], r[8];
+    // storage mode / residual branch / dropout scale as template arguments, clamped row index instead of predicates:
+    // all loads of a batch of 8 rows are issued before the first use (see grad_final_kernel's dense role)
+    auto rows = [&](auto stored, auto has_res, auto has_keep) {
+      constexpr bool SB = decltype(stored)::value, RES = decltype(has_res)::value, KEEP = decltype(has_keep)::value;
+      for (int bb = b0; bb < b1; bb += 8) {
+        float v[8], d[8], r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = bb + u < b1;
-        v[u] = ok ? a.p[(size_t)(bb + u) * a.n + e] : 0.f;
-        d[u] = ok ? a.dz[bb + u] : 0.f;
-        r[u] = (ok && a.rp) ? fmaf(a.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
-        if (ok && a.keep) d[u] *= a.keep[(size_t)(bb + u) * a.n + e];
+        for (int u = 0; u < 8; ++u) {
+          const size_t row = (size_t)min(bb + u, b1 - 1);
+          v[u] = load_elem<SB>(a.p, row * a.n + e);
+          d[u] = a.dz[row];
+          r[u] = 0.f;
+          if constexpr (RES) r[u] = a.rp[row * rstride + roff];
+          if constexpr (KEEP) d[u] *= a.keep[row * a.n + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if constexpr (RES) r[u] = fmaf(r[u], rsc, rsh);
+          if (bb + u >= b1) d[u] = 0.f;
+          acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), acc);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = fmaf(d[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), acc);
-    }
+    };
+    auto pick_keep = [&](auto stored, auto has_res) {
+      if (a.keep) rows(stored, has_res, std::true_type{});
+      else rows(stored, has_res, std::false_type{});
+    };
+    auto pick_res = [&](auto stored) {
+      if (a.rp) pick_keep(stored, std::true_type{});
+      else pick_keep(stored, std::false_type{});
+    };
+    if (a.p_bf16) pick_res(std::true_type{});
+    else pick_res(std::false_type{});
     a.part[(size_t)by * a.stride + e] = acc;
   } else if (e == a.n) {
     float s = 0.f;

@@ -3,6 +3,8 @@
 // gradient (dense_grad, batch-chunked) and the metric update (one workgroup).  Each is latency-bound on
 // its own (5-10 us for a few microseconds of work); as roles of one grid they overlap.
 #pragma once
+#include <type_traits>
+
 #include "kernels_bwd.hip.h"
 #include "kernels_head.hip.h"
 
@@ -68,6 +70,54 @@ struct GradFinalArgs {
   int apply_adam;
 };
 
+// The dense-weight gradient of one column over the batch chunks [c0, c1) (grad_final_kernel's dense role).  Storage mode,
+// residual branch and dropout scale are template arguments and the row index is clamped instead of predicated: with
+// run-time selects around them the 32 rows of a chunk became 32 dependent round trips (the round-2 ISA waited after every
+// row); now every load of a batch is issued before the first use.  Same arithmetic as dense_grad_kernel's batch chunks
+// summed as partial rows: an fma chain per chunk of d.chunk windows, the chunk sums added in order.
+template <bool SB, bool RES, bool KEEP>
+__device__ __forceinline__ float dense_role_chunks(const DenseGradArgs& d, int e, int c0, int c1, float sc, float sh, float rsc,
+                                                   float rsh, size_t roff, size_t rstride) {
+  constexpr int U = (RES || KEEP) ? 8 : 32;   // rows in flight per thread (a chunk of the headline batch is one round trip)
+  float acc = 0.f;
+  for (int ci = c0; ci < c1; ++ci) {
+    const int b0 = ci * d.chunk, b1 = min(d.B, b0 + d.chunk);
+    float sub = 0.f;
+    for (int bb = b0; bb < b1; bb += U) {
+      float v[U], dz[U], r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t row = (size_t)min(bb + u, b1 - 1);   // rows past the chunk re-read its last row (and are not summed)
+        v[u] = load_elem<SB>(d.p, row * d.n + e);
+        dz[u] = d.dz[row];
+        r[u] = 0.f;
+        if constexpr (RES) r[u] = d.rp[row * rstride + roff];
+        if constexpr (KEEP) dz[u] *= d.keep[row * d.n + e];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (RES) r[u] = fmaf(r[u], rsc, rsh);
+        if (bb + u < b1) sub = fmaf(dz[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), sub);
+      }
+    }
+    acc += sub;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float dense_role_dispatch(const DenseGradArgs& d, int e, int c0, int c1, float sc, float sh, float rsc,
+                                                     float rsh, size_t roff, size_t rstride) {
+#define MWW_DR(SB, RES, KEEP) return dense_role_chunks<SB, RES, KEEP>(d, e, c0, c1, sc, sh, rsc, rsh, roff, rstride)
+  if (d.p_bf16) {
+    if (d.rp) { if (d.keep) MWW_DR(true, true, true); else MWW_DR(true, true, false); }
+    else { if (d.keep) MWW_DR(true, false, true); else MWW_DR(true, false, false); }
+  } else {
+    if (d.rp) { if (d.keep) MWW_DR(false, true, true); else MWW_DR(false, true, false); }
+    else { if (d.keep) MWW_DR(false, false, true); else MWW_DR(false, false, false); }
+  }
+#undef MWW_DR
+}
+
 __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ unsigned sH101[2][101];
@@ -108,26 +158,7 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
       const float sc = d.scale[c], sh = d.shift[c];
       const float rsc = d.rp ? d.rscale[c] : 0.f, rsh = d.rp ? d.rshift[c] : 0.f;
       const size_t roff = d.rp ? (size_t)d.rdrop * d.C + e : 0, rstride = (size_t)d.rT * d.C;
-      constexpr int U = 32;   // rows in flight per thread (a chunk of the headline batch is one round trip)
-      for (int ci = c0; ci < c1; ++ci) {
-        const int b0 = ci * d.chunk, b1 = min(d.B, b0 + d.chunk);
-        float sub = 0.f;
-        for (int bb = b0; bb < b1; bb += U) {
-          float v[U], dz[U], r[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const bool ok = bb + u < b1;
-            v[u] = ok ? d.p[(size_t)(bb + u) * d.n + e] : 0.f;
-            dz[u] = ok ? d.dz[bb + u] : 0.f;
-            r[u] = (ok && d.rp) ? fmaf(d.rp[(size_t)(bb + u) * rstride + roff], rsc, rsh) : 0.f;
-            if (ok && d.keep) dz[u] *= d.keep[(size_t)(bb + u) * d.n + e];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (bb + u < b1) sub = fmaf(dz[u], fmaxf(fmaf(v[u], sc, sh) + r[u], 0.f), sub);
-        }
-        acc += sub;
-      }
+      acc = dense_role_dispatch(d, e, c0, c1, sc, sh, rsc, rsh, roff, rstride);
     } else if (in) {   // e == d.n: the dense bias
       for (int ci = c0; ci < c1; ++ci) {
         const int b0 = ci * d.chunk, b1 = min(d.B, b0 + d.chunk);

@@ -179,6 +179,7 @@ struct mww_ctx {
   bool use_side = false;  // "side_stream" option: metric update + dense-weight gradient on a second stream (measured: co-running
                           // kernels displace workgroups of the occupancy-tuned block kernels; serial is 8 us/step faster)
   bool pw_bf16 = false;   // 1x1 contractions with bf16 operands (mww_set_option "pointwise_bf16")
+  bool st_bf16 = false;   // p_k / g_k stored as bf16 ("storage_bf16", implies pointwise_bf16: BASELINE configs[4])
   bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
@@ -220,7 +221,9 @@ struct Launcher {
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    if (c->pw_bf16)                                                                                            \
+    if (c->st_bf16)                                                                                            \
+      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else if (c->pw_bf16)                                                                                       \
       hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     else                                                                                                       \
       hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
@@ -234,7 +237,9 @@ int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    if (c->pw_bf16)                                                                                            \
+    if (c->st_bf16)                                                                                            \
+      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else if (c->pw_bf16)                                                                                       \
       hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
     else                                                                                                       \
       hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
@@ -248,7 +253,9 @@ int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a, int grid) {
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (c->pw_bf16)                                                                                            \
+    if (c->st_bf16)                                                                                            \
+      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else if (c->pw_bf16)                                                                                       \
       hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);    \
     else                                                                                                       \
       hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
@@ -262,7 +269,11 @@ int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a
 int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (last && c->pw_bf16)                                                                                    \
+    if (last && c->st_bf16)                                                                                    \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
+    else if (c->st_bf16)                                                                                       \
+      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
+    else if (last && c->pw_bf16)                                                                               \
       hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
     else if (last)                                                                                             \
       hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
@@ -280,7 +291,10 @@ int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdB
 int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
 #define X(C, J)                                                                                                \
   if (ch == C && jmax <= J) {                                                                                  \
-    hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                      \
+    if (c->st_bf16)                                                                                            \
+      hipLaunchKernelGGL((head_kernel<C, J, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);              \
+    else                                                                                                       \
+      hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                    \
     return MWW_OK;                                                                                             \
   }
   X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
@@ -384,7 +398,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
       const int dchunk = (B + kDenseChunks - 1) / kDenseChunks;
       const int ndchunks = (B + dchunk - 1) / dchunk;
       DenseGradArgs dg{p_last, scale, shift, c->dz, c->dwd_part, B, c->t_last * c->c_last, c->c_last, c->dwd_stride, dchunk, keep,
-                       nullptr, nullptr, nullptr, 0, 0};
+                       nullptr, nullptr, nullptr, 0, 0, c->st_bf16 ? 1 : 0};
       if (c->generic && !c->head2 && c->G.back().res_src >= 0) {
         GOp& rr = c->G[c->G.back().res_src];
         dg.rp = rr.p;
@@ -593,7 +607,7 @@ int assemble_range(mww_ctx* c, int B, const GradReduceArgs& ga, int64_t lo, int6
   if (tail_dense && c->o_dense_w >= lo && c->o_dense_w < hi) {
     Layer& ll = c->L[c->d.n_blocks - 1];
     a.dense = DenseGradArgs{ll.p, bn_slot(ll, BN_SCALE), bn_slot(ll, BN_SHIFT), c->dz, nullptr, B, c->t_last * c->c_last,
-                            c->c_last, 0, (B + kDenseChunks - 1) / kDenseChunks, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                            c->c_last, 0, (B + kDenseChunks - 1) / kDenseChunks, nullptr, nullptr, nullptr, nullptr, 0, 0, c->st_bf16 ? 1 : 0};
     segs.push_back(FinalSegment{nullptr, B, 0, c->t_last * c->c_last + 1, (int)c->o_dense_w, kSegDense, 0});
   }
   std::sort(segs.begin(), segs.end(), [](const FinalSegment& x, const FinalSegment& y) { return x.dst < y.dst; });
@@ -752,7 +766,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       HeadTailArgs ht;
       ht.fin = f;
       ht.dense = DenseGradArgs{l.p, bn_slot(l, BN_SCALE), bn_slot(l, BN_SHIFT), c->dz, c->dwd_part, B, c->t_last * c->c_last,
-                               c->c_last, c->dwd_stride, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                               c->c_last, c->dwd_stride, dchunk, nullptr, nullptr, nullptr, nullptr, 0, 0, c->st_bf16 ? 1 : 0};
       ht.met = MetricsArgs{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
       ht.n_fin = l.cout;
       ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
@@ -2296,8 +2310,9 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
     int rcg = copy_out(c, host, src, (size_t)n * sizeof(float));
     return rcg ? rcg : n;
   }
-  if ((k = idx("p")) >= 0) { src = c->L[k].p; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
-  else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; }
+  bool stored = false;   // p_k / g_k: bf16 in HBM under "storage_bf16", widened for the caller
+  if ((k = idx("p")) >= 0) { src = c->L[k].p; n = (int64_t)B * c->L[k].tout * c->L[k].cout; stored = true; }
+  else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; stored = true; }
   else if ((k = idx("bn")) >= 0) { src = c->L[k].bn; n = (int64_t)9 * c->L[k].cout; }
   else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
   else if (!strncmp(name, "clkf", 4) || !strncmp(name, "clkb", 4)) {
@@ -2310,6 +2325,16 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
   else if (!strcmp(name, "x")) { src = c->x; n = (int64_t)B * c->d.frames * MWW_FEATURE_BINS; }
   else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
   if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");
+  if (stored && c->st_bf16) {
+    std::vector<unsigned short> half((size_t)n);
+    int rch = copy_out(c, half.data(), src, (size_t)n * sizeof(unsigned short));
+    if (rch) return rch;
+    for (int64_t i = 0; i < n; ++i) {
+      const unsigned bits = (unsigned)half[(size_t)i] << 16;
+      memcpy(host + i, &bits, 4);
+    }
+    return n;
+  }
   int rc = copy_out(c, host, src, (size_t)n * sizeof(float));
   return rc ? rc : n;
 }
@@ -2338,6 +2363,12 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "pointwise_bf16")) {
     if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");
     c->pw_bf16 = v != 0;
+    if (!v) c->st_bf16 = false;
+  }
+  else if (!strcmp(name, "storage_bf16")) {
+    if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");
+    c->st_bf16 = v != 0;
+    if (v) c->pw_bf16 = true;
   }
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }

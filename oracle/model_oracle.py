@@ -226,6 +226,35 @@ class _Bf16Pointwise(torch.autograd.Function):
         return torch.einsum("oc,bot->bct", wr, gr), torch.einsum("bot,bct->oc", gr, xr)
 
 
+class _StoredBatchNorm(torch.autograd.Function):
+    """Training-mode BatchNorm of a block output under the engine's "storage_bf16" option (BASELINE configs[4]):
+    the block output p lives in HBM as bf16, so every consumer sees round(p); the batch statistics are summed
+    in-kernel from the unrounded fp32 values.  Backward as the engine evaluates it: the sums (sum g, sum g*xhat)
+    come from the unrounded incoming gradient g while it is still in registers; the gradient that is stashed for
+    the next launch is round(g) (``round_g``: every block but the last, whose g is formed from the dense kernel).
+    x [B,C,T]; returns (y, mean, var)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, round_g):
+        mean = x.mean((0, 2))
+        var = ((x - mean.reshape(1, -1, 1)) ** 2).mean((0, 2))
+        rs = torch.rsqrt(var + BN_EPS)
+        xhat = (_round_bf16(x) - mean.reshape(1, -1, 1)) * rs.reshape(1, -1, 1)
+        ctx.save_for_backward(xhat, gamma, rs)
+        ctx.round_g = round_g
+        ctx.mark_non_differentiable(mean, var)
+        return xhat * gamma.reshape(1, -1, 1) + beta.reshape(1, -1, 1), mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        xhat, gamma, rs = ctx.saved_tensors
+        n = gy.shape[0] * gy.shape[2]
+        s1, s2 = gy.sum((0, 2)), (gy * xhat).sum((0, 2))
+        gs = _round_bf16(gy) if ctx.round_g else gy
+        dx = (gamma * rs).reshape(1, -1, 1) * (gs - (s1 / n).reshape(1, -1, 1) - xhat * (s2 / n).reshape(1, -1, 1))
+        return dx, s2, s1, None
+
+
 class _Cursor:
     def __init__(self, tensors: Dict[str, torch.Tensor], training: bool):
         self.t = tensors
@@ -265,6 +294,17 @@ class _Cursor:
         y = (xs - mean.reshape(shape)) * torch.rsqrt(var.reshape(shape) + BN_EPS) * g.reshape(shape) + b.reshape(shape)
         return y.reshape(B, C, T)
 
+    def bn_stored(self, x, name, round_g):
+        """BatchNorm over a block output that is stored as bf16 (see _StoredBatchNorm)."""
+        g, b = self.t[name + ".gamma"], self.t[name + ".beta"]
+        if self.training:
+            y, mean, var = _StoredBatchNorm.apply(x, g, b, round_g)
+            self.new_stats[name + ".moving_mean"] = self.t[name + ".moving_mean"] * BN_MOMENTUM + mean.detach() * (1 - BN_MOMENTUM)
+            self.new_stats[name + ".moving_variance"] = self.t[name + ".moving_variance"] * BN_MOMENTUM + var.detach() * (1 - BN_MOMENTUM)
+            return y
+        mean, var = self.t[name + ".moving_mean"], self.t[name + ".moving_variance"]
+        return (_round_bf16(x) - mean.reshape(1, -1, 1)) * torch.rsqrt(var.reshape(1, -1, 1) + BN_EPS) * g.reshape(1, -1, 1) + b.reshape(1, -1, 1)
+
 
 def mixednet_logits(flags, tensors, x, training, taps=None, relu_masks=None):
     """x [B,T,40] -> logits [B].  ``taps`` (dict) receives named intermediates ([B,T,C] layout).
@@ -298,13 +338,17 @@ def mixednet_logits(flags, tensors, x, training, taps=None, relu_masks=None):
                     net = torch.cat([o[:, :, o.shape[2] - last_t:] for o in outs], dim=1)
                 if taps is not None:
                     taps[p + ".dw"] = net.transpose(1, 2)
-            if _get(flags, "pw_bf16", False):
+            stored = _get(flags, "st_bf16", False)
+            if stored or _get(flags, "pw_bf16", False):
                 net = _Bf16Pointwise.apply(net, tensors[p + ".pw.kernel"][0, 0].t())
             else:
                 net = cur.conv(net, p + ".pw")
             if taps is not None:
                 taps[p + ".pre_bn"] = net.transpose(1, 2)
-            net = cur.bn(net, p + ".bn")
+            if stored:
+                net = cur.bn_stored(net, p + ".bn", round_g=not (bi == len(pf) - 1 and ri == repeat - 1))
+            else:
+                net = cur.bn(net, p + ".bn")
             if r:
                 residual = residual[:, :, residual.shape[2] - net.shape[2]:]
                 net = net + residual

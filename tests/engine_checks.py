@@ -39,6 +39,8 @@ def make_engine(lib, T, max_batch, om=None, flags=DEF):
     eng.set_grad_mask(lay.grad_mask())
     if flags.get("pw_bf16"):
         eng.set_option("pointwise_bf16", 1)
+    if flags.get("st_bf16"):
+        eng.set_option("storage_bf16", 1)
     if om is not None:
         p, s = lay.pack(om.get_weights())
         eng.set_params(p)
@@ -147,6 +149,12 @@ def check_sampler_matches_oracle_descriptors(lib, B=64, n_samples=48, seed=0):
 # filters, multi-kernel MixConv groups; spectrogram_length 204
 # BASELINE configs[4]: 1x1 contractions with bf16 operands (the oracle rounds the same operands)
 BF16 = dict(DEF, pw_bf16=True)
+# ... and with the block outputs p_k / stashed gradients g_k held in HBM as bf16 on top of it ("storage_bf16")
+BF16_STORED = dict(DEF, st_bf16=True)
+
+
+def _lowp(flags):
+    return bool(flags.get("pw_bf16") or flags.get("st_bf16"))
 NOTEBOOK = dict(DEF, first_conv_kernel_size=5, stride=3, first_conv_filters=32, pointwise_filters="64,64,64,64",
                 mixconv_kernel_sizes="[5],[7,11],[9,15],[23]")
 
@@ -166,15 +174,15 @@ def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
     zo, _ = om.logits(x, training, taps=taps)
     po = torch.sigmoid(zo).numpy()
     # bf16 mode vs the operand-rounding oracle: bounded by the rounding-boundary noise described below
-    fwd_tol = 5e-3 if flags.get("pw_bf16") else FWD_TOL
+    fwd_tol = 5e-3 if _lowp(flags) else FWD_TOL
     assert np.abs(pr - po).max() <= fwd_tol, (pr, po)
-    assert np.abs(z - zo.detach().numpy()).max() <= (2e-2 if flags.get("pw_bf16") else 1e-3) * max(1.0, np.abs(zo.detach().numpy()).max())
+    assert np.abs(z - zo.detach().numpy()).max() <= (2e-2 if _lowp(flags) else 1e-3) * max(1.0, np.abs(zo.detach().numpy()).max())
     for k, b in enumerate(lay.blocks):
         got = eng.debug_read("p%d" % (k + 1), B, B * b.tout * b.cout).reshape(B, b.tout, b.cout)
         ref = taps["b%d.r0.pre_bn" % k].detach().numpy()
         # bf16 mode: an engine fp32 operand and its oracle fp64 twin ~1e-6 apart round to different bf16
         # values with probability ~3e-4, each a 0.4 % operand error
-        tap_tol = 5e-3 if flags.get("pw_bf16") else 2e-5
+        tap_tol = 5e-3 if _lowp(flags) else 2e-5
         assert np.abs(got - ref).max() <= tap_tol * max(1.0, np.abs(ref).max()), (k, np.abs(got - ref).max())
     eng.close()
     return float(np.abs(pr - po).max())
@@ -234,8 +242,12 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
     # eps flips ~0.4*eps of the units, moving the gradient by ~sqrt of that), so the engine's own ReLU
     # decisions are read back, checked to differ from the oracle's only at near-zero values, and imposed
     # on the oracle (as in the Inception check): what is compared are identical graphs.
-    lowp = bool(flags.get("pw_bf16"))
+    lowp = _lowp(flags)
     loss_tol, l2_tol, el_tol, med_tol = (1e-3, 2e-2, 6e-2, 6e-3) if lowp else (1e-5, 1e-4, 1e-3, 2e-5)
+    if flags.get("st_bf16"):
+        # two more rounded tensors per block; the float32 and the float64 oracle differ from each other by as much
+        # (median 3e-3, worst 1e-2 per tensor on the default topology: the noise is that of the mode, not of the engine)
+        l2_tol, med_tol = 3e-2, 1.2e-2
     for s in range(steps):
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
@@ -320,7 +332,7 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
             np.testing.assert_array_equal(m[k], r[k])
     assert abs(m["loss"] - r["loss"]) < (loss_tol if lowp else 1e-5)
     worst["l2_max"], worst["l2_median"] = float(np.max(worst["l2s"])), float(np.median(worst["l2s"]))
-    assert np.median(worst.pop("l2s")) <= med_tol   # the typical tensor agrees to fp32 rounding (bf16 mode: to its boundary noise)
+    assert np.median(worst.pop("l2s")) <= med_tol, (worst["l2_median"], worst["l2_max"])   # the typical tensor agrees to fp32 rounding (bf16 mode: to its boundary noise)
     mm, vv, step = eng.get_opt_state()
     assert step == steps
     eng.close()

@@ -159,6 +159,11 @@ static inline void hipemu_buf_store32(unsigned v, hipemu_rsrc r, int off, int so
   const long long o = (long long)(unsigned)off + (unsigned)soff;
   if (o + 4 <= r.bytes) std::memcpy(r.base + o, &v, 4);
 }
+static inline void hipemu_buf_store16(unsigned short v, hipemu_rsrc r, int off, int soff, int) {
+  const long long o = (long long)(unsigned)off + (unsigned)soff;
+  if (o + 2 <= r.bytes) std::memcpy(r.base + o, &v, 2);
+}
+#define __builtin_amdgcn_raw_buffer_store_b16 hipemu_buf_store16
 #define __amdgpu_buffer_rsrc_t hipemu_rsrc
 #define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_buf_load128

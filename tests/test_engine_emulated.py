@@ -89,6 +89,14 @@ def test_bf16_pointwise_mode(emu_lib):
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=2, flags=ec.BF16)
 
 
+def test_bf16_storage_mode(emu_lib):
+    """... with p_k / g_k held as bf16 in HBM ("storage_bf16"), against the oracle rounding the same stored tensors
+    (statistics from the unrounded values, see oracle/model_oracle.py _StoredBatchNorm)."""
+    ec.check_forward_parity(emu_lib, B=2, T=111, training=True, grid=2, flags=ec.BF16_STORED)
+    ec.check_forward_parity(emu_lib, B=2, T=111, training=False, grid=1, flags=ec.BF16_STORED)
+    ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=2, flags=ec.BF16_STORED)
+
+
 def test_inception_unfused_branch_heads(emu_lib):
     """The 22-op form (one op per Keras layer) stays available and agrees as well."""
     ec.check_inception_forward(emu_lib, B=2, T=194, training=True, grid=2, fuse_heads=False)

@@ -221,6 +221,28 @@ def test_bf16_pointwise_mode(lib):
     eng.close()
 
 
+def test_bf16_storage_mode(lib):
+    """BASELINE configs[4], full form ("storage_bf16"): the block outputs p_k and the stashed gradients g_k live in HBM
+    as bf16 (fp32 accumulation, fp32 BN sums from the unrounded values), against the oracle that rounds the same stored
+    tensors; the notebook topology (64 channels, stride 3) and the BASELINE batch size included."""
+    ec.check_forward_parity(lib, B=7, T=194, training=False, flags=ec.BF16_STORED)
+    ec.check_forward_parity(lib, B=1024, T=194, training=True, flags=ec.BF16_STORED)
+    ec.check_train_steps(lib, B=8, T=194, steps=2, grid=0, flags=ec.BF16_STORED)
+    ec.check_train_steps(lib, B=5, T=130, steps=1, grid=0, graphs=True, flags=ec.BF16_STORED)
+    ec.check_train_steps(lib, B=6, T=204, steps=1, grid=0, flags=dict(ec.NOTEBOOK, st_bf16=True))
+    # switching the option off again restores the exact fp32 path
+    T, B = 194, 16
+    om = ec.perturbed_oracle(T)
+    lay, eng = ec.make_engine(lib, T, B, om, flags=ec.BF16_STORED)
+    eng.set_option("pointwise_bf16", 0)
+    x = ec.synth_x(np.random.default_rng(3), B, T)
+    eng.set_batch(x)
+    eng.forward(B, training=False)
+    pr, _, _ = eng.read_outputs(B, want_loss=False)
+    assert np.abs(pr - om.predict(x)).max() <= 1e-3
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["mixednet", "inception"])
 def test_train_loop_end_to_end(lib, tmp_path, kind):
     """The whole host loop (schedule, device-resident batches and validation, best-weights rule, checkpoint and

@@ -2,6 +2,7 @@
 // `tools/isa/dump.sh` compiles in seconds (the library itself instantiates ~160 kernels).
 #include "../../microwakeword_amd/csrc/kernels_bwd.hip.h"
 #include "../../microwakeword_amd/csrc/kernels_head.hip.h"
+#include "../../microwakeword_amd/csrc/kernels_tail.hip.h"
 namespace mww {
 template __global__ void fwd_first_kernel<3, 32, 48, 5, 1, false>(FwdFirstArgs);
 template __global__ void fwd_block_kernel<48, 48, 9, false>(FwdBlockArgs);
