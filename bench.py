@@ -402,6 +402,10 @@ def main():
             eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
         if os.environ.get("MWW_BENCH_TAIL_ROLES") is not None:
             eng.set_option("tail_roles", int(os.environ["MWW_BENCH_TAIL_ROLES"]))
+        if os.environ.get("MWW_BENCH_GRID_GRAPH") is not None:
+            eng.set_option("grid_graph", int(os.environ["MWW_BENCH_GRID_GRAPH"]))
+        if os.environ.get("MWW_BENCH_ROLE_SPLIT") is not None:
+            eng.set_option("graph_role_split", int(os.environ["MWW_BENCH_ROLE_SPLIT"]))
         if os.environ.get("MWW_BENCH_BN_INLINE") is not None:
             eng.set_option("bn_inline", int(os.environ["MWW_BENCH_BN_INLINE"]))
         if os.environ.get("MWW_BENCH_FUSED_INPUT") is not None:

@@ -10,26 +10,33 @@
 // backward pass recomputes activations from p.
 //
 // Mapping (all kernels: 256-thread workgroups that own whole windows, grid-stride over the batch):
-//   * staging / epilogues: thread -> (channel c = tid % C, frame group tid / C): a wave touches
-//     consecutive channels of consecutive frames => contiguous HBM segments;
-//   * convolution: lane <-> output frame, NC accumulators per lane, the activation tile of the whole
-//     window in LDS (odd row pitch => conflict-free column walks), weights through scalar loads
-//     (uniform addresses), so the inner loop is one ds_read + NC v_fma per input element;
+//   * staging: thread -> (group of 4 / 2 / 1 adjacent channels, frame group), buffer loads over the window's slab
+//     (workgroup-uniform descriptor, 32-bit lane offsets, at most 16 floats per thread and tensor in flight: these
+//     kernels are chains of memory round trips with a handful of windows per CU, so what counts is how many
+//     workgroups are resident - registers are occupancy here);
+//   * convolution: v_mfma_f32_16x16x4_f32 (exact fp32), per tap a [16 frames] x [4 channels] A tile of the window in LDS
+//     (odd row pitch) against a [4 channels] x [16 filters] B tile of the zero-padded weights in LDS; the four waves
+//     deal the window's 16-frame tiles among themselves;
 //   * the data gradient is the same convolution run on the BN-backward-transformed output gradient
 //     with reversed taps and transposed weights (gweights_transpose_kernel), its epilogue scatters
 //     into the sources' gradient tensors (first consumer stores, later ones accumulate, the last one
-//     also produces the BN statistics partials of that source);
-//   * the weight gradient maps thread -> (tap j, input channel ci, frame subset q) with NC
-//     accumulators held across the workgroup's windows; partials are summed by grad_reduce_kernel.
-// These channel counts (10..48) are far from MFMA tile shapes and the work is a few MFLOP per
-// window, so the kernels are VALU/LDS kernels by design.
+//     also produces the BN statistics of that source);
+//   * the weight gradient is dW = A^T B on the matrix cores with the (tap, input channel) tasks as rows, the filters as
+//     columns and the frames as the contraction; task tiles are dealt to the waves and kept in accumulators across the
+//     workgroup's windows; partials are summed by grad_final_kernel;
+//   * BN statistics travel through replicated fp64 accumulator rows and are folded by the first launch that consumes
+//     them (no finalize launches, see "statistics hand-over" below).
+// Measured (profiles/round2_*inception*): the matrix cores do not make these launches faster than the former VALU form
+// (one lane per output frame) - at 1024 windows per step a launch is 2-4 windows per CU and 12-30 us of latency chain
+// (weights -> slab -> tile -> epilogue) of which the contraction is 1-4 us.
 #pragma once
 #include "common.hip.h"
 
 namespace mww {
 
 constexpr int kGMaxSrc = 3;
-constexpr int kGB = 8;   // rows a thread keeps in flight in the staging / epilogue loops
+constexpr int kGB = 8;    // rows a thread keeps in flight in the staging loops (32 measured slower: 1.09 -> 1.65 ms/step)
+constexpr int kGE = 8;    // ... and in the data-gradient epilogue
 enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8, GSRC_LINEAR = 16 };   // LINEAR: affine only, no ReLU
 
 struct GSrc {
@@ -49,7 +56,142 @@ struct GSrc {
   const float* rscale;
   const float* rshift;
   int rT, rdrop;
+  StatAcc gacc;         // backward sums of this slice go to the producer's accumulator rows ([kStatRows][2][ld]) instead of gstat_part
 };
+
+// ---- BN statistics hand-over (common.hip.h) in the graph kernels -------------------------------------------
+// The producer of a BN'd tensor adds its per-workgroup sums to kStatRows replicated fp64 rows; the FIRST launch that
+// consumes the tensor folds them in every workgroup's prologue into an LDS table (its workgroup 0 also publishes the
+// folded arrays, the moving statistics and - backward - dgamma / dbeta for the later launches of the step), so no
+// finalize launch stands between a producer and its consumer.  Same arithmetic as gbn_*_finalize_body.
+constexpr int kGFoldC = 64;   // channels of a folded tensor (the instantiated widths end at 64)
+
+struct GFoldFwd {        // forward statistics of one source's producer
+  const double* acc;     // [kStatRows][2][C] sums of p, p^2 per channel; null: nothing to fold (the arrays are current)
+  int C, groups;         // producer channels, SubSpectralNormalization slots (1 = plain BN)
+  float inv_n;           // 1 / (B * T * channels per slot)
+  int publish;           // workgroup 0 of this role writes the arrays below
+  int update_moving;
+  const float *gamma, *beta;           // [slots]
+  float *moving_mean, *moving_var;     // [slots]
+  float *scale, *shift, *mean, *rstd;  // [C]
+};
+
+struct GFoldBwd {        // backward statistics (sum g, sum g*xhat) of the op a backward launch works on
+  const double* acc;     // [kStatRows][2][C]; null: c1 / mg / mgx are current
+  int groups;
+  float inv_n, dscale;
+  int publish;
+  const float* gamma;    // [slots]
+  float *c1, *mg, *mgx;  // [C]
+  float *dgamma, *dbeta; // [slots] -> flat gradient
+};
+
+// A fold runs in two halves so that its memory round trip overlaps whatever the prologue stages in between (weights):
+// load() issues the loads of thread ch = tid < C (the accumulator rows of its channel's slot members, gamma / beta and what
+// the publishing workgroup updates), finish() turns them into the table entries.  Plain BN (one member per slot) keeps the
+// kStatRows x 2 raw sums in registers; SubSpectralNormalization sums its members in load().
+struct GFoldRegs {
+  double v1[kStatRows], v2[kStatRows];
+  float p0, p1, m0, m1;   // forward: gamma, beta, old moving mean / variance;  backward: gamma, rstd
+};
+
+__device__ __forceinline__ void gfold_load_sums(const double* acc, int C, int groups, int ch, GFoldRegs& r) {
+  const int members = groups > 1 ? C / groups : 1, cstride = groups > 1 ? groups : 0;
+  const int slot = groups > 1 ? ch % groups : ch;
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    r.v1[j] = acc[(size_t)j * 2 * C + slot];
+    r.v2[j] = acc[(size_t)j * 2 * C + C + slot];
+  }
+  for (int m = 1; m < members; ++m) {   // SSN: the other channels of the slot
+    const int cc = slot + m * cstride;
+#pragma unroll
+    for (int j = 0; j < kStatRows; ++j) {
+      r.v1[j] += acc[(size_t)j * 2 * C + cc];
+      r.v2[j] += acc[(size_t)j * 2 * C + C + cc];
+    }
+  }
+}
+
+__device__ __forceinline__ void gfold_forward_load(const GFoldFwd& f, int bid, int tid, GFoldRegs& r) {
+  if (tid >= f.C) return;
+  const int slot = f.groups > 1 ? tid % f.groups : tid, nslots = f.groups > 1 ? f.groups : f.C;
+  gfold_load_sums(f.acc, f.C, f.groups, tid, r);
+  r.p0 = f.gamma[slot];
+  r.p1 = f.beta[slot];
+  r.m0 = r.m1 = 0.f;
+  if (f.publish && bid == 0 && f.update_moving && tid < nslots) {
+    r.m0 = f.moving_mean[tid];
+    r.m1 = f.moving_var[tid];
+  }
+}
+
+// tab = [4][kGFoldC]: scale, shift, mean, rstd of every producer channel
+__device__ __forceinline__ void gfold_forward_finish(const GFoldFwd& f, float* tab, int bid, int tid, const GFoldRegs& r) {
+  if (tid >= f.C) return;
+  const int ch = tid, nslots = f.groups > 1 ? f.groups : f.C;
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    t1 += r.v1[j];
+    t2 += r.v2[j];
+  }
+  const double mean = t1 * (double)f.inv_n;
+  double var = t2 * (double)f.inv_n - mean * mean;   // biased batch variance
+  if (var < 0.0) var = 0.0;
+  const float meanf = (float)mean, varf = (float)var;
+  const float rstd = 1.0f / sqrtf(varf + kBnEps);
+  const float sc = r.p0 * rstd, sh = r.p1 - meanf * sc;
+  tab[ch] = sc;
+  tab[kGFoldC + ch] = sh;
+  tab[2 * kGFoldC + ch] = meanf;
+  tab[3 * kGFoldC + ch] = rstd;
+  if (f.publish && bid == 0) {
+    f.scale[ch] = sc;
+    f.shift[ch] = sh;
+    f.mean[ch] = meanf;
+    f.rstd[ch] = rstd;
+    if (ch < nslots && f.update_moving) {   // ch == its slot
+      f.moving_mean[ch] = r.m0 * kBnMomentum + meanf * (1.0f - kBnMomentum);
+      f.moving_var[ch] = r.m1 * kBnMomentum + varf * (1.0f - kBnMomentum);
+    }
+  }
+}
+
+// C = channels of the op; rstd = its forward statistic (already published)
+__device__ __forceinline__ void gfold_backward_load(const GFoldBwd& f, int C, const float* rstd, int tid, GFoldRegs& r) {
+  if (tid >= C) return;
+  gfold_load_sums(f.acc, C, f.groups, tid, r);
+  r.p0 = f.gamma[f.groups > 1 ? tid % f.groups : tid];
+  r.p1 = rstd[tid];
+}
+
+// tab = [3][kGFoldC]: c1, mg, mgx of every channel of the op
+__device__ __forceinline__ void gfold_backward_finish(const GFoldBwd& f, int C, float* tab, int bid, int tid, const GFoldRegs& r) {
+  if (tid >= C) return;
+  const int ch = tid, nslots = f.groups > 1 ? f.groups : C;
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < kStatRows; ++j) {
+    t1 += r.v1[j];
+    t2 += r.v2[j];
+  }
+  const float c1 = r.p0 * r.p1;
+  const float mg = (float)(t1 * (double)f.inv_n), mgx = (float)(t2 * (double)f.inv_n);
+  tab[ch] = c1;
+  tab[kGFoldC + ch] = mg;
+  tab[2 * kGFoldC + ch] = mgx;
+  if (f.publish && bid == 0) {
+    f.c1[ch] = c1;
+    f.mg[ch] = mg;
+    f.mgx[ch] = mgx;
+    if (ch < nslots) {
+      f.dbeta[ch] = (float)t1 * f.dscale;
+      f.dgamma[ch] = (float)t2 * f.dscale;
+    }
+  }
+}
 
 // value of a source element before its activation clamp
 __device__ __forceinline__ float src_affine(const GSrc& s, float v, float sc, float sh, float rv, float rsc, float rsh) {
@@ -62,31 +204,127 @@ struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - x
   const float* g;         // [B][Tout][C]
   const float* p;
   const float *mean, *rstd, *c1, *mg, *mgx;
+  GFoldBwd fold;          // fold.acc set: c1 / mg / mgx come from the accumulator rows (folded in the prologue)
 };
 
 // ---------------------------------------------------------------------------------------------
 // staging helpers
-__device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b, int rows, float* sIn, int PI, int tid) {
+// A window's slab of a source is staged in ONE memory round trip wherever the layout allows: thread <-> (group of V
+// adjacent channels, frame group) with V = 4 / 2 / 1 floats per load (V divides the slice width, its offset and the
+// producer's row length, so every load is naturally aligned), kGB rows in flight per thread, row indices clamped instead
+// of predicated (every load of a batch is issued before the first use; the round-2 profile showed these kernels to be
+// chains of dependent round trips: 12-32 us per launch for a single window per workgroup).
+template <int V>
+struct GVec {
+  float f[V];
+};
+template <int V>
+__device__ __forceinline__ GVec<V> gvec_load(const float* p) {
+  GVec<V> r;
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.f[0] = t.x; r.f[1] = t.y; r.f[2] = t.z; r.f[3] = t.w;
+  } else if constexpr (V == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    r.f[0] = t.x; r.f[1] = t.y;
+  } else {
+    r.f[0] = *p;
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void gvec_store(float* p, const GVec<V>& r) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.f[0], r.f[1], r.f[2], r.f[3]);
+  else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(r.f[0], r.f[1]);
+  else *p = r.f[0];
+}
+// ... through a buffer resource over the window's slab (workgroup-uniform base in scalar registers, one 32-bit offset
+// register per load, elements past the slab read as 0: no clamp, no 64-bit address pair per load in flight)
+template <int V>
+__device__ __forceinline__ GVec<V> gvec_bload(BufRsrc r, int elem) {
+  GVec<V> o;
+  if constexpr (V == 4) {
+    const float4 t = tile_load4(r, elem * 4);
+    o.f[0] = t.x; o.f[1] = t.y; o.f[2] = t.z; o.f[3] = t.w;
+  } else if constexpr (V == 2) {
+    const uint2 t = tile_load2(r, elem * 4);
+    o.f[0] = __uint_as_float(t.x); o.f[1] = __uint_as_float(t.y);
+  } else {
+    o.f[0] = tile_load1(r, elem * 4);
+  }
+  return o;
+}
+__device__ __forceinline__ int gvec_width(int C, int ld, int c0) {
+  return ((C | ld | c0) & 3) == 0 ? 4 : (((C | ld | c0) & 1) == 0 ? 2 : 1);
+}
+
+// one source without a residual branch; coef = [2][...] scale / shift indexed by producer channel (global or LDS)
+template <int V>
+__device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows, float* sIn, int PI, int c0out, int tid,
+                                                 const float* cscale, const float* cshift) {
+  const int NQ = s.C / V, nrg = kThreads / NQ, q = tid % NQ, rg = tid / NQ;
+  if (rg >= nrg) return;
+  const bool ident = (s.flags & GSRC_IDENTITY) != 0;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    sc[e] = ident ? 1.f : cscale[s.c0 + q * V + e];
+    sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
+  }
+  const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
+  const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0, ((rows - 1) * s.ld + s.C) * 4);
+  float* dst = sIn + c0out + q * V;
+  constexpr int NB = V == 4 ? kGB / 2 : kGB;   // rows in flight: at most 16 floats per thread and tensor (these kernels live on
+                                               // the number of resident workgroups: registers are occupancy)
+  for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
+    GVec<V> v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = gvec_bload<V>(slab, (t0 + u * nrg) * s.ld + q * V);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int t = t0 + u * nrg;
+      if (t < rows) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) dst[t * PI + e] = fmaxf(fmaf(v[u].f[e], sc[e], sh[e]), lo);
+      }
+    }
+  }
+}
+
+// ftab: null, or [kGMaxSrc][4][kGFoldC] with the folded (scale, shift, ..) of the sources whose fold[i].acc is set
+__device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b, int rows, float* sIn, int PI, int tid,
+                                              const GFoldFwd* fold = nullptr, const float* ftab = nullptr) {
   int c0 = 0;
   for (int i = 0; i < n_src; ++i) {
     const GSrc& s = src[i];
+    const bool folded = fold != nullptr && ftab != nullptr && fold[i].acc != nullptr;
+    const float* tab = ftab + i * 4 * kGFoldC;
+    if (!s.rp) {
+      const float* cscale = folded ? tab : s.scale;
+      const float* cshift = folded ? tab + kGFoldC : s.shift;
+      const int V = gvec_width(s.C, s.ld, s.c0);
+      if (V == 4) stage_source_vec<4>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
+      else if (V == 2) stage_source_vec<2>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
+      else stage_source_vec<1>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
+      c0 += s.C;
+      continue;
+    }
+    // sources with a residual branch (MixedNet residual_connection): one channel per thread, two tensors
     const int C = s.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
     if (rg < nrg) {
-      const bool ident = (s.flags & GSRC_IDENTITY) != 0;
-      const float sc = ident ? 1.f : s.scale[s.c0 + c], sh = ident ? 0.f : s.shift[s.c0 + c];
-      const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
+      const float sc = folded ? tab[s.c0 + c] : s.scale[s.c0 + c];
+      const float sh = folded ? tab[kGFoldC + s.c0 + c] : s.shift[s.c0 + c];
+      const float lo = (s.flags & GSRC_LINEAR) ? -3.0e38f : 0.f;
       const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
-      const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
-      const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.toff + s.rdrop) * C + c : nullptr;
-      // kGB rows per thread in flight (a rolled loop with one load and one LDS write per row is one memory round trip
-      // per row: ~rows * C / 256 of them per window and source)
+      const float rsc = s.rscale[c], rsh = s.rshift[c];
+      const float* rbase = s.rp + ((size_t)b * s.rT + s.toff + s.rdrop) * C + c;
       for (int t0 = rg; t0 < rows; t0 += kGB * nrg) {
         float v[kGB], rv[kGB];
 #pragma unroll
         for (int u = 0; u < kGB; ++u) {
-          const int t = t0 + u * nrg;
-          v[u] = t < rows ? base[(size_t)t * s.ld] : 0.f;
-          rv[u] = (t < rows && rbase) ? rbase[(size_t)t * C] : 0.f;
+          const int t = min(t0 + u * nrg, rows - 1);
+          v[u] = base[(size_t)t * s.ld];
+          rv[u] = rbase[(size_t)t * C];
         }
 #pragma unroll
         for (int u = 0; u < kGB; ++u) {
@@ -99,26 +337,50 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
   }
 }
 
-__device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid) {
-  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
-  if (rg < nrg) {
-    const float mu = y.mean[c], rs = y.rstd[c], c1 = y.c1[c], mg = y.mg[c], mgx = y.mgx[c];
-    const size_t base = (size_t)b * rows * C + c;
-    for (int t0 = rg; t0 < rows; t0 += kGB * nrg) {
-      float g[kGB], p[kGB];
+// dp = BN backward of the op's output gradient, rows [0, rows) of window b -> dst[t * ld + c]
+template <int V>
+__device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab) {
+  const int NQ = C / V, nrg = kThreads / NQ, q = tid % NQ, rg = tid / NQ;
+  if (rg >= nrg) return;
+  const bool folded = btab != nullptr && y.fold.acc != nullptr;
+  float mu[V], rs[V], c1[V], mg[V], mgx[V];
 #pragma unroll
-      for (int u = 0; u < kGB; ++u) {
-        const int t = t0 + u * nrg;
-        g[u] = t < rows ? y.g[base + (size_t)t * C] : 0.f;
-        p[u] = t < rows ? y.p[base + (size_t)t * C] : 0.f;
-      }
+  for (int e = 0; e < V; ++e) {
+    const int c = q * V + e;
+    mu[e] = y.mean[c];
+    rs[e] = y.rstd[c];
+    c1[e] = folded ? btab[c] : y.c1[c];
+    mg[e] = folded ? btab[kGFoldC + c] : y.mg[c];
+    mgx[e] = folded ? btab[2 * kGFoldC + c] : y.mgx[c];
+  }
+  const BufRsrc gslab = tile_rsrc(y.g + (size_t)b * rows * C, rows * C * 4), pslab = tile_rsrc(y.p + (size_t)b * rows * C, rows * C * 4);
+  constexpr int NB = V == 4 ? kGB / 2 : kGB;
+  for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
+    GVec<V> g[NB], p[NB];
 #pragma unroll
-      for (int u = 0; u < kGB; ++u) {
-        const int t = t0 + u * nrg;
-        if (t < rows) dst[t * ld + c] = c1 * (g[u] - mg - (p[u] - mu) * rs * mgx);
+    for (int u = 0; u < NB; ++u) {
+      const int off = (t0 + u * nrg) * C + q * V;
+      g[u] = gvec_bload<V>(gslab, off);
+      p[u] = gvec_bload<V>(pslab, off);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int t = t0 + u * nrg;
+      if (t < rows) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) dst[t * ld + q * V + e] = c1[e] * (g[u].f[e] - mg[e] - (p[u].f[e] - mu[e]) * rs[e] * mgx[e]);
       }
     }
   }
+}
+
+// btab: [3][kGFoldC] folded (c1, mg, mgx) when y.fold.acc is set.  CW = the op's filter count when the kernel knows it at
+// compile time (vector width chosen there: a run-time choice between the three instantiations makes the compiler keep all
+// of them in registers at once), 0 = one channel per load.
+template <int CW>
+__device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab = nullptr) {
+  constexpr int V = CW == 0 ? 1 : (CW % 4 == 0 ? 4 : (CW % 2 == 0 ? 2 : 1));
+  stage_dp_vec<V>(y, C, b, rows, dst, ld, tid, btab);
 }
 
 // per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][ld] of this workgroup
@@ -138,6 +400,31 @@ __device__ __forceinline__ void write_channel_partials(float s1, float s2, int C
   }
 }
 
+// ... or, with acc.acc set (statistics hand-over), added to row bid % kStatRows of the accumulator rows [kStatRows][2][ld]
+// at column offset c0, and the same columns of the other parity's rows cleared (bid / nb: this workgroup's index and the
+// number of workgroups of its role, as in gconv_body)
+__device__ __forceinline__ void publish_channel_partials(float s1, float s2, int C, float* sRed, float* part, int tid, int ld,
+                                                         const StatAcc& acc, int c0, int bid, int nb) {
+  if (!acc.acc) {
+    write_channel_partials(s1, s2, C, sRed, part, tid, ld);
+    return;
+  }
+  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  __syncthreads();
+  if (rg < nrg) {
+    sRed[(rg * 2 + 0) * C + c] = s1;
+    sRed[(rg * 2 + 1) * C + c] = s2;
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    float v = 0.f;
+    for (int r = 0; r < nrg; ++r) v += sRed[r * 2 * C + tid];
+    const size_t col = (size_t)(tid / C) * ld + c0 + (tid % C);
+    unsafeAtomicAdd(acc.acc + (size_t)(bid % kStatRows) * 2 * ld + col, (double)v);
+    for (int r = bid; r < kStatRows; r += nb) acc.clear[(size_t)r * 2 * ld + col] = 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MODE 0: forward convolution.  MODE 1: data gradient.
 struct GConvArgs {
@@ -152,21 +439,28 @@ struct GConvArgs {
   float* out;           // MODE 0: pre-BN output [B][Tout][NC]
   float* stat_part;     // MODE 0: [grid][2][NC], or null when the op has no batch statistics
   GBnBwd y;             // MODE 1
+  GFoldFwd fold[kGMaxSrc];   // MODE 0: sources whose producer statistics this launch is the first to consume
+  StatAcc sacc;         // MODE 0: the output statistics go to these accumulator rows instead of stat_part
 };
 
 // bid / nb: this workgroup's index and the number of workgroups sharing the batch (a launch may hold several roles)
-template <int NC, int MODE>
+// CDP (MODE 1): the op's filter count = channels of dp, when the launch knows it at compile time
+template <int NC, int MODE, int CDP = 0>
 __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   __shared__ float sRed[2 * kThreads];
-  constexpr int NCP = (NC + 3) / 4 * 4;   // weight rows padded to whole float4 (broadcast ds_read_b128)
+  // The convolution runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): per tap j a [16 frames] x [4 channels]
+  // A tile of the window against a [4 channels] x [16 filters] B tile of the weights.  Weight rows are padded to whole
+  // k-steps (cin4) and whole filter tiles (NCW) with zeros, so the inner loop carries no predicate on B.
+  constexpr int NT = (NC + 15) / 16, NCW = NT * 16;
   const int tid = threadIdx.x;
   const int PI = a.cin | 1, PO = NC | 1;
+  const int cin4 = (a.cin + 3) & ~3;
   const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
   const int rows_in = a.Tin + 2 * pad;
-  float* sW = g_smem;                       // [k*cin][NCP], loaded once per workgroup
-  float* sIn = sW + a.k * a.cin * NCP;
+  float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
+  float* sIn = sW + a.k * cin4 * NCW;
   float* sOut = sIn + rows_in * PI;
   // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source, kept
   // in LDS so that the sources can be walked by a real loop (their descriptors stay in the kernel-argument
@@ -176,7 +470,46 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   if (MODE == 1)
     for (int i = 0; i < kGMaxSrc * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
 
-  for (int i = tid; i < a.k * a.cin * NC; i += kThreads) sW[(i / NC) * NCP + (i % NC)] = a.w[i];
+  // statistics hand-over: fold what this launch is the first to consume.  The loads go out before the weights are staged,
+  // the table is written after (visible to the other waves after the loop's first barrier).
+  __shared__ float sFold[MODE == 0 ? kGMaxSrc * 4 * kGFoldC : 3 * kGFoldC];
+  // (wave i folds source i: one set of fold registers per thread)
+  GFoldRegs fr;
+  const int fsrc = tid >> 6, ftid = tid & 63;
+  static_assert(kGFoldC <= 64 && kGMaxSrc <= kThreads / 64, "one wave folds one source");
+  if (MODE == 0) {
+    if (fsrc < a.n_src && a.fold[fsrc].acc) gfold_forward_load(a.fold[fsrc], bid, ftid, fr);
+  } else if (a.y.fold.acc) {
+    gfold_backward_load(a.y.fold, a.cin, a.y.rstd, tid, fr);
+  }
+  {
+    // (eight elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
+    // them in a row for the 5 x 40 x 24 stem)
+    constexpr int kWB = 8;
+    const int nw = a.k * cin4 * NCW, nreal = a.k * a.cin * NC;
+    for (int i0 = tid; i0 < nw; i0 += kWB * kThreads) {
+      float wv[kWB];
+#pragma unroll
+      for (int u = 0; u < kWB; ++u) {
+        const int i = i0 + u * kThreads;
+        const int co = i % NCW, rest = i / NCW, ci = rest % cin4, j = rest / cin4;
+        const bool real = i < nw && co < NC && ci < a.cin;
+        const int src = min((j * a.cin + ci) * NC + co, nreal - 1);
+        wv[u] = a.w[real ? src : 0];
+        if (!real) wv[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kWB; ++u) {
+        const int i = i0 + u * kThreads;
+        if (i < nw) sW[i] = wv[u];
+      }
+    }
+  }
+  if (MODE == 0) {
+    if (fsrc < a.n_src && a.fold[fsrc].acc) gfold_forward_finish(a.fold[fsrc], sFold + fsrc * 4 * kGFoldC, bid, ftid, fr);
+  } else if (a.y.fold.acc) {
+    gfold_backward_finish(a.y.fold, a.cin, sFold, bid, tid, fr);
+  }
   if (MODE == 1) {
     // the zero frames around dp are written once: staging only touches the middle
     for (int i = tid; i < pad * PI; i += kThreads) {
@@ -186,31 +519,41 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   }
   for (int b = bid; b < a.B; b += nb) {
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if (MODE == 0) stage_sources(a.src, a.n_src, b, a.Tin, sIn, PI, tid);
-    else stage_dp(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid);
+    if (MODE == 0) stage_sources(a.src, a.n_src, b, a.Tin, sIn, PI, tid, a.fold, sFold);
+    else stage_dp<CDP>(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
     __syncthreads();
-    for (int t = tid; t < a.Tout; t += kThreads) {
-      float acc[NCP];
+    {
+      const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+      const int ntile = (a.Tout + 15) >> 4;
+      const bool kfull = (a.cin & 3) == 0;
+      for (int rt = wave; rt < ntile; rt += kThreads / 64) {
+        f32x4 acc[NT];
 #pragma unroll
-      for (int co = 0; co < NCP; ++co) acc[co] = 0.f;
-      for (int j = 0; j < a.k; ++j) {
-        const float* row = sIn + ((MODE == 0 ? t * a.stride : t) + j * a.dil) * PI;
-        const float4* wj = reinterpret_cast<const float4*>(sW + j * a.cin * NCP);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
+        // A: lane (r16, g) holds frame rt*16 + r16 (frames past the window repeat its last one: their rows are not
+        // stored), channel ci0 + g;  B: lane holds W[ci0 + g][nt*16 + r16]
+        const int t = min(rt * 16 + r16, a.Tout - 1);
+        const float* arow = sIn + (MODE == 0 ? t * a.stride : t) * PI + g;
+        const float* wrow = sW + g * NCW + r16;
+        for (int j = 0; j < a.k; ++j) {
+          const float* ar = arow + j * a.dil * PI;
+          const float* wr = wrow + j * cin4 * NCW;
 #pragma unroll 2
-        for (int ci = 0; ci < a.cin; ++ci) {
-          const float v = row[ci];
+          for (int ci0 = 0; ci0 < cin4; ci0 += 4) {
+            float av = ar[ci0];
+            if (!kfull && ci0 + g >= a.cin) av = 0.f;   // the last k-step of a channel count that is no multiple of 4
 #pragma unroll
-          for (int c4 = 0; c4 < NCP / 4; ++c4) {
-            const float4 w = wj[ci * (NCP / 4) + c4];
-            acc[c4 * 4 + 0] = fmaf(v, w.x, acc[c4 * 4 + 0]);
-            if (c4 * 4 + 1 < NC) acc[c4 * 4 + 1] = fmaf(v, w.y, acc[c4 * 4 + 1]);
-            if (c4 * 4 + 2 < NC) acc[c4 * 4 + 2] = fmaf(v, w.z, acc[c4 * 4 + 2]);
-            if (c4 * 4 + 3 < NC) acc[c4 * 4 + 3] = fmaf(v, w.w, acc[c4 * 4 + 3]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(av, wr[ci0 * NCW + nt * 16], acc[nt]);
           }
         }
-      }
 #pragma unroll
-      for (int co = 0; co < NC; ++co) sOut[t * PO + co] = acc[co];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + g * 4 + r, col = nt * 16 + r16;
+            if (row < a.Tout && col < NC) sOut[row * PO + col] = acc[nt][r];
+          }
+      }
     }
     __syncthreads();
     if (MODE == 0) {
@@ -240,10 +583,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
             const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
             const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.rdrop) * C + c : nullptr;
             float t1 = 0.f, t2 = 0.f;
-            for (int tb = rg; tb < s.T; tb += kGB * nrg) {
-              float pv[kGB], rvv[kGB], gold[kGB];
+            for (int tb = rg; tb < s.T; tb += kGE * nrg) {
+              float pv[kGE], rvv[kGE], gold[kGE];
 #pragma unroll
-              for (int u = 0; u < kGB; ++u) {
+              for (int u = 0; u < kGE; ++u) {
                 const int t = tb + u * nrg;
                 const bool ok = t < s.T;
                 const size_t idx = base + (size_t)(ok ? t : 0) * s.ld;
@@ -252,7 +595,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
                 gold[u] = (ok && accum) ? s.g[idx] : 0.f;
               }
 #pragma unroll
-              for (int u = 0; u < kGB; ++u) {
+              for (int u = 0; u < kGE; ++u) {
                 const int t = tb + u * nrg;
                 if (t < s.T) {
                   const size_t idx = base + (size_t)t * s.ld;
@@ -275,13 +618,13 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     }
   }
   if (MODE == 0) {
-    if (a.stat_part) write_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)bid * 2 * NC, tid, NC);
+    if (a.stat_part) publish_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)bid * 2 * NC, tid, NC, a.sacc, 0, bid, nb);
   } else {
     for (int i = 0; i < a.n_src; ++i) {
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
-        write_channel_partials(sSrcAcc[(i * 2 + 0) * kThreads + tid], sSrcAcc[(i * 2 + 1) * kThreads + tid], s.C, sRed,
-                               s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld);
+        publish_channel_partials(sSrcAcc[(i * 2 + 0) * kThreads + tid], sSrcAcc[(i * 2 + 1) * kThreads + tid], s.C, sRed,
+                                 s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld, s.gacc, s.c0, bid, nb);
     }
   }
 }
@@ -311,77 +654,115 @@ struct GWgradArgs {
   float* grad_part;     // [grid * nq][k*cin*NC]
 };
 
-constexpr int kGWgChunk = 4;   // output channels per pass of the in-workgroup reduction over the frame subsets
+// On the matrix cores: dW = A^T B with A[t][m] = act[t*stride + j*dil][ci] (m = j*cin + ci, the "task" axis) and
+// B[t][co] = dp[t][co]; the contraction runs over the frames of a window (k-steps of 4 frames) and over the workgroup's
+// windows.  16-task tiles are dealt to the waves (every wave keeps all NT filter tiles of its task tiles in accumulators
+// for the whole launch); ops with fewer than three task tiles also split the frames over the waves (kparts) and sum the
+// parts through LDS at the end.  One partial row [k*cin][NC] per workgroup.
+constexpr int kGWgTilesPerWave = 4;   // 16 task tiles (k * cin <= 256) over four waves
+
+__host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (tasks > 16 ? 2 : 4); }
+// row pitch of the staged dp: a multiple of 16 that is 16 mod 32, so that the four k-rows of a B fragment fall on disjoint banks
+__host__ __device__ inline int gwg_dp_pitch(int nc) { const int w = (nc + 15) / 16 * 16; return (w / 16) % 2 ? w : w + 16; }
 
 template <int NC>
 __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
-  constexpr int PO = (NC + 3) / 4 * 4;
-  const int tid = threadIdx.x;
+  constexpr int NT = (NC + 15) / 16;
+  const int PO = gwg_dp_pitch(NC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int PI = a.cin | 1;
+  const int Tout4 = (a.Tout + 3) & ~3;
   float* sA = g_smem;
-  float* sDP = g_smem + (a.Tin * PI + 3) / 4 * 4;
-  const int tasks = a.k * a.cin, nq = a.nq;
-  const int task = tid % tasks, q = tid / tasks;
-  const bool active = q < nq;
-  const int j = task / a.cin, ci = task % a.cin;
-  float acc[NC];
+  float* sDP = g_smem + (a.Tin * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
+  const int tasks = a.k * a.cin, MT = (tasks + 15) >> 4;
+  const int KS = gwg_kparts(tasks), nslot = (kThreads / 64) / KS;
+  const int kp = wave % KS, slot = wave / KS;
+  // this wave's task tiles: mt = slot, slot + nslot, ...;  lane r16 <-> task m of the tile (tasks past the end repeat the
+  // last one: their rows are not written)
+  int offA[kGWgTilesPerWave];
 #pragma unroll
-  for (int co = 0; co < NC; ++co) acc[co] = 0.f;
-  if (PO != NC) {
-    // columns NC..PO-1 of dp stay zero
-    for (int i = tid; i < a.Tout * PO; i += kThreads) sDP[i] = 0.f;
+  for (int u = 0; u < kGWgTilesPerWave; ++u) {
+    const int m = min((slot + u * nslot) * 16 + r16, tasks - 1);
+    offA[u] = (m / a.cin) * a.dil * PI + (m % a.cin);
+  }
+  f32x4 acc[kGWgTilesPerWave][NT];
+#pragma unroll
+  for (int u = 0; u < kGWgTilesPerWave; ++u)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[u][nt] = zero4();
+  // dp columns NC..PO-1 and rows Tout..Tout4-1 stay zero: staging only writes the window's own elements
+  for (int i = tid; i < Tout4 * PO; i += kThreads) sDP[i] = 0.f;
+  // statistics hand-over: the op's backward coefficients folded from the accumulator rows; this role publishes them
+  __shared__ float sFoldB[3 * kGFoldC];
+  if (a.y.fold.acc) {
+    GFoldRegs fr;
+    gfold_backward_load(a.y.fold, NC, a.y.rstd, tid, fr);
+    gfold_backward_finish(a.y.fold, NC, sFoldB, bid, tid, fr);
   }
   for (int b = bid; b < a.B; b += nb) {
     __syncthreads();
     stage_sources(a.src, a.n_src, b, a.Tin, sA, PI, tid);
-    stage_dp(a.y, NC, b, a.Tout, sDP, PO, tid);
+    stage_dp<NC>(a.y, NC, b, a.Tout, sDP, PO, tid, sFoldB);
     __syncthreads();
-    if (active) {
-      const float* col = sA + j * a.dil * PI + ci;
-      for (int t = q; t < a.Tout; t += nq) {
-        const float v = col[t * a.stride * PI];
-        const float4* row = reinterpret_cast<const float4*>(sDP + t * PO);
+    for (int t0 = kp * 4; t0 < a.Tout; t0 += 4 * KS) {
+      // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
+      const int tf = min(t0 + g, a.Tout - 1);
+      const float* arow = sA + tf * a.stride * PI;
+      float bv[NT];
 #pragma unroll
-        for (int c4 = 0; c4 < PO / 4; ++c4) {
-          const float4 d = row[c4];
-          if (c4 * 4 + 0 < NC) acc[c4 * 4 + 0] = fmaf(v, d.x, acc[c4 * 4 + 0]);
-          if (c4 * 4 + 1 < NC) acc[c4 * 4 + 1] = fmaf(v, d.y, acc[c4 * 4 + 1]);
-          if (c4 * 4 + 2 < NC) acc[c4 * 4 + 2] = fmaf(v, d.z, acc[c4 * 4 + 2]);
-          if (c4 * 4 + 3 < NC) acc[c4 * 4 + 3] = fmaf(v, d.w, acc[c4 * 4 + 3]);
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[(t0 + g) * PO + nt * 16 + r16];
+#pragma unroll
+      for (int u = 0; u < kGWgTilesPerWave; ++u) {
+        if (slot + u * nslot < MT) {   // wave-uniform
+          const float av = arow[offA[u]];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
         }
       }
     }
   }
-  // sum over the frame subsets inside the workgroup (fixed order), kGWgChunk output channels at a time through
-  // LDS: one partial row per workgroup instead of nq of them (the rows are what grad_reduce_kernel has to read)
-  if (nq > 1) {
-    float* sQ = g_smem;   // [nq][tasks][kGWgChunk]
+  // D: lane (r16, g) holds dW[task g*4 + r of the tile][filter nt*16 + r16]
+  float* dst = a.grad_part + (size_t)bid * ((size_t)tasks * NC);
+  if (KS == 1) {
 #pragma unroll
-    for (int c0 = 0; c0 < NC; c0 += kGWgChunk) {
-      __syncthreads();
-      if (active) {
+    for (int u = 0; u < kGWgTilesPerWave; ++u) {
+      const int mt = slot + u * nslot;
+      if (mt < MT) {
 #pragma unroll
-        for (int u = 0; u < kGWgChunk; ++u)
-          if (c0 + u < NC) sQ[(q * tasks + task) * kGWgChunk + u] = acc[c0 + u];
-      }
-      __syncthreads();
-      if (active && q == 0) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int u = 0; u < kGWgChunk; ++u)
-          if (c0 + u < NC) {
-            float v = 0.f;
-            for (int qq = 0; qq < nq; ++qq) v += sQ[(qq * tasks + task) * kGWgChunk + u];
-            acc[c0 + u] = v;
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + g * 4 + r, co = nt * 16 + r16;
+            if (m < tasks && co < NC) dst[(size_t)m * NC + co] = acc[u][nt][r];
           }
       }
     }
-  }
-  if (active && q == 0) {
-    float* dst = a.grad_part + (size_t)bid * ((size_t)tasks * NC) + (size_t)task * NC;
+  } else {
+    // sum over the frame parts in a fixed order through LDS: sQ[kp][mt][nt][16][16]
+    float* sQ = g_smem;
+    __syncthreads();
 #pragma unroll
-    for (int co = 0; co < NC; ++co) dst[co] = acc[co];
+    for (int u = 0; u < kGWgTilesPerWave; ++u) {
+      const int mt = slot + u * nslot;
+      if (mt < MT) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sQ[(((kp * MT + mt) * NT + nt) * 16 + g * 4 + r) * 16 + r16] = acc[u][nt][r];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * NT * 256; e += kThreads) {
+      const int r16e = e & 15, rowe = (e >> 4) & 15, tile = e >> 8, nt = tile % NT, mt = tile / NT;
+      const int m = mt * 16 + rowe, co = nt * 16 + r16e;
+      if (m < tasks && co < NC) {
+        float v = 0.f;
+        for (int q = 0; q < KS; ++q) v += sQ[(((q * MT + mt) * NT + nt) * 16 + rowe) * 16 + r16e];
+        dst[(size_t)m * NC + co] = v;
+      }
+    }
   }
 }
 
@@ -396,7 +777,7 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
 template <int NCO, int NCI>
 __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nb) {
   if ((int)blockIdx.x < nb) gconv_wgrad_body<NCO>(w, blockIdx.x, nb);
-  else gconv_body<NCI, 1>(d, blockIdx.x - nb, nb);
+  else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nb, nb);
 }
 
 // ... and of twin ops: four roles
@@ -404,9 +785,9 @@ template <int NCO, int NCI>
 __global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GWgradArgs w0, GConvArgs d0, GWgradArgs w1, GConvArgs d1, int nb) {
   const int role = blockIdx.x / nb, bid = blockIdx.x - role * nb;
   if (role == 0) gconv_wgrad_body<NCO>(w0, bid, nb);
-  else if (role == 1) gconv_body<NCI, 1>(d0, bid, nb);
+  else if (role == 1) gconv_body<NCI, 1, NCO>(d0, bid, nb);
   else if (role == 2) gconv_wgrad_body<NCO>(w1, bid, nb);
-  else gconv_body<NCI, 1>(d1, bid, nb);
+  else gconv_body<NCI, 1, NCO>(d1, bid, nb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,7 +826,7 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
     if (MODE == 0) stage_sources(&a.src, 1, b, a.Tin, sIn, PI, tid);
-    else stage_dp(a.y, C, b, a.Tout, sIn + pad * PI, PI, tid);
+    else stage_dp<0>(a.y, C, b, a.Tout, sIn + pad * PI, PI, tid);
     __syncthreads();
     if (rg < nrg) {
       if (MODE == 0) {
@@ -501,7 +882,7 @@ __global__ __launch_bounds__(kThreads) void gdw_wgrad_kernel(GDwArgs a) {
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
     stage_sources(&a.src, 1, b, a.Tin, sA, PI, tid);
-    stage_dp(a.y, C, b, a.Tout, sDP, PI, tid);
+    stage_dp<0>(a.y, C, b, a.Tout, sDP, PI, tid);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kGDwTasks; ++u) {
@@ -726,6 +1107,8 @@ struct GHeadArgs {
   unsigned long long seed;
   const unsigned* counter;   // [2] low / high word of this step's counter (mapped mailbox)
   float rate;
+  GFoldFwd fold;           // fold.acc set: the last op's statistics are folded here (this is their first consumer)
+  StatAcc gacc;            // gacc.acc set: (sum g, sum g*xhat) go to the last op's accumulator rows instead of gstat_part
 };
 
 // Dropout keep value of element e in step `step`: counter-based hash of (seed, step, element) -> 0 or 1/(1-rate).
@@ -748,8 +1131,17 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const int C = a.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
   const bool active = rg < nrg;
   const int n = a.T * C;
-  const float sc = active ? a.scale[c] : 0.f, sh = active ? a.shift[c] : 0.f;
-  const float mu = (active && (a.training & kHeadTraining)) ? a.mean[c] : 0.f, rs = (active && (a.training & kHeadTraining)) ? a.rstd[c] : 0.f;
+  __shared__ float sFold[4 * kGFoldC];
+  const bool folded = a.fold.acc != nullptr;
+  if (folded) {
+    GFoldRegs fr;
+    gfold_forward_load(a.fold, blockIdx.x, tid, fr);
+    gfold_forward_finish(a.fold, sFold, blockIdx.x, tid, fr);
+    __syncthreads();
+  }
+  const float sc = active ? (folded ? sFold[c] : a.scale[c]) : 0.f, sh = active ? (folded ? sFold[kGFoldC + c] : a.shift[c]) : 0.f;
+  const float mu = (active && (a.training & kHeadTraining)) ? (folded ? sFold[2 * kGFoldC + c] : a.mean[c]) : 0.f;
+  const float rs = (active && (a.training & kHeadTraining)) ? (folded ? sFold[3 * kGFoldC + c] : a.rstd[c]) : 0.f;
   const float rsc = (active && a.rp) ? a.rscale[c] : 0.f, rsh = (active && a.rp) ? a.rshift[c] : 0.f;
   const float bias = a.bd[0];
   float g1 = 0.f, g2 = 0.f;
@@ -847,7 +1239,8 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       }
     }
   }
-  if (a.training & kHeadTraining) write_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
+  if (a.training & kHeadTraining)
+    publish_channel_partials(g1, g2, C, sStat, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C, a.gacc, 0, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------

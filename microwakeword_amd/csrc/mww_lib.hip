@@ -69,6 +69,13 @@ struct GOp {
   bool needs_dx = false;
   bool twin_next = false;     // op i+1 is an independent op of the same shape: the pair shares its launches
   size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
+  // statistics hand-over (kernels_graph.hip.h): [parity][kStatRows][2][cout] accumulator rows of the forward / backward sums,
+  // *_cur = the rows the latest producer launch added to; first_consumer = the lowest op index that reads this op
+  double* facc[2] = {nullptr, nullptr};
+  double* gacc[2] = {nullptr, nullptr};
+  double* facc_cur = nullptr;
+  double* gacc_cur = nullptr;
+  int first_consumer = -1;
 };
 
 struct ProfileEntry {
@@ -165,6 +172,10 @@ struct mww_ctx {
   // "bn_inline" option (default on): BN statistics travel through replicated fp64 accumulator rows and are folded by
   // their first consumer instead of by a finalize launch (off with sync-BN: the sums must be exchanged in between)
   bool bn_inline = true;
+  bool g_role_split = true;   // launches that hold several roles (twin ops, weight + data gradient) divide the workgroups between the
+                              // roles instead of multiplying them ("graph_role_split"; needs the statistics hand-over: the partial-row
+                              // readers assume one row count per tensor)
+  bool g_inline_ok = false;   // conv/BN graph: every op is a convolution with a BatchNorm and no residual branch => hand-over possible
   int fpar = 0, gpar = 0;   // accumulator parity of the next training forward / backward
   bool tail_pending = false, tail_metrics = false;   // dense gradient (+ metrics) ride in the first backward launch
   bool tail_in_reduce = false;   // ... or, with the statistics hand-over, in the gradient-reduction launch ("tail_roles" option)
@@ -926,7 +937,7 @@ bool launch_gbwd2(mww_ctx* c, int nc, const GWgradArgs& w0, const GConvArgs& d0,
 float* gbn_slot(GOp& o, int i) { return o.bn + (size_t)i * o.cout; }
 
 // source i of op `oi` as the kernels see it; `backward` adds the gradient routing flags
-GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
+GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward, bool inl = false) {
   GOp& o = c->G[oi];
   GSrc s;
   memset(&s, 0, sizeof(s));
@@ -967,6 +978,11 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward) {
     s.rdrop = pr.res_drop;
   }
   if (backward) s.flags |= GSRC_GRAD | (o.src_first[i] ? 0 : GSRC_ACCUM) | (o.src_last[i] ? GSRC_STATS : 0);
+  if (backward && inl && o.src_last[i]) {   // the slice's backward sums go to the producer's accumulator rows
+    s.gacc.acc = pr.gacc[c->gpar];
+    s.gacc.clear = pr.gacc[c->gpar ^ 1];
+    pr.gacc_cur = s.gacc.acc;
+  }
   return s;
 }
 
@@ -996,6 +1012,29 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   Launcher lp{c};
   const int n = (int)c->G.size();
   const int gg = std::min(B, c->grid_g);
+  // statistics hand-over instead of finalize launches (kernels_graph.hip.h)
+  const bool inl = training && c->bn_inline && c->g_inline_ok && !(c->hook && c->sync_bn) && !c->profile_split;
+  auto leader = [&](int oi) { return (oi > 0 && c->G[oi - 1].twin_next) ? oi - 1 : oi; };   // first op of the launch op oi rides in
+  auto fold_of = [&](int pi, bool publish) {
+    GOp& pr = c->G[pi];
+    GFoldFwd f;
+    memset(&f, 0, sizeof(f));
+    f.acc = pr.facc_cur;
+    f.C = pr.cout;
+    f.groups = pr.groups;
+    f.inv_n = 1.0f / ((float)B * (float)pr.tout * (float)(pr.groups > 1 ? pr.cout / pr.groups : 1));
+    f.publish = publish ? 1 : 0;
+    f.update_moving = update_moving ? 1 : 0;
+    f.gamma = c->params + pr.o_gamma;
+    f.beta = c->params + pr.o_beta;
+    f.moving_mean = c->bn_state + pr.o_mm;
+    f.moving_var = c->bn_state + pr.o_mv;
+    f.scale = gbn_slot(pr, BN_SCALE);
+    f.shift = gbn_slot(pr, BN_SHIFT);
+    f.mean = gbn_slot(pr, BN_MEAN);
+    f.rstd = gbn_slot(pr, BN_RSTD);
+    return f;
+  };
   for (int i = 0; i < n; ++i) {
     GOp& o = c->G[i];
     if (!training && o.norm == MWW_NORM_BN) {
@@ -1028,6 +1067,20 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       a.Tout = q.tout;
       a.out = q.p;
       a.stat_part = (training && q.norm == MWW_NORM_BN) ? q.stat_part : nullptr;
+      if (inl) {
+        a.sacc.acc = q.facc[c->fpar];
+        a.sacc.clear = q.facc[c->fpar ^ 1];
+        q.facc_cur = a.sacc.acc;
+        for (int s = 0; s < q.n_src; ++s) {
+          const int pi = q.src[s];
+          if (pi < 0) continue;
+          const int fc = c->G[pi].first_consumer;
+          if (leader(oi) != leader(fc)) continue;   // a later launch: the arrays were published by the first one
+          bool first_ref = true;
+          for (int s2 = 0; s2 < s; ++s2) first_ref = first_ref && q.src[s2] != pi;
+          a.fold[s] = fold_of(pi, oi == fc && first_ref);
+        }
+      }
       return a;
     };
     auto fin_args = [&](int oi, const StatSource& ss) {
@@ -1047,10 +1100,10 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       }
       const GConvArgs fa0 = fwd_args(i), fa1 = fwd_args(i + 1);
       lp.begin("conv_fwd2_", i);
-      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, gg, std::max(o.lds_fwd, o2.lds_fwd));
+      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, (inl && c->g_role_split) ? std::max(1, gg / 2) : gg, std::max(o.lds_fwd, o2.lds_fwd));
       lp.end();
       if (ok) {
-        if (training) {
+        if (training && !inl) {
           const float inv_n = 1.0f / ((float)B * (float)o.tout * (float)(o.groups > 1 ? o.cout / o.groups : 1));
           StatSource s0{o.stat_part, gg, inv_n, 1.0f}, s1{o2.stat_part, gg, inv_n, 1.0f};
           const GBnFwdArgs f0 = fin_args(i, s0), f1 = fin_args(i + 1, s1);
@@ -1073,7 +1126,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     int rc = launch_gconv<0>(c, o.cout, fa, gg, o.lds_fwd);
     lp.end();
     if (rc) return rc;
-    if (training && o.norm == MWW_NORM_BN) {
+    if (training && o.norm == MWW_NORM_BN && !inl) {
       const int members = o.groups > 1 ? o.cout / o.groups : 1;
       StatSource ss;
       int rcs = exchange_stats(c, lp, "bn_stat_exchange", i, o.stat_part, gg, o.cout, 0,
@@ -1125,6 +1178,15 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   h.C = lo.cout;
   h.inv_b = 1.0f / (float)B;
   h.training = (loss ? kHeadTraining : 0) | (c->bce_clipped ? kHeadClippedLoss : 0);
+  if (inl) {
+    h.fold = fold_of(n - 1, true);   // the head is the first (and only) consumer of the last op
+    c->fpar ^= 1;
+    if (loss) {
+      h.gacc.acc = lo.gacc[c->gpar];
+      h.gacc.clear = lo.gacc[c->gpar ^ 1];
+      lo.gacc_cur = h.gacc.acc;
+    }
+  }
   if (lo.res_src >= 0) {
     GOp& rr = c->G[lo.res_src];
     h.rp = rr.p;
@@ -1179,6 +1241,26 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
+  // statistics hand-over: the op's own backward launch folds (sum g, sum g*xhat) from the accumulator rows its consumers
+  // (or the head) added to; the weight-gradient role publishes c1 / mg / mgx / dgamma / dbeta
+  const bool inl = c->bn_inline && c->g_inline_ok && !(c->hook && c->sync_bn) && !c->profile_split;
+  auto bfold = [&](GOp& q, bool publish) {
+    GFoldBwd f;
+    memset(&f, 0, sizeof(f));
+    if (!inl) return f;
+    f.acc = q.gacc_cur;
+    f.groups = q.groups;
+    f.inv_n = 1.0f / ((float)B * (float)q.tout * (float)(q.groups > 1 ? q.cout / q.groups : 1));
+    f.dscale = 1.0f;
+    f.publish = publish ? 1 : 0;
+    f.gamma = c->params + q.o_gamma;
+    f.c1 = gbn_slot(q, BN_C1);
+    f.mg = gbn_slot(q, BN_MG);
+    f.mgx = gbn_slot(q, BN_MGX);
+    f.dgamma = c->grads + q.o_gamma;
+    f.dbeta = c->grads + q.o_beta;
+    return f;
+  };
   auto bwd_fin_args = [&](int oi, const StatSource& ss) {
     GOp& q = c->G[oi];
     return GBnBwdArgs{ss.part, ss.G, q.cout, q.groups, ss.inv_n,
@@ -1192,6 +1274,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     w.n_src = q.n_src;
     for (int s = 0; s < q.n_src; ++s) w.src[s] = g_make_src(c, oi, s, false);
     w.y = g_make_bnbwd(c, q);
+    w.y.fold = bfold(q, true);
     w.k = q.k;
     w.dil = q.dil;
     w.cin = q.cin;
@@ -1208,7 +1291,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     GConvArgs a;
     memset(&a, 0, sizeof(a));
     a.n_src = q.n_src;
-    for (int s = 0; s < q.n_src; ++s) a.src[s] = g_make_src(c, oi, s, true);
+    for (int s = 0; s < q.n_src; ++s) a.src[s] = g_make_src(c, oi, s, true, inl);
     a.w = c->wt + q.o_wt;
     a.k = q.k;
     a.dil = q.dil;
@@ -1218,13 +1301,16 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     a.Tin = q.tout;
     a.Tout = q.tin;
     a.y = g_make_bnbwd(c, q);
+    a.y.fold = bfold(q, false);
     return a;
   };
-  auto add_segment = [&](int oi) {
+  const bool split = inl && c->g_role_split;
+  const int gg2 = split ? std::max(1, gg / 2) : gg, gg4 = split ? std::max(1, gg / 4) : gg;
+  auto add_segment = [&](int oi, int rows) {
     GOp& q = c->G[oi];
     GradSegment s;
     s.part = q.grad_part;
-    s.G = gg;
+    s.G = rows;
     s.stride = q.k * q.cin * q.cout;
     s.n = s.stride;
     s.dst = (int)q.o_w;
@@ -1244,13 +1330,13 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       const GConvArgs d0 = dgrad_args(i), d1 = dgrad_args(i - 1);
       const int n0 = o.slots;
       lp.begin("conv_bwd2_", i);
-      hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
-      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, gg,
+      if (!inl) hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
+      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, gg4,
                                    std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)));
       lp.end();
       if (!ok) return fail(MWW_ERR_UNSUPPORTED, "twin ops without a fused backward instantiation");
-      add_segment(i);
-      add_segment(i - 1);
+      add_segment(i, gg4);
+      add_segment(i - 1, gg4);
       --i;
       continue;
     }
@@ -1276,7 +1362,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       hipLaunchKernelGGL(gres_gather_kernel, dim3(gg), dim3(kThreads), 0, c->stream, ra);
       lp.end();
     }
-    if (o.norm == MWW_NORM_BN) {
+    if (o.norm == MWW_NORM_BN && !inl) {
       StatSource ss;
       int rcs = exchange_stats(c, lp, "bn_gstat_exchange", i, o.gstat_part, i == n - 1 ? ghead : gg, o.cout, 1,
                                1.0f / ((float)B * (float)o.tout * (float)members), &ss);
@@ -1318,6 +1404,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     w.n_src = o.n_src;
     for (int s = 0; s < o.n_src; ++s) w.src[s] = g_make_src(c, i, s, false);
     w.y = g_make_bnbwd(c, o);
+    w.y.fold = bfold(o, true);
     w.k = o.k;
     w.dil = o.dil;
     w.cin = o.cin;
@@ -1331,7 +1418,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     memset(&a, 0, sizeof(a));
     if (o.needs_dx) {
       a.n_src = o.n_src;
-      for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, true);
+      for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, true, inl);
       a.w = c->wt + o.o_wt;
       a.k = o.k;
       a.dil = o.dil;
@@ -1341,11 +1428,12 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.Tin = o.tout;
       a.Tout = o.tin;
       a.y = g_make_bnbwd(c, o);
+      a.y.fold = bfold(o, false);
     }
     bool fused = false;
     if (o.needs_dx && !c->profile_split) {
       lp.begin("conv_bwd", i);
-      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, gg, std::max(o.lds_wg, o.lds_dx));
+      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, gg2, std::max(o.lds_wg, o.lds_dx));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
         (void)hipEventDestroy(c->prof.back().a);
@@ -1367,7 +1455,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     GradSegment s;
     s.part = o.grad_part;
-    s.G = gg;
+    s.G = fused ? gg2 : gg;
     s.stride = o.k * o.cin * o.cout;
     s.n = s.stride;
     s.dst = (int)o.o_w;
@@ -1382,6 +1470,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     s.dst = (int)c->o_att;
     ga.seg[ga.nseg++] = s;
   }
+  if (inl) c->gpar ^= 1;
   return enqueue_grad_assembly(c, B, ga, fuse_adam);
 }
 
@@ -1545,7 +1634,7 @@ int open_device(mww_ctx* c, int device, void* stream) {
   c->grid_fwd = c->n_cu * 4;
   c->grid_bwd = c->n_cu * 2;
   c->grid_head = c->n_cu * 2;   // one window per workgroup at a time, two resident per CU (177 VGPRs): measured 13.5 us vs 15.4 (x4) / 17.4 (x1)
-  c->grid_g = c->n_cu * 4;
+  c->grid_g = c->n_cu * 3;   // measured on the Inception step: 3 workgroups per CU and launch (roles share them) beats 2 and 4
   return MWW_OK;
 }
 
@@ -1713,12 +1802,19 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
       if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
       if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
-      o.nq = std::max(1, std::min(8, kThreads / (o.k * o.cin)));
-      const size_t wf = (size_t)o.k * o.cin * ((o.cout + 3) / 4 * 4), wb = (size_t)o.k * o.cout * ((o.cin + 3) / 4 * 4);
-      o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1)) * sizeof(float);
-      o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1)) * sizeof(float);
-      o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 3) / 4 * 4 + (size_t)o.tout * ((o.cout + 3) / 4 * 4)) * sizeof(float);
-      o.lds_wg = std::max(o.lds_wg, (size_t)kThreads * kGWgChunk * sizeof(float));   // scratch of the reduction over the frame subsets
+      o.nq = 1;
+      // LDS tiles of the MFMA kernels (kernels_graph.hip.h): weights [k][cin4][NCW] zero-padded to whole k-steps / filter tiles
+      auto up4 = [](int v) { return (size_t)((v + 3) & ~3); };
+      auto up16 = [](int v) { return (size_t)((v + 15) / 16 * 16); };
+      const size_t wf = (size_t)o.k * up4(o.cin) * up16(o.cout), wb = (size_t)o.k * up4(o.cout) * up16(o.cin);
+      o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1) + 4) * sizeof(float);
+      o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1) + 4) * sizeof(float);
+      {
+        const int tasks = o.k * o.cin, mt = (tasks + 15) / 16, nt = (o.cout + 15) / 16;
+        o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 6) / 4 * 4 + up4(o.tout) * (size_t)gwg_dp_pitch(o.cout)) * sizeof(float);
+        if (gwg_kparts(tasks) > 1)   // scratch of the sum over the frame parts
+          o.lds_wg = std::max(o.lds_wg, (size_t)gwg_kparts(tasks) * mt * nt * 256 * sizeof(float));
+      }
       if (!o.needs_dx) o.lds_dx = 0;
     }
     if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > kMaxDynLds) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the LDS tile");
@@ -1813,6 +1909,18 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   c->dropout = d.dropout;
   c->G = ops;
   {
+    // statistics hand-over: possible when every op is a convolution followed by a BatchNorm / SSN, none has a residual
+    // branch and every folded tensor fits the kernels' fold table; first_consumer = the op whose launch folds
+    bool ok = true;
+    for (int i = 0; i < d.n_ops; ++i) {
+      GOp& o = c->G[i];
+      if (o.kind != MWW_OP_CONV || o.norm != MWW_NORM_BN || o.res_src >= 0 || !o.adders.empty() || o.cout > kGFoldC) ok = false;
+      for (int j = 0; j < o.n_src; ++j)
+        if (o.src[j] >= 0 && c->G[o.src[j]].first_consumer < 0) c->G[o.src[j]].first_consumer = i;
+    }
+    c->g_inline_ok = ok && !d.head_attention && !d.head_pool;
+  }
+  {
     int rco = open_device(c, device, stream);
     if (rco) { mww_destroy(c); return rco; }
   }
@@ -1857,6 +1965,10 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));
     A(dev_alloc(&o.bn, (size_t)9 * o.cout));
+    for (int par = 0; par < 2; ++par) {
+      A(dev_alloc(&o.facc[par], (size_t)kStatRows * 2 * o.cout));
+      A(dev_alloc(&o.gacc[par], (size_t)kStatRows * 2 * o.cout));
+    }
     if (o.norm == MWW_NORM_BN) bn.push_back(BnSlots{o.o_gamma, o.o_beta, o.o_mv, o.slots});
     else if (o.norm == MWW_NORM_BIAS) bn.push_back(BnSlots{o.o_beta, o.o_beta, -1, o.cout});   // bias gradient is written directly too
   }
@@ -1924,7 +2036,7 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : lp) if (p) (void)hipFree(p);
   }
   for (auto& o : c->G) {
-    void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn};
+    void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn, o.facc[0], o.facc[1], o.gacc[0], o.gacc[1]};
     for (void* p : op) if (p) (void)hipFree(p);
   }
   if (c->sync_buf) (void)hipFree(c->sync_buf);
@@ -2174,8 +2286,8 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     // only the Adam / dropout nodes and the gather of a descriptor-only batch read the mailbox
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
-    const bool flips = !c->generic && c->bn_inline;
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0);
+    const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2351,6 +2463,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
   else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
+  else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;
   else if (!strcmp(name, "bce_from_logits")) c->bce_clipped = v == 0;
   else if (!strcmp(name, "grad_buckets")) { if (v < 1 || v > 2) return fail(MWW_ERR_INVALID, "grad_buckets must be 1 or 2"); c->grad_buckets = (int)v; }

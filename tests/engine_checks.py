@@ -1056,6 +1056,70 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
             np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)
 
 
+def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=INC, fuse_heads=True):
+    """The statistics hand-over of the conv/BN graph kernels (accumulator rows folded by the first consumer launch, no
+    finalize launches) against the finalize-launch path on the Inception graph: same sums, same arithmetic, so parameters,
+    moving statistics, probabilities, gradients agree to rounding (1e-6 relative); through captured graphs, with a
+    training-mode forward between steps, with a batch smaller than the accumulator row count in between (stale rows),
+    and the profile of a step lists no finalize launch."""
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 667, size=(steps + 1, B, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
+    y = (rng.random((steps + 1, B)) < 0.4).astype(np.float32)
+    w = np.ones(B, np.float32)
+    om = perturbed_inception_oracle(T, flags)
+    outs = []
+    for inline, graphs in ((0, 0), (1, 0), (1, 1)):
+        lay, eng = make_inception_engine(lib, T, B, om, flags, fuse_heads)
+        eng.set_option("bn_inline", inline)
+        eng.set_option("graphs", graphs)
+        eng.set_option("graph_role_split", 0)   # same workgroups per role => same summation order of the weight-gradient partials
+        probs = []
+        for k in range(steps):
+            nb = B if k != 1 else min(B, 3)     # fewer workgroups than accumulator rows in the middle step
+            eng.set_batch(x[k][:nb])
+            eng.set_targets(y[k][:nb], w[:nb])
+            eng.set_dropout_mask(np.ones((nb, eng_dense_inputs(lay)), np.uint8))
+            eng.train_step(nb, 1e-2)
+            probs.append(eng.read_outputs(nb)[0].copy())
+            if k == 0:
+                eng.set_batch(x[steps])
+                eng.forward(B, training=True)
+                probs.append(eng.read_outputs(B, want_loss=False)[0].copy())
+        outs.append((eng.get_params().copy(), eng.get_bn_state().copy(), np.concatenate(probs), eng.get_grads().copy()))
+        if not graphs:
+            eng.set_option("profile", 1)
+            eng.set_batch(x[0])
+            eng.set_targets(y[0], w)
+            eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+            eng.train_step(B, 1e-2, flags=native.STEP_NO_APPLY)
+            names = [nm for nm, _ in eng.profile_read()]
+            eng.set_option("profile", 0)
+            assert any("finalize" in nm for nm in names) == (inline == 0), names
+        eng.close()
+    ref = outs[0]
+    for got in outs[1:]:
+        for a, b in zip(ref, got):
+            np.testing.assert_allclose(b, a, rtol=2e-6, atol=1e-7)
+    # multi-role launches that divide their workgroups between the roles (the default with the hand-over): other partial
+    # sums, same gradient up to float32 summation order
+    grads = []
+    for split in (0, 1):
+        lay, eng = make_inception_engine(lib, T, B, om, flags, fuse_heads)
+        eng.set_option("graph_role_split", split)
+        eng.set_batch(x[0])
+        eng.set_targets(y[0], w)
+        eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+        eng.train_step(B, 1e-2, flags=native.STEP_NO_APPLY)
+        grads.append(eng.get_grads().copy())
+        eng.close()
+    assert np.abs(grads[1] - grads[0]).max() <= 5e-4 * np.abs(grads[0]).max()   # (a wrong row count or a dropped role is O(1))
+
+
+def eng_dense_inputs(lay):
+    last = lay.engine_args(1)["conv_ops"][-1]
+    return last["tout"] * last["filters"]
+
+
 # ------------------------------------------------------------------------------------------ fused input
 def check_fused_input(lib, B=8, T=60, steps=4, dtype="u16", graphs=False):
     """"fused_input" (descriptor-only batches: the first block's kernels gather, scale and mask their rows straight from

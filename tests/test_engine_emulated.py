@@ -75,6 +75,11 @@ def test_inception_variant_dilation_groups_two_stems(emu_lib):
     ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=2, graphs=True, flags=ec.INC_VARIANT)
 
 
+def test_inception_statistics_hand_over_matches_finalize_launches(emu_lib):
+    ec.check_inception_bn_inline_matches_finalize(emu_lib, B=5, T=120, steps=3)
+    ec.check_inception_bn_inline_matches_finalize(emu_lib, B=4, T=120, steps=2, flags=ec.INC_VARIANT)
+
+
 def test_inception_generated_dropout(emu_lib):
     ec.check_inception_generated_dropout(emu_lib, B=3, T=120)
 

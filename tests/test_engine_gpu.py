@@ -221,6 +221,14 @@ def test_bf16_pointwise_mode(lib):
     eng.close()
 
 
+def test_inception_statistics_hand_over_matches_finalize_launches(lib):
+    """conv/BN graph kernels: accumulator rows folded by the first consumer launch (no finalize launches) against the
+    finalize-launch path, default and SubSpectralNormalization variant topology, eager and captured."""
+    ec.check_inception_bn_inline_matches_finalize(lib, B=64, T=194, steps=3)
+    ec.check_inception_bn_inline_matches_finalize(lib, B=9, T=150, steps=3, flags=ec.INC_VARIANT)
+    ec.check_inception_bn_inline_matches_finalize(lib, B=6, T=194, steps=2, fuse_heads=False)
+
+
 def test_bf16_storage_mode(lib):
     """BASELINE configs[4], full form ("storage_bf16"): the block outputs p_k and the stashed gradients g_k live in HBM
     as bf16 (fp32 accumulation, fp32 BN sums from the unrounded values), against the oracle that rounds the same stored
