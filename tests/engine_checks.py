@@ -1112,7 +1112,10 @@ def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=I
         eng.train_step(B, 1e-2, flags=native.STEP_NO_APPLY)
         grads.append(eng.get_grads().copy())
         eng.close()
-    assert np.abs(grads[1] - grads[0]).max() <= 5e-4 * np.abs(grads[0]).max()   # (a wrong row count or a dropped role is O(1))
+    # (another summation order of the BN sums can flip a ReLU unit that sits within rounding of zero, which moves every
+    # upstream gradient by ~1e-3: seen on the GPU for some (batch, workgroups) pairs, tools/gpu_split_diag.py; a wrong row
+    # count or a dropped role is O(1))
+    assert np.linalg.norm(grads[1] - grads[0]) <= 1e-2 * np.linalg.norm(grads[0])
 
 
 def eng_dense_inputs(lay):

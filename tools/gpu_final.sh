@@ -17,6 +17,11 @@ echo "== bench inception"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; tail -c 400 $OUT/bench_inception.json | head -c 400; echo
 echo "== bench bf16-operand"
 timeout 900 python bench.py --pointwise-bf16 --no-cpu-baseline --no-validation > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; head -c 300 $OUT/bench_bf16.json; echo
+echo "== bench bf16 storage (configs[4] full form), batch 1024 and 4096; fp32 and bf16-operand at 4096"
+timeout 600 python bench.py --storage-bf16 --no-cpu-baseline --no-validation > $OUT/bench_bf16_storage.json 2> $OUT/bench_bf16_storage.err; head -c 200 $OUT/bench_bf16_storage.json; echo
+for m in "--storage-bf16:bf16_storage" "--pointwise-bf16:bf16" ":f32"; do
+  timeout 600 python bench.py ${m%%:*} --batch 4096 --steps 100 --warmup 10 --no-cpu-baseline --no-validation > $OUT/bench_${m##*:}_b4096.json 2> $OUT/bench_${m##*:}_b4096.err; head -c 200 $OUT/bench_${m##*:}_b4096.json; echo
+done
 echo "== collective path forced on one GPU (RCCL world of one): local-BN with two buckets / one bucket, sync-BN"
 MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation 2> $OUT/bench_dp.err | tee $OUT/bench_dp.json | head -c 300; echo
 MWW_BENCH_FORCE_DP=1 timeout 600 python bench.py --no-cpu-baseline --no-validation --grad-buckets 1 2> $OUT/bench_dp1.err | tee $OUT/bench_dp1.json | head -c 300; echo
@@ -33,9 +38,11 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VA
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $B > /dev/null 2> $OUT/pmc3.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $B > /dev/null 2> $OUT/pmc4.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inc -o t -- $B --model inception > /dev/null 2> $OUT/trace_inc.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_st -o t -- $B --storage-bf16 > /dev/null 2> $OUT/trace_st.err
 cd $R
 python tools/pmc_summary.py $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 > $OUT/kernel_stats_and_pmc.txt 2>&1
 python tools/pmc_summary.py $OUT/trace_inc > $OUT/kernel_stats_inception.txt 2>&1
+python tools/pmc_summary.py $OUT/trace_st > $OUT/kernel_stats_bf16_storage.txt 2>&1
 head -30 $OUT/kernel_stats_and_pmc.txt | cut -c1-160
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +12M -delete
