@@ -269,16 +269,21 @@ class FeatureHandler:
                     draw_windows=buf["win"].copy(), draw_masks=buf["masks"].copy())
 
     def next_training_batch_on_device(self, batch_size, features_length, truncation_strategy="default",
-                                      augmentation_policy=None, class_weights=(1.0, 1.0)):
+                                      augmentation_policy=None, class_weights=(1.0, 1.0), weight_broadcast="per_sample"):
         """Fast path of the train loop: leaves x in the engine's batch buffer (no host copy of the
         spectrograms) and the labels / per-sample weights (penalty x class weight, train.py:288-293) next
         to it — they travel in the same mailbox as the window descriptors, so no separate copy is
-        enqueued.  ``class_weights`` = (negative, positive).  Returns ``(labels, penalty_weights)``."""
+        enqueued.  ``class_weights`` = (negative, positive); ``weight_broadcast``: model.combine_weights.  Returns
+        ``(labels, penalty_weights)``."""
         buf, tc, fc, arrs = self._sample(int(batch_size), features_length, truncation_strategy, augmentation_policy, 1)
         y = arrs["labels"][buf["prov"]]
         w = arrs["penalty"][buf["prov"]]
         neg, pos = class_weights
-        self.engine.set_targets(y, w if (neg == 1.0 and pos == 1.0) else w * np.where(y > 0.5, pos, neg))
+        if neg == 1.0 and pos == 1.0 and weight_broadcast == "per_sample":
+            self.engine.set_targets(y, w)
+        else:
+            from .model import combine_weights
+            self.engine.set_targets(y, combine_weights(w, y, neg, pos, weight_broadcast))
         self.engine.assemble(buf["win"], buf["masks"], tc, fc)
         return y, w
 

@@ -77,6 +77,35 @@ class _Counts:
         return self._a
 
 
+WEIGHT_BROADCAST_MODES = ("per_sample", "keras_last_axis", "keras_first_axis")
+
+
+def combine_weights(penalty, labels, negative_class_weight, positive_class_weight, mode="per_sample"):
+    """The per-sample loss weights of a training batch.  train.py:288-293 multiplies penalty[B] by class_weight(y)[B,1],
+    which broadcasts to a [B,B] matrix W[i,j] = penalty_j * cw(y_i) that Keras then reduces against the [B] per-sample
+    losses.  ``per_sample`` (default) is what the code evidently means: w_i = penalty_i * cw(y_i).  The two
+    readings of what Keras 3 actually evaluates are available for parity runs against the reference's loss curves:
+    ``keras_last_axis`` - the losses broadcast along the last axis of W and everything is divided by B*B:
+    w_j = penalty_j * mean_i cw(y_i) (what keras/src/losses/loss.py reduce_weighted_values does as we read it: a [B] loss
+    vector against a [B,B] weight is left as is by squeeze_or_expand_to_same_rank, multiplied with ordinary broadcasting
+    and divided by the element count B*B - not verifiable here, TensorFlow is not installable); ``keras_first_axis`` -
+    w_i = cw(y_i) * mean_j penalty_j.  per_sample equals keras_last_axis when the class weights are uniform over the batch
+    and keras_first_axis when the penalty weights are; with both non-uniform (e.g. negative_class_weight 20 and mixed
+    penalty_weight providers) the loss curves differ: set ``sample_weight_broadcast: keras_last_axis`` in the training
+    config to follow the reference's arithmetic rather than its intent."""
+    penalty = np.asarray(penalty, np.float64).reshape(-1)
+    cw = np.where(np.asarray(labels).reshape(-1) > 0.5, positive_class_weight, negative_class_weight).astype(np.float64)
+    if mode == "per_sample":
+        w = penalty * cw
+    elif mode == "keras_last_axis":
+        w = penalty * cw.mean()
+    elif mode == "keras_first_axis":
+        w = cw * penalty.mean()
+    else:
+        raise ValueError("sample_weight_broadcast must be one of %s" % (WEIGHT_BROADCAST_MODES,))
+    return w.astype(np.float32)
+
+
 class Model:
     def __init__(self, flags, shape, batch_size, device=0, stream=None, lib=None, seed=None, max_batch=None, layout=None,
                  name="mixednet"):
@@ -95,6 +124,7 @@ class Model:
         self.loss = None
         self.train_function = None
         self._compiled = False
+        self.sample_weight_broadcast = "per_sample"   # how a [B,B] sample_weight matrix is reduced (combine_weights)
 
     # ---- Keras surface
     def compile(self, optimizer=None, loss=None, metrics=None):
@@ -133,16 +163,23 @@ class Model:
     def _metric_results(self):
         return native.metrics_from_raw(self.engine.metrics_raw())
 
-    @staticmethod
-    def _per_sample_weights(sample_weight, n):
+    def _per_sample_weights(self, sample_weight, n):
         if sample_weight is None:
             return np.ones(n, np.float32)
         sw = np.asarray(sample_weight, np.float64)
-        if sw.ndim == 2 and sw.shape == (n, n):
-            # train.py:291-293 broadcasts penalty[B] * class_weight(y)[B,1] to [B,B] with
-            # W[i,j] = penalty_j * cw(y_i).  The intended per-sample weight is the diagonal
-            # (identical to every reading of Keras' behaviour when either factor is uniform).
-            sw = np.diagonal(sw)
+        if sw.ndim == 2 and sw.shape == (n, n) and n > 1:
+            # train.py:291-293 broadcasts penalty[B] * class_weight(y)[B,1] to [B,B] with W[i,j] = penalty_j * cw(y_i).
+            # Default: the intended per-sample weight, i.e. the diagonal; the two readings of Keras' reduction of the
+            # matrix (combine_weights) are the column / row means.  All agree when either factor is uniform.
+            mode = self.sample_weight_broadcast
+            if mode == "per_sample":
+                sw = np.diagonal(sw)
+            elif mode == "keras_last_axis":
+                sw = sw.mean(axis=0)
+            elif mode == "keras_first_axis":
+                sw = sw.mean(axis=1)
+            else:
+                raise ValueError("sample_weight_broadcast must be one of %s" % (WEIGHT_BROADCAST_MODES,))
         sw = sw.reshape(-1)
         if sw.size != n:
             raise ValueError("sample_weight does not match the batch")

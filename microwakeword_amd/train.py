@@ -26,6 +26,8 @@ import os
 
 import numpy as np
 
+from .model import combine_weights
+
 log = logging.getLogger("microwakeword_amd.train")
 
 
@@ -190,13 +192,14 @@ def train(model, config, data_processor, verbose=True):
         cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
         if fast:
             data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy,
-                                                         class_weights=(cw_neg, cw_pos))
+                                                         class_weights=(cw_neg, cw_pos),
+                                                         weight_broadcast=config.get("sample_weight_broadcast", "per_sample"))
             result = model.train_on_device_batch(config["batch_size"])
         else:
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",
                                               augmentation_policy=policy)
-            combined = w * np.where(y > 0.5, cw_pos, cw_neg)
+            combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", "per_sample"))
             result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
         if verbose:
             print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(

@@ -168,6 +168,29 @@ def test_train_loop_schedule_and_weights(tmp_path):
     assert out["best_maximization"] == 0.9
 
 
+def test_sample_weight_broadcast_modes():
+    """train.py:288-293's [B,B] weight matrix W[i,j] = penalty_j * cw(y_i): the default reduces it to its diagonal (the
+    intended per-sample weight); the two readings of Keras' reduction are its column / row means; the vector form
+    (combine_weights) agrees with the matrix form; per_sample equals keras_last_axis when the class weights are uniform
+    and keras_first_axis when the penalties are."""
+    from microwakeword_amd.model import Model, combine_weights
+    rng = np.random.default_rng(0)
+    B = 7
+    y = (rng.random(B) < 0.5).astype(np.float32)
+    pen = rng.choice([0.5, 1.0, 2.0], size=B)
+    cw = np.where(y > 0.5, 3.0, 0.25)
+    W = pen[None, :] * cw[:, None]            # what the reference's broadcast produces
+    m = Model.__new__(Model)                  # the reduction is host arithmetic: no engine needed
+    for mode, want in (("per_sample", pen * cw), ("keras_last_axis", pen * cw.mean()), ("keras_first_axis", cw * pen.mean())):
+        m.sample_weight_broadcast = mode
+        np.testing.assert_allclose(m._per_sample_weights(W, B), want, rtol=1e-6)
+        np.testing.assert_allclose(combine_weights(pen, y, 0.25, 3.0, mode), want, rtol=1e-6)
+    np.testing.assert_allclose(combine_weights(pen, y, 2.0, 2.0, "keras_last_axis"), combine_weights(pen, y, 2.0, 2.0, "per_sample"))
+    np.testing.assert_allclose(combine_weights(np.ones(B), y, 0.25, 3.0, "keras_first_axis"), combine_weights(np.ones(B), y, 0.25, 3.0, "per_sample"))
+    with pytest.raises(ValueError):
+        combine_weights(pen, y, 1.0, 1.0, "diagonal")
+
+
 def test_best_model_rule():
     f = tr._is_better
     assert f(0.5, 0.1, 10000, 0.0, 0.9)        # first time under target
