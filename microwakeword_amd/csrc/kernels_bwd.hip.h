@@ -78,12 +78,12 @@ struct DpStage {
         const int r = i / QO, q = i - r * QO;
         float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nvalid) {
+          // sKp rows: 0 = c1, 1 = kA, 2 = kB with dp = c1*(g - mg - (p - mean)*rstd*mgx) = c1*g + (kA*p + kB)
+          // (kA = -c1*rstd*mgx, kB = -c1*mg - kA*mean, formed once per channel in the prologue: two fma per element)
           const float4 p = pk[j];
-          const float4 mean = *reinterpret_cast<const float4*>(sKp + 0 * COUT + q * 4);
-          const float4 rstd = *reinterpret_cast<const float4*>(sKp + 1 * COUT + q * 4);
-          const float4 c1 = *reinterpret_cast<const float4*>(sKp + 2 * COUT + q * 4);
-          const float4 mg = *reinterpret_cast<const float4*>(sKp + 3 * COUT + q * 4);
-          const float4 mgx = *reinterpret_cast<const float4*>(sKp + 4 * COUT + q * 4);
+          const float4 c1 = *reinterpret_cast<const float4*>(sKp + 0 * COUT + q * 4);
+          const float4 kA = *reinterpret_cast<const float4*>(sKp + 1 * COUT + q * 4);
+          const float4 kB = *reinterpret_cast<const float4*>(sKp + 2 * COUT + q * 4);
           float4 g = gg[j];
           if (LAST) {
             const float4 sc = *reinterpret_cast<const float4*>(sKp + 5 * COUT + q * 4);
@@ -93,10 +93,10 @@ struct DpStage {
             g.z = fmaf(p.z, sc.z, sh.z) > 0.f ? dzb * g.z : 0.f;
             g.w = fmaf(p.w, sc.w, sh.w) > 0.f ? dzb * g.w : 0.f;
           }
-          dp.x = c1.x * (g.x - mg.x - (p.x - mean.x) * rstd.x * mgx.x);
-          dp.y = c1.y * (g.y - mg.y - (p.y - mean.y) * rstd.y * mgx.y);
-          dp.z = c1.z * (g.z - mg.z - (p.z - mean.z) * rstd.z * mgx.z);
-          dp.w = c1.w * (g.w - mg.w - (p.w - mean.w) * rstd.w * mgx.w);
+          dp.x = fmaf(g.x, c1.x, fmaf(p.x, kA.x, kB.x));
+          dp.y = fmaf(g.y, c1.y, fmaf(p.y, kA.y, kB.y));
+          dp.z = fmaf(g.z, c1.z, fmaf(p.z, kA.z, kB.z));
+          dp.w = fmaf(g.w, c1.w, fmaf(p.w, kA.w, kB.w));
         }
         *reinterpret_cast<float4*>(sDP + r * CPO + q * 4) = dp;
       }
@@ -140,6 +140,16 @@ __device__ __forceinline__ void carry_du(float* sDU, bool first_tile, int tid) {
   for (int i = tid; i < (K - 1) * CPI; i += kThreads) sDU[i] = first_tile ? 0.f : sDU[TT * CPI + i];
 }
 
+// REPS x ([READS LDS reads] [MFMAS MFMAs]) in the instruction schedule of the enclosing block
+template <int REPS, int READS, int MFMAS>
+__device__ __forceinline__ void sched_read_mfma_groups() {
+  if constexpr (REPS > 0) {
+    if constexpr (READS > 0) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+    sched_read_mfma_groups<REPS - 1, READS, MFMAS>();
+  }
+}
+
 // MFMA part shared by both backward kernels:
 //   dwacc[mt][nt] += U^T DP over this wave's 16 rows;  du = DP W^T -> sDU rows [K-1+16*wave, ...)
 //   sWt = W_pw^T staged in LDS as [COUT][pitch(CIN)] (B[k=co][n=ci] = W[ci][co])
@@ -154,6 +164,50 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
   if (!live) {
     // (wave-uniform) this wave's 16 rows lie past the sample: dp = 0 there, so dW gains nothing and du = 0
   } else if constexpr (!BF) {
+    // The operands of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued, and the schedule is pinned
+    // that way (read group, MFMA group, ...): left to itself the scheduler sank every read to just in front of its first
+    // use (register pressure), so each group of 2-3 MFMAs waited for an LDS round trip (27 waits for 72 MFMAs in the
+    // round-2 ISA; the phase took 3.7k cycles alone for 2.3k of MFMA issue).
+#ifndef MWW_NO_MFMA_PIPELINE
+    {
+      float av[2][MT], bv[2][NT];
+      auto load_dw = [&](int kk, int s) {
+        const int row = wave * 16 + kk * 4 + g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[s][mt] = sU[row * CPI + mt * 16 + r16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[s][nt] = sDP[row * CPO + nt * 16 + r16];
+      };
+      float a2[2], b2[2][MT];
+      auto load_du = [&](int kk, int s) {
+        a2[s] = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b2[s][mt] = sWt[(kk * 4 + g) * CPI + mt * 16 + r16];
+      };
+      load_dw(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk + 1 < 4) load_dw(kk + 1, (kk + 1) & 1);
+        else load_du(0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma4(av[kk & 1][mt], bv[kk & 1][nt], dwacc[mt][nt]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KSO; ++kk) {
+        if (kk + 1 < KSO) load_du(kk + 1, (kk + 1) & 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(a2[kk & 1], b2[kk & 1][mt], du[mt]);
+      }
+      // pinned order: [reads k0] ([reads k+1][MFMAs k]) x 4, then ([reads k+1][MFMAs k]) x KSO
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+      sched_read_mfma_groups<3, MT + NT, MT * NT>();
+      sched_read_mfma_groups<1, 1 + MT, MT * NT>();
+      sched_read_mfma_groups<KSO - 1, 1 + MT, MT>();
+      sched_read_mfma_groups<1, 0, MT>();
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int row = wave * 16 + kk * 4 + g;
@@ -173,6 +227,7 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, sWt[(kk * 4 + g) * CPI + mt * 16 + r16], du[mt]);
     }
+#endif
   } else {
     // bf16 operands: one MFMA spans the wave's 16 rows (dW) / 16 output channels (du)
     const int row = wave * 16 + 4 * g;
@@ -289,6 +344,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
   __shared__ __attribute__((aligned(16))) float sDW[K * CIN];      // depthwise taps
+  __shared__ __attribute__((aligned(16))) float sAct[2 * CIN];     // BN_{k-1} folded scale / shift (activation at commit)
   float* sP = smem + OFF_P;
   float* sDP = smem + OFF_DP;
   float* sU = smem + OFF_U;
@@ -350,11 +406,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       mg = a.k_mg[i];
       mgx = a.k_mgx[i];
     }
-    sKp[0 * COUT + i] = kmean;
-    sKp[1 * COUT + i] = krs;
-    sKp[2 * COUT + i] = c1;
-    sKp[3 * COUT + i] = mg;
-    sKp[4 * COUT + i] = mgx;
+    const float kA = -c1 * krs * mgx;
+    sKp[0 * COUT + i] = c1;
+    sKp[1 * COUT + i] = kA;
+    sKp[2 * COUT + i] = -c1 * mg - kA * kmean;
     sKp[5 * COUT + i] = ksc;
     sKp[6 * COUT + i] = ksh;
   }
@@ -368,7 +423,24 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
+#ifndef MWW_NO_COMMIT_ACT
+  // The block input is activated ONCE, while its rows are committed to LDS: sP holds a = relu(BN_{k-1}(p_{k-1})), so the
+  // depthwise recompute (P1) and the depthwise weight gradient (P4) read their windows as they are (before, each of the
+  // L + K - 1 window rows went through the fma + max twice per (channel, chunk): 2 x 66 of ~1150 VALU instructions per
+  // wave and tile at K = 21).  What P4 still needs of the raw tensor follows from a for the units it matters for (a > 0,
+  // i.e. a = gamma * xhat + beta):  the ReLU decision is a > 0, and xhat = (a - beta) / gamma = a * xk1 + xk0.
+  // (gamma = 0 gives xk1 = 0: such a channel passes no gradient to p_{k-1}; its own d gamma = sum g * xhat is then formed
+  // with xhat = 0 - the one deviation from the two-pass form, for a value of gamma training does not produce.)
+  if (chunk == 0) {
+    sAct[c] = sc_c;
+    sAct[CIN + c] = sh_c;
+  }
+  float xk1 = sc_c != 0.f ? rs_c / sc_c : 0.f;
+  float xk0 = -(sh_c + mu_c * sc_c) * xk1;
+  pin(dwb); pin(xk1); pin(xk0);
+#else
   pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
+#endif
   __syncthreads();
 
   MWW_PC_AT(1);   // prologue done
@@ -384,7 +456,17 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       const int i = tid + j * kThreads;
       if (i < RA * QI) {
         const int r = i / QI, q = i - r * QI;
+#ifndef MWW_NO_COMMIT_ACT
+        const float4 s4 = *reinterpret_cast<const float4*>(sAct + q * 4), h4 = *reinterpret_cast<const float4*>(sAct + CIN + q * 4);
+        float4 v = pre_p[j];
+        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = v;
+#else
         *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = pre_p[j];
+#endif
       }
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
@@ -400,7 +482,11 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         float o[L], dww[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
+#ifndef MWW_NO_COMMIT_ACT
+        dw_chunk<K, L, false, false>(sP, CPI, chunk * L, c, dww, dwb, o);
+#else
         dw_chunk<K, L, false, true>(sP, CPI, chunk * L, c, dww, dwb, o, sc_c, sh_c);
+#endif
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int tl = chunk * L + t;
@@ -444,15 +530,26 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         for (int t = 0; t < L; ++t) {
           const int sl = cch * L + t;
           // (row TT of the last chunk belongs to the next tile: its da is still partial)
+#ifndef MWW_NO_COMMIT_ACT
+          const float gg = (sl < rows_da && raw[t] > 0.f) ? da[t] : 0.f;   // raw = the activated value here
+          tile_store1s<SB>(gtile, goff + t * CIN, gg);
+          gs1 += gg;
+          gs2 = fmaf(gg, fmaf(raw[t], xk1, xk0), gs2);
+#else
           const float gg = (sl < rows_da && fmaf(raw[t], sc_c, sh_c) > 0.f) ? da[t] : 0.f;
           tile_store1s<SB>(gtile, goff + t * CIN, gg);
           gs1 += gg;
           gs2 = fmaf(gg, (raw[t] - mu_c) * rs_c, gs2);
+#endif
         }
       }
       if (cch * L < nrows_new)   // du = 0 past the sample's last output row
         depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
+#ifndef MWW_NO_COMMIT_ACT
+                                               [&](int row) { return sP[row * CPI + c]; });
+#else
                                                [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
+#endif
     }
     MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
     if (!MWW_ABLATE(a, 8)) __syncthreads();
@@ -590,11 +687,10 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
       mg = a.k_mg[i];
       mgx = a.k_mgx[i];
     }
-    sKp[0 * COUT + i] = kmean;
-    sKp[1 * COUT + i] = krs;
-    sKp[2 * COUT + i] = c1;
-    sKp[3 * COUT + i] = mg;
-    sKp[4 * COUT + i] = mgx;
+    const float kA = -c1 * krs * mgx;
+    sKp[0 * COUT + i] = c1;
+    sKp[1 * COUT + i] = kA;
+    sKp[2 * COUT + i] = -c1 * mg - kA * kmean;
     sKp[5 * COUT + i] = 0.f;
     sKp[6 * COUT + i] = 0.f;
   }
@@ -671,18 +767,31 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) 
     }
     __syncthreads();
     // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s*S + m/40][m%40], B[k=s][n] = g0[s][n]
+    // (operands one k-step ahead of their MFMAs, schedule pinned: see pointwise_backward_tile)
+    {
+      float av[2][MPW], bv[2][NT1];
+      auto load_w1 = [&](int kk, int sl) {
+        const int s = kk * 4 + g;
 #pragma unroll
-    for (int kk = 0; kk < TT / 4; ++kk) {
-      const int s = kk * 4 + g;
-      float bv[NT1];
+        for (int nt = 0; nt < NT1; ++nt) bv[sl][nt] = sG0[s * CPI + nt * 16 + r16];
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) bv[nt] = sG0[s * CPI + nt * 16 + r16];
+        for (int mi = 0; mi < MPW; ++mi) {
+          const float v = sX[s * S * PX + offm[mi]];   // (rows past M1 read offset 0 and are zeroed: no conditional load)
+          av[sl][mi] = okm[mi] ? v : 0.f;
+        }
+      };
+      load_w1(0, 0);
 #pragma unroll
-      for (int mi = 0; mi < MPW; ++mi) {
-        const float av = okm[mi] ? sX[s * S * PX + offm[mi]] : 0.f;
+      for (int kk = 0; kk < TT / 4; ++kk) {
+        if (kk + 1 < TT / 4) load_w1(kk + 1, (kk + 1) & 1);
 #pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av, bv[nt], w1acc[mi][nt]);
+        for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+          for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[kk & 1][mi], bv[kk & 1][nt], w1acc[mi][nt]);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, MPW + NT1, 0);
+      sched_read_mfma_groups<TT / 4 - 1, MPW + NT1, MPW * NT1>();
+      sched_read_mfma_groups<1, 0, MPW * NT1>();
     }
     __syncthreads();
   }
