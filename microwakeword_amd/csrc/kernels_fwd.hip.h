@@ -439,15 +439,26 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
     // first conv as im2col GEMM: A[row][k] = x[row*S + k/40][k%40]; a0 rows past the sample are zero
     {
       const BufRsrc a0s = tile_rsrc(a.a0 ? a.a0 + (size_t)b * Ta * C1 : nullptr, a.a0 ? Ta * C1 * 4 : 0);
-      for (int rt = wave / NT1; rt < RT1; rt += 4 / NT1) {
-        f32x4 acc = zero4();
-        const float* xr = sX + (rt * 16 + r16) * S * PX + g;
+      // the wave's row tiles advance together through the k-steps: independent accumulator chains (one chain is a
+      // sequence of MFMAs each waiting for the one before it) that share the weight fragment of the k-step
+      constexpr int RSTEP = 4 / NT1, RPW = RT1 / RSTEP;
+      static_assert(4 % NT1 == 0 && RT1 % RSTEP == 0, "row tiles must divide among the waves");
+      f32x4 acc[RPW];
 #pragma unroll
-        for (int kk = 0; kk < KS1; ++kk) acc = mfma4(xr[(kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc);
+      for (int i = 0; i < RPW; ++i) acc[i] = zero4();
+      const float* xr = sX + ((wave / NT1) * 16 + r16) * S * PX + g;
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+          acc[i] = mfma4(xr[i * RSTEP * 16 * S * PX + (kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc[i]);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int rt = wave / NT1 + i * RSTEP;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = rt * 16 + g * 4 + r;
-          const float v = (row < rows_a) ? fmaxf(acc[r], 0.f) : 0.f;
+          const float v = (row < rows_a) ? fmaxf(acc[i][r], 0.f) : 0.f;
           sA[(K - 1 + row) * CP1 + nt1 * 16 + r16] = v;
           tile_store1(a0s, ((t0 + row) * C1 + nt1 * 16 + r16) * 4, v);
         }
