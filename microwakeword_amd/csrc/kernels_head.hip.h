@@ -78,25 +78,29 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   const float bias = a.bd[0];
   float4 g1 = make_float4(0, 0, 0, 0), g2 = g1;
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    float4 raw[JMAX], wdv[JMAX];
-    float dot = 0.f;
+  // The dense kernel rows of this thread are the same for every window: loaded once.  A window's rows are fetched while
+  // the previous window is reduced (its label / weight too: thread 0 used to load them after the reduction, a second
+  // round trip per window on the critical path).  Rows past T read as zeros through the buffer resource.
+  float4 wdv[JMAX];
+  {
+    const BufRsrc wr = tile_rsrc(a.wd, active ? a.T * C * 4 : 0);
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      const int t = rg + NRG * j;
-      raw[j] = make_float4(0, 0, 0, 0);
-      wdv[j] = raw[j];
-      if (active && t < a.T) {
-        if constexpr (SB) {
-          const uint2 v = *reinterpret_cast<const uint2*>(elem_ptr<SB>(a.p, ((size_t)b * a.T + t) * C + q * 4));
-          raw[j] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                               __uint_as_float(v.y & 0xffff0000u));
-        } else {
-          raw[j] = *reinterpret_cast<const float4*>(a.p + ((size_t)b * a.T + t) * C + q * 4);
-        }
-        wdv[j] = *reinterpret_cast<const float4*>(a.wd + (size_t)t * C + q * 4);
-      }
-    }
+    for (int j = 0; j < JMAX; ++j) wdv[j] = tile_load4(wr, ((rg + NRG * j) * C + q * 4) * 4);
+  }
+  auto fetch = [&](int b, float4 (&dst)[JMAX], float& yy, float& ww) {
+    const bool ok = b < a.B;
+    const BufRsrc pr = tile_rsrc(elem_ptr<SB>(a.p, (size_t)(ok ? b : 0) * a.T * C), (ok && active) ? a.T * C * elem_bytes(SB) : 0);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) dst[j] = tile_load4s<SB>(pr, (rg + NRG * j) * Q + q);
+    yy = (ok && a.y != nullptr) ? a.y[b] : 0.f;
+    ww = (ok && a.y != nullptr && (a.training & kHeadTraining)) ? a.sw[b] : 0.f;
+  };
+  float4 raw[JMAX], nxt[JMAX];
+  float y_cur = 0.f, w_cur = 0.f, y_nxt = 0.f, w_nxt = 0.f;
+  fetch(blockIdx.x, raw, y_cur, w_cur);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    float dot = 0.f;
+    fetch(b + gridDim.x, nxt, y_nxt, w_nxt);
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
       // rows past T hold raw = 0 and wd = 0: relu(shift)*0 contributes nothing
@@ -115,11 +119,11 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
       a.prob[b] = pr;
       float dzz = 0.f;
       if (a.y != nullptr) {
-        const float yy = a.y[b];
+        const float yy = y_cur;
         const bool clipped_form = (a.training & kHeadClippedLoss) != 0;
         const float bce = bce_value(zz, pr, yy, clipped_form);
         if (a.training & kHeadTraining) {
-          const float w = a.sw[b];
+          const float w = w_cur;
           a.loss_part[b] = w * bce * a.inv_b;
           dzz = w * bce_dz(pr, yy, clipped_form) * a.inv_b;
           a.dz[b] = dzz;
@@ -145,6 +149,10 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
       }
     }
     // sRed / sBcast are rewritten only after the next window's first barrier
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) raw[j] = nxt[j];
+    y_cur = y_nxt;
+    w_cur = w_nxt;
   }
   if (a.training & kHeadTraining) {
     if (active) {
