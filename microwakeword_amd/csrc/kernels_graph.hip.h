@@ -211,35 +211,15 @@ struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - x
 // staging helpers
 // A window's slab of a source is staged in ONE memory round trip wherever the layout allows: thread <-> (group of V
 // adjacent channels, frame group) with V = 4 / 2 / 1 floats per load (V divides the slice width, its offset and the
-// producer's row length, so every load is naturally aligned), kGB rows in flight per thread, row indices clamped instead
-// of predicated (every load of a batch is issued before the first use; the round-2 profile showed these kernels to be
-// chains of dependent round trips: 12-32 us per launch for a single window per workgroup).
+// producer's row length, so every load is naturally aligned), at most 16 floats per thread and tensor in flight, every
+// load of a batch issued before the first use (the round-2 profile showed these kernels to be chains of dependent round
+// trips: 12-32 us per launch for a single window per workgroup).  The loads go through a buffer resource over the
+// window's slab: workgroup-uniform base in scalar registers, one 32-bit offset register per load, elements past the slab
+// read as 0 - no clamp, no predicate, no 64-bit address pair per load in flight.
 template <int V>
 struct GVec {
   float f[V];
 };
-template <int V>
-__device__ __forceinline__ GVec<V> gvec_load(const float* p) {
-  GVec<V> r;
-  if constexpr (V == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    r.f[0] = t.x; r.f[1] = t.y; r.f[2] = t.z; r.f[3] = t.w;
-  } else if constexpr (V == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    r.f[0] = t.x; r.f[1] = t.y;
-  } else {
-    r.f[0] = *p;
-  }
-  return r;
-}
-template <int V>
-__device__ __forceinline__ void gvec_store(float* p, const GVec<V>& r) {
-  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.f[0], r.f[1], r.f[2], r.f[3]);
-  else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(r.f[0], r.f[1]);
-  else *p = r.f[0];
-}
-// ... through a buffer resource over the window's slab (workgroup-uniform base in scalar registers, one 32-bit offset
-// register per load, elements past the slab read as 0: no clamp, no 64-bit address pair per load in flight)
 template <int V>
 __device__ __forceinline__ GVec<V> gvec_bload(BufRsrc r, int elem) {
   GVec<V> o;
@@ -650,8 +630,7 @@ struct GWgradArgs {
   GBnBwd y;
   int k, dil, cin, B, Tin, Tout;
   int stride;           // time stride of the forward convolution
-  int nq;               // frame subsets per (tap, channel) task: nq * k * cin <= 256
-  float* grad_part;     // [grid * nq][k*cin*NC]
+  float* grad_part;     // [workgroups of the role][k*cin*NC]
 };
 
 // On the matrix cores: dW = A^T B with A[t][m] = act[t*stride + j*dil][ci] (m = j*cin + ci, the "task" axis) and

@@ -65,7 +65,6 @@ struct GOp {
   std::vector<int> adders;           // (residual ops) the ops that add this one
   int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
-  int nq = 1;                 // frame subsets of the weight-gradient mapping
   bool needs_dx = false;
   bool twin_next = false;     // op i+1 is an independent op of the same shape: the pair shares its launches
   size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
@@ -1282,7 +1281,6 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     w.B = B;
     w.Tin = q.tin;
     w.Tout = q.tout;
-    w.nq = q.nq;
     w.grad_part = q.grad_part;
     return w;
   };
@@ -1412,7 +1410,6 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     w.B = B;
     w.Tin = o.tin;
     w.Tout = o.tout;
-    w.nq = o.nq;
     w.grad_part = o.grad_part;
     GConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1797,12 +1794,10 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       o.lds_fwd = (wsz + (size_t)o.tin * pi) * sizeof(float);
       o.lds_dx = o.needs_dx ? (wsz + (size_t)(o.tout + 2 * pad) * pi) * sizeof(float) : 0;
       o.lds_wg = ((size_t)o.tin * pi + (size_t)o.tout * pi) * sizeof(float);
-      o.nq = 1;
     } else {
       if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
       if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
       if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
-      o.nq = 1;
       // LDS tiles of the MFMA kernels (kernels_graph.hip.h): weights [k][cin4][NCW] zero-padded to whole k-steps / filter tiles
       auto up4 = [](int v) { return (size_t)((v + 3) & ~3); };
       auto up16 = [](int v) { return (size_t)((v + 15) / 16 * 16); };
