@@ -242,7 +242,9 @@ __device__ __forceinline__ int gvec_width(int C, int ld, int c0) {
 template <int V>
 __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows, float* sIn, int PI, int c0out, int tid,
                                                  const float* cscale, const float* cshift) {
-  const int NQ = s.C / V, nrg = kThreads / NQ, q = tid % NQ, rg = tid / NQ;
+  const int NQ = s.C / V, nrg = fast_div(kThreads, NQ);
+  int q, rg;
+  fast_divmod(tid, NQ, rg, q);
   if (rg >= nrg) return;
   const bool ident = (s.flags & GSRC_IDENTITY) != 0;
   float sc[V], sh[V];
@@ -320,7 +322,9 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
 // dp = BN backward of the op's output gradient, rows [0, rows) of window b -> dst[t * ld + c]
 template <int V>
 __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab) {
-  const int NQ = C / V, nrg = kThreads / NQ, q = tid % NQ, rg = tid / NQ;
+  const int NQ = C / V, nrg = fast_div(kThreads, NQ);
+  int q, rg;
+  fast_divmod(tid, NQ, rg, q);
   if (rg >= nrg) return;
   const bool folded = btab != nullptr && y.fold.acc != nullptr;
   float mu[V], rs[V], c1[V], mg[V], mgx[V];
@@ -366,7 +370,9 @@ __device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows
 // per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][ld] of this workgroup
 // (columns [0, C) of each statistic's row; ld = C unless the channels are a slice of a wider tensor)
 __device__ __forceinline__ void write_channel_partials(float s1, float s2, int C, float* sRed, float* part, int tid, int ld) {
-  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  const int nrg = fast_div(kThreads, C);
+  int c, rg;
+  fast_divmod(tid, C, rg, c);
   __syncthreads();
   if (rg < nrg) {
     sRed[(rg * 2 + 0) * C + c] = s1;
@@ -376,7 +382,7 @@ __device__ __forceinline__ void write_channel_partials(float s1, float s2, int C
   if (tid < 2 * C) {
     float v = 0.f;
     for (int r = 0; r < nrg; ++r) v += sRed[r * 2 * C + tid];
-    part[(tid / C) * ld + (tid % C)] = v;
+    part[(tid >= C ? ld - C : 0) + tid] = v;   // (tid / C) * ld + tid % C for tid < 2 C
   }
 }
 
@@ -389,7 +395,9 @@ __device__ __forceinline__ void publish_channel_partials(float s1, float s2, int
     write_channel_partials(s1, s2, C, sRed, part, tid, ld);
     return;
   }
-  const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+  const int nrg = fast_div(kThreads, C);
+  int c, rg;
+  fast_divmod(tid, C, rg, c);
   __syncthreads();
   if (rg < nrg) {
     sRed[(rg * 2 + 0) * C + c] = s1;
@@ -399,7 +407,7 @@ __device__ __forceinline__ void publish_channel_partials(float s1, float s2, int
   if (tid < 2 * C) {
     float v = 0.f;
     for (int r = 0; r < nrg; ++r) v += sRed[r * 2 * C + tid];
-    const size_t col = (size_t)(tid / C) * ld + c0 + (tid % C);
+    const size_t col = (size_t)((tid >= C ? ld - C : 0) + c0 + tid);   // (tid / C) * ld + c0 + tid % C for tid < 2 C
     unsafeAtomicAdd(acc.acc + (size_t)(bid % kStatRows) * 2 * ld + col, (double)v);
     for (int r = bid; r < kStatRows; r += nb) acc.clear[(size_t)r * 2 * ld + col] = 0.0;
   }
@@ -472,7 +480,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
 #pragma unroll
       for (int u = 0; u < kWB; ++u) {
         const int i = i0 + u * kThreads;
-        const int co = i % NCW, rest = i / NCW, ci = rest % cin4, j = rest / cin4;
+        const int co = i % NCW, rest = i / NCW;   // (compile-time divisor)
+        int ci, j;
+        fast_divmod(rest, cin4, j, ci);
         const bool real = i < nw && co < NC && ci < a.cin;
         const int src = min((j * a.cin + ci) * NC + co, nreal - 1);
         wv[u] = a.w[real ? src : 0];
@@ -553,7 +563,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         const GSrc& s = a.src[i];
         const int C = s.C;
         if (s.flags & GSRC_GRAD) {
-          const int nrg = kThreads / C, c = tid % C, rg = tid / C;
+          const int nrg = fast_div(kThreads, C);
+          int c, rg;
+          fast_divmod(tid, C, rg, c);
           if (rg < nrg) {
             const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
             const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
@@ -664,7 +676,9 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 #pragma unroll
   for (int u = 0; u < kGWgTilesPerWave; ++u) {
     const int m = min((slot + u * nslot) * 16 + r16, tasks - 1);
-    offA[u] = (m / a.cin) * a.dil * PI + (m % a.cin);
+    int mj, mc;
+    fast_divmod(m, a.cin, mj, mc);
+    offA[u] = mj * a.dil * PI + mc;
   }
   f32x4 acc[kGWgTilesPerWave][NT];
 #pragma unroll
