@@ -289,3 +289,42 @@ def test_local_bn_two_ranks_with_product_kernels(tmp_path):
     p1 = p0 - alpha * m / (np.sqrt(v) + 1e-7)
     well = np.abs(gavg) > 1e-4 * np.abs(gavg).max()
     assert np.abs(outs[0]["params"] - p1)[well].max() <= 0.05 * 1e-3
+
+
+def test_local_bn_two_ranks_inception_graph_kernels(tmp_path):
+    """The conv/BN graph engine under the exchange hook with rank-local BatchNorm: the statistics hand-over (no finalize
+    launches) and the gradient exchange in one step.  Two ranks x 3 windows of the default Inception graph (host-emulated
+    product kernels) against two single-rank oracle passes summed by hand; identical reduced gradient and weights on both
+    ranks, rank-local moving statistics."""
+    import conftest
+    import engine_checks as ec
+    from microwakeword_amd.layout import InceptionLayout
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W, Bl = 2, 3
+    rng = np.random.default_rng(4)
+    x = ec.synth_x(rng, W * Bl, T)
+    y = (rng.random(W * Bl) < 0.5).astype(np.float32)
+    w = rng.choice([0.5, 1.0, 2.0], size=W * Bl).astype(np.float32)
+    lay = InceptionLayout(ec.INC, T)
+    last = lay.engine_args(1)["conv_ops"][-1]
+    keep = (rng.random((W * Bl, last["tout"] * last["filters"])) > 0.2)
+    np.savez(tmp_path / "inputs.npz", x=x, y=y, w=w, keep=keep)
+    mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "inception", False), nprocs=W, join=True)
+    outs = [np.load(tmp_path / ("out%d.npz" % r)) for r in range(W)]
+    np.testing.assert_array_equal(outs[0]["grads"], outs[1]["grads"])
+    np.testing.assert_array_equal(outs[0]["params"], outs[1]["params"])
+    assert np.abs(outs[0]["state"] - outs[1]["state"]).max() > 0
+    gsum = 0.0
+    for r in range(W):
+        om = ec.perturbed_inception_oracle(T, ec.INC)
+        sl = slice(r * Bl, (r + 1) * Bl)
+        _, _, grads, _ = om.loss_and_grads(x[sl], y[sl], w[sl], dropout_mask=keep[sl])
+        gsum = gsum + lay.pack([grads[n].numpy().astype(np.float32) if k == "param" else np.zeros(sh, np.float32)
+                                for n, sh, k in lay.keras_vars])[0].astype(np.float64)
+        om.train_step(x[sl], y[sl], w[sl], 1e-3, dropout_mask=keep[sl])
+        s_ref = lay.pack(om.get_weights())[1]
+        assert np.abs(outs[r]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+    g = outs[0]["grads"].astype(np.float64)
+    assert np.linalg.norm(g - gsum) <= 2e-3 * np.linalg.norm(gsum)
