@@ -1706,7 +1706,7 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
     A(dev_alloc(&l.g, mb * l.tout * l.cout));
     A(dev_alloc(&l.stat_part, (size_t)gmax_f * 2 * l.cout));
-    A(dev_alloc(&l.gstat_part, (size_t)std::max(gmax_b, gmax_h) * 2 * l.cout));
+    A(dev_alloc(&l.gstat_part, (size_t)std::max(gmax_b, c->n_cu * 4) * 2 * l.cout));
     for (int par = 0; par < 2; ++par) {
       A(dev_alloc(&l.facc[par], (size_t)kStatRows * 2 * l.cout));
       A(dev_alloc(&l.gacc[par], (size_t)kStatRows * 2 * l.cout));
@@ -1958,7 +1958,7 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     A(dev_alloc(&o.g, mb * o.tout * o.cout));
     A(dev_alloc(&o.stat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
-    A(dev_alloc(&o.grad_part, (size_t)c->grid_g * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));
+    A(dev_alloc(&o.grad_part, (size_t)gmax * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));   // ("grid_graph" may be raised to gmax)
     A(dev_alloc(&o.bn, (size_t)9 * o.cout));
     for (int par = 0; par < 2; ++par) {
       A(dev_alloc(&o.facc[par], (size_t)kStatRows * 2 * o.cout));
