@@ -35,8 +35,10 @@
 namespace mww {
 
 constexpr int kGMaxSrc = 3;
-constexpr int kGB = 8;    // rows a thread keeps in flight in the staging loops (32 measured slower: 1.09 -> 1.65 ms/step)
-constexpr int kGE = 8;    // ... and in the data-gradient epilogue
+constexpr int kGB = 4;    // rows a thread keeps in flight in the staging loops and in the data-gradient epilogue: same-session A/B of
+                          // the Inception step, 2 / 4 / 8 / 12 rows = 1.112 / 1.079 / 1.108 / 1.134 ms (4 keeps the fused backward kernels at
+                          // <= 128 VGPRs = four resident workgroups per CU; 32 rows: 1.65 ms)
+constexpr int kGE = 4;
 enum { GSRC_IDENTITY = 1, GSRC_ACCUM = 2, GSRC_STATS = 4, GSRC_GRAD = 8, GSRC_LINEAR = 16 };   // LINEAR: affine only, no ReLU
 
 struct GSrc {
