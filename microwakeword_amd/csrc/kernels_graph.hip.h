@@ -11,7 +11,7 @@
 //
 // Mapping (all kernels: 256-thread workgroups that own whole windows, grid-stride over the batch):
 //   * staging: thread -> (group of 4 / 2 / 1 adjacent channels, frame group), buffer loads over the window's slab
-//     (workgroup-uniform descriptor, 32-bit lane offsets, at most 16 floats per thread and tensor in flight: these
+//     (workgroup-uniform descriptor, 32-bit lane offsets, kGB rows per thread and tensor in flight: these
 //     kernels are chains of memory round trips with a handful of windows per CU, so what counts is how many
 //     workgroups are resident - registers are occupancy here);
 //   * convolution: v_mfma_f32_16x16x4_f32 (exact fp32), per tap a [16 frames] x [4 channels] A tile of the window in LDS
@@ -213,7 +213,7 @@ struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - x
 // staging helpers
 // A window's slab of a source is staged in ONE memory round trip wherever the layout allows: thread <-> (group of V
 // adjacent channels, frame group) with V = 4 / 2 / 1 floats per load (V divides the slice width, its offset and the
-// producer's row length, so every load is naturally aligned), at most 16 floats per thread and tensor in flight, every
+// producer's row length, so every load is naturally aligned), kGB rows per thread and tensor in flight, every
 // load of a batch issued before the first use (the round-2 profile showed these kernels to be chains of dependent round
 // trips: 12-32 us per launch for a single window per workgroup).  The loads go through a buffer resource over the
 // window's slab: workgroup-uniform base in scalar registers, one 32-bit offset register per load, elements past the slab
@@ -258,7 +258,7 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
   const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
   const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0, ((rows - 1) * s.ld + s.C) * 4);
   float* dst = sIn + c0out + q * V;
-  constexpr int NB = V == 4 ? kGB / 2 : kGB;   // rows in flight: at most 16 floats per thread and tensor (these kernels live on
+  constexpr int NB = kGB;   // rows in flight (these kernels live on
                                                // the number of resident workgroups: registers are occupancy)
   for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
     GVec<V> v[NB];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int 
     mgx[e] = folded ? btab[2 * kGFoldC + c] : y.mgx[c];
   }
   const BufRsrc gslab = tile_rsrc(y.g + (size_t)b * rows * C, rows * C * 4), pslab = tile_rsrc(y.p + (size_t)b * rows * C, rows * C * 4);
-  constexpr int NB = V == 4 ? kGB / 2 : kGB;
+  constexpr int NB = kGB;
   for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
     GVec<V> g[NB], p[NB];
 #pragma unroll
@@ -473,9 +473,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     gfold_backward_load(a.y.fold, a.cin, a.y.rstd, tid, fr);
   }
   {
-    // (eight elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
-    // them in a row for the 5 x 40 x 24 stem)
-    constexpr int kWB = 8;
+    // (four elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
+    // them in a row for the 5 x 40 x 24 stem; most ops have two elements per thread, and every predicated-off slot of a
+    // wider batch still pays its index arithmetic: 16 / 8 / 4 / 2 / 1 per batch = 1.090 / 1.074 / 1.064 / 1.068 / 1.065 ms
+    // per Inception step in same-session A/B)
+    constexpr int kWB = 4;
     const int nw = a.k * cin4 * NCW, nreal = a.k * a.cin * NC;
     for (int i0 = tid; i0 < nw; i0 += kWB * kThreads) {
       float wv[kWB];
