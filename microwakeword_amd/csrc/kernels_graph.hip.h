@@ -575,33 +575,63 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
             const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
             const bool linear = (s.flags & GSRC_LINEAR) != 0;
             const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
-            const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
-            const float rsc = s.rp ? s.rscale[c] : 0.f, rsh = s.rp ? s.rshift[c] : 0.f;
-            const float* rbase = s.rp ? s.rp + ((size_t)b * s.rT + s.rdrop) * C + c : nullptr;
             float t1 = 0.f, t2 = 0.f;
-            for (int tb = rg; tb < s.T; tb += kGE * nrg) {
-              float pv[kGE], rvv[kGE], gold[kGE];
+            if (!s.rp) {
+              // the slice's rows of p and g through buffer resources over the window's slab: 32-bit lane offsets, no
+              // predicate around a load (rows past the window read 0 and their stores are dropped; a first consumer reads
+              // its "old" gradient through an empty resource = 0)
+              const size_t woff = (size_t)b * s.T * s.ld + s.c0;
+              const int wbytes = ((s.T - 1) * s.ld + C) * 4;
+              const BufRsrc pr = tile_rsrc(s.p + woff, wbytes), gr = tile_rsrc(s.g + woff, wbytes), go = tile_rsrc(s.g + woff, accum ? wbytes : 0);
+              for (int tb = rg; tb < s.T; tb += kGE * nrg) {
+                float pv[kGE], gold[kGE];
 #pragma unroll
-              for (int u = 0; u < kGE; ++u) {
-                const int t = tb + u * nrg;
-                const bool ok = t < s.T;
-                const size_t idx = base + (size_t)(ok ? t : 0) * s.ld;
-                pv[u] = ok ? s.p[idx] : 0.f;
-                rvv[u] = (ok && rbase) ? rbase[(size_t)t * C] : 0.f;
-                gold[u] = (ok && accum) ? s.g[idx] : 0.f;
+                for (int u = 0; u < kGE; ++u) {
+                  const int off = ((tb + u * nrg) * s.ld + c) * 4;
+                  pv[u] = tile_load1(pr, off);
+                  gold[u] = tile_load1(go, off);
+                }
+#pragma unroll
+                for (int u = 0; u < kGE; ++u) {
+                  const int t = tb + u * nrg;
+                  if (t < s.T) {
+                    const float p = pv[u];
+                    const int r = t - s.toff;
+                    const float gv = ((r >= 0 && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f) + gold[u];
+                    tile_store1(gr, (t * s.ld + c) * 4, gv);
+                    t1 += gv;
+                    t2 = fmaf(gv, (p - mu) * rs, t2);
+                  }
+                }
               }
+            } else {
+              // producer with a residual branch (MixedNet residual_connection): two tensors decide the ReLU mask
+              const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
+              const float rsc = s.rscale[c], rsh = s.rshift[c];
+              const float* rbase = s.rp + ((size_t)b * s.rT + s.rdrop) * C + c;
+              for (int tb = rg; tb < s.T; tb += kGE * nrg) {
+                float pv[kGE], rvv[kGE], gold[kGE];
 #pragma unroll
-              for (int u = 0; u < kGE; ++u) {
-                const int t = tb + u * nrg;
-                if (t < s.T) {
+                for (int u = 0; u < kGE; ++u) {
+                  const int t = min(tb + u * nrg, s.T - 1);
                   const size_t idx = base + (size_t)t * s.ld;
-                  const float p = pv[u];
-                  const int r = t - s.toff;
-                  float gv = (r >= 0 && (linear || src_affine(s, p, sc, sh, rvv[u], rsc, rsh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
-                  if (accum) gv += gold[u];
-                  s.g[idx] = gv;
-                  t1 += gv;
-                  t2 = fmaf(gv, (p - mu) * rs, t2);
+                  pv[u] = s.p[idx];
+                  rvv[u] = rbase[(size_t)t * C];
+                  gold[u] = accum ? s.g[idx] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kGE; ++u) {
+                  const int t = tb + u * nrg;
+                  if (t < s.T) {
+                    const size_t idx = base + (size_t)t * s.ld;
+                    const float p = pv[u];
+                    const int r = t - s.toff;
+                    float gv = (r >= 0 && (linear || src_affine(s, p, sc, sh, rvv[u], rsc, rsh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f;
+                    gv += gold[u];
+                    s.g[idx] = gv;
+                    t1 += gv;
+                    t2 = fmaf(gv, (p - mu) * rs, t2);
+                  }
                 }
               }
             }
