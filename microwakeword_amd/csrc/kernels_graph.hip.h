@@ -1172,6 +1172,17 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const float rsc = (active && a.rp) ? a.rscale[c] : 0.f, rsh = (active && a.rp) ? a.rshift[c] : 0.f;
   const float bias = a.bd[0];
   float g1 = 0.f, g2 = 0.f;
+  // Register-resident path (windows with at most kHR rows per thread and no residual branch: Inception's head): a window's
+  // rows are loaded once (buffer loads, no predicate) and stay in registers for the backward half; the dense kernel rows
+  // of the thread are loaded once per workgroup.
+  constexpr int kHR = 12;
+  const bool fast = a.rp == nullptr && (a.T + nrg - 1) / nrg <= kHR;
+  float wvf[kHR];
+  if (fast) {
+    const BufRsrc wrs = tile_rsrc(a.wd, active ? n * 4 : 0);
+#pragma unroll
+    for (int u = 0; u < kHR; ++u) wvf[u] = tile_load1(wrs, ((rg + u * nrg) * C + c) * 4);
+  }
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* pb = a.p + (size_t)b * n;
     const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
@@ -1181,7 +1192,32 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     // rows in batches of kHB per thread: every load of a batch is issued before the first use (one load, one wait per
     // row made this kernel a chain of ~2 T C / 256 memory round trips per window: 51 us per launch for 10 MB in round 2)
     constexpr int kHB = 8;
-    if (active) {
+    float pvf[kHR], kvf[kHR];
+    if (fast) {
+      const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
+      const BufRsrc prs = tile_rsrc(pb, active ? n * 4 : 0), krs = tile_rsrc(kb, (active && kb && !kgen) ? n * 4 : 0);
+#pragma unroll
+      for (int u = 0; u < kHR; ++u) {
+        const int off = ((rg + u * nrg) * C + c) * 4;
+        pvf[u] = tile_load1(prs, off);
+        kvf[u] = tile_load1(krs, off);
+      }
+#pragma unroll
+      for (int u = 0; u < kHR; ++u) {
+        const int t = rg + u * nrg;
+        if (active && t < a.T) {
+          const int i = t * C + c;
+          const float act = fmaxf(fmaf(pvf[u], sc, sh), 0.f);
+          float k1 = (kb && !kgen) ? kvf[u] : 1.f;
+          if (kgen) {
+            k1 = dropout_keep(a.seed, step, (unsigned long long)b * n + i, a.rate);
+            kgen[i] = k1;   // read by the dense-weight gradient
+          }
+          kvf[u] = k1;
+          dot = fmaf(act * k1, wvf[u], dot);
+        }
+      }
+    } else if (active) {
       const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
       for (int t0 = rg; t0 < a.T; t0 += kHB * nrg) {
         float pv[kHB], wv[kHB], rv[kHB], kv[kHB];
@@ -1235,7 +1271,21 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       sBcast[0] = dzz;
     }
     __syncthreads();
-    if ((a.training & kHeadTraining) && active) {
+    if ((a.training & kHeadTraining) && active && fast) {
+      const float dzz = sBcast[0];
+      const BufRsrc grs = tile_rsrc(a.g + (size_t)b * n, n * 4);
+#pragma unroll
+      for (int u = 0; u < kHR; ++u) {
+        const int t = rg + u * nrg;
+        if (t < a.T) {
+          const float raw = pvf[u];
+          const float gv = (fmaf(raw, sc, sh) > 0.f ? dzz * wvf[u] : 0.f) * kvf[u];
+          tile_store1(grs, (t * C + c) * 4, gv);
+          g1 += gv;
+          g2 = fmaf(gv, (raw - mu) * rs, g2);
+        }
+      }
+    } else if ((a.training & kHeadTraining) && active) {
       const float dzz = sBcast[0];
       float* gb = a.g + (size_t)b * n;
       for (int t0 = rg; t0 < a.T; t0 += kHB * nrg) {
