@@ -18,7 +18,7 @@
 //     (odd row pitch) against a [4 channels] x [16 filters] B tile of the zero-padded weights in LDS; the four waves
 //     deal the window's 16-frame tiles among themselves;
 //   * the data gradient is the same convolution run on the BN-backward-transformed output gradient
-//     with reversed taps and transposed weights (gweights_transpose_kernel), its epilogue scatters
+//     with reversed taps and transposed weights (read in place from the forward weights), its epilogue scatters
 //     into the sources' gradient tensors (first consumer stores, later ones accumulate, the last one
 //     also produces the BN statistics of that source);
 //   * the weight gradient is dW = A^T B on the matrix cores with the (tap, input channel) tasks as rows, the filters as
@@ -420,7 +420,7 @@ __device__ __forceinline__ void publish_channel_partials(float s1, float s2, int
 struct GConvArgs {
   GSrc src[kGMaxSrc];
   int n_src;
-  const float* w;       // MODE 0: [k][cin][NC];  MODE 1: reversed taps, transposed: [k][cin = fwd cout][NC = fwd cin]
+  const float* w;       // the op's weights [k][fwd cin][fwd cout] (MODE 0: cin = fwd cin, NC = fwd cout; MODE 1: cin = fwd cout, NC = fwd cin)
   int k, dil, cin;      // cin = channels reduced over
   int stride;           // MODE 0 only: time stride (ops fed by the spectrogram, e.g. MixedNet's first conv); else 1
   int B;
@@ -488,7 +488,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         int ci, j;
         fast_divmod(rest, cin4, j, ci);
         const bool real = i < nw && co < NC && ci < a.cin;
-        const int src = min((j * a.cin + ci) * NC + co, nreal - 1);
+        // MODE 1 reads the forward weights [k][fwd cin = NC][fwd cout = cin] as its transposed, tap-reversed operand in
+        // place (a separate transpose launch per step used to prepare a copy)
+        const int src = min(MODE == 0 ? (j * a.cin + ci) * NC + co : ((a.k - 1 - j) * NC + co) * a.cin + ci, nreal - 1);
         wv[u] = a.w[real ? src : 0];
         if (!real) wv[u] = 0.f;
       }
@@ -965,22 +967,6 @@ __global__ __launch_bounds__(kThreads) void gres_gather_kernel(GResGatherArgs a)
   write_channel_partials(s1, s2, C, sRed, a.gstat_part + (size_t)blockIdx.x * 2 * C, tid, C);
 }
 
-// W[k][cin][cout] -> WT[k][cout][cin] with reversed taps, for every op that needs a data gradient
-struct GTransposeItem { int src, dst, k, cin, cout; };
-constexpr int kGMaxOps = 48;
-struct GTransposeArgs {
-  GTransposeItem item[kGMaxOps];
-  const float* params;
-  float* wt;
-};
-// grid = (ceil(max n / 256), items)
-__global__ __launch_bounds__(kThreads) void gweights_transpose_kernel(GTransposeArgs a) {
-  const GTransposeItem it = a.item[blockIdx.y];
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= it.k * it.cin * it.cout) return;
-  const int ci = e % it.cin, co = (e / it.cin) % it.cout, j = e / (it.cin * it.cout);
-  a.wt[it.dst + e] = a.params[it.src + ((it.k - 1 - j) * it.cin + ci) * it.cout + co];
-}
 
 // ---------------------------------------------------------------------------------------------
 // BN / SSN finalize: one workgroup per slot (slot s owns channels s, s+g, s+2g, ... when g > 1)

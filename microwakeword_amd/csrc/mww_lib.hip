@@ -63,7 +63,7 @@ struct GOp {
   int kind = MWW_OP_CONV, stride = 1, norm = MWW_NORM_BN, act = MWW_ACT_RELU;
   int res_src = -1, res_drop = 0;     // residual branch added before this op's activation
   std::vector<int> adders;           // (residual ops) the ops that add this one
-  int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0, o_wt = -1;
+  int64_t o_w = 0, o_gamma = 0, o_beta = 0, o_mm = 0, o_mv = 0;
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   bool needs_dx = false;
   bool twin_next = false;     // op i+1 is an independent op of the same shape: the pair shares its launches
@@ -112,8 +112,6 @@ struct mww_ctx {
   float *hact = nullptr, *watt_part = nullptr;
   size_t lds_head2 = 0;
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
-  float* wt = nullptr;              // transposed weights of the ops with a data gradient
-  int64_t wt_total = 0;
   int grid_g = 0;
   // data-parallel exchange hook (mww_set_allreduce_hook)
   mww_allreduce_fn hook = nullptr;
@@ -1220,24 +1218,6 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   const int n = (int)c->G.size();
   const int gg = std::min(B, c->grid_g);
   const int ghead = std::min(B, c->grid_head);
-  {
-    GTransposeArgs t;
-    memset(&t, 0, sizeof(t));
-    int ni = 0, maxn = 0;
-    for (int i = 0; i < n; ++i) {
-      GOp& o = c->G[i];
-      if (!o.needs_dx || o.kind != MWW_OP_CONV) continue;
-      t.item[ni++] = GTransposeItem{(int)o.o_w, (int)o.o_wt, o.k, o.cin, o.cout};
-      maxn = std::max(maxn, o.k * o.cin * o.cout);
-    }
-    t.params = c->params;
-    t.wt = c->wt;
-    if (ni) {
-      lp.begin("weights_transpose");
-      hipLaunchKernelGGL(gweights_transpose_kernel, dim3((maxn + kThreads - 1) / kThreads, ni), dim3(kThreads), 0, c->stream, t);
-      lp.end();
-    }
-  }
   GradReduceArgs ga;
   memset(&ga, 0, sizeof(ga));
   // statistics hand-over: the op's own backward launch folds (sum g, sum g*xhat) from the accumulator rows its consumers
@@ -1290,7 +1270,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     memset(&a, 0, sizeof(a));
     a.n_src = q.n_src;
     for (int s = 0; s < q.n_src; ++s) a.src[s] = g_make_src(c, oi, s, true, inl);
-    a.w = c->wt + q.o_wt;
+    a.w = c->params + q.o_w;   // (the data-gradient kernel reads them transposed / tap-reversed in place)
     a.k = q.k;
     a.dil = q.dil;
     a.cin = q.cout;
@@ -1416,7 +1396,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     if (o.needs_dx) {
       a.n_src = o.n_src;
       for (int s = 0; s < o.n_src; ++s) a.src[s] = g_make_src(c, i, s, true, inl);
-      a.w = c->wt + o.o_wt;
+      a.w = c->params + o.o_w;
       a.k = o.k;
       a.dil = o.dil;
       a.cin = o.cout;
@@ -1735,7 +1715,7 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   if (!(d.dropout >= 0.f && d.dropout < 1.f)) return fail(MWW_ERR_INVALID, "dropout rate must be in [0, 1)");
   std::vector<GOp> ops(d.n_ops);
   std::vector<int> n_consumers(d.n_ops, 0);
-  int64_t off = 0, soff = 0, wtoff = 0;
+  int64_t off = 0, soff = 0;
   for (int i = 0; i < d.n_ops; ++i) {
     const mww_conv_bn_op& s = d.ops[i];
     GOp& o = ops[i];
@@ -1822,7 +1802,6 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     } else if (o.norm == MWW_NORM_BIAS) {
       o.o_beta = off; off += o.cout;
     }
-    if (o.needs_dx && o.kind == MWW_OP_CONV) { o.o_wt = wtoff; wtoff += (int64_t)o.k * o.cin * o.cout; }
   }
   for (int i = 0; i < d.n_ops; ++i) {
     GOp& o = ops[i];
@@ -1939,14 +1918,12 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   c->o_dense_b = off; off += 1;
   c->P = off;
   c->S = soff;
-  c->wt_total = wtoff;
   c->dwd_stride = c->t_last * lo.cout + 4;
   const size_t mb = (size_t)d.max_batch;
   const int gmax = c->n_cu * 4;
   int rc = 0;
 #define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
   A(alloc_common(c));
-  A(dev_alloc(&c->wt, (size_t)wtoff));
   A(dev_alloc(&c->keep, mb * lo.tout * lo.cout));
   if (c->head2) {
     A(dev_alloc(&c->hact, mb * c->t_last * lo.cout));
@@ -2039,7 +2016,6 @@ void mww_destroy(mww_ctx* c) {
   if (c->watt_part) (void)hipFree(c->watt_part);
   if (c->ones) (void)hipFree(c->ones);
   if (c->zeros) (void)hipFree(c->zeros);
-  if (c->wt) (void)hipFree(c->wt);
   if (c->keep) (void)hipFree(c->keep);
   for (int i = 0; i < MWW_MAX_STORES; ++i) if (c->store[i]) (void)hipFree(c->store[i]);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
