@@ -317,3 +317,20 @@ def test_ragged_store_reader_refuses_anything_but_the_exact_layout(tmp_path):
     r2 = RaggedStoreReader(str(e))
     for i, s in enumerate(samples):
         np.testing.assert_array_equal(r2[i], s)
+
+
+def test_bench_refuses_to_report_a_smaller_job_under_a_bigger_label():
+    """`python bench.py --gpus N` outside a launcher becomes the launcher of N ranks; where fewer GPUs are visible it must
+    fail loudly instead of printing a line with another n_gpus (round-1 verdict: `--gpus 8` ran one rank), and without the
+    HIP library / a GPU the single-rank run must fail as well (no CPU fallback behind the product path)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "GPU(s) are visible" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
