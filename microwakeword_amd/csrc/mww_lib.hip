@@ -222,9 +222,14 @@ struct Launcher {
 
 // ---------------------------------------------------------------------------------- dispatch
 // (conv1 kernel, conv1 filters, block-1 pointwise filters, block-1 depthwise kernel, conv1 stride)
-#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1) X(5, 32, 64, 5, 3) X(5, 32, 64, 5, 1)
+// Shapes with specialised block kernels: the reference's argparse defaults (3x1 first conv, 48 filters, [5],[9],[13],[21]),
+// its training notebook (5x1 first conv stride 3, 64 filters, [5],[7,11],[9,15],[23] - multi-kernel groups are fused to
+// their longest kernel) and the crosses of the two (either width with either kernel set, either first conv); everything
+// else runs on the conv / depthwise graph kernels.
+#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1) X(5, 32, 64, 5, 3) X(5, 32, 64, 5, 1) X(3, 32, 64, 5, 1) X(5, 32, 48, 5, 3) X(5, 32, 48, 5, 1)
 #define MWW_BLOCK_SHAPES(X)                                                                               \
-  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21) X(64, 64, 11) X(64, 64, 15) X(64, 64, 23)
+  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21) X(48, 48, 11) X(48, 48, 15) X(48, 48, 23)         \
+  X(64, 64, 11) X(64, 64, 15) X(64, 64, 23) X(64, 64, 5) X(64, 64, 9) X(64, 64, 13) X(64, 64, 21)
 
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \

@@ -157,6 +157,13 @@ def _lowp(flags):
     return bool(flags.get("pw_bf16") or flags.get("st_bf16"))
 NOTEBOOK = dict(DEF, first_conv_kernel_size=5, stride=3, first_conv_filters=32, pointwise_filters="64,64,64,64",
                 mixconv_kernel_sizes="[5],[7,11],[9,15],[23]")
+# crosses of the two documented topologies that the specialised block kernels also instantiate (either width with either
+# kernel set, either first conv)
+CROSSED = (dict(DEF, mixconv_kernel_sizes="[5],[7,11],[9,15],[23]"),
+           dict(NOTEBOOK, mixconv_kernel_sizes="[5],[9],[13],[21]"),
+           dict(DEF, pointwise_filters="64,64,64,64"),
+           dict(NOTEBOOK, pointwise_filters="48,48,48,48"),
+           dict(NOTEBOOK, stride=1))
 
 
 def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):

@@ -88,6 +88,13 @@ def test_validation_on_device(emu_lib, gold):
     ec.check_validation_on_device(emu_lib, gold, "u16")
 
 
+@pytest.mark.parametrize("which", range(5))
+def test_crossed_topologies_on_the_block_kernels(emu_lib, which):
+    """Either documented width with either kernel set and either first conv: all on the specialised block kernels."""
+    flags = ec.CROSSED[which]
+    ec.check_train_steps(emu_lib, B=3, T=204 if flags.get("stride", 1) == 3 else 150, steps=1, grid=2, flags=flags)
+
+
 def test_bf16_pointwise_mode(emu_lib):
     """BASELINE configs[4]: 1x1 contractions with bf16 operands, against the oracle rounding the same operands."""
     ec.check_forward_parity(emu_lib, B=2, T=111, training=True, grid=2, flags=ec.BF16)

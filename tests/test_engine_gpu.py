@@ -229,6 +229,17 @@ def test_inception_statistics_hand_over_matches_finalize_launches(lib):
     ec.check_inception_bn_inline_matches_finalize(lib, B=6, T=194, steps=2, fuse_heads=False)
 
 
+@pytest.mark.parametrize("which", range(5))
+def test_crossed_topologies_on_the_block_kernels(lib, which):
+    """Either documented width (48 / 64 filters) with either kernel set ([5],[9],[13],[21] / [5],[7,11],[9,15],[23]) and either
+    first conv (3x1 / 5x1 stride 3 or 1) runs on the specialised block kernels: forward and train steps vs the oracle."""
+    flags = ec.CROSSED[which]
+    T = 204 if flags.get("stride", 1) == 3 else 194
+    ec.check_forward_parity(lib, B=9, T=T, training=True, flags=flags)
+    ec.check_train_steps(lib, B=8, T=T, steps=2, grid=0, flags=flags)
+    ec.check_train_steps(lib, B=5, T=T - 37, steps=1, grid=3, flags=flags)
+
+
 def test_bf16_storage_mode(lib):
     """BASELINE configs[4], full form ("storage_bf16"): the block outputs p_k and the stashed gradients g_k live in HBM
     as bf16 (fp32 accumulation, fp32 BN sums from the unrounded values), against the oracle that rounds the same stored
