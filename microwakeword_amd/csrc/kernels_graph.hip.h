@@ -439,7 +439,6 @@ template <int NC, int MODE, int CDP = 0>
 __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
-  __shared__ float sRed[2 * kThreads];
   // The convolution runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): per tap j a [16 frames] x [4 channels]
   // A tile of the window against a [4 channels] x [16 filters] B tile of the weights.  Weight rows are padded to whole
   // k-steps (cin4) and whole filter tiles (NCW) with zeros, so the inner loop carries no predicate on B.
@@ -452,13 +451,17 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
   float* sIn = sW + a.k * cin4 * NCW;
   float* sOut = sIn + rows_in * PI;
-  // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source, kept
-  // in LDS so that the sources can be walked by a real loop (their descriptors stay in the kernel-argument
-  // segment instead of pinning ~100 SGPRs)
+  // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source - the first
+  // source's in registers, the others' in LDS so that the sources can be walked by a real loop (their descriptors stay
+  // in the kernel-argument segment instead of pinning ~100 SGPRs).  Static LDS is occupancy here: the windows of the
+  // 48-channel ops take 45-47 KB and three workgroups per CU need <= 53 760 B each (1280-byte granules), so the pairs
+  // live behind the tiles only for the sources that exist and the reduction scratch of the final publish reuses the
+  // weight tile (the host sizes the dynamic segment to match: mww_lib.hip, lds_fwd / lds_dx).
   float s1o = 0.f, s2o = 0.f;
-  __shared__ float sSrcAcc[MODE == 1 ? kGMaxSrc * 2 * kThreads : 1];
+  float* sSrcAcc = g_smem + max(a.k * cin4 * NCW + rows_in * PI + a.Tout * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
+  float* sRed = g_smem;   // [2 * kThreads], after the window loop
   if (MODE == 1)
-    for (int i = 0; i < kGMaxSrc * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
+    for (int i = 0; i < (a.n_src - 1) * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
 
   // statistics hand-over: fold what this launch is the first to consume.  The loads go out before the weights are staged,
   // the table is written after (visible to the other waves after the loop's first barrier).
@@ -637,8 +640,13 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
                 }
               }
             }
-            sSrcAcc[(i * 2 + 0) * kThreads + tid] += t1;
-            sSrcAcc[(i * 2 + 1) * kThreads + tid] += t2;
+            if (i == 0) {
+              s1o += t1;
+              s2o += t2;
+            } else {
+              sSrcAcc[(i * 2 - 2) * kThreads + tid] += t1;
+              sSrcAcc[(i * 2 - 1) * kThreads + tid] += t2;
+            }
           }
         }
         c0 += C;
@@ -651,8 +659,8 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     for (int i = 0; i < a.n_src; ++i) {
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
-        publish_channel_partials(sSrcAcc[(i * 2 + 0) * kThreads + tid], sSrcAcc[(i * 2 + 1) * kThreads + tid], s.C, sRed,
-                                 s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld, s.gacc, s.c0, bid, nb);
+        publish_channel_partials(i == 0 ? s1o : sSrcAcc[(i * 2 - 2) * kThreads + tid], i == 0 ? s2o : sSrcAcc[(i * 2 - 1) * kThreads + tid],
+                                 s.C, sRed, s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld, s.gacc, s.c0, bid, nb);
     }
   }
 }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -113,6 +114,8 @@ struct mww_ctx {
   size_t lds_head2 = 0;
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   int grid_g = 0;
+  bool grid_g_auto = true;   // per-launch grids from the kernel's occupancy (g_role_grid); "grid_graph" > 0 fixes one grid
+  std::map<std::pair<const void*, size_t>, int> g_occ;   // workgroups per CU of (kernel, dynamic LDS)
   // data-parallel exchange hook (mww_set_allreduce_hook)
   mww_allreduce_fn hook = nullptr;
   void* hook_user = nullptr;
@@ -858,6 +861,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
 }
 
 // ---------------------------------------------------------------------------------- conv/BN graphs
+constexpr int kGFwdWgPerCu = 4, kGBwdWgPerCu = 3;   // g_role_grid
 #define MWW_G_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(30) X(32) X(36) X(40) X(48) X(60) X(64)
 
 bool g_width_supported(int n) {
@@ -870,13 +874,43 @@ bool g_width_supported(int n) {
 // gfx950 has 160 KB of LDS per CU; tiles above the 64 KB default need the function attribute
 constexpr size_t kMaxDynLds = 144 * 1024;
 
+// Workgroups per role of a conv/BN graph launch.  The kernels are latency-bound, so the grid that suits a launch is the
+// one its own LDS tile lets a CU hold: the per-op times of the Inception step at 2 / 3 / 4 workgroups per CU
+// (profiles/round2_batch_sweep_inception.txt) follow the occupancy - forward launches want up to four resident workgroups,
+// backward launches up to three (a fourth costs more in per-workgroup weight staging and partial rows than it hides), and
+// a launch whose tile only fits twice is faster with 2 x n_cu workgroups than with a third that waits for a free slot.
+// `fixed` > 0 (no statistics hand-over: the partial statistics rows of a tensor are shared by all its launches; or
+// "grid_graph" set by the caller) keeps the given grid.
+struct GridPick {
+  int fixed;          // workgroups per role, or 0: choose
+  int B, roles, cap;  // windows; roles sharing the launch's workgroups; workgroups per CU at most
+  int* used;          // out: workgroups per role
+};
+
+int g_role_grid(mww_ctx* c, const void* func, size_t lds, const GridPick& pk) {
+  int grid = pk.fixed;
+  if (grid <= 0) {
+    const auto key = std::make_pair(func, lds);
+    auto it = c->g_occ.find(key);
+    if (it == c->g_occ.end()) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, func, kThreads, lds) != hipSuccess || occ < 1) occ = 3;
+      it = c->g_occ.emplace(key, occ).first;
+    }
+    const int wpc = std::max(1, std::min(it->second, pk.cap));
+    grid = std::max(1, std::min(pk.B, c->n_cu * wpc / std::max(1, pk.roles)));
+  }
+  if (pk.used) *pk.used = grid;
+  return grid;
+}
+
 template <int MODE>
-int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, int grid, size_t lds) {
+int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
-    if (lds > 64 * 1024)                                                                                       \
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_kernel<N, MODE>),                        \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+    const void* f = reinterpret_cast<const void*>(&gconv_kernel<N, MODE>);                                     \
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
     hipLaunchKernelGGL((gconv_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
     return MWW_OK;                                                                                             \
   }
@@ -885,9 +919,12 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, int grid, size_t lds) {
   return fail(MWW_ERR_UNSUPPORTED, "conv width not instantiated");
 }
 
-int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds) {
+int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
+    const void* f = reinterpret_cast<const void*>(&gconv_wgrad_kernel<N>);                                     \
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
     hipLaunchKernelGGL((gconv_wgrad_kernel<N>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
     return MWW_OK;                                                                                             \
   }
@@ -899,12 +936,12 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, int grid, size_t lds)
 // (filters, input channels) pairs with a fused weight-gradient + data-gradient launch; others use two launches
 #define MWW_G_BWD_PAIRS(X) X(30, 24) X(10, 10) X(10, 30) X(30, 10) X(48, 10) X(16, 16) X(16, 48) X(24, 16) X(16, 24) X(36, 24) X(12, 36) X(48, 32) X(48, 48) X(64, 32) X(64, 64)
 
-bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, int grid, size_t lds) {
+bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, const GridPick& pk, size_t lds) {
 #define X(NCO, NCI)                                                                                            \
   if (nco == NCO && nci == NCI) {                                                                              \
-    if (lds > 64 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gconv_bwd_kernel<NCO, NCI>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    const void* f = reinterpret_cast<const void*>(&gconv_bwd_kernel<NCO, NCI>);                                \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
     hipLaunchKernelGGL((gconv_bwd_kernel<NCO, NCI>), dim3(2 * grid), dim3(kThreads), lds, c->stream, w, d, grid); \
     return true;                                                                                               \
   }
@@ -914,9 +951,12 @@ bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const 
 }
 
 #define MWW_G_TWIN_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
-bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, int grid, size_t lds) {
+bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
+    const void* f = reinterpret_cast<const void*>(&gconv_fwd2_kernel<N>);                                      \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
     hipLaunchKernelGGL((gconv_fwd2_kernel<N>), dim3(2 * grid), dim3(kThreads), lds, c->stream, a0, a1, grid);  \
     return true;                                                                                               \
   }
@@ -925,9 +965,12 @@ bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, 
   return false;
 }
 bool launch_gbwd2(mww_ctx* c, int nc, const GWgradArgs& w0, const GConvArgs& d0, const GWgradArgs& w1, const GConvArgs& d1,
-                  int grid, size_t lds) {
+                  const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
+    const void* f = reinterpret_cast<const void*>(&gconv_bwd2_kernel<N, N>);                                   \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
     hipLaunchKernelGGL((gconv_bwd2_kernel<N, N>), dim3(4 * grid), dim3(kThreads), lds, c->stream, w0, d0, w1, d1, grid); \
     return true;                                                                                               \
   }
@@ -1016,6 +1059,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
   const int gg = std::min(B, c->grid_g);
   // statistics hand-over instead of finalize launches (kernels_graph.hip.h)
   const bool inl = training && c->bn_inline && c->g_inline_ok && !(c->hook && c->sync_bn) && !c->profile_split;
+  const bool pick = inl && c->grid_g_auto;   // per-launch grids (g_role_grid)
   auto leader = [&](int oi) { return (oi > 0 && c->G[oi - 1].twin_next) ? oi - 1 : oi; };   // first op of the launch op oi rides in
   auto fold_of = [&](int pi, bool publish) {
     GOp& pr = c->G[pi];
@@ -1102,7 +1146,9 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       }
       const GConvArgs fa0 = fwd_args(i), fa1 = fwd_args(i + 1);
       lp.begin("conv_fwd2_", i);
-      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, (inl && c->g_role_split) ? std::max(1, gg / 2) : gg, std::max(o.lds_fwd, o2.lds_fwd));
+      const bool split2 = inl && c->g_role_split;
+      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, GridPick{pick ? 0 : (split2 ? std::max(1, gg / 2) : gg), B, split2 ? 2 : 1, kGFwdWgPerCu, nullptr},
+                                   std::max(o.lds_fwd, o2.lds_fwd));
       lp.end();
       if (ok) {
         if (training && !inl) {
@@ -1125,7 +1171,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     }
     const GConvArgs fa = fwd_args(i);
     lp.begin("conv_fwd", i);
-    int rc = launch_gconv<0>(c, o.cout, fa, gg, o.lds_fwd);
+    int rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, kGFwdWgPerCu, nullptr}, o.lds_fwd);
     lp.end();
     if (rc) return rc;
     if (training && o.norm == MWW_NORM_BN && !inl) {
@@ -1288,6 +1334,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     return a;
   };
   const bool split = inl && c->g_role_split;
+  const bool pick = inl && c->grid_g_auto;   // per-launch grids (g_role_grid)
   const int gg2 = split ? std::max(1, gg / 2) : gg, gg4 = split ? std::max(1, gg / 4) : gg;
   auto add_segment = [&](int oi, int rows) {
     GOp& q = c->G[oi];
@@ -1314,12 +1361,13 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       const int n0 = o.slots;
       lp.begin("conv_bwd2_", i);
       if (!inl) hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
-      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, gg4,
+      int rows = gg4;
+      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, GridPick{pick ? 0 : gg4, B, split ? 4 : 1, kGBwdWgPerCu, &rows},
                                    std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)));
       lp.end();
       if (!ok) return fail(MWW_ERR_UNSUPPORTED, "twin ops without a fused backward instantiation");
-      add_segment(i, gg4);
-      add_segment(i - 1, gg4);
+      add_segment(i, rows);
+      add_segment(i - 1, rows);
       --i;
       continue;
     }
@@ -1413,9 +1461,10 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       a.y.fold = bfold(o, false);
     }
     bool fused = false;
+    int rows = gg;
     if (o.needs_dx && !c->profile_split) {
       lp.begin("conv_bwd", i);
-      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, gg2, std::max(o.lds_wg, o.lds_dx));
+      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, GridPick{pick ? 0 : gg2, B, split ? 2 : 1, kGBwdWgPerCu, &rows}, std::max(o.lds_wg, o.lds_dx));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
         (void)hipEventDestroy(c->prof.back().a);
@@ -1425,19 +1474,19 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     if (!fused) {
       lp.begin("conv_wgrad", i);
-      int rc = launch_gwgrad(c, o.cout, w, gg, o.lds_wg);
+      int rc = launch_gwgrad(c, o.cout, w, GridPick{pick ? 0 : gg, B, 1, kGBwdWgPerCu, &rows}, o.lds_wg);
       lp.end();
       if (rc) return rc;
       if (o.needs_dx) {
         lp.begin("conv_dgrad", i);
-        rc = launch_gconv<1>(c, o.cin, a, gg, o.lds_dx);
+        rc = launch_gconv<1>(c, o.cin, a, GridPick{pick ? 0 : gg, B, 1, kGBwdWgPerCu, nullptr}, o.lds_dx);
         lp.end();
         if (rc) return rc;
       }
     }
     GradSegment s;
     s.part = o.grad_part;
-    s.G = fused ? gg2 : gg;
+    s.G = rows;
     s.stride = o.k * o.cin * o.cout;
     s.n = s.stride;
     s.dst = (int)o.o_w;
@@ -1787,8 +1836,11 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       auto up4 = [](int v) { return (size_t)((v + 3) & ~3); };
       auto up16 = [](int v) { return (size_t)((v + 15) / 16 * 16); };
       const size_t wf = (size_t)o.k * up4(o.cin) * up16(o.cout), wb = (size_t)o.k * up4(o.cout) * up16(o.cin);
-      o.lds_fwd = (wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1) + 4) * sizeof(float);
-      o.lds_dx = (wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1) + 4) * sizeof(float);
+      // + gconv_body's tail: the publish scratch aliases the first 2 * kThreads floats, MODE 1 keeps the statistics
+      // pairs of its second and third source behind the tiles
+      auto body = [](size_t tiles, int pairs) { return (std::max(tiles, (size_t)2 * kThreads) + (size_t)pairs * 2 * kThreads + 4) * sizeof(float); };
+      o.lds_fwd = body(wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1), 0);
+      o.lds_dx = body(wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1), o.n_src - 1);
       {
         const int tasks = o.k * o.cin, mt = (tasks + 15) / 16, nt = (o.cout + 15) / 16;
         o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 6) / 4 * 4 + up4(o.tout) * (size_t)gwg_dp_pitch(o.cout)) * sizeof(float);
@@ -2263,7 +2315,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2461,7 +2513,11 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   }
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
-  else if (!strcmp(name, "grid_graph")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_graph out of range"); c->grid_g = (int)v; }
+  else if (!strcmp(name, "grid_graph")) {   // 0: per-launch grids by occupancy (default); > 0: this many workgroups per launch
+    if (v < 0 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_graph out of range");
+    c->grid_g_auto = v == 0;
+    if (v > 0) c->grid_g = (int)v;
+  }
   else if (!strcmp(name, "dropout_seed")) { c->dropout_seed = (unsigned long long)v; c->dropout_counter = 0; }
   else if (!strcmp(name, "grid_head")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_head out of range"); c->grid_head = (int)v; }
   else return fail(MWW_ERR_INVALID, std::string("unknown option: ") + name);
