@@ -404,6 +404,10 @@ def main():
             eng.set_option("tail_roles", int(os.environ["MWW_BENCH_TAIL_ROLES"]))
         if os.environ.get("MWW_BENCH_GRID_GRAPH") is not None:
             eng.set_option("grid_graph", int(os.environ["MWW_BENCH_GRID_GRAPH"]))
+        for kv in filter(None, os.environ.get("MWW_BENCH_OPTIONS", "").split(",")):   # "name=value,..." (tools/: knob sweeps)
+            eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        if os.environ.get("MWW_BENCH_DGRAD_SHARE") is not None:
+            eng.set_option("graph_dgrad_share", int(os.environ["MWW_BENCH_DGRAD_SHARE"]))
         if os.environ.get("MWW_BENCH_ROLE_SPLIT") is not None:
             eng.set_option("graph_role_split", int(os.environ["MWW_BENCH_ROLE_SPLIT"]))
         if os.environ.get("MWW_BENCH_BN_INLINE") is not None:

@@ -257,9 +257,11 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * gradient and the metric update ride in the gradient-assembly launch), "bce_from_logits" (default 1: the loss is the
  * logits form Keras 3 evaluates for a sigmoid output, 0: clipped probability form), "graph_role_split" (default 1, conv/BN
  * graph contexts with bn_inline: launches that hold several roles - twin ops, weight + data gradient - divide the launch's
- * workgroups between the roles), "grid_graph" (conv/BN graph contexts: 0 = default, with bn_inline every launch takes the
- * grid its own LDS tile lets the CUs hold - up to 4 workgroups per CU forward, 3 backward; > 0 = that many workgroups per
- * launch; without bn_inline one grid of 3 per CU, because a tensor's partial statistics rows are shared by its launches),
+ * workgroups between the roles; "graph_dgrad_share" = percent of an op's workgroups that form its data gradient, 10..90),
+ * "grid_graph" (conv/BN graph contexts: 0 = default, with bn_inline every launch takes the
+ * grid its own LDS tile and registers let the CUs hold - at most "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" workgroups per
+ * CU, default 4 / 4; > 0 = that many workgroups per launch; without bn_inline one grid of 3 per CU, because a tensor's
+ * partial statistics rows are shared by its launches),
  * "grad_buckets" (data-parallel step: 2 =
  * overlapped two-bucket gradient exchange, 1 = one exchange after the backward pass), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's

@@ -672,10 +672,12 @@ __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
 
 // Two independent ops of the same shape ("twins": Inception's k x 1 convs of branch 2 and branch 3) as the two
 // halves of one launch: workgroups [0, nb) run op a0, [nb, 2 nb) op a1.
+// (the twin's descriptors are picked by a run-time index into the kernel-argument segment: one copy of the body's code)
+struct GConv2Args { GConvArgs op[2]; };
 template <int NC>
-__global__ __launch_bounds__(kThreads) void gconv_fwd2_kernel(GConvArgs a0, GConvArgs a1, int nb) {
-  if ((int)blockIdx.x < nb) gconv_body<NC, 0>(a0, blockIdx.x, nb);
-  else gconv_body<NC, 0>(a1, blockIdx.x - nb, nb);
+__global__ __launch_bounds__(kThreads) void gconv_fwd2_kernel(GConv2Args a, int nb) {
+  const int op = (int)blockIdx.x >= nb ? 1 : 0;
+  gconv_body<NC, 0>(a.op[op], blockIdx.x - op * nb, nb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,8 +699,10 @@ struct GWgradArgs {
 constexpr int kGWgTilesPerWave = 4;   // 16 task tiles (k * cin <= 256) over four waves
 
 __host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (tasks > 16 ? 2 : 4); }
-// row pitch of the staged dp: a multiple of 16 that is 16 mod 32, so that the four k-rows of a B fragment fall on disjoint banks
-__host__ __device__ inline int gwg_dp_pitch(int nc) { const int w = (nc + 15) / 16 * 16; return (w / 16) % 2 ? w : w + 16; }
+// row pitch of the staged dp: the filter tiles, unpadded.  (A pitch of 16 mod 32 keeps the four k-rows of a B fragment on
+// disjoint banks, but for 17-32 filters it costs 16 floats per frame = 12 KB of a 190-frame window - the difference between
+// two and three resident workgroups for the 24 -> 30 op; same-session A/B of the Inception step: 0.943 against 0.949 ms.)
+__host__ __device__ inline int gwg_dp_pitch(int nc) { return (nc + 15) / 16 * 16; }
 
 template <int NC>
 __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
@@ -812,19 +816,18 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
 // gradient.  They are independent (both only read the op's output gradient) and each is latency-bound on its
 // own, so sharing the launch hides one of the two.
 template <int NCO, int NCI>
-__global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nb) {
-  if ((int)blockIdx.x < nb) gconv_wgrad_body<NCO>(w, blockIdx.x, nb);
-  else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nb, nb);
+__global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
+  if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO>(w, blockIdx.x, nbw);
+  else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nbw, nbd);
 }
 
 // ... and of twin ops: four roles
+struct GBwd2Args { GWgradArgs w[2]; GConvArgs d[2]; };
 template <int NCO, int NCI>
-__global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GWgradArgs w0, GConvArgs d0, GWgradArgs w1, GConvArgs d1, int nb) {
-  const int role = blockIdx.x / nb, bid = blockIdx.x - role * nb;
-  if (role == 0) gconv_wgrad_body<NCO>(w0, bid, nb);
-  else if (role == 1) gconv_body<NCI, 1, NCO>(d0, bid, nb);
-  else if (role == 2) gconv_wgrad_body<NCO>(w1, bid, nb);
-  else gconv_body<NCI, 1, NCO>(d1, bid, nb);
+__global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GBwd2Args a, int nbw, int nbd) {
+  const int pair = nbw + nbd, op = (int)blockIdx.x >= pair ? 1 : 0, bid = blockIdx.x - op * pair;
+  if (bid < nbw) gconv_wgrad_body<NCO>(a.w[op], bid, nbw);
+  else gconv_body<NCI, 1, NCO>(a.d[op], bid - nbw, nbd);
 }
 
 // ---------------------------------------------------------------------------------------------

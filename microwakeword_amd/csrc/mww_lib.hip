@@ -114,6 +114,8 @@ struct mww_ctx {
   size_t lds_head2 = 0;
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   int grid_g = 0;
+  int g_cap_fwd = 4, g_cap_bwd = 4;   // "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" (g_role_grid)
+  int g_dgrad_share = 50;   // "graph_dgrad_share"
   bool grid_g_auto = true;   // per-launch grids from the kernel's occupancy (g_role_grid); "grid_graph" > 0 fixes one grid
   std::map<std::pair<const void*, size_t>, int> g_occ;   // workgroups per CU of (kernel, dynamic LDS)
   // data-parallel exchange hook (mww_set_allreduce_hook)
@@ -861,7 +863,6 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
 }
 
 // ---------------------------------------------------------------------------------- conv/BN graphs
-constexpr int kGFwdWgPerCu = 4, kGBwdWgPerCu = 3;   // g_role_grid
 #define MWW_G_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(30) X(32) X(36) X(40) X(48) X(60) X(64)
 
 bool g_width_supported(int n) {
@@ -874,11 +875,16 @@ bool g_width_supported(int n) {
 // gfx950 has 160 KB of LDS per CU; tiles above the 64 KB default need the function attribute
 constexpr size_t kMaxDynLds = 144 * 1024;
 
-// Workgroups per role of a conv/BN graph launch.  The kernels are latency-bound, so the grid that suits a launch is the
-// one its own LDS tile lets a CU hold: the per-op times of the Inception step at 2 / 3 / 4 workgroups per CU
-// (profiles/round2_batch_sweep_inception.txt) follow the occupancy - forward launches want up to four resident workgroups,
-// backward launches up to three (a fourth costs more in per-workgroup weight staging and partial rows than it hides), and
-// a launch whose tile only fits twice is faster with 2 x n_cu workgroups than with a third that waits for a free slot.
+// Workgroups per role of a conv/BN graph launch.  The kernels are latency-bound (one wave per SIMD and workgroup, ~15
+// cycles per issued instruction), so a launch wants as many resident workgroups as its own LDS tile and registers let a
+// CU hold - and no more: a workgroup that has to wait for a free slot costs more than it brings.  With one grid for the
+// whole step (3 workgroups per CU, the best single value) the 48-channel ops, whose tiles fit twice, ran a third of their
+// workgroups as a second round, and the 10- and 16-channel ops left half of the CU's wave slots empty.  Same-session
+// sweeps of the Inception step (B = 1024, tools/gpu_knobs.sh): one grid of 768 = 0.993 ms; per launch
+// n_cu x min(occupancy, cap) with caps forward / backward 4 / 2 = 1.035, 4 / 3 = 0.941, 3 / 4 = 0.96 (cap 3 forward),
+// 4 / 4 = 0.884 (default), 8 / 4 = 0.882, 4 / 5 with the 10-channel backward kernels compiled for five waves = 0.881 (not
+// kept); rounding a role's workgroups down to the fewest that keep the number of windows per workgroup = 0.981 (the
+// workgroups with one window fewer leave the CU early: fewer, evenly loaded ones are slower).
 // `fixed` > 0 (no statistics hand-over: the partial statistics rows of a tensor are shared by all its launches; or
 // "grid_graph" set by the caller) keeps the given grid.
 struct GridPick {
@@ -898,10 +904,21 @@ int g_role_grid(mww_ctx* c, const void* func, size_t lds, const GridPick& pk) {
       it = c->g_occ.emplace(key, occ).first;
     }
     const int wpc = std::max(1, std::min(it->second, pk.cap));
-    grid = std::max(1, std::min(pk.B, c->n_cu * wpc / std::max(1, pk.roles)));
+    grid = std::max(1, std::min(std::min(pk.B, c->n_cu * 4), c->n_cu * wpc / std::max(1, pk.roles)));   // (n_cu * 4 rows of weight-gradient partials)
   }
   if (pk.used) *pk.used = grid;
   return grid;
+}
+
+// weight-gradient and data-gradient roles that divide a launch's workgroups (pk.roles > 1) need not take equal halves:
+// "graph_dgrad_share" percent of an op's workgroups form the data gradient
+void g_share_roles(mww_ctx* c, const GridPick& pk, int* nbw, int* nbd) {
+  if (pk.roles > 1 && c->g_dgrad_share != 50) {
+    const int pair = *nbw + *nbd;
+    *nbd = std::max(1, std::min(pair - 1, (pair * c->g_dgrad_share + 50) / 100));
+    *nbw = std::max(1, pair - *nbd);
+  }
+  if (pk.used) *pk.used = *nbw;
 }
 
 template <int MODE>
@@ -941,8 +958,9 @@ bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const 
   if (nco == NCO && nci == NCI) {                                                                              \
     const void* f = reinterpret_cast<const void*>(&gconv_bwd_kernel<NCO, NCI>);                                \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_bwd_kernel<NCO, NCI>), dim3(2 * grid), dim3(kThreads), lds, c->stream, w, d, grid); \
+    int nbw = g_role_grid(c, f, lds, pk), nbd = nbw;                                                           \
+    g_share_roles(c, pk, &nbw, &nbd);                                                                          \
+    hipLaunchKernelGGL((gconv_bwd_kernel<NCO, NCI>), dim3(nbw + nbd), dim3(kThreads), lds, c->stream, w, d, nbw, nbd); \
     return true;                                                                                               \
   }
   MWW_G_BWD_PAIRS(X)
@@ -957,7 +975,7 @@ bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, 
     const void* f = reinterpret_cast<const void*>(&gconv_fwd2_kernel<N>);                                      \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
     const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_fwd2_kernel<N>), dim3(2 * grid), dim3(kThreads), lds, c->stream, a0, a1, grid);  \
+    hipLaunchKernelGGL((gconv_fwd2_kernel<N>), dim3(2 * grid), dim3(kThreads), lds, c->stream, GConv2Args{{a0, a1}}, grid); \
     return true;                                                                                               \
   }
   MWW_G_TWIN_WIDTHS(X)
@@ -970,8 +988,9 @@ bool launch_gbwd2(mww_ctx* c, int nc, const GWgradArgs& w0, const GConvArgs& d0,
   if (nc == N) {                                                                                               \
     const void* f = reinterpret_cast<const void*>(&gconv_bwd2_kernel<N, N>);                                   \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_bwd2_kernel<N, N>), dim3(4 * grid), dim3(kThreads), lds, c->stream, w0, d0, w1, d1, grid); \
+    int nbw = g_role_grid(c, f, lds, pk), nbd = nbw;                                                           \
+    g_share_roles(c, pk, &nbw, &nbd);                                                                          \
+    hipLaunchKernelGGL((gconv_bwd2_kernel<N, N>), dim3(2 * (nbw + nbd)), dim3(kThreads), lds, c->stream, GBwd2Args{{w0, w1}, {d0, d1}}, nbw, nbd); \
     return true;                                                                                               \
   }
   MWW_G_TWIN_WIDTHS(X)
@@ -1147,7 +1166,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       const GConvArgs fa0 = fwd_args(i), fa1 = fwd_args(i + 1);
       lp.begin("conv_fwd2_", i);
       const bool split2 = inl && c->g_role_split;
-      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, GridPick{pick ? 0 : (split2 ? std::max(1, gg / 2) : gg), B, split2 ? 2 : 1, kGFwdWgPerCu, nullptr},
+      const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, GridPick{pick ? 0 : (split2 ? std::max(1, gg / 2) : gg), B, split2 ? 2 : 1, c->g_cap_fwd, nullptr},
                                    std::max(o.lds_fwd, o2.lds_fwd));
       lp.end();
       if (ok) {
@@ -1171,7 +1190,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     }
     const GConvArgs fa = fwd_args(i);
     lp.begin("conv_fwd", i);
-    int rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, kGFwdWgPerCu, nullptr}, o.lds_fwd);
+    int rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd);
     lp.end();
     if (rc) return rc;
     if (training && o.norm == MWW_NORM_BN && !inl) {
@@ -1362,7 +1381,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       lp.begin("conv_bwd2_", i);
       if (!inl) hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
       int rows = gg4;
-      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, GridPick{pick ? 0 : gg4, B, split ? 4 : 1, kGBwdWgPerCu, &rows},
+      const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, GridPick{pick ? 0 : gg4, B, split ? 4 : 1, c->g_cap_bwd, &rows},
                                    std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)));
       lp.end();
       if (!ok) return fail(MWW_ERR_UNSUPPORTED, "twin ops without a fused backward instantiation");
@@ -1464,7 +1483,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     int rows = gg;
     if (o.needs_dx && !c->profile_split) {
       lp.begin("conv_bwd", i);
-      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, GridPick{pick ? 0 : gg2, B, split ? 2 : 1, kGBwdWgPerCu, &rows}, std::max(o.lds_wg, o.lds_dx));
+      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, GridPick{pick ? 0 : gg2, B, split ? 2 : 1, c->g_cap_bwd, &rows}, std::max(o.lds_wg, o.lds_dx));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
         (void)hipEventDestroy(c->prof.back().a);
@@ -1474,12 +1493,12 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     if (!fused) {
       lp.begin("conv_wgrad", i);
-      int rc = launch_gwgrad(c, o.cout, w, GridPick{pick ? 0 : gg, B, 1, kGBwdWgPerCu, &rows}, o.lds_wg);
+      int rc = launch_gwgrad(c, o.cout, w, GridPick{pick ? 0 : gg, B, 1, c->g_cap_bwd, &rows}, o.lds_wg);
       lp.end();
       if (rc) return rc;
       if (o.needs_dx) {
         lp.begin("conv_dgrad", i);
-        rc = launch_gconv<1>(c, o.cin, a, GridPick{pick ? 0 : gg, B, 1, kGBwdWgPerCu, nullptr}, o.lds_dx);
+        rc = launch_gconv<1>(c, o.cin, a, GridPick{pick ? 0 : gg, B, 1, c->g_cap_bwd, nullptr}, o.lds_dx);
         lp.end();
         if (rc) return rc;
       }
@@ -2315,7 +2334,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2492,6 +2511,9 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
+  else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
+  else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
+  else if (!strcmp(name, "graph_dgrad_share")) { if (v < 10 || v > 90) return fail(MWW_ERR_INVALID, "graph_dgrad_share must be 10..90"); c->g_dgrad_share = (int)v; }
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;
   else if (!strcmp(name, "bce_from_logits")) c->bce_clipped = v == 0;
   else if (!strcmp(name, "grad_buckets")) { if (v < 1 || v > 2) return fail(MWW_ERR_INVALID, "grad_buckets must be 1 or 2"); c->grad_buckets = (int)v; }
