@@ -1112,7 +1112,11 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     if (o.kind == MWW_OP_DEPTHWISE) {
       GDwArgs dw = g_make_dw(c, i, B, false);
       lp.begin("dw_fwd", i);
-      hipLaunchKernelGGL(gdw_kernel<0>, dim3(gg), dim3(kThreads), o.lds_fwd, c->stream, dw);
+      // (no statistics leave this launch: its grid is free to follow its occupancy even without the hand-over)
+      const void* f = reinterpret_cast<const void*>(&gdw_kernel<0>);
+      if (o.lds_fwd > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds_fwd));
+      const int gdw = g_role_grid(c, f, o.lds_fwd, GridPick{c->grid_g_auto ? 0 : gg, B, 1, c->g_cap_fwd, nullptr});
+      hipLaunchKernelGGL(gdw_kernel<0>, dim3(gdw), dim3(kThreads), o.lds_fwd, c->stream, dw);
       lp.end();
       continue;
     }
@@ -1433,7 +1437,10 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     if (o.kind == MWW_OP_DEPTHWISE) {
       GDwArgs dw = g_make_dw(c, i, B, true);
       lp.begin("dw_wgrad", i);
-      hipLaunchKernelGGL(gdw_wgrad_kernel, dim3(gg), dim3(kThreads), o.lds_wg, c->stream, dw);
+      const void* f = reinterpret_cast<const void*>(&gdw_wgrad_kernel);
+      if (o.lds_wg > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds_wg));
+      const int gwg = g_role_grid(c, f, o.lds_wg, GridPick{c->grid_g_auto ? 0 : gg, B, 1, c->g_cap_bwd, nullptr});   // (its partial rows are its own)
+      hipLaunchKernelGGL(gdw_wgrad_kernel, dim3(gwg), dim3(kThreads), o.lds_wg, c->stream, dw);
       lp.end();
       if (o.needs_dx) {
         lp.begin("dw_dgrad", i);
@@ -1442,7 +1449,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       }
       GradSegment s;
       s.part = o.grad_part;
-      s.G = gg;
+      s.G = gwg;
       s.stride = o.k * o.cout;
       s.n = s.stride;
       s.dst = (int)o.o_w;
@@ -1843,10 +1850,11 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       if (o.n_src != 1 || o.cin != o.cout || o.dil != 1 || o.stride != 1) return fail(MWW_ERR_INVALID, tag + "a depthwise op has one source with as many channels as filters, no dilation, no stride");
       if (o.norm == MWW_NORM_BN) return fail(MWW_ERR_UNSUPPORTED, tag + "depthwise + BatchNorm is not implemented (bias or nothing)");
       if (o.cout > kThreads || o.k * o.cout > kGDwTasks * kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "depthwise op too large (channels <= 256, taps x channels <= 2048)");
-      const size_t pi = (size_t)(o.cout | 1), wsz = (size_t)o.k * o.cout;
-      o.lds_fwd = (wsz + (size_t)o.tin * pi) * sizeof(float);
-      o.lds_dx = o.needs_dx ? (wsz + (size_t)(o.tout + 2 * pad) * pi) * sizeof(float) : 0;
-      o.lds_wg = ((size_t)o.tin * pi + (size_t)o.tout * pi) * sizeof(float);
+      // tap blocks of 8 with zero weights, kGDwTail zero rows behind every staged window (kernels_graph.hip.h)
+      const size_t pi = (size_t)(o.cout | 1), wsz = (size_t)gdw_kpad(o.k) * o.cout;
+      o.lds_fwd = (wsz + (size_t)(o.tin + kGDwTail) * pi) * sizeof(float);
+      o.lds_dx = o.needs_dx ? (wsz + (size_t)(o.tout + 2 * pad + kGDwTail) * pi) * sizeof(float) : 0;
+      o.lds_wg = std::max((size_t)(o.tin + kGDwTail) * pi + (size_t)(o.tout + kGDwJ) * pi, (size_t)2 * kThreads * kGDwJ) * sizeof(float);   // (.. or the scratch of the final sum)
     } else {
       if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
       if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
