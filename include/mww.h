@@ -252,8 +252,9 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * "fused_input" (default 1, specialised MixedNet kernels: mww_assemble_batch uploads descriptors only and the first
  * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
  * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of
- * by finalize launches, in the MixedNet block kernels and in conv/BN graphs whose ops are all convolution + BatchNorm without
- * residual branches; forced off by the sync-BN exchange hook), "tail_roles" (default 1, with bn_inline: the dense-weight
+ * by finalize launches, in the MixedNet block kernels and in conv/BN graphs whose ops are convolutions with a BatchNorm (or
+ * nothing) and depthwise ops with a bias (or nothing), without residual branches and attention / pooled heads; forced off by
+ * the sync-BN exchange hook), "tail_roles" (default 1, with bn_inline: the dense-weight
  * gradient and the metric update ride in the gradient-assembly launch), "bce_from_logits" (default 1: the loss is the
  * logits form Keras 3 evaluates for a sigmoid output, 0: clipped probability form), "graph_role_split" (default 1, conv/BN
  * graph contexts with bn_inline: launches that hold several roles - twin ops, weight + data gradient - divide the launch's

@@ -842,6 +842,10 @@ struct GDwArgs {
   float* out;           // MODE 0: [B][Tout][C]
   GBnBwd y;             // MODE 1 / weight gradient: the op's output gradient (coefficients are the constants 1, 0, 0)
   float* grad_part;     // weight gradient: [grid][k*C]
+  // statistics hand-over (graphs of convolutions + BatchNorm and depthwise ops + bias):
+  GFoldFwd fold;            // MODE 0: the source's forward statistics, when this launch is their first consumer
+  const double* bias_acc;   // weight gradient: [kStatRows][2][C] rows whose first statistic is sum g of this op (its consumer's data gradient added them)
+  float* dbeta;             // ... folded into the bias gradient by workgroup 0
 };
 
 // Register blocking (end of round 2; the first version spent two LDS reads per FMA and staged dp one float per load,
@@ -927,10 +931,18 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
       sIn[i] = 0.f;
       sIn[(pad + a.Tout) * PI + i] = 0.f;
     }
+  // statistics hand-over: the first consumer of the source folds its producer's sums (one wave; the table is visible
+  // to the others after the loop's first barrier)
+  __shared__ float sFold[MODE == 0 ? 4 * kGFoldC : 1];
+  if (MODE == 0 && a.fold.acc && tid < 64) {
+    GFoldRegs fr;
+    gfold_forward_load(a.fold, blockIdx.x, tid, fr);
+    gfold_forward_finish(a.fold, sFold, blockIdx.x, tid, fr);
+  }
   const int nblk = (rows_out + kGDwJ - 1) / kGDwJ;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
-    if (MODE == 0) stage_sources(&a.src, 1, b, a.Tin, sIn, PI, tid);
+    if (MODE == 0) stage_sources(&a.src, 1, b, a.Tin, sIn, PI, tid, &a.fold, sFold);
     else gdw_stage_rows(a.y.g + (size_t)b * a.Tout * C, a.Tout, C, sIn + pad * PI, PI, tid);
     __syncthreads();
     if (rg < nrg) {
@@ -989,7 +1001,8 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
     }
   }
   if (MODE == 1 && (a.src.flags & GSRC_STATS))
-    write_channel_partials(s1, s2, C, sRed, a.src.gstat_part + (size_t)blockIdx.x * 2 * a.src.ld + a.src.c0, tid, a.src.ld);
+    publish_channel_partials(s1, s2, C, sRed, a.src.gstat_part + (size_t)blockIdx.x * 2 * a.src.ld + a.src.c0, tid, a.src.ld, a.src.gacc,
+                             a.src.c0, blockIdx.x, gridDim.x);
 }
 
 // dw[j][c] = sum_{b,t} act[b][t+j][c] * dp[b][t][c].  thread <-> (channel, tap block, frame part): the 8 taps of a block
@@ -1015,6 +1028,12 @@ __global__ __launch_bounds__(kThreads) void gdw_wgrad_kernel(GDwArgs a) {
     for (int jj = 0; jj < kGDwJ; ++jj) acc[u][jj] = 0.f;
   for (int i = tid; i < kGDwTail * PI; i += kThreads) sA[a.Tin * PI + i] = 0.f;
   for (int i = tid; i < kGDwJ * PI; i += kThreads) sDP[a.Tout * PI + i] = 0.f;
+  if (a.bias_acc && blockIdx.x == 0 && tid < C) {   // d bias = sum of the output gradient, in the fixed order of the rows
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < kStatRows; ++j) t += a.bias_acc[(size_t)j * 2 * C + tid];
+    a.dbeta[tid] = (float)t;
+  }
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     __syncthreads();
     stage_sources(&a.src, 1, b, a.Tin, sA, PI, tid);

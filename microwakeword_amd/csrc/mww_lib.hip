@@ -1055,11 +1055,11 @@ GBnBwd g_make_bnbwd(mww_ctx* c, GOp& o) {
   return GBnBwd{o.g, o.p, gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX)};
 }
 
-GDwArgs g_make_dw(mww_ctx* c, int oi, int B, bool backward) {
+GDwArgs g_make_dw(mww_ctx* c, int oi, int B, bool backward, bool inl = false) {
   GOp& o = c->G[oi];
   GDwArgs a;
   memset(&a, 0, sizeof(a));
-  a.src = g_make_src(c, oi, 0, backward);
+  a.src = g_make_src(c, oi, 0, backward, inl);
   a.w = c->params + o.o_w;
   a.k = o.k;
   a.C = o.cout;
@@ -1111,6 +1111,8 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     }
     if (o.kind == MWW_OP_DEPTHWISE) {
       GDwArgs dw = g_make_dw(c, i, B, false);
+      if (inl && o.src[0] >= 0 && c->G[o.src[0]].norm == MWW_NORM_BN && c->G[o.src[0]].first_consumer == i)
+        dw.fold = fold_of(o.src[0], true);
       lp.begin("dw_fwd", i);
       // (no statistics leave this launch: its grid is free to follow its occupancy even without the hand-over)
       const void* f = reinterpret_cast<const void*>(&gdw_kernel<0>);
@@ -1142,7 +1144,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
         q.facc_cur = a.sacc.acc;
         for (int s = 0; s < q.n_src; ++s) {
           const int pi = q.src[s];
-          if (pi < 0) continue;
+          if (pi < 0 || c->G[pi].norm != MWW_NORM_BN) continue;   // (no statistics to fold)
           const int fc = c->G[pi].first_consumer;
           if (leader(oi) != leader(fc)) continue;   // a later launch: the arrays were published by the first one
           bool first_ref = true;
@@ -1300,7 +1302,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   auto bfold = [&](GOp& q, bool publish) {
     GFoldBwd f;
     memset(&f, 0, sizeof(f));
-    if (!inl) return f;
+    if (!inl || q.norm != MWW_NORM_BN) return f;
     f.acc = q.gacc_cur;
     f.groups = q.groups;
     f.inv_n = 1.0f / ((float)B * (float)q.tout * (float)(q.groups > 1 ? q.cout / q.groups : 1));
@@ -1427,7 +1429,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       lp.begin("bn_bwd_finalize", i);
       hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(o.slots), dim3(kThreads), 0, c->stream, f);
       lp.end();
-    } else if (o.norm == MWW_NORM_BIAS) {
+    } else if (o.norm == MWW_NORM_BIAS && !inl) {
       // d bias = sum of the output gradient = the first statistic the consumers already accumulated
       GBnBwdArgs f{o.gstat_part, gg, o.cout, 1, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->grads + o.o_beta, 1.0f, 1};
       lp.begin("bias_grad", i);
@@ -1435,7 +1437,11 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       lp.end();
     }
     if (o.kind == MWW_OP_DEPTHWISE) {
-      GDwArgs dw = g_make_dw(c, i, B, true);
+      GDwArgs dw = g_make_dw(c, i, B, true, inl);
+      if (inl && o.norm == MWW_NORM_BIAS) {   // the rows this op's consumer added (sum g, ..) to: folded by the weight-gradient launch
+        dw.bias_acc = o.gacc_cur;
+        dw.dbeta = c->grads + o.o_beta;
+      }
       lp.begin("dw_wgrad", i);
       const void* f = reinterpret_cast<const void*>(&gdw_wgrad_kernel);
       if (o.lds_wg > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds_wg));
@@ -1444,7 +1450,10 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       lp.end();
       if (o.needs_dx) {
         lp.begin("dw_dgrad", i);
-        hipLaunchKernelGGL(gdw_kernel<1>, dim3(gg), dim3(kThreads), o.lds_dx, c->stream, dw);
+        const void* fd = reinterpret_cast<const void*>(&gdw_kernel<1>);
+        if (o.lds_dx > 64 * 1024) HIPCHK(hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o.lds_dx));
+        const int gdx = g_role_grid(c, fd, o.lds_dx, GridPick{pick ? 0 : gg, B, 1, c->g_cap_bwd, nullptr});   // (partial statistics rows are shared without the hand-over)
+        hipLaunchKernelGGL(gdw_kernel<1>, dim3(gdx), dim3(kThreads), o.lds_dx, c->stream, dw);
         lp.end();
       }
       GradSegment s;
@@ -1967,12 +1976,15 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   c->dropout = d.dropout;
   c->G = ops;
   {
-    // statistics hand-over: possible when every op is a convolution followed by a BatchNorm / SSN, none has a residual
-    // branch and every folded tensor fits the kernels' fold table; first_consumer = the op whose launch folds
+    // statistics hand-over: possible when every op is a convolution followed by a BatchNorm / SSN (or by nothing: a
+    // MixedNet's first convolution) or a depthwise op with a bias (or nothing), none has a residual branch and every folded
+    // tensor fits the kernels' fold table; first_consumer = the op whose launch folds
     bool ok = true;
     for (int i = 0; i < d.n_ops; ++i) {
       GOp& o = c->G[i];
-      if (o.kind != MWW_OP_CONV || o.norm != MWW_NORM_BN || o.res_src >= 0 || !o.adders.empty() || o.cout > kGFoldC) ok = false;
+      const bool conv_ok = o.kind == MWW_OP_CONV && (o.norm == MWW_NORM_BN || o.norm == MWW_NORM_NONE);
+      const bool dw_ok = o.kind == MWW_OP_DEPTHWISE && (o.norm == MWW_NORM_BIAS || o.norm == MWW_NORM_NONE);
+      if (!(conv_ok || dw_ok) || o.res_src >= 0 || !o.adders.empty() || o.cout > kGFoldC) ok = false;
       for (int j = 0; j < o.n_src; ++j)
         if (o.src[j] >= 0 && c->G[o.src[j]].first_consumer < 0) c->G[o.src[j]].first_consumer = i;
     }

@@ -755,8 +755,10 @@ GRAPH_MIXEDNET_NOCONV1 = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", p
                               mixconv_kernel_sizes="[5],[7,9]", first_conv_filters=0)
 
 
-def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, graphs=False, lr=1e-3):
-    """Forward intermediates and train step of a MixedNet running on the generic conv/BN graph kernels."""
+def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, graphs=False, lr=1e-3, bn_inline=None):
+    """Forward intermediates and train step of a MixedNet running on the generic conv/BN graph kernels.  bn_inline: None =
+    the engine's default (graphs of convolutions + BN and depthwise ops + bias hand their statistics over; residual /
+    attention / pooled graphs use finalize launches), 0 = finalize launches everywhere."""
     from microwakeword_amd.layout import GraphMixedNetLayout
     om = perturbed_oracle(T, flags=flags)
     lay = GraphMixedNetLayout(flags, T)
@@ -771,6 +773,8 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
             eng.set_option(k, grid)
     if graphs:
         eng.set_option("graphs", 1)
+    if bn_inline is not None:
+        eng.set_option("bn_inline", bn_inline)
     rng = np.random.default_rng(13)
     wts = dict(zip([n for n, _, _ in lay.keras_vars], om.get_weights()))
     for training in (False, True):

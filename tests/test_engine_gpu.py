@@ -273,6 +273,7 @@ def test_mixednet_on_generic_graph_kernels(lib):
     """MixedNet flag combinations outside the specialised block kernels (repeat_in_block 2,
     a block without depthwise, odd filter counts, strided first conv, no first conv) on the graph kernels."""
     ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET, B=8, T=100, steps=2, grid=0)
+    ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET, B=8, T=100, steps=1, grid=0, bn_inline=0)   # finalize launches instead of the hand-over
     ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET_NOCONV1, B=6, T=60, steps=2, grid=0, graphs=True)
     # the default topology through the generic route agrees with the oracle as well (cross-check of both kernel families)
     ec.check_graph_mixednet(lib, ec.DEF, B=4, T=194, steps=1, grid=0)
