@@ -701,7 +701,9 @@ constexpr int kGWgTilesPerWave = 4;   // 16 task tiles (k * cin <= 256) over fou
 __host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (tasks > 16 ? 2 : 4); }
 // row pitch of the staged dp: the filter tiles, unpadded.  (A pitch of 16 mod 32 keeps the four k-rows of a B fragment on
 // disjoint banks, but for 17-32 filters it costs 16 floats per frame = 12 KB of a 190-frame window - the difference between
-// two and three resident workgroups for the 24 -> 30 op; same-session A/B of the Inception step: 0.943 against 0.949 ms.)
+// two and three resident workgroups for the 24 -> 30 op; same-session A/B of the Inception step: 0.943 against 0.949 ms.
+// Going further - 8-float granularity, B fragments of the last tile wrapping into the next row, whose products only reach
+// columns that are never stored - puts the stem's weight gradient at three per CU too, but measured 0.891 against 0.887.)
 __host__ __device__ inline int gwg_dp_pitch(int nc) { return (nc + 15) / 16 * 16; }
 
 template <int NC>
