@@ -1131,6 +1131,36 @@ def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=I
         assert np.linalg.norm(g - grads[0]) <= 1e-2 * np.linalg.norm(grads[0])
 
 
+def check_graph_grid_options(lib, B=6, T=120, flags=INC):
+    """The grid knobs of the conv/BN graph launches (workgroups per CU forward / backward, one fixed grid) only change how the
+    windows are dealt to workgroups: same gradients up to float32 summation order; values outside their ranges are refused."""
+    rng = np.random.default_rng(29)
+    x = synth_x(rng, B, T)
+    y = (rng.random(B) < 0.4).astype(np.float32)
+    w = np.ones(B, np.float32)
+    om = perturbed_inception_oracle(T, flags)
+    grads = []
+    for opts in ({}, {"graph_fwd_wg_per_cu": 1, "graph_bwd_wg_per_cu": 1}, {"grid_graph": 3, "graph_role_split": 0}):
+        lay, eng = make_inception_engine(lib, T, B, om, flags, True)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+        eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+        eng.train_step(B, 1e-2, flags=native.STEP_NO_APPLY)
+        grads.append(eng.get_grads().copy())
+        if not opts:
+            for k, v in (("graph_fwd_wg_per_cu", 0), ("graph_bwd_wg_per_cu", 9), ("graph_dgrad_share", 5), ("graph_dgrad_share", 95), ("grid_graph", -1)):
+                try:
+                    eng.set_option(k, v)
+                except Exception:
+                    continue
+                raise AssertionError("%s = %d was accepted" % (k, v))
+        eng.close()
+    for g in grads[1:]:
+        assert np.linalg.norm(g - grads[0]) <= 1e-2 * np.linalg.norm(grads[0])
+
+
 def eng_dense_inputs(lay):
     last = lay.engine_args(1)["conv_ops"][-1]
     return last["tout"] * last["filters"]

@@ -80,6 +80,10 @@ def test_inception_statistics_hand_over_matches_finalize_launches(emu_lib):
     ec.check_inception_bn_inline_matches_finalize(emu_lib, B=4, T=120, steps=2, flags=ec.INC_VARIANT)
 
 
+def test_graph_grid_options(emu_lib):
+    ec.check_graph_grid_options(emu_lib, B=5, T=100)
+
+
 def test_inception_generated_dropout(emu_lib):
     ec.check_inception_generated_dropout(emu_lib, B=3, T=120)
 

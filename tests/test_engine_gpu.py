@@ -139,6 +139,10 @@ def test_inception_variant_dilation_groups_two_stems(lib):
     ec.check_inception_train_steps(lib, B=6, T=120, steps=2, grid=3, flags=ec.INC_VARIANT)
 
 
+def test_graph_grid_options(lib):
+    ec.check_graph_grid_options(lib, B=96, T=150)
+
+
 def test_inception_generated_dropout(lib):
     ec.check_inception_generated_dropout(lib, B=16, T=194)
 
