@@ -241,9 +241,10 @@ __device__ __forceinline__ int gvec_width(int C, int ld, int c0) {
 }
 
 // one source without a residual branch; coef = [2][...] scale / shift indexed by producer channel (global or LDS)
+// f0: first frame of the staged rows within the (aligned) window - frame chunks of 1x1 ops, else 0
 template <int V>
 __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows, float* sIn, int PI, int c0out, int tid,
-                                                 const float* cscale, const float* cshift) {
+                                                 const float* cscale, const float* cshift, int f0 = 0) {
   const int NQ = s.C / V, nrg = fast_div(kThreads, NQ);
   int q, rg;
   fast_divmod(tid, NQ, rg, q);
@@ -256,7 +257,7 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
     sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
   }
   const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
-  const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0, ((rows - 1) * s.ld + s.C) * 4);
+  const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff + f0) * s.ld + s.c0, ((rows - 1) * s.ld + s.C) * 4);
   float* dst = sIn + c0out + q * V;
   constexpr int NB = kGB;   // rows in flight (these kernels live on
                                                // the number of resident workgroups: registers are occupancy)
@@ -277,7 +278,7 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
 
 // ftab: null, or [kGMaxSrc][4][kGFoldC] with the folded (scale, shift, ..) of the sources whose fold[i].acc is set
 __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b, int rows, float* sIn, int PI, int tid,
-                                              const GFoldFwd* fold = nullptr, const float* ftab = nullptr) {
+                                              const GFoldFwd* fold = nullptr, const float* ftab = nullptr, int f0 = 0) {
   int c0 = 0;
   for (int i = 0; i < n_src; ++i) {
     const GSrc& s = src[i];
@@ -287,9 +288,9 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
       const float* cscale = folded ? tab : s.scale;
       const float* cshift = folded ? tab + kGFoldC : s.shift;
       const int V = gvec_width(s.C, s.ld, s.c0);
-      if (V == 4) stage_source_vec<4>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
-      else if (V == 2) stage_source_vec<2>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
-      else stage_source_vec<1>(s, b, rows, sIn, PI, c0, tid, cscale, cshift);
+      if (V == 4) stage_source_vec<4>(s, b, rows, sIn, PI, c0, tid, cscale, cshift, f0);
+      else if (V == 2) stage_source_vec<2>(s, b, rows, sIn, PI, c0, tid, cscale, cshift, f0);
+      else stage_source_vec<1>(s, b, rows, sIn, PI, c0, tid, cscale, cshift, f0);
       c0 += s.C;
       continue;
     }
@@ -299,9 +300,9 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
       const float sc = folded ? tab[s.c0 + c] : s.scale[s.c0 + c];
       const float sh = folded ? tab[kGFoldC + s.c0 + c] : s.shift[s.c0 + c];
       const float lo = (s.flags & GSRC_LINEAR) ? -3.0e38f : 0.f;
-      const float* base = s.p + ((size_t)b * s.T + s.toff) * s.ld + s.c0 + c;
+      const float* base = s.p + ((size_t)b * s.T + s.toff + f0) * s.ld + s.c0 + c;
       const float rsc = s.rscale[c], rsh = s.rshift[c];
-      const float* rbase = s.rp + ((size_t)b * s.rT + s.toff + s.rdrop) * C + c;
+      const float* rbase = s.rp + ((size_t)b * s.rT + s.toff + f0 + s.rdrop) * C + c;
       for (int t0 = rg; t0 < rows; t0 += kGB * nrg) {
         float v[kGB], rv[kGB];
 #pragma unroll
@@ -322,8 +323,10 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
 }
 
 // dp = BN backward of the op's output gradient, rows [0, rows) of window b -> dst[t * ld + c]
+// (f0, Ttot: rows [f0, f0 + rows) of a window of Ttot frames - frame chunks of 1x1 ops; Ttot < 0: the whole window)
 template <int V>
-__device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab) {
+__device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab,
+                                             int f0 = 0, int Ttot = -1) {
   const int NQ = C / V, nrg = fast_div(kThreads, NQ);
   int q, rg;
   fast_divmod(tid, NQ, rg, q);
@@ -339,7 +342,8 @@ __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int 
     mg[e] = folded ? btab[kGFoldC + c] : y.mg[c];
     mgx[e] = folded ? btab[2 * kGFoldC + c] : y.mgx[c];
   }
-  const BufRsrc gslab = tile_rsrc(y.g + (size_t)b * rows * C, rows * C * 4), pslab = tile_rsrc(y.p + (size_t)b * rows * C, rows * C * 4);
+  const size_t w0 = ((size_t)b * (Ttot < 0 ? rows : Ttot) + f0) * C;
+  const BufRsrc gslab = tile_rsrc(y.g + w0, rows * C * 4), pslab = tile_rsrc(y.p + w0, rows * C * 4);
   constexpr int NB = kGB;
   for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
     GVec<V> g[NB], p[NB];
@@ -364,9 +368,10 @@ __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int 
 // compile time (vector width chosen there: a run-time choice between the three instantiations makes the compiler keep all
 // of them in registers at once), 0 = one channel per load.
 template <int CW>
-__device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab = nullptr) {
+__device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab = nullptr,
+                                         int f0 = 0, int Ttot = -1) {
   constexpr int V = CW == 0 ? 1 : (CW % 4 == 0 ? 4 : (CW % 2 == 0 ? 2 : 1));
-  stage_dp_vec<V>(y, C, b, rows, dst, ld, tid, btab);
+  stage_dp_vec<V>(y, C, b, rows, dst, ld, tid, btab, f0, Ttot);
 }
 
 // per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][ld] of this workgroup
@@ -431,11 +436,15 @@ struct GConvArgs {
   GBnBwd y;             // MODE 1
   GFoldFwd fold[kGMaxSrc];   // MODE 0: sources whose producer statistics this launch is the first to consume
   StatAcc sacc;         // MODE 0: the output statistics go to these accumulator rows instead of stat_part
+  int S, Tc;            // frame chunks (the CH instantiations, 1x1 ops only): a window is S work items of Tc frames (the last one shorter)
 };
 
 // bid / nb: this workgroup's index and the number of workgroups sharing the batch (a launch may hold several roles)
 // CDP (MODE 1): the op's filter count = channels of dp, when the launch knows it at compile time
-template <int NC, int MODE, int CDP = 0>
+// CH: frame chunks.  A 1x1 op has no halo, so a chunk of its frames is just a shorter window: the LDS tiles shrink to Tc
+// frames (a 64 -> 64 op of a MixedNet holds 105 KB for a whole window = one workgroup per CU), the work items are
+// (window, chunk) pairs.  Separate instantiations: the whole-window kernels are unchanged by it.
+template <int NC, int MODE, int CDP = 0, bool CH = false>
 __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
@@ -447,7 +456,8 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   const int PI = a.cin | 1, PO = NC | 1;
   const int cin4 = (a.cin + 3) & ~3;
   const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
-  const int rows_in = a.Tin + 2 * pad;
+  const int rows_in = CH ? a.Tc : a.Tin + 2 * pad;   // rows of the input tile / of the output tile (CH: k = 1, no halo)
+  const int rows_o = CH ? a.Tc : a.Tout;
   float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
   float* sIn = sW + a.k * cin4 * NCW;
   float* sOut = sIn + rows_in * PI;
@@ -458,7 +468,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // live behind the tiles only for the sources that exist and the reduction scratch of the final publish reuses the
   // weight tile (the host sizes the dynamic segment to match: mww_lib.hip, lds_fwd / lds_dx).
   float s1o = 0.f, s2o = 0.f;
-  float* sSrcAcc = g_smem + max(a.k * cin4 * NCW + rows_in * PI + a.Tout * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
+  float* sSrcAcc = g_smem + max(a.k * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
   float* sRed = g_smem;   // [2 * kThreads], after the window loop
   if (MODE == 1)
     for (int i = 0; i < (a.n_src - 1) * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
@@ -516,14 +526,24 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       sIn[(pad + a.Tin) * PI + i] = 0.f;
     }
   }
-  for (int b = bid; b < a.B; b += nb) {
+  for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
+    // work item v = window b, frames [f0, f0 + Tout) of its Ttot (whole-window kernels: f0 = 0, Tout = Ttot)
+    int b = v, f0 = 0, chunk = 0;
+    const int Ttot = MODE == 0 ? a.Tout : a.Tin;
+    int Tin = a.Tin, Tout = a.Tout;
+    if (CH) {
+      fast_divmod(v, a.S, b, chunk);
+      f0 = chunk * a.Tc;
+      Tin = Tout = min(a.Tc, Ttot - f0);
+    }
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if (MODE == 0) stage_sources(a.src, a.n_src, b, a.Tin, sIn, PI, tid, a.fold, sFold);
+    if (MODE == 0) stage_sources(a.src, a.n_src, b, Tin, sIn, PI, tid, a.fold, sFold, f0);
+    else if (CH) stage_dp<CDP>(a.y, a.cin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
     else stage_dp<CDP>(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
     __syncthreads();
     {
       const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-      const int ntile = (a.Tout + 15) >> 4;
+      const int ntile = (Tout + 15) >> 4;
       const bool kfull = (a.cin & 3) == 0;
       for (int rt = wave; rt < ntile; rt += kThreads / 64) {
         f32x4 acc[NT];
@@ -531,7 +551,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
         // A: lane (r16, g) holds frame rt*16 + r16 (frames past the window repeat its last one: their rows are not
         // stored), channel ci0 + g;  B: lane holds W[ci0 + g][nt*16 + r16]
-        const int t = min(rt * 16 + r16, a.Tout - 1);
+        const int t = min(rt * 16 + r16, Tout - 1);
         const float* arow = sIn + (MODE == 0 ? t * a.stride : t) * PI + g;
         const float* wrow = sW + g * NCW + r16;
         for (int j = 0; j < a.k; ++j) {
@@ -550,7 +570,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + g * 4 + r, col = nt * 16 + r16;
-            if (row < a.Tout && col < NC) sOut[row * PO + col] = acc[nt][r];
+            if (row < Tout && col < NC) sOut[row * PO + col] = acc[nt][r];
           }
       }
     }
@@ -558,8 +578,8 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     if (MODE == 0) {
       const int nrg = kThreads / NC, c = tid % NC, rg = tid / NC;
       if (rg < nrg) {
-        float* dst = a.out + (size_t)b * a.Tout * NC + c;
-        for (int t = rg; t < a.Tout; t += nrg) {
+        float* dst = a.out + ((size_t)b * Ttot + f0) * NC + c;
+        for (int t = rg; t < Tout; t += nrg) {
           const float v = sOut[t * PO + c];
           dst[(size_t)t * NC] = v;
           s1o += v;
@@ -588,7 +608,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
               const size_t woff = (size_t)b * s.T * s.ld + s.c0;
               const int wbytes = ((s.T - 1) * s.ld + C) * 4;
               const BufRsrc pr = tile_rsrc(s.p + woff, wbytes), gr = tile_rsrc(s.g + woff, wbytes), go = tile_rsrc(s.g + woff, accum ? wbytes : 0);
-              for (int tb = rg; tb < s.T; tb += kGE * nrg) {
+              // rows of the source this work item writes: all of them, or (CH) the chunk's - the first chunk also takes the
+              // rows in front of the aligned input, the last one those behind it
+              const int tlo = (CH && chunk > 0) ? s.toff + f0 : 0, thi = (CH && chunk < a.S - 1) ? s.toff + f0 + Tout : s.T;
+              for (int tb = tlo + rg; tb < thi; tb += kGE * nrg) {
                 float pv[kGE], gold[kGE];
 #pragma unroll
                 for (int u = 0; u < kGE; ++u) {
@@ -599,10 +622,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
 #pragma unroll
                 for (int u = 0; u < kGE; ++u) {
                   const int t = tb + u * nrg;
-                  if (t < s.T) {
+                  if (t < thi) {
                     const float p = pv[u];
-                    const int r = t - s.toff;
-                    const float gv = ((r >= 0 && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f) + gold[u];
+                    const int r = t - s.toff - f0;   // row of the output tile
+                    const float gv = ((r >= 0 && (!CH || r < Tout) && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f) + gold[u];
                     tile_store1(gr, (t * s.ld + c) * 4, gv);
                     t1 += gv;
                     t2 = fmaf(gv, (p - mu) * rs, t2);
@@ -611,6 +634,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
               }
             } else {
               // producer with a residual branch (MixedNet residual_connection): two tensors decide the ReLU mask
+              // (whole windows only: the host never chunks a graph with residual branches)
               const size_t base = (size_t)b * s.T * s.ld + s.c0 + c;
               const float rsc = s.rscale[c], rsh = s.rshift[c];
               const float* rbase = s.rp + ((size_t)b * s.rT + s.rdrop) * C + c;
@@ -669,6 +693,10 @@ template <int NC, int MODE>
 __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
   gconv_body<NC, MODE>(a, blockIdx.x, gridDim.x);
 }
+template <int NC, int MODE>
+__global__ __launch_bounds__(kThreads) void gconv_chunk_kernel(GConvArgs a) {
+  gconv_body<NC, MODE, 0, true>(a, blockIdx.x, gridDim.x);
+}
 
 // Two independent ops of the same shape ("twins": Inception's k x 1 convs of branch 2 and branch 3) as the two
 // halves of one launch: workgroups [0, nb) run op a0, [nb, 2 nb) op a1.
@@ -689,6 +717,7 @@ struct GWgradArgs {
   int k, dil, cin, B, Tin, Tout;
   int stride;           // time stride of the forward convolution
   float* grad_part;     // [workgroups of the role][k*cin*NC]
+  int S, Tc;            // frame chunks (CH instantiations, 1x1 ops): see GConvArgs
 };
 
 // On the matrix cores: dW = A^T B with A[t][m] = act[t*stride + j*dil][ci] (m = j*cin + ci, the "task" axis) and
@@ -706,7 +735,7 @@ __host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (
 // columns that are never stored - puts the stem's weight gradient at three per CU too, but measured 0.891 against 0.887.)
 __host__ __device__ inline int gwg_dp_pitch(int nc) { return (nc + 15) / 16 * 16; }
 
-template <int NC>
+template <int NC, bool CH = false>
 __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
@@ -714,9 +743,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   const int PO = gwg_dp_pitch(NC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int PI = a.cin | 1;
-  const int Tout4 = (a.Tout + 3) & ~3;
+  const int cap = CH ? a.Tc : a.Tout;                   // frames of the tiles (CH: k = 1, Tin = Tout = the chunk)
+  const int Tout4 = (cap + 3) & ~3;
   float* sA = g_smem;
-  float* sDP = g_smem + (a.Tin * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
+  float* sDP = g_smem + ((CH ? a.Tc : a.Tin) * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
   const int tasks = a.k * a.cin, MT = (tasks + 15) >> 4;
   const int KS = gwg_kparts(tasks), nslot = (kThreads / 64) / KS;
   const int kp = wave % KS, slot = wave / KS;
@@ -744,14 +774,27 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
     gfold_backward_load(a.y.fold, NC, a.y.rstd, tid, fr);
     gfold_backward_finish(a.y.fold, NC, sFoldB, bid, tid, fr);
   }
-  for (int b = bid; b < a.B; b += nb) {
+  for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
+    int b = v, f0 = 0, Tin = a.Tin, Tout = a.Tout;
+    if (CH) {
+      int chunk;
+      fast_divmod(v, a.S, b, chunk);
+      f0 = chunk * a.Tc;
+      Tin = Tout = min(a.Tc, a.Tout - f0);
+    }
     __syncthreads();
-    stage_sources(a.src, a.n_src, b, a.Tin, sA, PI, tid);
-    stage_dp<NC>(a.y, NC, b, a.Tout, sDP, PO, tid, sFoldB);
+    stage_sources(a.src, a.n_src, b, Tin, sA, PI, tid, nullptr, nullptr, f0);
+    if (CH) {
+      stage_dp<NC>(a.y, NC, b, Tout, sDP, PO, tid, sFoldB, f0, a.Tout);
+      // a shorter last chunk leaves the previous item's rows behind its own: the k-step that straddles the end reads them
+      for (int i = tid; i < (((Tout + 3) & ~3) - Tout) * PO; i += kThreads) sDP[Tout * PO + i] = 0.f;
+    } else {
+      stage_dp<NC>(a.y, NC, b, a.Tout, sDP, PO, tid, sFoldB);
+    }
     __syncthreads();
-    for (int t0 = kp * 4; t0 < a.Tout; t0 += 4 * KS) {
+    for (int t0 = kp * 4; t0 < Tout; t0 += 4 * KS) {
       // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
-      const int tf = min(t0 + g, a.Tout - 1);
+      const int tf = min(t0 + g, Tout - 1);
       const float* arow = sA + tf * a.stride * PI;
       float bv[NT];
 #pragma unroll
@@ -813,6 +856,10 @@ template <int NC>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
   gconv_wgrad_body<NC>(a, blockIdx.x, gridDim.x);
 }
+template <int NC>
+__global__ __launch_bounds__(kThreads) void gconv_wgrad_chunk_kernel(GWgradArgs a) {
+  gconv_wgrad_body<NC, true>(a, blockIdx.x, gridDim.x);
+}
 
 // Both halves of an op's backward in one launch: workgroups [0, nb) form the weight gradient, [nb, 2 nb) the data
 // gradient.  They are independent (both only read the op's output gradient) and each is latency-bound on its
@@ -821,6 +868,11 @@ template <int NCO, int NCI>
 __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
   if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO>(w, blockIdx.x, nbw);
   else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nbw, nbd);
+}
+template <int NCO, int NCI>
+__global__ __launch_bounds__(kThreads) void gconv_bwd_chunk_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
+  if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO, true>(w, blockIdx.x, nbw);
+  else gconv_body<NCI, 1, NCO, true>(d, blockIdx.x - nbw, nbd);
 }
 
 // ... and of twin ops: four roles

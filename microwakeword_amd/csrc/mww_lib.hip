@@ -115,6 +115,7 @@ struct mww_ctx {
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   int grid_g = 0;
   int g_cap_fwd = 4, g_cap_bwd = 4;   // "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" (g_role_grid)
+  int g_chunks = 0;   // "graph_frame_chunks" (g_chunks())
   int g_dgrad_share = 50;   // "graph_dgrad_share"
   bool grid_g_auto = true;   // per-launch grids from the kernel's occupancy (g_role_grid); "grid_graph" > 0 fixes one grid
   std::map<std::pair<const void*, size_t>, int> g_occ;   // workgroups per CU of (kernel, dynamic LDS)
@@ -875,6 +876,47 @@ bool g_width_supported(int n) {
 // gfx950 has 160 KB of LDS per CU; tiles above the 64 KB default need the function attribute
 constexpr size_t kMaxDynLds = 144 * 1024;
 
+// Dynamic LDS of the MFMA graph kernels (kernels_graph.hip.h) for an op whose tiles hold rin input rows / rout output rows
+// (forward naming; the whole window, or a frame chunk of a 1x1 op): weights [k][cin4][NCW] zero-padded to whole k-steps /
+// filter tiles; gconv_body's publish scratch aliases the first 2 * kThreads floats, its MODE 1 keeps the statistics pairs of
+// the second and third source behind the tiles.
+size_t g_up4(int v) { return (size_t)((v + 3) & ~3); }
+size_t g_up16(int v) { return (size_t)((v + 15) / 16 * 16); }
+size_t g_lds_body(size_t tiles, int pairs) { return (std::max(tiles, (size_t)2 * kThreads) + (size_t)pairs * 2 * kThreads + 4) * sizeof(float); }
+size_t g_lds_fwd(const GOp& o, int rin, int rout) {
+  return g_lds_body((size_t)o.k * g_up4(o.cin) * g_up16(o.cout) + (size_t)rin * (o.cin | 1) + (size_t)rout * (o.cout | 1), 0);
+}
+size_t g_lds_dx(const GOp& o, int rows_dp_padded, int rows_dx) {
+  return g_lds_body((size_t)o.k * g_up4(o.cout) * g_up16(o.cin) + (size_t)rows_dp_padded * (o.cout | 1) + (size_t)rows_dx * (o.cin | 1), o.n_src - 1);
+}
+size_t g_lds_wg(const GOp& o, int rin, int rout) {
+  const int tasks = o.k * o.cin, mt = (tasks + 15) / 16, nt = (o.cout + 15) / 16;
+  size_t b = (((size_t)rin * (o.cin | 1) + 6) / 4 * 4 + g_up4(rout) * (size_t)gwg_dp_pitch(o.cout)) * sizeof(float);
+  if (gwg_kparts(tasks) > 1) b = std::max(b, (size_t)gwg_kparts(tasks) * mt * nt * 256 * sizeof(float));   // scratch of the sum over the frame parts
+  return b;
+}
+
+// Frame chunks of a 1x1 op ("graph_frame_chunks"; kernels_graph.hip.h, CH instantiations): S work items of Tc frames per
+// window.  0 = whole windows (the default: the chunked kernels are covered by the parity tests but have not been timed
+// on the GPU yet), 1 = as many chunks (<= 4) as it takes for the launch's tiles to fit four times per CU, 2..4 = that many.
+// Only with the statistics hand-over (such graphs have no residual branches, which the chunked data gradient does not
+// handle) and never for twin launches.
+int g_chunks(const mww_ctx* c, const GOp& o, bool inl, bool backward, int* Tc) {
+  *Tc = o.tout;
+  if (!inl || c->g_chunks == 0 || o.kind != MWW_OP_CONV || o.k != 1 || o.stride != 1 || o.tin != o.tout || o.tout < 32) return 1;
+  int S = c->g_chunks;
+  if (S == 1) {
+    for (S = 1; S < 4; ++S) {
+      const int t = (o.tout + S - 1) / S;
+      const size_t lds = backward ? std::max(g_lds_wg(o, t, t), o.needs_dx ? g_lds_dx(o, t, t) : 0) : g_lds_fwd(o, t, t);
+      if (lds + 3072 <= 40960) break;
+    }
+  }
+  S = std::min(S, 4);
+  *Tc = (o.tout + S - 1) / S;
+  return (S - 1) * *Tc < o.tout ? S : 1;   // (every chunk non-empty)
+}
+
 // Workgroups per role of a conv/BN graph launch.  The kernels are latency-bound (one wave per SIMD and workgroup, ~15
 // cycles per issued instruction), so a launch wants as many resident workgroups as its own LDS tile and registers let a
 // CU hold - and no more: a workgroup that has to wait for a free slot costs more than it brings.  With one grid for the
@@ -921,14 +963,16 @@ void g_share_roles(mww_ctx* c, const GridPick& pk, int* nbw, int* nbd) {
   if (pk.used) *pk.used = *nbw;
 }
 
-template <int MODE>
+// (CH: the frame-chunk instantiations, a.S > 1)
+template <int MODE, bool CH = false>
 int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
-    const void* f = reinterpret_cast<const void*>(&gconv_kernel<N, MODE>);                                     \
+    auto k = CH ? &gconv_chunk_kernel<N, MODE> : &gconv_kernel<N, MODE>;                                       \
+    const void* f = reinterpret_cast<const void*>(k);                                                          \
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, c->stream, a);                                      \
     return MWW_OK;                                                                                             \
   }
   MWW_G_WIDTHS(X)
@@ -936,13 +980,15 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, siz
   return fail(MWW_ERR_UNSUPPORTED, "conv width not instantiated");
 }
 
+template <bool CH = false>
 int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
-    const void* f = reinterpret_cast<const void*>(&gconv_wgrad_kernel<N>);                                     \
+    auto k = CH ? &gconv_wgrad_chunk_kernel<N> : &gconv_wgrad_kernel<N>;                                       \
+    const void* f = reinterpret_cast<const void*>(k);                                                          \
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_wgrad_kernel<N>), dim3(grid), dim3(kThreads), lds, c->stream, a);                \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, c->stream, a);                                      \
     return MWW_OK;                                                                                             \
   }
   MWW_G_WIDTHS(X)
@@ -953,14 +999,16 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, s
 // (filters, input channels) pairs with a fused weight-gradient + data-gradient launch; others use two launches
 #define MWW_G_BWD_PAIRS(X) X(30, 24) X(10, 10) X(10, 30) X(30, 10) X(48, 10) X(16, 16) X(16, 48) X(24, 16) X(16, 24) X(36, 24) X(12, 36) X(48, 32) X(48, 48) X(64, 32) X(64, 64)
 
+template <bool CH = false>
 bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, const GridPick& pk, size_t lds) {
 #define X(NCO, NCI)                                                                                            \
   if (nco == NCO && nci == NCI) {                                                                              \
-    const void* f = reinterpret_cast<const void*>(&gconv_bwd_kernel<NCO, NCI>);                                \
+    auto k = CH ? &gconv_bwd_chunk_kernel<NCO, NCI> : &gconv_bwd_kernel<NCO, NCI>;                             \
+    const void* f = reinterpret_cast<const void*>(k);                                                          \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
     int nbw = g_role_grid(c, f, lds, pk), nbd = nbw;                                                           \
     g_share_roles(c, pk, &nbw, &nbd);                                                                          \
-    hipLaunchKernelGGL((gconv_bwd_kernel<NCO, NCI>), dim3(nbw + nbd), dim3(kThreads), lds, c->stream, w, d, nbw, nbd); \
+    hipLaunchKernelGGL(k, dim3(nbw + nbd), dim3(kThreads), lds, c->stream, w, d, nbw, nbd);                    \
     return true;                                                                                               \
   }
   MWW_G_BWD_PAIRS(X)
@@ -1194,9 +1242,18 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
         c->prof.pop_back();
       }
     }
-    const GConvArgs fa = fwd_args(i);
+    GConvArgs fa = fwd_args(i);
+    int Tc = 0;
+    const int S = g_chunks(c, o, inl, false, &Tc);
     lp.begin("conv_fwd", i);
-    int rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd);
+    int rc;
+    if (S > 1) {
+      fa.S = S;
+      fa.Tc = Tc;
+      rc = launch_gconv<0, true>(c, o.cout, fa, GridPick{pick ? 0 : gg, B * S, 1, c->g_cap_fwd, nullptr}, g_lds_fwd(o, Tc, Tc));
+    } else {
+      rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd);
+    }
     lp.end();
     if (rc) return rc;
     if (training && o.norm == MWW_NORM_BN && !inl) {
@@ -1497,9 +1554,21 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     bool fused = false;
     int rows = gg;
+    int Tc = 0;
+    const int S = g_chunks(c, o, inl, true, &Tc);   // frame chunks (1x1 ops): S work items per window for both roles
+    size_t lds_wg = o.lds_wg, lds_dx = o.lds_dx;
+    if (S > 1) {
+      w.S = a.S = S;
+      w.Tc = a.Tc = Tc;
+      lds_wg = g_lds_wg(o, Tc, Tc);
+      lds_dx = o.needs_dx ? g_lds_dx(o, Tc, Tc) : 0;
+    }
+    const int items = B * S;
     if (o.needs_dx && !c->profile_split) {
       lp.begin("conv_bwd", i);
-      fused = launch_gbwd_fused(c, o.cout, o.cin, w, a, GridPick{pick ? 0 : gg2, B, split ? 2 : 1, c->g_cap_bwd, &rows}, std::max(o.lds_wg, o.lds_dx));
+      const GridPick pkf{pick ? 0 : gg2, items, split ? 2 : 1, c->g_cap_bwd, &rows};
+      fused = S > 1 ? launch_gbwd_fused<true>(c, o.cout, o.cin, w, a, pkf, std::max(lds_wg, lds_dx))
+                    : launch_gbwd_fused(c, o.cout, o.cin, w, a, pkf, std::max(lds_wg, lds_dx));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
         (void)hipEventDestroy(c->prof.back().a);
@@ -1509,12 +1578,14 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     }
     if (!fused) {
       lp.begin("conv_wgrad", i);
-      int rc = launch_gwgrad(c, o.cout, w, GridPick{pick ? 0 : gg, B, 1, c->g_cap_bwd, &rows}, o.lds_wg);
+      const GridPick pkw{pick ? 0 : gg, items, 1, c->g_cap_bwd, &rows};
+      int rc = S > 1 ? launch_gwgrad<true>(c, o.cout, w, pkw, lds_wg) : launch_gwgrad(c, o.cout, w, pkw, lds_wg);
       lp.end();
       if (rc) return rc;
       if (o.needs_dx) {
         lp.begin("conv_dgrad", i);
-        rc = launch_gconv<1>(c, o.cin, a, GridPick{pick ? 0 : gg, B, 1, c->g_cap_bwd, nullptr}, o.lds_dx);
+        const GridPick pkd{pick ? 0 : gg, items, 1, c->g_cap_bwd, nullptr};
+        rc = S > 1 ? launch_gconv<1, true>(c, o.cin, a, pkd, lds_dx) : launch_gconv<1>(c, o.cin, a, pkd, lds_dx);
         lp.end();
         if (rc) return rc;
       }
@@ -1868,22 +1939,9 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
       if (!g_width_supported(o.cout)) return fail(MWW_ERR_UNSUPPORTED, tag + "filter count not instantiated (8,10,12,16,20,24,30,32,36,40,48,60,64)");
       if (o.needs_dx && !g_width_supported(o.cin)) return fail(MWW_ERR_UNSUPPORTED, tag + "input channel count not instantiated");
       if (o.k * o.cin > kThreads) return fail(MWW_ERR_UNSUPPORTED, tag + "kernel x input channels exceeds 256");
-      // LDS tiles of the MFMA kernels (kernels_graph.hip.h): weights [k][cin4][NCW] zero-padded to whole k-steps / filter tiles
-      auto up4 = [](int v) { return (size_t)((v + 3) & ~3); };
-      auto up16 = [](int v) { return (size_t)((v + 15) / 16 * 16); };
-      const size_t wf = (size_t)o.k * up4(o.cin) * up16(o.cout), wb = (size_t)o.k * up4(o.cout) * up16(o.cin);
-      // + gconv_body's tail: the publish scratch aliases the first 2 * kThreads floats, MODE 1 keeps the statistics
-      // pairs of its second and third source behind the tiles
-      auto body = [](size_t tiles, int pairs) { return (std::max(tiles, (size_t)2 * kThreads) + (size_t)pairs * 2 * kThreads + 4) * sizeof(float); };
-      o.lds_fwd = body(wf + (size_t)o.tin * (o.cin | 1) + (size_t)o.tout * (o.cout | 1), 0);
-      o.lds_dx = body(wb + (size_t)(o.tout + 2 * pad) * (o.cout | 1) + (size_t)o.tin * (o.cin | 1), o.n_src - 1);
-      {
-        const int tasks = o.k * o.cin, mt = (tasks + 15) / 16, nt = (o.cout + 15) / 16;
-        o.lds_wg = (((size_t)o.tin * (o.cin | 1) + 6) / 4 * 4 + up4(o.tout) * (size_t)gwg_dp_pitch(o.cout)) * sizeof(float);
-        if (gwg_kparts(tasks) > 1)   // scratch of the sum over the frame parts
-          o.lds_wg = std::max(o.lds_wg, (size_t)gwg_kparts(tasks) * mt * nt * 256 * sizeof(float));
-      }
-      if (!o.needs_dx) o.lds_dx = 0;
+      o.lds_fwd = g_lds_fwd(o, o.tin, o.tout);   // (g_lds_*: the LDS tiles of the MFMA kernels)
+      o.lds_dx = o.needs_dx ? g_lds_dx(o, o.tout + 2 * pad, o.tin) : 0;
+      o.lds_wg = g_lds_wg(o, o.tin, o.tout);
     }
     if (std::max(o.lds_fwd, std::max(o.lds_dx, o.lds_wg)) > kMaxDynLds) return fail(MWW_ERR_UNSUPPORTED, tag + "window does not fit the LDS tile");
     o.o_w = off; off += o.kind == MWW_OP_DEPTHWISE ? (int64_t)o.k * o.cout : (int64_t)o.k * o.cin * o.cout;
@@ -2354,7 +2412,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2533,6 +2591,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
+  else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }
   else if (!strcmp(name, "graph_dgrad_share")) { if (v < 10 || v > 90) return fail(MWW_ERR_INVALID, "graph_dgrad_share must be 10..90"); c->g_dgrad_share = (int)v; }
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;
   else if (!strcmp(name, "bce_from_logits")) c->bce_clipped = v == 0;

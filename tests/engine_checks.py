@@ -505,12 +505,14 @@ def check_inception_forward(lib, B=3, T=194, training=False, grid=None, flags=IN
     return float(np.abs(pr - po).max())
 
 
-def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=INC, fuse_heads=True):
+def check_inception_train_steps(lib, B=4, T=194, steps=2, grid=2, lr=1e-3, graphs=False, flags=INC, fuse_heads=True, options=None):
     om = perturbed_inception_oracle(T, flags)
     lay, eng = make_inception_engine(lib, T, B, om, flags, fuse_heads)
     if grid:
         for k in ("grid_graph", "grid_head"):
             eng.set_option(k, grid)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
     if graphs:
         eng.set_option("graphs", 1)
     rng = np.random.default_rng(11)
@@ -755,7 +757,7 @@ GRAPH_MIXEDNET_NOCONV1 = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", p
                               mixconv_kernel_sizes="[5],[7,9]", first_conv_filters=0)
 
 
-def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, graphs=False, lr=1e-3, bn_inline=None):
+def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, graphs=False, lr=1e-3, bn_inline=None, options=None):
     """Forward intermediates and train step of a MixedNet running on the generic conv/BN graph kernels.  bn_inline: None =
     the engine's default (graphs of convolutions + BN and depthwise ops + bias hand their statistics over; residual /
     attention / pooled graphs use finalize launches), 0 = finalize launches everywhere."""
@@ -775,6 +777,8 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         eng.set_option("graphs", 1)
     if bn_inline is not None:
         eng.set_option("bn_inline", bn_inline)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
     rng = np.random.default_rng(13)
     wts = dict(zip([n for n, _, _ in lay.keras_vars], om.get_weights()))
     for training in (False, True):

@@ -80,6 +80,16 @@ def test_inception_statistics_hand_over_matches_finalize_launches(emu_lib):
     ec.check_inception_bn_inline_matches_finalize(emu_lib, B=4, T=120, steps=2, flags=ec.INC_VARIANT)
 
 
+def test_frame_chunks_of_the_pointwise_graph_ops(emu_lib):
+    """"graph_frame_chunks": the 1x1 ops of a conv/BN graph process a window as 2-4 frame chunks (smaller LDS tiles); same
+    results against the oracle as with whole windows, uneven last chunks included."""
+    ec.check_inception_train_steps(emu_lib, B=3, T=121, steps=2, grid=2, options={"graph_frame_chunks": 2})
+    ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=0, options={"graph_frame_chunks": 3})
+    ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=2, flags=ec.INC_VARIANT, options={"graph_frame_chunks": 4})
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=2, grid=0, options={"graph_frame_chunks": 3})
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_NOCONV1, B=2, T=60, steps=1, grid=1, graphs=True, options={"graph_frame_chunks": 2})
+
+
 def test_graph_grid_options(emu_lib):
     ec.check_graph_grid_options(emu_lib, B=5, T=100)
 
