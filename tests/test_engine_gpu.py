@@ -419,4 +419,3 @@ def test_inception_topology_fuzz(lib):
 def test_shape_fuzz(lib):
     """12 of the random (frames, batch, grid) cases; tools/gpu_shape_fuzz.py ran 400 of them green."""
     ec.check_shape_fuzz(lib, cases=12, first=40)
-
