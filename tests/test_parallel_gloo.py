@@ -158,6 +158,15 @@ def _sync_worker(rank, world, port, out_dir, emu_path, kind, sync=True, buckets=
     if kind == "mixednet":
         om = ec.perturbed_oracle(T)
         lay, eng = ec.make_engine(lib, T, Bl, om)
+    elif kind == "graph_mixednet":   # a MixedNet flag set that runs on the conv / depthwise graph kernels
+        from microwakeword_amd.layout import GraphMixedNetLayout
+        om = ec.perturbed_oracle(T, flags=ec.GRAPH_MIXEDNET)
+        lay = GraphMixedNetLayout(ec.GRAPH_MIXEDNET, T)
+        eng = native.Engine(lib=lib, **lay.engine_args(Bl))
+        eng.set_grad_mask(lay.grad_mask())
+        p0, s0 = lay.pack(om.get_weights())
+        eng.set_params(p0)
+        eng.set_bn_state(s0)
     else:
         om = ec.perturbed_inception_oracle(T, ec.INC)
         lay, eng = ec.make_inception_engine(lib, T, Bl, om, ec.INC)
@@ -324,6 +333,42 @@ def test_local_bn_two_ranks_inception_graph_kernels(tmp_path):
         gsum = gsum + lay.pack([grads[n].numpy().astype(np.float32) if k == "param" else np.zeros(sh, np.float32)
                                 for n, sh, k in lay.keras_vars])[0].astype(np.float64)
         om.train_step(x[sl], y[sl], w[sl], 1e-3, dropout_mask=keep[sl])
+        s_ref = lay.pack(om.get_weights())[1]
+        assert np.abs(outs[r]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+    g = outs[0]["grads"].astype(np.float64)
+    assert np.linalg.norm(g - gsum) <= 2e-3 * np.linalg.norm(gsum)
+
+
+def test_local_bn_two_ranks_mixednet_graph_kernels(tmp_path):
+    """As above for a MixedNet on the graph engine (convolution + BN and depthwise + bias ops): the hand-over through the
+    depthwise kernels (forward fold as first consumer, backward sums added for the producing convolution, bias gradient
+    folded by the weight-gradient launch) together with the gradient exchange."""
+    import conftest
+    import engine_checks as ec
+    from microwakeword_amd.layout import GraphMixedNetLayout
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W, Bl = 2, 3
+    rng = np.random.default_rng(5)
+    x = ec.synth_x(rng, W * Bl, T)
+    y = (rng.random(W * Bl) < 0.5).astype(np.float32)
+    w = rng.choice([0.5, 1.0, 2.0], size=W * Bl).astype(np.float32)
+    lay = GraphMixedNetLayout(ec.GRAPH_MIXEDNET, T)
+    np.savez(tmp_path / "inputs.npz", x=x, y=y, w=w, keep=np.zeros(1))
+    mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "graph_mixednet", False), nprocs=W, join=True)
+    outs = [np.load(tmp_path / ("out%d.npz" % r)) for r in range(W)]
+    np.testing.assert_array_equal(outs[0]["grads"], outs[1]["grads"])
+    np.testing.assert_array_equal(outs[0]["params"], outs[1]["params"])
+    assert np.abs(outs[0]["state"] - outs[1]["state"]).max() > 0
+    gsum = 0.0
+    for r in range(W):
+        om = ec.perturbed_oracle(T, flags=ec.GRAPH_MIXEDNET)
+        sl = slice(r * Bl, (r + 1) * Bl)
+        _, _, grads, _ = om.loss_and_grads(x[sl], y[sl], w[sl])
+        gsum = gsum + lay.pack([grads[n].numpy().astype(np.float32) if k == "param" else np.zeros(sh, np.float32)
+                                for n, sh, k in lay.keras_vars])[0].astype(np.float64)
+        om.train_step(x[sl], y[sl], w[sl], 1e-3)
         s_ref = lay.pack(om.get_weights())[1]
         assert np.abs(outs[r]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
     g = outs[0]["grads"].astype(np.float64)
