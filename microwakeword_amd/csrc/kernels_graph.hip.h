@@ -28,7 +28,9 @@
 //     them (no finalize launches, see "statistics hand-over" below).
 // Measured (profiles/round2_*inception*): the matrix cores do not make these launches faster than the former VALU form
 // (one lane per output frame) - at 1024 windows per step a launch is 2-4 windows per CU and 12-30 us of latency chain
-// (weights -> slab -> tile -> epilogue) of which the contraction is 1-4 us.
+// (weights -> slab -> tile -> epilogue) of which the contraction is 1-4 us.  What counts is how many workgroups a CU
+// holds: static LDS is kept to the fold tables, every launch takes the grid its own occupancy allows (g_role_grid in
+// mww_lib.hip: 1.030 -> 0.884 ms per Inception step), and the depthwise ops of MixedNet graphs are register-blocked.
 #pragma once
 #include "common.hip.h"
 
