@@ -872,7 +872,7 @@ __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConv
   else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nbw, nbd);
 }
 template <int NCO, int NCI>
-__global__ __launch_bounds__(kThreads) void gconv_bwd_chunk_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
+__global__ __launch_bounds__(kThreads, 3) void gconv_bwd_chunk_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
   if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO, true>(w, blockIdx.x, nbw);
   else gconv_body<NCI, 1, NCO, true>(d, blockIdx.x - nbw, nbd);
 }
