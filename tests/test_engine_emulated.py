@@ -137,7 +137,7 @@ def test_mixednet_on_generic_graph_kernels(emu_lib):
     """Flag combinations outside the specialised kernels (repeat 2, a block without depthwise, odd filters,
     strided 5x1 first conv; and no first conv at all) run on the conv/BN graph kernels."""
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2)
-    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=2, grid=0)                # per-launch grids, both accumulator parities
+    ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=3, grid=0, graphs=True)   # per-launch grids, both accumulator parities, replayed
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2, bn_inline=0)   # finalize launches
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_NOCONV1, B=2, T=60, steps=1, grid=1, graphs=True)
 
