@@ -85,6 +85,7 @@ def test_frame_chunks_of_the_pointwise_graph_ops(emu_lib):
     results against the oracle as with whole windows, uneven last chunks included."""
     ec.check_inception_train_steps(emu_lib, B=3, T=121, steps=2, grid=2, options={"graph_frame_chunks": 2})
     ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=0, options={"graph_frame_chunks": 3})
+    ec.check_inception_train_steps(emu_lib, B=2, T=194, steps=1, grid=0, options={"graph_frame_chunks": 1})   # automatic: only the 24 -> 30, 10 -> 48 and 48 -> 16 ops are chunked
     ec.check_inception_train_steps(emu_lib, B=3, T=120, steps=1, grid=2, flags=ec.INC_VARIANT, options={"graph_frame_chunks": 4})
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET, B=3, T=100, steps=2, grid=0, options={"graph_frame_chunks": 3})
     ec.check_graph_mixednet(emu_lib, ec.GRAPH_MIXEDNET_NOCONV1, B=2, T=60, steps=1, grid=1, graphs=True, options={"graph_frame_chunks": 2})
