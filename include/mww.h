@@ -263,8 +263,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * grid its own LDS tile and registers let the CUs hold - at most "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" workgroups per
  * CU, default 4 / 4; > 0 = that many workgroups per launch; without bn_inline one grid of 3 per CU, because a tensor's
  * partial statistics rows are shared by its launches),
- * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops process a window as up to 4 frame chunks with
- * correspondingly smaller LDS tiles; 0 = off, the default - parity-tested, not yet timed on the GPU; 1 = automatic; 2..4),
+ * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops - and the forward convolution of any op - process
+ * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, the default - parity-tested, not yet timed on the GPU; 1 = automatic; 2..4),
  * "grad_buckets" (data-parallel step: 2 =
  * overlapped two-bucket gradient exchange, 1 = one exchange after the backward pass), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's

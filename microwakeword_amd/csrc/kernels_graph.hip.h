@@ -445,7 +445,9 @@ struct GConvArgs {
 // CDP (MODE 1): the op's filter count = channels of dp, when the launch knows it at compile time
 // CH: frame chunks.  A 1x1 op has no halo, so a chunk of its frames is just a shorter window: the LDS tiles shrink to Tc
 // frames (a 64 -> 64 op of a MixedNet holds 105 KB for a whole window = one workgroup per CU), the work items are
-// (window, chunk) pairs.  Separate instantiations: the whole-window kernels are unchanged by it.
+// (window, chunk) pairs.  The forward convolution and the weight gradient also take k > 1 (a chunk stages its input frames
+// plus halo: the 5 x 40 -> 24 stem); the data gradient only k = 1.  Separate instantiations: the whole-window kernels are
+// unchanged by it.
 template <int NC, int MODE, int CDP = 0, bool CH = false>
 __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
   HIP_DYNAMIC_SHARED(float4, g_smem4)
@@ -458,7 +460,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   const int PI = a.cin | 1, PO = NC | 1;
   const int cin4 = (a.cin + 3) & ~3;
   const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
-  const int rows_in = CH ? a.Tc : a.Tin + 2 * pad;   // rows of the input tile / of the output tile (CH: k = 1, no halo)
+  // rows of the input tile / of the output tile.  CH: a chunk of Tc output frames; the forward convolution stages the
+  // chunk's input frames with their halo, the data gradient is only chunked for k = 1 (no halo, no zero frames)
+  const int rows_in = CH ? (MODE == 0 ? (a.Tc - 1) * a.stride + (a.k - 1) * a.dil + 1 : a.Tc) : a.Tin + 2 * pad;
   const int rows_o = CH ? a.Tc : a.Tout;
   float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
   float* sIn = sW + a.k * cin4 * NCW;
@@ -536,10 +540,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     if (CH) {
       fast_divmod(v, a.S, b, chunk);
       f0 = chunk * a.Tc;
-      Tin = Tout = min(a.Tc, Ttot - f0);
+      Tout = min(a.Tc, Ttot - f0);
+      Tin = MODE == 0 ? (Tout - 1) * a.stride + (a.k - 1) * a.dil + 1 : Tout;
     }
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if (MODE == 0) stage_sources(a.src, a.n_src, b, Tin, sIn, PI, tid, a.fold, sFold, f0);
+    if (MODE == 0) stage_sources(a.src, a.n_src, b, Tin, sIn, PI, tid, a.fold, sFold, CH ? f0 * a.stride : 0);
     else if (CH) stage_dp<CDP>(a.y, a.cin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
     else stage_dp<CDP>(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
     __syncthreads();
@@ -745,10 +750,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   const int PO = gwg_dp_pitch(NC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int PI = a.cin | 1;
-  const int cap = CH ? a.Tc : a.Tout;                   // frames of the tiles (CH: k = 1, Tin = Tout = the chunk)
+  const int cap = CH ? a.Tc : a.Tout;                   // frames of the dp tile (CH: a chunk; the A tile holds its input frames + halo)
   const int Tout4 = (cap + 3) & ~3;
   float* sA = g_smem;
-  float* sDP = g_smem + ((CH ? a.Tc : a.Tin) * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
+  float* sDP = g_smem + ((CH ? (a.Tc - 1) * a.stride + (a.k - 1) * a.dil + 1 : a.Tin) * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
   const int tasks = a.k * a.cin, MT = (tasks + 15) >> 4;
   const int KS = gwg_kparts(tasks), nslot = (kThreads / 64) / KS;
   const int kp = wave % KS, slot = wave / KS;
@@ -782,10 +787,11 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       int chunk;
       fast_divmod(v, a.S, b, chunk);
       f0 = chunk * a.Tc;
-      Tin = Tout = min(a.Tc, a.Tout - f0);
+      Tout = min(a.Tc, a.Tout - f0);
+      Tin = (Tout - 1) * a.stride + (a.k - 1) * a.dil + 1;
     }
     __syncthreads();
-    stage_sources(a.src, a.n_src, b, Tin, sA, PI, tid, nullptr, nullptr, f0);
+    stage_sources(a.src, a.n_src, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * a.stride : 0);
     if (CH) {
       stage_dp<NC>(a.y, NC, b, Tout, sDP, PO, tid, sFoldB, f0, a.Tout);
       // a shorter last chunk leaves the previous item's rows behind its own: the k-step that straddles the end reads them

@@ -896,19 +896,24 @@ size_t g_lds_wg(const GOp& o, int rin, int rout) {
   return b;
 }
 
-// Frame chunks of a 1x1 op ("graph_frame_chunks"; kernels_graph.hip.h, CH instantiations): S work items of Tc frames per
-// window.  0 = whole windows (the default: the chunked kernels are covered by the parity tests but have not been timed
+// Frame chunks ("graph_frame_chunks"; kernels_graph.hip.h, CH instantiations): S work items of Tc output frames per window -
+// the 1x1 ops in all three roles, ops with k > 1 in the forward convolution and in a weight gradient that has no data
+// gradient next to it (the stem).  0 = whole windows (the default: the chunked kernels are covered by the parity tests but have not been timed
 // on the GPU yet), 1 = as many chunks (<= 4) as it takes for the launch's tiles to fit four times per CU, 2..4 = that many.
 // Only with the statistics hand-over (such graphs have no residual branches, which the chunked data gradient does not
 // handle) and never for twin launches.
+// input frames (with halo) of a chunk of t output frames
+int g_chunk_in(const GOp& o, int t) { return (t - 1) * o.stride + (o.k - 1) * o.dil + 1; }
+
 int g_chunks(const mww_ctx* c, const GOp& o, bool inl, bool backward, int* Tc) {
   *Tc = o.tout;
-  if (!inl || c->g_chunks == 0 || o.kind != MWW_OP_CONV || o.k != 1 || o.stride != 1 || o.tin != o.tout || o.tout < 32) return 1;
+  // the data gradient is only chunked without a halo (k = 1); forward convolution and a weight gradient on its own take any k
+  if (!inl || c->g_chunks == 0 || o.kind != MWW_OP_CONV || o.tout < 32 || (backward && o.needs_dx && o.k != 1)) return 1;
   int S = c->g_chunks;
   if (S == 1) {
     for (S = 1; S < 4; ++S) {
-      const int t = (o.tout + S - 1) / S;
-      const size_t lds = backward ? std::max(g_lds_wg(o, t, t), o.needs_dx ? g_lds_dx(o, t, t) : 0) : g_lds_fwd(o, t, t);
+      const int t = (o.tout + S - 1) / S, ti = g_chunk_in(o, t);
+      const size_t lds = backward ? std::max(g_lds_wg(o, ti, t), o.needs_dx ? g_lds_dx(o, t, t) : 0) : g_lds_fwd(o, ti, t);
       if (lds + 3072 <= 40960) break;
     }
   }
@@ -1250,7 +1255,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
     if (S > 1) {
       fa.S = S;
       fa.Tc = Tc;
-      rc = launch_gconv<0, true>(c, o.cout, fa, GridPick{pick ? 0 : gg, B * S, 1, c->g_cap_fwd, nullptr}, g_lds_fwd(o, Tc, Tc));
+      rc = launch_gconv<0, true>(c, o.cout, fa, GridPick{pick ? 0 : gg, B * S, 1, c->g_cap_fwd, nullptr}, g_lds_fwd(o, g_chunk_in(o, Tc), Tc));
     } else {
       rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd);
     }
@@ -1560,7 +1565,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     if (S > 1) {
       w.S = a.S = S;
       w.Tc = a.Tc = Tc;
-      lds_wg = g_lds_wg(o, Tc, Tc);
+      lds_wg = g_lds_wg(o, g_chunk_in(o, Tc), Tc);
       lds_dx = o.needs_dx ? g_lds_dx(o, Tc, Tc) : 0;
     }
     const int items = B * S;

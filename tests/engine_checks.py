@@ -822,7 +822,8 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         for key, tap in step_taps.items():
             if key == "conv1" or key.endswith(".bn_out"):
                 v = np.abs(tap.detach().numpy())
-                near_zero += int((v < 4e-6 * max(1.0, float(v.max()))).sum())
+                near_zero += int((v < 1e-5 * max(1.0, float(v.max()))).sum())   # (half the 2e-5 bound on the intermediates above;
+                # tools/emu_fuzz.py case 1331: a unit at 4.9e-6 of the tensor's maximum flipped when one workgroup summed all five windows)
         grad_tol = 1e-3 if near_zero == 0 else 5e-2
         eng.set_batch(x)
         eng.set_targets(y, w)
