@@ -38,6 +38,7 @@ for case in range(1000, 1000 + n_mix):
         fail += 1
         print("FAIL mixednet case=%d %s %s: %s" % (case, kw, flags, str(e)[:300]), flush=True)
 print("mixednet topologies ok=%d skipped=%d fail=%d in %.0f s" % (done, skipped, fail, time.time() - t0), flush=True)
+fail_mix, fail = fail, 0
 t0, done = time.time(), 0
 for case in range(1000, 1000 + n_inc):
     flags = ec.random_inception_flags(case)
@@ -52,4 +53,4 @@ for case in range(1000, 1000 + n_inc):
         fail += 1
         print("FAIL inception case=%d %s %s: %s" % (case, kw, flags, str(e)[:300]), flush=True)
 print("inception topologies ok=%d fail=%d in %.0f s" % (done, fail, time.time() - t0), flush=True)
-sys.exit(1 if fail else 0)
+sys.exit(1 if fail + fail_mix else 0)
