@@ -806,6 +806,7 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
             assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
         assert np.abs(pr - torch.sigmoid(zo).numpy()).max() <= FWD_TOL
     l2s = []
+    flipped = False
     for st in range(steps):
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
@@ -822,8 +823,15 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         for key, tap in step_taps.items():
             if key == "conv1" or key.endswith(".bn_out"):
                 v = np.abs(tap.detach().numpy())
-                near_zero += int((v < 1e-5 * max(1.0, float(v.max()))).sum())   # (half the 2e-5 bound on the intermediates above;
-                # tools/emu_fuzz.py case 1331: a unit at 4.9e-6 of the tensor's maximum flipped when one workgroup summed all five windows)
+                near_zero += int((v < 4e-6 * max(1.0, float(v.max()))).sum())
+        if flags.get("spatial_attention"):
+            # the attention gate takes a max over the channels of every frame: a near tie (seen at 1.4e-7 and 3.4e-7 of the
+            # tensor's maximum, tools/emu_fuzz.py cases 3468 and 1331) lets float32 pick the other channel and the gradient
+            # takes the other route - the same kind of one-unit decision as a ReLU at zero
+            last = [k for k in step_taps if k.endswith(".bn_out")][-1]
+            act = np.maximum(step_taps[last].detach().numpy(), 0.0)
+            top2 = np.sort(act, axis=2)[:, :, -2:]
+            near_zero += int(((top2[:, :, 1] - top2[:, :, 0]) < 4e-6 * max(1.0, float(act.max()))).sum())
         grad_tol = 1e-3 if near_zero == 0 else 5e-2
         eng.set_batch(x)
         eng.set_targets(y, w)
@@ -851,7 +859,10 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         om.train_step(x, y, w, lr)
         p_ref, s_ref = lay.pack(om.get_weights())
         well = np.abs(gref) > (1e-4 if near_zero == 0 else 0.2) * scale
-        assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * lr
+        # (after a step in which a one-unit decision may have gone the other way the engine's Adam moments are no longer the
+        # oracle's: from then on the update is only held to the size of an Adam step)
+        assert np.abs(eng.get_params() - p_ref)[well].max() <= (2.5 if flipped else 0.05) * lr
+        flipped = flipped or near_zero > 0
         assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
         eng.set_params(p_ref)
         eng.set_bn_state(s_ref)

@@ -2,9 +2,10 @@
 the host): random MixedNet flag sets and random Inception topologies, each with a random batch, length, number of steps,
 grid option (0 = per-launch grids), frame-chunk option and eager / captured-graph execution, against the float64 oracle
 with the tolerances of tests/engine_checks.py.  usage (repo root):  python tools/emu_fuzz.py [mixednet cases] [inception cases]
-End of round 2: 785 + 400 and 500 + 250 cases green; the one exception (case 1331, a residual topology, one workgroup summing
-five windows) was a ReLU unit at 4.9e-6 of its tensor's maximum taking the other side in float32 - the near-zero detector of
-check_graph_mixednet now looks at 1e-5."""
+End of round 2: 3 750 random MixedNet flag sets and 1 850 random Inception topologies.  Two MixedNet cases (1331, 3468: spatial
+attention) differed from the oracle by ~1 % in the gradient: a near tie (1.4e-7 / 3.4e-7 of the tensor's maximum) in the
+attention gate's max over the channels, where float32 picks the other channel - check_graph_mixednet now counts such ties
+like ReLU units at zero."""
 import os
 import random
 import sys
