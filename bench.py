@@ -188,8 +188,13 @@ def parse_args():
     ap.add_argument("--grid-bwd", type=int, default=0)
     ap.add_argument("--grid-head", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: skip kernel phases (results invalid)")
-    ap.add_argument("--grad-buckets", type=int, default=2, choices=(1, 2),
-                    help="N > 1: 2 = the gradient all-reduce goes in two buckets, the first one overlapped with the backward tail (default)")
+    ap.add_argument("--grad-buckets", type=int, default=1, choices=(1, 2),
+                    help="N > 1: 1 = one gradient all-reduce after the backward pass (default: the faster schedule at W = 1, the only one measured "
+                         "so far); 2 = two buckets, the first one overlapped with the backward tail")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="N > 1: issue the exchange through the mww_set_allreduce_hook callback into torch.distributed instead of "
+                         "RCCL called from the library (mww_allreduce_init, the default)")
+    ap.add_argument("--no-prefetch", action="store_true", help="draw every batch on the launching thread (default: a worker thread draws two batches ahead)")
     return ap.parse_args()
 
 
@@ -385,9 +390,12 @@ def main():
             shard_feature_handler(fh, rank, world, seed=0)
         else:
             fh.use_private_rng()
+        if args.no_prefetch:
+            fh.use_private_rng(prefetch=0)
         dp = None
         if world > 1 or force_dp:
-            dp = DataParallel.for_engine(eng, device, sync_bn=args.sync_bn, grad_buckets=args.grad_buckets)
+            dp = DataParallel.for_engine(eng, device, sync_bn=args.sync_bn, grad_buckets=args.grad_buckets,
+                                         library_comm=not args.torch_collectives)
             dp.broadcast_parameters(0)
         for opt, v in (("grid_fwd", args.grid_fwd), ("grid_bwd", args.grid_bwd), ("grid_head", args.grid_head)):
             if v:
@@ -500,7 +508,10 @@ def main():
                     dp.train_step(B, lr)          # forced-DP on one GPU: the exchanges are degenerate but present
                 elif dp is not None:
                     # the other ranks are past their timed loop: no collective may be issued from here on
-                    eng.set_allreduce_hook(None)
+                    if dp.library_comm:
+                        eng.allreduce_destroy()
+                    else:
+                        eng.set_allreduce_hook(None)
                     dp = None
                     eng.train_step(B, lr)
                 else:
@@ -555,7 +566,10 @@ def main():
                                   B, "bf16 p_k/g_k + bf16 MFMA operands" if args.storage_bf16 else "bf16 MFMA operands" if args.pointwise_bf16 else "fp32",
                                   args.store_samples),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": bool(args.graphs and not args.no_graphs),
-                   "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch"},
+                   "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch",
+                   "sampler": "synchronous" if args.no_prefetch else "worker thread, 2 batches ahead",
+                   "collectives": (("torch.distributed via callback" if args.torch_collectives else "RCCL called from the library")
+                                   + ", %d gradient bucket(s)" % args.grad_buckets) if (world > 1 or force_dp) else None},
         "roofline": {**roof, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,

@@ -205,14 +205,29 @@ int mww_apply_gradients(mww_ctx* ctx, float learning_rate, float grad_scale);
  *   sync_bn = 0: local-batch statistics ("throughput mode").
  *   reduce_grads = 1: mww_train_step also all-reduces the flat gradient through the callback and applies
  *                Adam to the rank average, i.e. it is the complete data-parallel step.  With the specialised MixedNet
- *                kernels and option "grad_buckets" 2 (default) the gradient goes in two buckets: [dense + the last two
- *                blocks] as soon as their backward kernels are enqueued (deferred), the rest after the first block's.
+ *                kernels and option "grad_buckets" 2 the gradient goes in two buckets: [dense + the last two
+ *                blocks] as soon as their backward kernels are enqueued (deferred), the rest after the first block's
+ *                (default 1 = one exchange after the backward pass: the faster schedule at world size 1, and the only
+ *                one measured so far).
  * fn = NULL removes the hook. */
 #define MWW_EXCHANGE_IN_ORDER 0
 #define MWW_EXCHANGE_DEFERRED 1
 #define MWW_EXCHANGE_FLUSH 2
 typedef int (*mww_allreduce_fn)(void* user, float* device_buf, int64_t n, int flags);
 int mww_set_allreduce_hook(mww_ctx* ctx, mww_allreduce_fn fn, void* user, int world_size, int sync_bn, int reduce_grads);
+
+/* ---- the same exchange with RCCL called from the library (SURVEY 8b `mww_allreduce_init`, 8e): one process per GPU,
+ * rank 0 obtains a unique id (ncclGetUniqueId) and hands its MWW_UNIQUE_ID_BYTES bytes to every rank by whatever channel
+ * the launcher has (torch.distributed store / broadcast, MPI, a file); every rank then calls mww_allreduce_init, which
+ * joins the communicator (collective: returns when all ranks have called it) and installs an internal exchange in place of
+ * the callback above with reduce_grads = 1: in-order exchanges are ncclAllReduce calls on the context's stream, a deferred
+ * bucket runs on a library-owned side stream ordered by events - no callback into the host language per step.
+ * librccl.so is bound at run time (dlopen), so a single-GPU user needs no RCCL.  mww_allreduce_destroy leaves the
+ * communicator (also done by mww_destroy). */
+#define MWW_UNIQUE_ID_BYTES 128
+int mww_allreduce_unique_id(void* out_id, int capacity);
+int mww_allreduce_init(mww_ctx* ctx, int rank, int world_size, const void* unique_id, int sync_bn);
+int mww_allreduce_destroy(mww_ctx* ctx);
 
 /* ---- inference forward on the current batch: replaces model(x, training=...) /
  * model.evaluate's per-batch forward (train.py:50-58). training=1 uses batch statistics without
@@ -238,6 +253,7 @@ int mww_metrics_reset(mww_ctx* ctx);
 #define MWW_BUF_GRADS 1
 #define MWW_BUF_BN_STATE 2
 #define MWW_BUF_X 3
+#define MWW_HANDLE_STREAM 4   /* not a buffer: the hipStream_t the context enqueues on (to order foreign work against it) */
 void* mww_device_ptr(mww_ctx* ctx, int which);
 
 /* named internal tensors for parity tests ("p1".."p8" pre-BN block outputs, "g1".. gradients at
@@ -265,8 +281,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * partial statistics rows are shared by its launches),
  * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops - and the forward convolution of any op - process
  * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, the default - parity-tested, not yet timed on the GPU; 1 = automatic; 2..4),
- * "grad_buckets" (data-parallel step: 2 =
- * overlapped two-bucket gradient exchange, 1 = one exchange after the backward pass), "assemble_split" (workgroups per window of the
+ * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
+ * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's
  * gradient reduction — measured slower), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);
@@ -302,6 +318,32 @@ int mww_sample_training_batch(const mww_sampler_desc* d, uint32_t* py_state, uin
                               mww_window* out_windows, int32_t* out_masks, int32_t* out_provider, int32_t* out_sample,
                               int32_t* out_order);
 int mww_rng_selftest(uint32_t* state, int which, int n, double* out_real, uint32_t* out_int, uint32_t bound);
+
+/* ---- batch prefetcher: the draws of FeatureHandler.get_data("training") for the NEXT steps made by a worker thread
+ * while the launching thread enqueues the current one (the reference alternates get_data and train_on_batch on one
+ * thread, train.py:276-299; at 0.3 ms per step the 0.16 ms the draws of 1024 windows take is most of the host's share).
+ * The worker owns private copies of the two MT19937 streams (py_state / np_state: 625 words each, as above) and calls
+ * mww_sample_training_batch(..., apply_order = 1) in sequence, so batch n is the batch the synchronous path draws from
+ * those states with its n-th call.  provider_label / provider_weight: label and per-sample weight (penalty_weight x
+ * class weight, train.py:288-293) of each provider's windows.  depth = batches drawn ahead (1..16).
+ * Host-only objects: no device or context is involved until mww_assemble_prefetched. */
+typedef struct mww_prefetcher mww_prefetcher;
+int mww_prefetch_create(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
+                        const uint32_t* py_state, const uint32_t* np_state, int B, int T, int tmax, int tcount, int fmax,
+                        int fcount, int32_t default_strategy, int depth, mww_prefetcher** out);
+/* waits for the next batch; the arrays ([B] windows, [B][tcount+fcount][2] masks, [B] labels / weights / provider /
+ * index of the sample inside its provider's training set) stay valid until mww_prefetch_release.  Any pointer may be NULL. */
+int mww_prefetch_acquire(mww_prefetcher* p, const mww_window** windows, const int32_t** masks, const float** labels,
+                         const float** weights, const int32_t** provider, const int32_t** sample);
+int mww_prefetch_release(mww_prefetcher* p);
+/* the two streams as they stood after the last batch handed out (batches drawn ahead of it do not count): what the
+ * synchronous sampler continues from when the prefetcher is dropped.  Returns the number of batches handed out. */
+int64_t mww_prefetch_rng_state(mww_prefetcher* p, uint32_t* py_state, uint32_t* np_state);
+int mww_prefetch_shape(const mww_prefetcher* p, int* B, int* n_time_masks, int* n_freq_masks);   /* as created */
+void mww_prefetch_destroy(mww_prefetcher* p);
+/* mww_prefetch_acquire + mww_set_targets + mww_assemble_batch + mww_prefetch_release in one call; out_labels /
+ * out_weights ([B], may be NULL) receive copies of what went to the device. */
+int mww_assemble_prefetched(mww_ctx* ctx, mww_prefetcher* p, float* out_labels, float* out_weights);
 
 #ifdef __cplusplus
 }

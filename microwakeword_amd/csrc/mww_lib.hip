@@ -2,6 +2,8 @@
 // One context = one device + one HIP stream + one model; every call enqueues on that stream.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -83,6 +85,18 @@ struct ProfileEntry {
   hipEvent_t a, b;
 };
 
+// RCCL bound at run time (dlopen: the library loads on hosts without RCCL and shares the copy a framework in the same
+// process has already loaded); only the five entry points the gradient / statistics exchange needs
+struct RcclApi {
+  void* so = nullptr;
+  struct UniqueId { char internal[128]; };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
 constexpr int kRing = 8;
 constexpr int kDenseChunks = 32;  // batch chunks of the dense-weight gradient reduction
 
@@ -124,13 +138,15 @@ struct mww_ctx {
   void* hook_user = nullptr;
   int world = 1;
   bool sync_bn = false, reduce_grads = false;
+  struct RcclState* rccl = nullptr;  // mww_allreduce_init: the library's own communicator + side stream (the hook then points at it)
   float* sync_buf = nullptr;        // [layers][fwd 2C | bwd 2C] statistics sums being exchanged
   std::vector<int64_t> sync_off;    // offset of layer i in sync_buf
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr, *mask = nullptr;
   unsigned char* direct = nullptr;
   std::vector<unsigned char> direct_host;   // host copy: which parameters' gradients are written directly by a folding kernel
   bool exchange_pending = false;            // a deferred bucket exchange is in flight (data-parallel step)
-  int grad_buckets = 2;                     // data-parallel step: gradient exchanged in this many buckets ("grad_buckets" option)
+  int grad_buckets = 1;                     // data-parallel step: gradient exchanged in this many buckets ("grad_buckets" option; 2 = first
+                                            // bucket overlapped with the backward tail - slower at W = 1, unmeasured at W > 1, so not the default)
   float* bn_state = nullptr;
   float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
   float* a0 = nullptr;     // relu(conv1(x)) [max_batch][Ta][conv1_filters]: written by the training forward, read by bwd_first_kernel
@@ -2137,6 +2153,128 @@ int mww_set_allreduce_hook(mww_ctx* c, mww_allreduce_fn fn, void* user, int worl
   return MWW_OK;
 }
 
+// ---- RCCL inside the library (mww_allreduce_init).  The exchange the caller's hook performed through
+// Python / torch.distributed (two ctypes callbacks, two dispatcher round trips and a pair of cross-stream event waits
+// per step: +38 us at W = 1 for the two-bucket schedule in round 2) is issued here, from the launching thread:
+//   MWW_EXCHANGE_IN_ORDER  ncclAllReduce on the context's stream itself
+//   MWW_EXCHANGE_DEFERRED  event on the context's stream -> the library's side stream waits for it -> ncclAllReduce there
+//   MWW_EXCHANGE_FLUSH     the context's stream waits for the side stream's last exchange
+struct RcclState {
+  RcclApi api;
+  void* comm = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  mww_ctx* c = nullptr;
+  bool deferred = false;
+};
+
+namespace {
+int rccl_load(RcclApi* a) {
+  if (a->so) return MWW_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    a->so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (a->so) break;
+  }
+  if (!a->so) return fail(MWW_ERR_UNSUPPORTED, std::string("librccl.so not found: ") + dlerror());
+  a->GetUniqueId = reinterpret_cast<decltype(a->GetUniqueId)>(dlsym(a->so, "ncclGetUniqueId"));
+  a->CommInitRank = reinterpret_cast<decltype(a->CommInitRank)>(dlsym(a->so, "ncclCommInitRank"));
+  a->AllReduce = reinterpret_cast<decltype(a->AllReduce)>(dlsym(a->so, "ncclAllReduce"));
+  a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->so, "ncclCommDestroy"));
+  a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->so, "ncclGetErrorString"));
+  if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy || !a->GetErrorString)
+    return fail(MWW_ERR_UNSUPPORTED, "librccl.so lacks an entry point");
+  return MWW_OK;
+}
+
+int rccl_exchange(void* user, float* buf, int64_t n, int flags) {
+  RcclState* r = static_cast<RcclState*>(user);
+  mww_ctx* c = r->c;
+  constexpr int kFloat = 7, kSum = 0;   // ncclFloat32, ncclSum (rccl.h)
+  if (flags == MWW_EXCHANGE_FLUSH) {
+    if (r->deferred) {
+      if (hipStreamWaitEvent(c->stream, r->ev_done, 0) != hipSuccess) return -1;
+      r->deferred = false;
+    }
+    return 0;
+  }
+  hipStream_t st = c->stream;
+  if (flags == MWW_EXCHANGE_DEFERRED) {
+    if (hipEventRecord(r->ev_ready, c->stream) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(r->side, r->ev_ready, 0) != hipSuccess) return -1;
+    st = r->side;
+  }
+  const int e = r->api.AllReduce(buf, buf, (size_t)n, kFloat, kSum, r->comm, st);
+  if (e != 0) {
+    g_err = std::string("ncclAllReduce: ") + r->api.GetErrorString(e);
+    return -1;
+  }
+  if (flags == MWW_EXCHANGE_DEFERRED) {
+    if (hipEventRecord(r->ev_done, r->side) != hipSuccess) return -1;
+    r->deferred = true;
+  }
+  return 0;
+}
+}  // namespace
+
+int mww_allreduce_unique_id(void* out_id, int capacity) {
+  if (!out_id || capacity < MWW_UNIQUE_ID_BYTES) return fail(MWW_ERR_INVALID, "unique-id buffer too small");
+  static RcclApi api;
+  int rc = rccl_load(&api);
+  if (rc) return rc;
+  RcclApi::UniqueId id;
+  const int e = api.GetUniqueId(&id);
+  if (e != 0) return fail(MWW_ERR_HIP, std::string("ncclGetUniqueId: ") + api.GetErrorString(e));
+  memcpy(out_id, id.internal, sizeof(id.internal));
+  return MWW_OK;
+}
+
+int mww_allreduce_destroy(mww_ctx* c) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  RcclState* r = c->rccl;
+  if (!r) return MWW_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (r->side) (void)hipStreamSynchronize(r->side);
+  if (c->hook == rccl_exchange) {
+    c->hook = nullptr;
+    c->hook_user = nullptr;
+    c->world = 1;
+    c->sync_bn = c->reduce_grads = false;
+  }
+  if (r->comm) (void)r->api.CommDestroy(r->comm);
+  if (r->side) (void)hipStreamDestroy(r->side);
+  if (r->ev_ready) (void)hipEventDestroy(r->ev_ready);
+  if (r->ev_done) (void)hipEventDestroy(r->ev_done);
+  delete r;
+  c->rccl = nullptr;
+  return MWW_OK;
+}
+
+int mww_allreduce_init(mww_ctx* c, int rank, int world, const void* unique_id, int sync_bn) {
+  if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return fail(MWW_ERR_INVALID, "bad rank / world size");
+  int rc = mww_allreduce_destroy(c);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  RcclState* r = new RcclState();
+  r->c = c;
+  rc = rccl_load(&r->api);
+  if (rc) { delete r; return rc; }
+  RcclApi::UniqueId id;
+  memcpy(id.internal, unique_id, sizeof(id.internal));
+  const int e = r->api.CommInitRank(&r->comm, world, id, rank);
+  if (e != 0) {
+    const std::string msg = std::string("ncclCommInitRank: ") + r->api.GetErrorString(e);
+    delete r;
+    return fail(MWW_ERR_HIP, msg);
+  }
+  c->rccl = r;
+  HIPCHK(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&r->ev_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&r->ev_done, hipEventDisableTiming));
+  return mww_set_allreduce_hook(c, rccl_exchange, r, world, sync_bn, 1);
+}
+
 int mww_set_dropout_mask(mww_ctx* c, const uint8_t* keep, int B) {
   if (!c || !c->generic) return fail(MWW_ERR_INVALID, "context has no dropout layer");
   if (!keep) { c->keep_explicit = false; return MWW_OK; }
@@ -2157,6 +2295,7 @@ void mww_destroy(mww_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)mww_allreduce_destroy(c);
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto& e : c->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   void* flat[] = {c->params, c->grads, c->adam_m, c->adam_v, c->mask, c->direct, c->bn_state, c->x, c->y, c->sw,
@@ -2386,6 +2525,23 @@ int mww_set_targets(mww_ctx* c, const float* hy, const float* hw, int B) {
   return MWW_OK;
 }
 
+int mww_assemble_prefetched(mww_ctx* c, mww_prefetcher* p, float* out_labels, float* out_weights) {
+  if (!c || !p) return fail(MWW_ERR_INVALID, "null context / prefetcher");
+  const mww_window* win = nullptr;
+  const int32_t* masks = nullptr;
+  const float *y = nullptr, *w = nullptr;
+  int rc = mww_prefetch_acquire(p, &win, &masks, &y, &w, nullptr, nullptr);
+  if (rc) return fail(rc, "the prefetcher's sampler failed (a provider's truncation strategy cannot form a fixed-length window)");
+  int B = 0, ntm = 0, nfm = 0;
+  mww_prefetch_shape(p, &B, &ntm, &nfm);
+  rc = mww_set_targets(c, y, w, B);
+  if (!rc) rc = mww_assemble_batch(c, win, masks, B, ntm, nfm);
+  if (!rc && out_labels) memcpy(out_labels, y, (size_t)B * sizeof(float));
+  if (!rc && out_weights) memcpy(out_weights, w, (size_t)B * sizeof(float));
+  mww_prefetch_release(p);
+  return rc;
+}
+
 int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
   if (!c || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   if (c->have_batch < B || c->have_targets < B) return fail(MWW_ERR_STATE, "train step needs a batch and targets of at least B rows");
@@ -2513,6 +2669,7 @@ void* mww_device_ptr(mww_ctx* c, int which) {
     case MWW_BUF_GRADS: return c->grads;
     case MWW_BUF_BN_STATE: return c->bn_state;
     case MWW_BUF_X: return c->x;
+    case MWW_HANDLE_STREAM: return c->stream;
     default: return nullptr;
   }
 }

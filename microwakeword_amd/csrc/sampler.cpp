@@ -195,3 +195,181 @@ extern "C" int mww_rng_selftest(uint32_t* state, int which, int n, double* out_r
   }
   return MWW_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Batch prefetcher: the draws of get_data("training") for step n+1 .. n+depth are made by a worker thread while
+// the launching thread enqueues step n (reference loop: microwakeword/train.py:276-299, where get_data and
+// train_on_batch alternate on one thread).  The worker owns private copies of the two MT19937 streams and calls the
+// same mww_sample_training_batch in the same order, so the sequence of batches is the one the synchronous path draws
+// from those states (bit-exact: tests/engine_checks.py::check_prefetched_batches_match_synchronous_sampler).  The
+// stream positions "after the last batch handed out" are kept with every slot, so the host can take the streams back
+// at any batch boundary (policy change between training phases, checkpoint, switching the prefetch off).
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+struct mww_prefetcher {
+  // deep copies of the sampler description (the caller's arrays need not outlive the call)
+  std::vector<double> sampling_weight;
+  std::vector<int32_t> strategy, set_store, set_len, cutoff_offsets, cutoffs;
+  std::vector<int64_t> set_offsets, set_src_elem;
+  std::vector<float> label, weight;   // per provider
+  mww_sampler_desc d;
+  int B = 0, T = 0, tmax = 0, tcount = 0, fmax = 0, fcount = 0, depth = 0;
+  int32_t default_strategy = -1;
+  uint32_t py[625], np_[625];         // worker's streams
+  uint32_t last_py[625], last_np[625];   // positions after the last batch handed out
+  struct Slot {
+    std::vector<mww_window> win;
+    std::vector<int32_t> masks, prov, samp, order;
+    std::vector<float> y, w;
+    uint32_t py[625], np_[625];
+    int rc = MWW_OK;
+  };
+  std::vector<Slot> slots;
+  int head = 0, tail = 0, ready = 0;   // ring: head = next slot handed out, tail = next slot filled
+  bool held = false, stop = false;
+  int64_t handed = 0;
+  std::mutex mu;
+  std::condition_variable cv_ready, cv_free;
+  std::thread worker;
+
+  void run() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_free.wait(lk, [&] { return stop || ready < depth; });
+        if (stop) return;
+      }
+      Slot& s = slots[tail];
+      s.rc = mww_sample_training_batch(&d, py, np_, B, T, tmax, tcount, fmax, fcount, default_strategy, 1, s.win.data(),
+                                       s.masks.data(), s.prov.data(), s.samp.data(), s.order.data());
+      if (s.rc == MWW_OK)
+        for (int j = 0; j < B; ++j) {
+          s.y[j] = label[s.prov[j]];
+          s.w[j] = weight[s.prov[j]];
+        }
+      memcpy(s.py, py, sizeof(py));
+      memcpy(s.np_, np_, sizeof(np_));
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        tail = (tail + 1) % depth;
+        ++ready;
+      }
+      cv_ready.notify_one();
+      if (s.rc != MWW_OK) return;   // the error is handed out with this slot; nothing is drawn after it
+    }
+  }
+};
+
+extern "C" int mww_prefetch_create(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
+                                   const uint32_t* py_state, const uint32_t* np_state, int B, int T, int tmax, int tcount,
+                                   int fmax, int fcount, int32_t default_strategy, int depth, mww_prefetcher** out) {
+  if (!d || !provider_label || !provider_weight || !py_state || !np_state || !out || B <= 0 || depth < 1 || depth > 16 ||
+      d->n_providers <= 0 || d->n_providers > 64 || tcount < 0 || fcount < 0)
+    return MWW_ERR_INVALID;
+  mww_prefetcher* p = new mww_prefetcher();
+  const int n = d->n_providers;
+  p->sampling_weight.assign(d->sampling_weight, d->sampling_weight + n);
+  p->strategy.assign(d->strategy, d->strategy + n);
+  p->set_offsets.assign(d->set_offsets, d->set_offsets + n + 1);
+  const int64_t ns = p->set_offsets[n];
+  p->set_store.assign(d->set_store, d->set_store + ns);
+  p->set_src_elem.assign(d->set_src_elem, d->set_src_elem + ns);
+  p->set_len.assign(d->set_len, d->set_len + ns);
+  p->cutoff_offsets.assign(d->cutoff_offsets, d->cutoff_offsets + n + 1);
+  const int nc = p->cutoff_offsets[n];
+  p->cutoffs.assign(d->cutoffs, d->cutoffs + (nc > 0 ? nc : 1));
+  p->label.assign(provider_label, provider_label + n);
+  p->weight.assign(provider_weight, provider_weight + n);
+  p->d.n_providers = n;
+  p->d.sampling_weight = p->sampling_weight.data();
+  p->d.strategy = p->strategy.data();
+  p->d.set_offsets = p->set_offsets.data();
+  p->d.set_store = p->set_store.data();
+  p->d.set_src_elem = p->set_src_elem.data();
+  p->d.set_len = p->set_len.data();
+  p->d.cutoff_offsets = p->cutoff_offsets.data();
+  p->d.cutoffs = p->cutoffs.data();
+  p->B = B; p->T = T; p->tmax = tmax; p->tcount = tcount; p->fmax = fmax; p->fcount = fcount;
+  p->default_strategy = default_strategy;
+  p->depth = depth;
+  memcpy(p->py, py_state, sizeof(p->py));
+  memcpy(p->np_, np_state, sizeof(p->np_));
+  memcpy(p->last_py, py_state, sizeof(p->py));
+  memcpy(p->last_np, np_state, sizeof(p->np_));
+  const int nm = tcount + fcount;
+  p->slots.resize(depth);
+  for (auto& s : p->slots) {
+    s.win.resize(B);
+    s.masks.resize((size_t)B * (nm > 0 ? nm : 1) * 2);
+    s.prov.resize(B); s.samp.resize(B); s.order.resize(B);
+    s.y.resize(B); s.w.resize(B);
+  }
+  p->worker = std::thread([p] { p->run(); });
+  *out = p;
+  return MWW_OK;
+}
+
+// blocks until the next batch is drawn; the pointers stay valid until mww_prefetch_release
+extern "C" int mww_prefetch_acquire(mww_prefetcher* p, const mww_window** win, const int32_t** masks, const float** y,
+                                    const float** w, const int32_t** provider, const int32_t** sample) {
+  if (!p) return MWW_ERR_INVALID;
+  std::unique_lock<std::mutex> lk(p->mu);
+  if (p->held) return MWW_ERR_STATE;
+  p->cv_ready.wait(lk, [&] { return p->ready > 0; });
+  mww_prefetcher::Slot& s = p->slots[p->head];
+  if (s.rc != MWW_OK) return s.rc;   // stays at the head: every later acquire reports it too
+  p->held = true;
+  p->handed += 1;
+  memcpy(p->last_py, s.py, sizeof(s.py));
+  memcpy(p->last_np, s.np_, sizeof(s.np_));
+  if (win) *win = s.win.data();
+  if (masks) *masks = s.masks.data();
+  if (y) *y = s.y.data();
+  if (w) *w = s.w.data();
+  if (provider) *provider = s.prov.data();
+  if (sample) *sample = s.samp.data();
+  return MWW_OK;
+}
+
+extern "C" int mww_prefetch_release(mww_prefetcher* p) {
+  if (!p) return MWW_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->held) return MWW_ERR_STATE;
+    p->held = false;
+    p->head = (p->head + 1) % p->depth;
+    --p->ready;
+  }
+  p->cv_free.notify_one();
+  return MWW_OK;
+}
+
+// the two streams as they stood after the last batch handed out (batches drawn ahead of it are not counted)
+extern "C" int64_t mww_prefetch_rng_state(mww_prefetcher* p, uint32_t* py_state, uint32_t* np_state) {
+  if (!p) return MWW_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (py_state) memcpy(py_state, p->last_py, sizeof(p->last_py));
+  if (np_state) memcpy(np_state, p->last_np, sizeof(p->last_np));
+  return p->handed;
+}
+
+extern "C" int mww_prefetch_shape(const mww_prefetcher* p, int* B, int* n_time_masks, int* n_freq_masks) {
+  if (!p) return MWW_ERR_INVALID;
+  if (B) *B = p->B;
+  if (n_time_masks) *n_time_masks = p->tcount;
+  if (n_freq_masks) *n_freq_masks = p->fcount;
+  return MWW_OK;
+}
+
+extern "C" void mww_prefetch_destroy(mww_prefetcher* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->stop = true;
+  }
+  p->cv_free.notify_all();
+  if (p->worker.joinable()) p->worker.join();
+  delete p;
+}

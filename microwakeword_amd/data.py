@@ -126,6 +126,8 @@ class FeatureHandler:
         self.engine: Optional[native.Engine] = None
         self._sampler = None
         self._private_rng = None
+        self._prefetch_depth = 0
+        self._pf = None
         if engine is not None:
             self.attach(engine)
 
@@ -203,11 +205,26 @@ class FeatureHandler:
         random.setstate((ps[0], tuple(int(v) for v in py), ps[2]))
         np.random.set_state((ns[0], npst[:624].copy(), int(npst[624]), ns[3], ns[4]))
 
-    def use_private_rng(self):
+    def use_private_rng(self, prefetch: int = 2):
         """Snapshot the global RNG states now and keep advancing private copies from here on
-        (same streams, no per-batch get/setstate cost).  The global generators are left untouched."""
+        (same streams, no per-batch get/setstate cost).  The global generators are left untouched.
+        ``prefetch`` > 0 additionally lets ``next_training_batch_on_device`` take its batches from a worker thread that
+        draws that many batches ahead from those private streams (``native.Prefetcher``): same batches in the same order,
+        off the launching thread."""
+        self._drop_prefetcher(keep_streams=False)
         py, npst, _, _ = self._export_global_rng()
         self._private_rng = (py, npst)
+        self._prefetch_depth = int(prefetch)
+
+    def _drop_prefetcher(self, keep_streams=True):
+        """Stop the worker; the private streams continue from the last batch it HANDED OUT (what it drew ahead is discarded)."""
+        pf = self.__dict__.get("_pf")
+        if pf is not None:
+            if keep_streams and self._private_rng is not None:
+                py, npst, _ = pf[1].rng_state()
+                self._private_rng = (py, npst)
+            pf[1].close()
+            self._pf = None
 
     def _policy(self, augmentation_policy, truncation_strategy):
         pol = dict(DEFAULT_POLICY)
@@ -228,6 +245,7 @@ class FeatureHandler:
 
     def _sample(self, B, features_length, truncation_strategy, augmentation_policy, apply_order):
         self._need_engine()
+        self._drop_prefetcher()   # a synchronous draw continues the streams where the last handed-out batch left them
         if self._sampler is None:
             self._build_sampler()
         d, arrs, live = self._sampler
@@ -269,16 +287,35 @@ class FeatureHandler:
                     draw_windows=buf["win"].copy(), draw_masks=buf["masks"].copy())
 
     def next_training_batch_on_device(self, batch_size, features_length, truncation_strategy="default",
-                                      augmentation_policy=None, class_weights=(1.0, 1.0), weight_broadcast="per_sample"):
+                                      augmentation_policy=None, class_weights=(1.0, 1.0), weight_broadcast="per_sample",
+                                      want_targets=False):
         """Fast path of the train loop: leaves x in the engine's batch buffer (no host copy of the
         spectrograms) and the labels / per-sample weights (penalty x class weight, train.py:288-293) next
         to it — they travel in the same mailbox as the window descriptors, so no separate copy is
         enqueued.  ``class_weights`` = (negative, positive); ``weight_broadcast``: model.combine_weights.  Returns
         ``(labels, penalty_weights)``."""
+        neg, pos = class_weights
+        if self._prefetch_depth > 0 and self._private_rng is not None and weight_broadcast == "per_sample":
+            # batches drawn ahead by the worker thread: one native call per step on this thread
+            self._need_engine()
+            pol = dict(DEFAULT_POLICY)
+            pol.update(augmentation_policy or {})
+            key = (int(batch_size), int(features_length), truncation_strategy, float(neg), float(pos),
+                   tuple(int(pol[k]) for k in ("time_mask_max_size", "time_mask_count", "freq_mask_max_size", "freq_mask_count")))
+            if self._pf is None or self._pf[0] != key or self._sampler is None:
+                self._drop_prefetcher()
+                if self._sampler is None:
+                    self._build_sampler()
+                d, arrs, live = self._sampler
+                tmax, tc, fmax, fc, dstrat = self._policy(augmentation_policy, truncation_strategy)
+                cw = np.where(arrs["labels"] != 0, float(pos), float(neg))   # train.py:288-293, per-sample form
+                py, npst = self._private_rng
+                self._pf = (key, native.Prefetcher(self.engine.nl, d, arrs["labels"], arrs["penalty"] * cw, py, npst, int(batch_size),
+                                                   int(features_length), tmax, tc, fmax, fc, dstrat, self._prefetch_depth))
+            return self.engine.assemble_prefetched(self._pf[1], want_targets)
         buf, tc, fc, arrs = self._sample(int(batch_size), features_length, truncation_strategy, augmentation_policy, 1)
         y = arrs["labels"][buf["prov"]]
         w = arrs["penalty"][buf["prov"]]
-        neg, pos = class_weights
         if neg == 1.0 and pos == 1.0 and weight_broadcast == "per_sample":
             self.engine.set_targets(y, w)
         else:

@@ -22,7 +22,8 @@ MWW_MAX_STORES = 64
 MAX_MASKS = 16
 STEP_NO_APPLY = 1
 STEP_NO_METRICS = 2
-BUF_PARAMS, BUF_GRADS, BUF_BN_STATE, BUF_X = 0, 1, 2, 3
+BUF_PARAMS, BUF_GRADS, BUF_BN_STATE, BUF_X, BUF_STREAM = 0, 1, 2, 3, 4
+UNIQUE_ID_BYTES = 128
 DTYPE_U16, DTYPE_F32 = 0, 1
 STRATEGIES = {"random": 0, "truncate_start": 1, "truncate_end": 2, "fixed_right_cutoff": 3, "none": 4}
 
@@ -93,6 +94,9 @@ EXPORTS = [
     "mww_assemble_batch", "mww_set_batch", "mww_get_batch", "mww_set_targets", "mww_train_step", "mww_apply_gradients",
     "mww_forward", "mww_read_outputs", "mww_metrics_read", "mww_metrics_reset", "mww_device_ptr", "mww_debug_read",
     "mww_set_option", "mww_profile_read", "mww_sample_training_batch", "mww_rng_selftest",
+    "mww_prefetch_create", "mww_prefetch_acquire", "mww_prefetch_release", "mww_prefetch_rng_state", "mww_prefetch_shape",
+    "mww_prefetch_destroy", "mww_assemble_prefetched",
+    "mww_allreduce_unique_id", "mww_allreduce_init", "mww_allreduce_destroy",
 ]
 
 
@@ -160,6 +164,19 @@ class NativeLib:
                                                 C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]
         L.mww_rng_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.mww_prefetch_create.argtypes = [C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
+        L.mww_prefetch_acquire.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 6
+        L.mww_prefetch_release.argtypes = [C.c_void_p]
+        L.mww_prefetch_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mww_prefetch_rng_state.restype = C.c_int64
+        L.mww_prefetch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mww_prefetch_destroy.argtypes = [C.c_void_p]
+        L.mww_prefetch_destroy.restype = None
+        L.mww_assemble_prefetched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mww_allreduce_unique_id.argtypes = [C.c_void_p, C.c_int]
+        L.mww_allreduce_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.mww_allreduce_destroy.argtypes = [C.c_void_p]
 
     @classmethod
     def get(cls, path: Optional[str] = None) -> "NativeLib":
@@ -178,6 +195,67 @@ class NativeLib:
 
     def device_count(self) -> int:
         return int(self.lib.mww_device_count())
+
+    def allreduce_unique_id(self) -> np.ndarray:
+        """ncclGetUniqueId through the library: 128 bytes rank 0 hands to every rank before ``Engine.allreduce_init``."""
+        uid = np.zeros(UNIQUE_ID_BYTES, np.uint8)
+        self.check(self.lib.mww_allreduce_unique_id(uid.ctypes.data_as(C.c_void_p), uid.size))
+        return uid
+
+
+class Prefetcher:
+    """``mww_prefetcher``: a worker thread that draws the training batches of the next steps (csrc/sampler.cpp) from
+    private copies of the two MT19937 streams.  ``py_state`` / ``np_state``: uint32[625] as exported by
+    ``FeatureHandler._export_global_rng``.  Host-only (usable without a GPU)."""
+
+    def __init__(self, nl: NativeLib, desc: SamplerDesc, labels, weights, py_state, np_state, B, T, tmax, tcount, fmax, fcount,
+                 default_strategy=-1, depth=2):
+        self.nl = nl
+        self.B, self.nm = int(B), int(tcount) + int(fcount)
+        lab = np.ascontiguousarray(labels, np.float32)
+        wts = np.ascontiguousarray(weights, np.float32)
+        py = np.ascontiguousarray(py_state, np.uint32)
+        npst = np.ascontiguousarray(np_state, np.uint32)
+        if py.size != 625 or npst.size != 625 or lab.size != desc.n_providers or wts.size != desc.n_providers:
+            raise ValueError("bad prefetcher arguments")
+        h = C.c_void_p()
+        nl.check(nl.lib.mww_prefetch_create(C.byref(desc), lab.ctypes.data_as(C.c_void_p), wts.ctypes.data_as(C.c_void_p),
+                                            py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p), int(B), int(T), int(tmax),
+                                            int(tcount), int(fmax), int(fcount), int(default_strategy), int(depth), C.byref(h)))
+        self.h = h
+
+    def acquire(self):
+        """Next batch as numpy copies: dict(windows, masks, labels, weights, provider, sample).  (Tests; the train loop
+        uses ``Engine.assemble_prefetched``, which never copies to Python.)"""
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self.nl.check(self.nl.lib.mww_prefetch_acquire(self.h, *[C.byref(p) for p in ptrs]))
+        B, nm = self.B, max(self.nm, 1)
+
+        def arr(p, ctype, n, dtype):
+            return np.frombuffer((ctype * n).from_address(p.value), dtype=dtype).copy()
+        out = dict(windows=np.frombuffer((C.c_char * (B * WINDOW_DTYPE.itemsize)).from_address(ptrs[0].value), dtype=WINDOW_DTYPE).copy(),
+                   masks=arr(ptrs[1], C.c_int32, B * nm * 2, np.int32).reshape(B, nm, 2)[:, :self.nm],
+                   labels=arr(ptrs[2], C.c_float, B, np.float32), weights=arr(ptrs[3], C.c_float, B, np.float32),
+                   provider=arr(ptrs[4], C.c_int32, B, np.int32), sample=arr(ptrs[5], C.c_int32, B, np.int32))
+        self.nl.check(self.nl.lib.mww_prefetch_release(self.h))
+        return out
+
+    def rng_state(self):
+        """(py_state, np_state, batches handed out): the streams as they stood after the last batch handed out."""
+        py, npst = np.zeros(625, np.uint32), np.zeros(625, np.uint32)
+        n = self.nl.lib.mww_prefetch_rng_state(self.h, py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p))
+        return py, npst, int(n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.nl.lib.mww_prefetch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:
@@ -333,6 +411,26 @@ class Engine:
         if y.size != w.size:
             raise ValueError("labels and weights differ in length")
         self.nl.check(self.nl.lib.mww_set_targets(self.h, _fptr(y), _fptr(w), y.size))
+
+    def assemble_prefetched(self, pf: "Prefetcher", want_targets=False):
+        """The next prefetched batch becomes the engine's current batch (descriptors, labels, weights): one native call,
+        no numpy work on the launching thread."""
+        if want_targets:
+            y, w = np.empty(pf.B, np.float32), np.empty(pf.B, np.float32)
+            self.nl.check(self.nl.lib.mww_assemble_prefetched(self.h, pf.h, y.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
+            return y, w
+        self.nl.check(self.nl.lib.mww_assemble_prefetched(self.h, pf.h, None, None))
+        return None
+
+    def allreduce_init(self, rank, world, unique_id, sync_bn=False):
+        """Join the library-owned RCCL communicator (collective over the ranks; include/mww.h mww_allreduce_init)."""
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        if uid.size != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % UNIQUE_ID_BYTES)
+        self.nl.check(self.nl.lib.mww_allreduce_init(self.h, int(rank), int(world), uid.ctypes.data_as(C.c_void_p), int(bool(sync_bn))))
+
+    def allreduce_destroy(self):
+        self.nl.check(self.nl.lib.mww_allreduce_destroy(self.h))
 
     def set_dropout_mask(self, keep):
         """``keep`` [B, T_last*C_last] of 0/1 (None = built-in generator)."""

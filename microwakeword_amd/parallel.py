@@ -1,7 +1,5 @@
-"""Data-parallel training over the GPUs of one node: one process per GPU, ``torch.distributed``
-(backend "nccl" == RCCL over xGMI) for the single exchange step of the path — an all-reduce(sum)
-of the flat 22 177-float gradient (88.7 KB: latency-bound), issued in two buckets so that the first one
-([dense + blocks 4, 3], 54.5 KB) overlaps the backward kernels of blocks 2 and 1.
+"""Data-parallel training over the GPUs of one node: one process per GPU, one exchange step per train step —
+an all-reduce(sum) of the flat 22 177-float gradient (88.7 KB: latency-bound) over RCCL / xGMI.
 
 The reference has no distributed code at all (SURVEY §2 "Parallelism strategies: none"); this is
 new work defined by SURVEY §8(e):
@@ -13,11 +11,18 @@ new work defined by SURVEY §8(e):
     applies the same reduced gradient;
   * BatchNorm: ``sync_bn=False`` ("throughput mode", the default and what bench.py measures) normalises
     over the rank's own batch; ``sync_bn=True`` ("parity mode") exchanges the per-channel statistics
-    sums of every BN layer in the forward and in the backward through ``mww_set_allreduce_hook``, so
-    W ranks x B/W windows reproduce the single-device step on the global batch (no hipGraph replay).
+    sums of every BN layer in the forward and in the backward, so W ranks x B/W windows reproduce the
+    single-device step on the global batch (no hipGraph replay).
+
+Who issues the collective: on the GPU the LIBRARY does (``mww_allreduce_init``: ncclAllReduce from the launching
+thread, on the engine's stream or on a library-owned side stream for a deferred bucket - no Python in the step);
+``torch.distributed`` only carries the 128-byte communicator id to the ranks, the initial weight broadcast and the
+barriers of the caller.  The callback form (``mww_set_allreduce_hook`` -> ``DataParallel._allreduce`` ->
+``dist.all_reduce``) remains for process groups RCCL cannot serve (the two-rank gloo tests on the host-emulated kernels).
 """
 from __future__ import annotations
 
+import contextlib
 import random
 from typing import Optional
 
@@ -55,16 +60,18 @@ class DataParallel:
     """Wraps one engine per rank.  ``grad_view`` / ``param_view`` are torch tensors aliasing the
     engine's flat gradient / parameter vectors (device memory on the GPU path).
 
-    With ``wrap`` (the normal case: ``for_engine``) the engine drives the exchange through
-    ``mww_set_allreduce_hook``: ``engine.train_step`` is the complete data-parallel step.  In throughput
-    mode (local BatchNorm) the specialised MixedNet kernels hand the gradient over in TWO buckets - [dense +
-    the last two blocks] right after those blocks' backward kernels are enqueued, as a *deferred* exchange
-    that RCCL runs on its own stream next to the remaining backward kernels, and the rest after the first
-    block's backward - then Adam consumes grad/W.  Without ``wrap`` (engines that only expose
-    NO_APPLY + apply, e.g. the test stub) the single all-reduce is issued from here."""
+    ``for_engine`` (the GPU path) joins the ranks' engines into an RCCL communicator owned by the library:
+    ``engine.train_step`` is then the complete data-parallel step and nothing of it runs in Python.
+    With ``wrap`` and no library communicator the engine drives the exchange through the ``mww_set_allreduce_hook``
+    callback into ``_allreduce`` (gloo groups, host-emulated kernels).  ``grad_buckets`` = 2 hands the gradient over in
+    two buckets - [dense + the last two blocks] right after those blocks' backward kernels are enqueued, as a *deferred*
+    exchange that runs on a side stream next to the remaining backward kernels, the rest after the first block's
+    backward; it is bit-identical to the single exchange and 8 % slower at W = 1, unmeasured at W > 1, so the
+    default is 1.  Without ``wrap`` (engines that only expose NO_APPLY + apply, e.g. the test stub) the single
+    all-reduce is issued from here."""
 
     def __init__(self, engine, grad_view: torch.Tensor, param_view: torch.Tensor, state_view: Optional[torch.Tensor] = None,
-                 group=None, sync_bn: bool = False, wrap=None, grad_buckets: int = 2):
+                 group=None, sync_bn: bool = False, wrap=None, grad_buckets: int = 1, library_comm: bool = False):
         """``wrap(ptr, n) -> tensor`` turns a device address handed out by the engine into a tensor the
         process group can reduce in place (defaults to a zero-copy view of HBM on the engine's device)."""
         self.engine = engine
@@ -77,41 +84,74 @@ class DataParallel:
         self._views = {}
         self._pending = []
         self.exchanges = []   # (n, flags) of the hook calls of the last step (tests / diagnostics)
-        if self.sync_bn and wrap is None:
+        self._step_open = False
+        self.library_comm = bool(library_comm)
+        if self.sync_bn and wrap is None and not library_comm:
             raise ValueError("sync_bn needs a wrap(ptr, n) function")
-        self.engine_driven = wrap is not None
-        if self.engine_driven:
+        self.engine_driven = wrap is not None or library_comm
+        if library_comm:
+            self._join_library_communicator()
+            engine.set_option("grad_buckets", int(grad_buckets))
+        elif self.engine_driven:
             # the engine calls back for every BN layer (sync-BN) and for the gradient buckets: the complete DP step
             engine.set_allreduce_hook(self._allreduce, self.world, sync_bn=self.sync_bn, reduce_grads=True)
             engine.set_option("grad_buckets", int(grad_buckets))
 
     @classmethod
-    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False, grad_buckets: int = 2):
+    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False, grad_buckets: int = 1,
+                   library_comm: bool = True):
         g = wrap_device_floats(engine.device_ptr(native.BUF_GRADS), engine.n_params, device)
         p = wrap_device_floats(engine.device_ptr(native.BUF_PARAMS), engine.n_params, device)
         s = wrap_device_floats(engine.device_ptr(native.BUF_BN_STATE), engine.n_state, device)
         return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=lambda ptr, n: wrap_device_floats(ptr, n, device),
-                   grad_buckets=grad_buckets)
+                   grad_buckets=grad_buckets, library_comm=library_comm)
+
+    def _join_library_communicator(self):
+        """rank 0 asks the library for an RCCL unique id, the process group carries its 128 bytes to the other
+        ranks, every rank joins (``mww_allreduce_init`` is collective)."""
+        dev = self.grad_view.device
+        uid = torch.zeros(native.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            uid.copy_(torch.from_numpy(self.engine.nl.allreduce_unique_id()))
+        if dist.is_initialized() and self.world > 1:
+            dist.broadcast(uid, src=0, group=self.group)
+            torch.cuda.synchronize(dev)
+        self.engine.allreduce_init(self.rank, self.world, uid.cpu().numpy(), sync_bn=self.sync_bn)
+
+    def _engine_stream(self):
+        """The callback's collectives are ordered against torch's CURRENT stream; the engine's kernels run on the engine's
+        stream.  Entering that stream here makes the two the same whatever the caller's stream context is (an engine on a
+        private stream, or a train_step called outside ``torch.cuda.stream(...)``, would otherwise race the all-reduce
+        against the backward kernels and Adam)."""
+        if self.grad_view.is_cuda:
+            h = self.engine.device_ptr(native.BUF_STREAM)
+            if h:
+                return torch.cuda.stream(torch.cuda.ExternalStream(h, device=self.grad_view.device))
+        return contextlib.nullcontext()
 
     def _allreduce(self, ptr: int, n: int, flags: int = native.EXCHANGE_IN_ORDER):
-        """Hook target (include/mww.h mww_allreduce_fn).  The engine lives on torch's current stream, so an in-order
-        exchange is a plain ``dist.all_reduce`` (the NCCL backend orders it after, and the current stream behind, the
-        collective); a deferred bucket is issued ``async_op`` - it starts once the kernels enqueued so far are done and
-        runs on the communicator's stream - and its ``wait()`` is what the flush call enqueues."""
+        """Hook target (include/mww.h mww_allreduce_fn).  With the engine's stream current, an in-order exchange is a
+        plain ``dist.all_reduce`` (the NCCL backend orders it after, and the current stream behind, the collective); a
+        deferred bucket is issued ``async_op`` - it starts once the kernels enqueued so far are done and runs on the
+        communicator's stream - and its ``wait()`` is what the flush call enqueues."""
+        if not self._step_open:      # a caller driving engine.train_step directly: keep one step's worth of records
+            self.exchanges = []
+            self._step_open = True
         self.exchanges.append((int(n), int(flags)))
-        if flags == native.EXCHANGE_FLUSH:
-            for w in self._pending:
-                w.wait()
-            self._pending = []
-            return
-        t = self._views.get((ptr, n))
-        if t is None:
-            t = self._views[(ptr, n)] = self._wrap(ptr, n)
-        if dist.is_initialized():
-            if flags == native.EXCHANGE_DEFERRED:
-                self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        with self._engine_stream():
+            if flags == native.EXCHANGE_FLUSH:
+                for w in self._pending:
+                    w.wait()
+                self._pending = []
+                return
+            t = self._views.get((ptr, n))
+            if t is None:
+                t = self._views[(ptr, n)] = self._wrap(ptr, n)
+            if dist.is_initialized():
+                if flags == native.EXCHANGE_DEFERRED:
+                    self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_parameters(self, src=0):
         if dist.is_initialized():
@@ -119,23 +159,28 @@ class DataParallel:
             dist.broadcast(self.param_view, src=src, group=self.group)
             if self.state_view is not None:
                 dist.broadcast(self.state_view, src=src, group=self.group)
+            if self.grad_view.is_cuda:
+                torch.cuda.synchronize(self.grad_view.device)   # the engine's stream is not torch's: order by completion
 
     def train_step(self, B, lr, flags=0, prefetch=None):
-        """Local forward/backward, gradient all-reduce (overlapped with the backward tail when the engine drives
-        it), Adam on the averaged gradient.  ``prefetch`` (optional callable, e.g. the draw of the next batch) runs
-        after the step has been enqueued."""
+        """Local forward/backward, gradient all-reduce, Adam on the averaged gradient.  ``prefetch`` (optional
+        callable, e.g. the draw of the next batch) runs after the step has been enqueued."""
         self.exchanges = []
-        if self.engine_driven:
-            self.engine.train_step(B, lr, flags)   # statistics / gradient exchanges happen inside, via the hook
+        self._step_open = True
+        try:
+            if self.engine_driven:
+                self.engine.train_step(B, lr, flags)   # statistics / gradient exchanges happen inside
+                if prefetch is not None:
+                    prefetch()
+                return
+            self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
+            work = None
+            if dist.is_initialized():
+                work = dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if prefetch is not None:
                 prefetch()
-            return
-        self.engine.train_step(B, lr, flags | native.STEP_NO_APPLY)
-        work = None
-        if dist.is_initialized():
-            work = dist.all_reduce(self.grad_view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if prefetch is not None:
-            prefetch()
-        if work is not None:
-            work.wait()   # orders the compute stream after the collective; no host block on RCCL
-        self.engine.apply_gradients(lr, 1.0 / self.world)
+            if work is not None:
+                work.wait()   # orders the compute stream after the collective; no host block on RCCL
+            self.engine.apply_gradients(lr, 1.0 / self.world)
+        finally:
+            self._step_open = False

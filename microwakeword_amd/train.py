@@ -172,6 +172,13 @@ def train(model, config, data_processor, verbose=True):
     fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
         and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
 
+    if fast and hasattr(data_processor, "use_private_rng") and int(config.get("prefetch_batches", 2)) > 0:
+        # the draws of get_data("training") (data.py:540-569) continue the global random / numpy.random streams from where
+        # they stand now, on a worker thread that runs `prefetch_batches` batches ahead of the step being enqueued
+        # (native.Prefetcher); nothing else in this loop consumes those streams.  prefetch_batches: 0 keeps every draw on
+        # this thread and in the global generators, as the reference does.
+        data_processor.use_private_rng(prefetch=int(config.get("prefetch_batches", 2)))
+
     def save_ckpt():
         os.makedirs(ckpt_dir, exist_ok=True)
         model.save_weights(ckpt + ".weights")

@@ -38,7 +38,7 @@ def build_emulator_lib():
         return None
     if not os.path.isfile(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
         cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "hipemu"),
-               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value"] + srcs + ["-o", EMU]
+               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value", "-pthread"] + srcs + ["-o", EMU, "-ldl"]
         subprocess.run(cmd, check=True)
     return EMU
 

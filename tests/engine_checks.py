@@ -1040,6 +1040,49 @@ def check_assemble_overlap(lib, B=8, T=60, steps=5):
         np.testing.assert_array_equal(a, b)
 
 
+# ------------------------------------------------------------------------------------------ prefetched batches
+def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
+    """Batches drawn ahead by the prefetcher's worker thread (native.Prefetcher, csrc/sampler.cpp) against the synchronous
+    sampler on the launching thread: the same private streams give the same windows / masks / labels / weights in the same
+    order, so parameters and outputs after a few train steps are bit-identical - also across a change of the augmentation
+    policy and of the class weights (the prefetcher is rebuilt from the stream positions of the last batch handed out) and
+    across a synchronous draw in between (the streams go back to the synchronous sampler and return)."""
+    from microwakeword_amd import mixednet
+    pol_a = dict(time_mask_max_size=4, time_mask_count=2, freq_mask_max_size=4, freq_mask_count=2)
+    pol_b = dict(time_mask_max_size=6, time_mask_count=1, freq_mask_max_size=3, freq_mask_count=3)
+    results = []
+    for depth in (0, 1, 3):
+        random.seed(3)
+        np.random.seed(3)
+        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=11, max_batch=B)
+        eng = model.engine
+        fh = FeatureHandler(learnable_config(T=T), engine=eng)
+        fh.use_private_rng(prefetch=depth)
+        seen, targets = [], []
+        for k in range(steps):
+            pol, cw = (pol_a, (1.0, 1.0)) if k < 3 else (pol_b, (0.5, 2.0))
+            got = fh.next_training_batch_on_device(B, T, "default", pol, class_weights=cw, want_targets=True)
+            assert (fh._pf is not None) == (depth > 0)
+            if depth:   # (labels, per-sample weights) as they went to the device
+                targets.append(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in got]))
+            eng.train_step(B, 1e-2)
+            if k == 4:   # a synchronous draw between two prefetched batches
+                d = fh.draw_training_batch(B, T, "default", pol_b)
+                seen.append(np.asarray(d["masks"], np.float32).reshape(-1))
+        seen.append(eng.read_outputs(B)[0].copy())
+        seen.append(eng.get_batch(B).copy())
+        results.append((eng.get_params().copy(), seen, targets))
+        fh._drop_prefetcher()
+        eng.close()
+    for r in results[1:]:
+        np.testing.assert_array_equal(results[0][0], r[0])
+        for a, b in zip(results[0][1], r[1]):   # the synchronous draw's masks, last outputs, last batch
+            np.testing.assert_array_equal(a, b)
+    assert len(results[1][2]) == steps
+    for a, b in zip(results[1][2], results[2][2]):
+        np.testing.assert_array_equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ statistics hand-over
 def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
     """"bn_inline" (BN sums in replicated fp64 accumulator rows, folded by their first consumer) against the

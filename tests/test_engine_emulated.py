@@ -250,6 +250,10 @@ def test_assemble_overlap_is_schedule_only(emu_lib):
     ec.check_assemble_overlap(emu_lib)
 
 
+def test_prefetched_batches_train_like_the_synchronous_sampler(emu_lib):
+    ec.check_prefetched_training_matches_synchronous(emu_lib)
+
+
 def test_bn_inline_matches_finalize(emu_lib):
     ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)
 

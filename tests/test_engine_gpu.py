@@ -153,8 +153,51 @@ def test_validation_on_device(lib, gold, tag):
     ec.check_validation_on_device(lib, gold, tag)
 
 
+def _dp_world1_step(lib, library_comm, sync_bn, buckets):
+    """One data-parallel train step in a world of one rank on the real device path, against the oracle."""
+    import torch
+
+    from microwakeword_amd.layout import MixedNetLayout
+    from microwakeword_amd.parallel import DataParallel
+    T, B = 194, 8
+    device = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        om = ec.perturbed_oracle(T)
+        lay = MixedNetLayout(ec.DEF, T)
+        eng = native.Engine(lib=lib, stream=stream.cuda_stream, **lay.engine_args(B))
+        p, st = lay.pack(om.get_weights())
+        eng.set_params(p)
+        eng.set_bn_state(st)
+        dp = DataParallel.for_engine(eng, device, sync_bn=sync_bn, grad_buckets=buckets, library_comm=library_comm)
+        rng = np.random.default_rng(11)
+        x = ec.synth_x(rng, B, T)
+        y = (rng.random(B) < 0.5).astype(np.float32)
+        w = np.ones(B, np.float32)
+        eng.set_batch(x)
+        eng.set_targets(y, w)
+    # the step itself is issued OUTSIDE the torch stream context: the exchange must order itself against the engine's
+    # stream, not against whatever stream happens to be current (ADVICE round 2)
+    dp.train_step(B, 1e-3)
+    pr, _, loss = eng.read_outputs(B)
+    g = eng.get_grads()
+    lo, po, grads, _ = om.loss_and_grads(x, y, w)
+    gref = ec.oracle_grads_native_order(lay, om, grads)
+    assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo))
+    assert np.abs(pr - po).max() <= ec.FWD_TOL
+    assert np.linalg.norm(g - gref) <= 2e-3 * np.linalg.norm(gref)
+    om.train_step(x, y, w, 1e-3)
+    p_ref, s_ref = lay.pack(om.get_weights())
+    well = np.abs(gref) > 1e-4 * np.abs(gref).max()
+    assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * 1e-3
+    assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
+    out = (eng.get_params().copy(), g.copy(), [f for _, f in dp.exchanges])
+    eng.close()
+    return out
+
+
 def test_sync_bn_exchange_through_rccl_world1(lib):
-    """The statistics / gradient exchange hook on the real device path: engine on a torch stream, RCCL
+    """The statistics / gradient exchange CALLBACK on the real device path: engine on a torch stream, RCCL
     process group of one rank, zero-copy views of the engine's HBM.  With W=1 the step must equal the
     plain one; what is exercised is the collapse -> all-reduce -> single-row finalize route, the hook
     trampoline and the stream ordering between the engine's kernels and the collectives."""
@@ -162,48 +205,30 @@ def test_sync_bn_exchange_through_rccl_world1(lib):
 
     import torch
     import torch.distributed as dist
-
-    from microwakeword_amd.layout import MixedNetLayout
-    from microwakeword_amd.parallel import DataParallel
-    T, B = 194, 8
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    device = torch.device("cuda", 0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        stream = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(stream):
-            om = ec.perturbed_oracle(T)
-            lay = MixedNetLayout(ec.DEF, T)
-            eng = native.Engine(lib=lib, stream=stream.cuda_stream, **lay.engine_args(B))
-            p, st = lay.pack(om.get_weights())
-            eng.set_params(p)
-            eng.set_bn_state(st)
-            dp = DataParallel.for_engine(eng, device, sync_bn=True)
-            rng = np.random.default_rng(11)
-            x = ec.synth_x(rng, B, T)
-            y = (rng.random(B) < 0.5).astype(np.float32)
-            w = np.ones(B, np.float32)
-            eng.set_batch(x)
-            eng.set_targets(y, w)
-            dp.train_step(B, 1e-3)
-            pr, _, loss = eng.read_outputs(B)
-            g = eng.get_grads()
-            lo, po, grads, _ = om.loss_and_grads(x, y, w)
-            gref = ec.oracle_grads_native_order(lay, om, grads)
-            assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo))
-            assert np.abs(pr - po).max() <= ec.FWD_TOL
-            assert np.linalg.norm(g - gref) <= 2e-3 * np.linalg.norm(gref)
-            om.train_step(x, y, w, 1e-3)
-            p_ref, s_ref = lay.pack(om.get_weights())
-            well = np.abs(gref) > 1e-4 * np.abs(gref).max()
-            assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * 1e-3
-            assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
-            eng.close()
+        _, _, ex = _dp_world1_step(lib, library_comm=False, sync_bn=True, buckets=1)
+        assert ex and all(f == native.EXCHANGE_IN_ORDER for f in ex)
+        _, _, ex = _dp_world1_step(lib, library_comm=False, sync_bn=False, buckets=2)
+        assert ex == [native.EXCHANGE_DEFERRED, native.EXCHANGE_IN_ORDER, native.EXCHANGE_FLUSH]
     finally:
         dist.destroy_process_group()
+
+
+def test_exchange_through_the_library_s_own_rccl_communicator_world1(lib):
+    """mww_allreduce_unique_id / mww_allreduce_init: ncclAllReduce issued by the library - on the engine's
+    stream (in-order exchanges: sync-BN statistics, the one-bucket gradient) and on its own side stream ordered by events
+    (the deferred first bucket of the two-bucket schedule).  One rank: the step equals the plain one, and the schedules
+    equal each other bit for bit."""
+    a = _dp_world1_step(lib, library_comm=True, sync_bn=False, buckets=1)
+    b = _dp_world1_step(lib, library_comm=True, sync_bn=False, buckets=2)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    _dp_world1_step(lib, library_comm=True, sync_bn=True, buckets=1)
 
 
 def test_bf16_pointwise_mode(lib):
@@ -386,6 +411,10 @@ def test_against_frozen_oracle_outputs(lib, golden_dir):
 
 def test_assemble_overlap_is_schedule_only(lib):
     ec.check_assemble_overlap(lib, B=64, T=194, steps=6)
+
+
+def test_prefetched_batches_train_like_the_synchronous_sampler(lib):
+    ec.check_prefetched_training_matches_synchronous(lib, B=64, T=194, steps=7)
 
 
 def test_bn_inline_matches_finalize(lib):

@@ -264,10 +264,11 @@ def test_local_bn_two_ranks_with_product_kernels(tmp_path):
     lay = MixedNetLayout(ec.DEF, T)
     from microwakeword_amd import native
     ex = outs[0]["exchanges"].tolist()
-    n_tail = lay.n_params - lay.blocks[2].o_dw_w if hasattr(lay.blocks[2], "o_dw_w") else None
+    segs = lay.segments()
+    n_tail = sum(n for name, n in segs[[name for name, _ in segs].index("b2.dw.kernel"):])   # [blocks 3, 4 (0-based 2, 3) + dense]
     assert [f for _, f in ex] == [native.EXCHANGE_DEFERRED, native.EXCHANGE_IN_ORDER, native.EXCHANGE_FLUSH], ex
     assert ex[0][0] + ex[1][0] == lay.n_params and ex[2][0] == 0 and min(ex[0][0], ex[1][0]) > 0, ex
-    assert n_tail is None or ex[0][0] == n_tail
+    assert ex[0][0] == n_tail, (ex, n_tail)
     # ... and the overlapped schedule is bit-identical to the single exchange after the backward pass
     mp.spawn(_sync_worker, args=(W, _free_port(), str(tmp_path), emu, "mixednet", False, 1, "one"), nprocs=W, join=True)
     ones = [np.load(tmp_path / ("one%d.npz" % r)) for r in range(W)]
