@@ -234,6 +234,14 @@ int mww_allreduce_destroy(mww_ctx* ctx);
  * touching the moving averages. update_metrics=1 also accumulates the compiled metrics. */
 int mww_forward(mww_ctx* ctx, int B, int training, int update_metrics);
 
+/* ---- evaluation of a whole window list: replaces model.evaluate(x, y, batch_size=1024) over the result of
+ * FeatureHandler.get_data(<validation / testing mode>) (train.py:42-58,75-96; the ambient sets arrive as the 100 ms-stride
+ * windows of data.py:301-311).  `windows` / `labels` ([n]) are host arrays; the library walks them in batches of `batch`:
+ * descriptor upload, gather from the HBM-resident stores, inference forward (moving statistics folded once for the whole
+ * call), threshold / AUC / loss counters accumulated on the device (read them with mww_metrics_read).  One call per
+ * evaluation instead of three per batch. */
+int mww_evaluate_windows(mww_ctx* ctx, const mww_window* windows, const float* labels, int64_t n, int batch);
+
 /* outputs of the last train step / forward (waits for the stream). Any pointer may be NULL. */
 int mww_read_outputs(mww_ctx* ctx, int B, float* probs, float* logits, float* loss);
 
@@ -280,7 +288,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * CU, default 4 / 4; > 0 = that many workgroups per launch; without bn_inline one grid of 3 per CU, because a tensor's
  * partial statistics rows are shared by its launches),
  * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops - and the forward convolution of any op - process
- * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, the default - parity-tested, not yet timed on the GPU; 1 = automatic; 2..4),
+ * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, 1 = automatic, 2..4 = that many; default 1 for graphs
+ * with depthwise ops (MixedNet flag sets: -7 % step time measured), 0 for pure convolution graphs (Inception: +0.5 ... +8 %)),
  * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
  * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
  * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's

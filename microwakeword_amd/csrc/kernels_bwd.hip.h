@@ -43,7 +43,8 @@ struct BwdBlockArgs {
   float* gstat_part;      // [gridDim.x][2][CIN]
   float* grad_part;       // [gridDim.x][K*CIN + CIN + CIN*COUT]  (dW_dw, db, dW_pw)
   int B, Tin, Tout;
-  int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid); bit 16: phase clocks
+  int ablate;             // profiling only: bit0 skip P1, bit1 skip MFMA, bit2 skip P4 (results invalid); bit 16: phase clocks;
+                          // parts of P4: 32 skip the g_{k-1} stores, 64 skip the depthwise weight gradient, 128 skip the input gradient
   unsigned long long* phase_clk;   // [gridDim.x][8]
   StatAcc gacc;           // (sum g, sum g*xhat) of g_{k-1} go to the accumulator rows instead of gstat_part when set
   BnGradFoldArgs gfold;   // gfold.acc set: k_c1 / k_mg / k_mgx are folded here from the producer's accumulator rows
@@ -168,7 +169,6 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
     // that way (read group, MFMA group, ...): left to itself the scheduler sank every read to just in front of its first
     // use (register pressure), so each group of 2-3 MFMAs waited for an LDS round trip (27 waits for 72 MFMAs in the
     // round-2 ISA; the phase took 3.7k cycles alone for 2.3k of MFMA issue).
-#ifndef MWW_NO_MFMA_PIPELINE
     {
       float av[2][MT], bv[2][NT];
       auto load_dw = [&](int kk, int s) {
@@ -207,27 +207,6 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
       sched_read_mfma_groups<KSO - 1, 1 + MT, MT>();
       sched_read_mfma_groups<1, 0, MT>();
     }
-#else
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int row = wave * 16 + kk * 4 + g;
-      float av[MT], bv[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt] = sU[row * CPI + mt * 16 + r16];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[row * CPO + nt * 16 + r16];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = mfma4(av[mt], bv[nt], dwacc[mt][nt]);
-    }
-#pragma unroll
-    for (int kk = 0; kk < KSO; ++kk) {
-      const float av = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) du[mt] = mfma4(av, sWt[(kk * 4 + g) * CPI + mt * 16 + r16], du[mt]);
-    }
-#endif
   } else {
     // bf16 operands: one MFMA spans the wave's 16 rows (dW) / 16 output channels (du)
     const int row = wave * 16 + 4 * g;
@@ -423,7 +402,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
-#ifndef MWW_NO_COMMIT_ACT
   // The block input is activated ONCE, while its rows are committed to LDS: sP holds a = relu(BN_{k-1}(p_{k-1})), so the
   // depthwise recompute (P1) and the depthwise weight gradient (P4) read their windows as they are (before, each of the
   // L + K - 1 window rows went through the fma + max twice per (channel, chunk): 2 x 66 of ~1150 VALU instructions per
@@ -438,9 +416,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
   float xk1 = sc_c != 0.f ? rs_c / sc_c : 0.f;
   float xk0 = -(sh_c + mu_c * sc_c) * xk1;
   pin(dwb); pin(xk1); pin(xk0);
-#else
-  pin(dwb); pin(sc_c); pin(sh_c); pin(mu_c); pin(rs_c);
-#endif
   __syncthreads();
 
   MWW_PC_AT(1);   // prologue done
@@ -456,7 +431,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
       const int i = tid + j * kThreads;
       if (i < RA * QI) {
         const int r = i / QI, q = i - r * QI;
-#ifndef MWW_NO_COMMIT_ACT
         const float4 s4 = *reinterpret_cast<const float4*>(sAct + q * 4), h4 = *reinterpret_cast<const float4*>(sAct + CIN + q * 4);
         float4 v = pre_p[j];
         v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f);
@@ -464,9 +438,6 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f);
         v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
         *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = v;
-#else
-        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = pre_p[j];
-#endif
       }
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
@@ -482,11 +453,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         float o[L], dww[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-#ifndef MWW_NO_COMMIT_ACT
         dw_chunk<K, L, false, false>(sP, CPI, chunk * L, c, dww, dwb, o);
-#else
-        dw_chunk<K, L, false, true>(sP, CPI, chunk * L, c, dww, dwb, o, sc_c, sh_c);
-#endif
 #pragma unroll
         for (int t = 0; t < L; ++t) {
           const int tl = chunk * L + t;
@@ -517,7 +484,7 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         float da[L], raw[L];
 #pragma unroll
         for (int t = 0; t < L; ++t) raw[t] = sP[(cch * L + t) * CPI + c];   // in flight under the da FMAs
-        if (cch * L < rows_da) {   // chunks past the sample's last row: da = 0, nothing to compute
+        if (cch * L < rows_da && !MWW_ABLATE(a, 128)) {   // chunks past the sample's last row: da = 0, nothing to compute
           float dww[K];
 #pragma unroll
           for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
@@ -530,26 +497,15 @@ __global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) 
         for (int t = 0; t < L; ++t) {
           const int sl = cch * L + t;
           // (row TT of the last chunk belongs to the next tile: its da is still partial)
-#ifndef MWW_NO_COMMIT_ACT
           const float gg = (sl < rows_da && raw[t] > 0.f) ? da[t] : 0.f;   // raw = the activated value here
-          tile_store1s<SB>(gtile, goff + t * CIN, gg);
+          if (!MWW_ABLATE(a, 32)) tile_store1s<SB>(gtile, goff + t * CIN, gg);
           gs1 += gg;
           gs2 = fmaf(gg, fmaf(raw[t], xk1, xk0), gs2);
-#else
-          const float gg = (sl < rows_da && fmaf(raw[t], sc_c, sh_c) > 0.f) ? da[t] : 0.f;
-          tile_store1s<SB>(gtile, goff + t * CIN, gg);
-          gs1 += gg;
-          gs2 = fmaf(gg, (raw[t] - mu_c) * rs_c, gs2);
-#endif
         }
       }
-      if (cch * L < nrows_new)   // du = 0 past the sample's last output row
+      if (cch * L < nrows_new && !MWW_ABLATE(a, 64))   // du = 0 past the sample's last output row
         depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
-#ifndef MWW_NO_COMMIT_ACT
                                                [&](int row) { return sP[row * CPI + c]; });
-#else
-                                               [&](int row) { return fmaxf(fmaf(sP[row * CPI + c], sc_c, sh_c), 0.f); });
-#endif
     }
     MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
     if (!MWW_ABLATE(a, 8)) __syncthreads();

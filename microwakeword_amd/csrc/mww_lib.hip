@@ -211,6 +211,7 @@ struct mww_ctx {
   bool pw_bf16 = false;   // 1x1 contractions with bf16 operands (mww_set_option "pointwise_bf16")
   bool st_bf16 = false;   // p_k / g_k stored as bf16 ("storage_bf16", implies pointwise_bf16: BASELINE configs[4])
   bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
+  bool bn_eval_ready = false;   // inside mww_evaluate_windows: the moving statistics are folded once, not per batch
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
@@ -248,10 +249,15 @@ struct Launcher {
 // its training notebook (5x1 first conv stride 3, 64 filters, [5],[7,11],[9,15],[23] - multi-kernel groups are fused to
 // their longest kernel) and the crosses of the two (either width with either kernel set, either first conv); everything
 // else runs on the conv / depthwise graph kernels.
+#ifdef MWW_SLIM   // kernel-tuning builds (tools/build_variant.sh): the default topology only, compiles in a quarter of the time
+#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1)
+#define MWW_BLOCK_SHAPES(X) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21)
+#else
 #define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1) X(5, 32, 64, 5, 3) X(5, 32, 64, 5, 1) X(3, 32, 64, 5, 1) X(5, 32, 48, 5, 3) X(5, 32, 48, 5, 1)
 #define MWW_BLOCK_SHAPES(X)                                                                               \
   X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21) X(48, 48, 11) X(48, 48, 15) X(48, 48, 23)         \
   X(64, 64, 11) X(64, 64, 15) X(64, 64, 23) X(64, 64, 5) X(64, 64, 9) X(64, 64, 13) X(64, 64, 21)
+#endif
 
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
@@ -501,7 +507,7 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
   Launcher lp{c};
   const mww_mixednet_desc& d = c->d;
   const int nb = d.n_blocks;
-  if (!training) {
+  if (!training && !c->bn_eval_ready) {
     for (int i = 0; i < nb; ++i) {
       Layer& l = c->L[i];
       BnEvalPrepareArgs a{c->params + l.o_gamma, c->params + l.o_beta, c->bn_state + l.o_mm, c->bn_state + l.o_mv,
@@ -880,7 +886,11 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
 }
 
 // ---------------------------------------------------------------------------------- conv/BN graphs
+#ifdef MWW_SLIM
+#define MWW_G_WIDTHS(X) X(48)
+#else
 #define MWW_G_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(30) X(32) X(36) X(40) X(48) X(60) X(64)
+#endif
 
 bool g_width_supported(int n) {
 #define X(N) if (n == N) return true;
@@ -1018,7 +1028,11 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, s
 }
 
 // (filters, input channels) pairs with a fused weight-gradient + data-gradient launch; others use two launches
+#ifdef MWW_SLIM
+#define MWW_G_BWD_PAIRS(X) X(48, 48)
+#else
 #define MWW_G_BWD_PAIRS(X) X(30, 24) X(10, 10) X(10, 30) X(30, 10) X(48, 10) X(16, 16) X(16, 48) X(24, 16) X(16, 24) X(36, 24) X(12, 36) X(48, 32) X(48, 48) X(64, 32) X(64, 64)
+#endif
 
 template <bool CH = false>
 bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, const GridPick& pk, size_t lds) {
@@ -1037,7 +1051,11 @@ bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const 
   return false;
 }
 
+#ifdef MWW_SLIM
+#define MWW_G_TWIN_WIDTHS(X) X(32)
+#else
 #define MWW_G_TWIN_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
+#endif
 bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, const GridPick& pk, size_t lds) {
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
@@ -2054,6 +2072,12 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   c->generic = true;
   c->dropout = d.dropout;
   c->G = ops;
+  // frame chunks ("graph_frame_chunks"): automatic for graphs with depthwise ops, i.e. MixedNet flag sets on this engine - their
+  // wide 1x1 ops hold 45-105 KB of LDS per whole-window workgroup; measured on the default MixedNet forced onto this engine
+  // 0.877 -> 0.815 ms/step (3: 0.818).  Off for pure convolution graphs: Inception 0.892 / 0.897 / 0.957 / 0.960 ms for 0 / 1 / 2 / 3
+  // (profiles/round3_frame_chunks.txt)
+  for (const GOp& o : ops)
+    if (o.kind == MWW_OP_DEPTHWISE) c->g_chunks = 1;
   {
     // statistics hand-over: possible when every op is a convolution followed by a BatchNorm / SSN (or by nothing: a
     // MixedNet's first convolution) or a depthwise op with a bias (or nothing), none has a residual branch and every folded
@@ -2631,6 +2655,21 @@ int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
   if (rc) return rc;
   HIPCHK(hipGetLastError());
   return mail_commit(c);
+}
+
+int mww_evaluate_windows(mww_ctx* c, const mww_window* windows, const float* labels, int64_t n, int batch) {
+  if (!c || !windows || !labels || n < 0 || batch <= 0 || batch > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad evaluation arguments");
+  std::vector<float> ones((size_t)batch, 1.0f);
+  int rc = MWW_OK;
+  for (int64_t s = 0; s < n && !rc; s += batch) {
+    const int b = (int)std::min<int64_t>(batch, n - s);
+    rc = mww_set_targets(c, labels + s, ones.data(), b);
+    if (!rc) rc = mww_assemble_batch(c, windows + s, nullptr, b, 0, 0);
+    if (!rc) rc = mww_forward(c, b, 0, 1);
+    c->bn_eval_ready = !c->generic;   // the weights cannot change between the batches of this call
+  }
+  c->bn_eval_ready = false;
+  return rc;
 }
 
 int mww_read_outputs(mww_ctx* c, int B, float* probs, float* logits, float* loss) {

@@ -337,7 +337,7 @@ class FeatureHandler:
         return out
 
     def _index_eval_windows(self, mode, features_length, truncation_strategy):
-        win, labels, weights = [], [], []
+        win, labels, weights, split_blocks = [], [], [], []
         for p in self.feature_providers:
             strat = p.strategy(truncation_strategy)
             for fi, sub in p.feature_sets[mode]:
@@ -346,10 +346,14 @@ class FeatureHandler:
                 sid = p.store_id[p.feature_dtype[fi]]
                 if strat == "split":  # data.py:301-311
                     hop = int(1000 * p.step * p.stride)
-                    for s0 in range(0, length - features_length, hop):
-                        win.append((sid, 0, features_length, 0, base + s0 * FEATURE_BINS))
-                        labels.append(p.label)
-                        weights.append(p.penalty_weight)
+                    starts = np.arange(0, length - features_length, hop, dtype=np.int64)
+                    if starts.size:
+                        blk = np.zeros(starts.size, native.WINDOW_DTYPE)
+                        blk["store"], blk["copy_rows"], blk["src_elem"] = sid, features_length, base + starts * FEATURE_BINS
+                        split_blocks.append((len(win), blk))
+                        win.extend([None] * starts.size)
+                        labels.extend([p.label] * starts.size)
+                        weights.extend([p.penalty_weight] * starts.size)
                     continue
                 for cutoff in p.fixed_right_cutoffs:  # data.py:312-321
                     if length > features_length:
@@ -370,8 +374,17 @@ class FeatureHandler:
                         win.append((sid, features_length - length, length, 0, base))
                     labels.append(p.label)
                     weights.append(p.penalty_weight)
-        return np.array(win, native.WINDOW_DTYPE) if win else np.zeros(0, native.WINDOW_DTYPE), \
-            np.array(labels), np.array(weights)
+        if not win:
+            return np.zeros(0, native.WINDOW_DTYPE), np.array(labels), np.array(weights)
+        out = np.zeros(len(win), native.WINDOW_DTYPE)
+        covered = np.zeros(len(win), bool)
+        for at, blk in split_blocks:   # the ambient sets' 100 ms-stride windows, built as arrays (tens of thousands of them)
+            out[at:at + blk.size] = blk
+            covered[at:at + blk.size] = True
+        rest = [w for w in win if w is not None]
+        if rest:
+            out[~covered] = np.array(rest, native.WINDOW_DTYPE)
+        return out, np.array(labels), np.array(weights)
 
     def evaluate_on_device(self, model, mode: str, features_length: int, truncation_strategy: str = "default",
                            batch_size: int = 1024):
@@ -394,12 +407,8 @@ class FeatureHandler:
         win, labels = win[indices], labels[indices].astype(np.float32)
         model.reset_metrics()
         bs = min(int(batch_size), self.engine.max_batch)
-        ones = np.ones(bs, np.float32)
-        for s in range(0, n, bs):
-            e = min(n, s + bs)
-            self.engine.set_targets(labels[s:e], ones[:e - s])
-            self.engine.assemble(win[s:e], None, 0, 0)
-            self.engine.forward(e - s, training=False, update_metrics=True)
+        if n:
+            self.engine.evaluate_windows(win, labels, bs)   # one native call: the batches are walked inside the library
         return n, labels, model.evaluation_results()
 
     def get_data(self, mode: str, batch_size: int, features_length: int, truncation_strategy: str = "default",

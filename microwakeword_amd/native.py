@@ -96,7 +96,7 @@ EXPORTS = [
     "mww_set_option", "mww_profile_read", "mww_sample_training_batch", "mww_rng_selftest",
     "mww_prefetch_create", "mww_prefetch_acquire", "mww_prefetch_release", "mww_prefetch_rng_state", "mww_prefetch_shape",
     "mww_prefetch_destroy", "mww_assemble_prefetched",
-    "mww_allreduce_unique_id", "mww_allreduce_init", "mww_allreduce_destroy",
+    "mww_allreduce_unique_id", "mww_allreduce_init", "mww_allreduce_destroy", "mww_evaluate_windows",
 ]
 
 
@@ -177,6 +177,7 @@ class NativeLib:
         L.mww_allreduce_unique_id.argtypes = [C.c_void_p, C.c_int]
         L.mww_allreduce_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.mww_allreduce_destroy.argtypes = [C.c_void_p]
+        L.mww_evaluate_windows.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int]
 
     @classmethod
     def get(cls, path: Optional[str] = None) -> "NativeLib":
@@ -471,6 +472,14 @@ class Engine:
 
     def forward(self, B, training=False, update_metrics=False):
         self.nl.check(self.nl.lib.mww_forward(self.h, int(B), int(bool(training)), int(bool(update_metrics))))
+
+    def evaluate_windows(self, windows: np.ndarray, labels: np.ndarray, batch: int):
+        """Inference forward + metric counters over a whole window list in batches of ``batch`` (one native call)."""
+        windows = np.ascontiguousarray(windows, WINDOW_DTYPE)
+        labels = np.ascontiguousarray(labels, np.float32).reshape(-1)
+        if labels.size != windows.shape[0]:
+            raise ValueError("one label per window")
+        self.nl.check(self.nl.lib.mww_evaluate_windows(self.h, windows.ctypes.data_as(C.c_void_p), _fptr(labels), windows.shape[0], int(batch)))
 
     def read_outputs(self, B, want_loss=True):
         p, z = np.empty(B, np.float32), np.empty(B, np.float32)

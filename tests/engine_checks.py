@@ -806,7 +806,6 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
             assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
         assert np.abs(pr - torch.sigmoid(zo).numpy()).max() <= FWD_TOL
     l2s = []
-    flipped = False
     for st in range(steps):
         x = synth_x(rng, B, T)
         y = (rng.random(B) < 0.5).astype(np.float32)
@@ -859,13 +858,21 @@ def check_graph_mixednet(lib, flags=GRAPH_MIXEDNET, B=3, T=100, steps=1, grid=2,
         om.train_step(x, y, w, lr)
         p_ref, s_ref = lay.pack(om.get_weights())
         well = np.abs(gref) > (1e-4 if near_zero == 0 else 0.2) * scale
-        # (after a step in which a one-unit decision may have gone the other way the engine's Adam moments are no longer the
-        # oracle's: from then on the update is only held to the size of an Adam step)
-        assert np.abs(eng.get_params() - p_ref)[well].max() <= (2.5 if flipped else 0.05) * lr
-        flipped = flipped or near_zero > 0
+        # every step starts from the oracle's weights, moving statistics AND Adam moments (installed below), so a step in
+        # which a one-unit decision went the other way does not loosen the steps after it: the update is always held to
+        # 5 % of an Adam step (a flagged step itself: only where the gradient is well away from the flipped unit's share)
+        assert np.abs(eng.get_params() - p_ref)[well].max() <= 0.05 * lr, (st, near_zero)
         assert np.abs(eng.get_bn_state() - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
         eng.set_params(p_ref)
         eng.set_bn_state(s_ref)
+        tr = [v.name for v in om.vars if v.trainable]
+        for slot in ("m", "v"):
+            d = dict(zip(tr, getattr(om.adam, slot)))
+            flat = lay.pack([d[n].numpy().astype(np.float32) if kind == "param" else np.zeros(shape, np.float32)
+                             for n, shape, kind in lay.keras_vars])[0]
+            if slot == "m":
+                m_flat = flat
+        eng.set_opt_state(m_flat, flat, om.adam.t)
     assert not l2s or np.median(l2s) <= 2e-5
     eng.close()
     return max(l2s) if l2s else 0.0

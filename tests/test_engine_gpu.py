@@ -409,6 +409,19 @@ def test_against_frozen_oracle_outputs(lib, golden_dir):
     ec.check_against_frozen_oracle(lib, golden_dir)
 
 
+def test_frame_chunks_of_the_pointwise_graph_ops(lib):
+    """"graph_frame_chunks" on the GPU (round 2 shipped these kernels emulator-tested only): the 1x1 ops of a conv/BN graph
+    process a window as 2-4 frame chunks - Inception and MixedNet graphs, uneven last chunks, the automatic setting, a captured
+    graph - against the oracle; and every setting gives the same parameters as whole windows up to fp32 summation order."""
+    ec.check_inception_train_steps(lib, B=6, T=121, steps=2, grid=2, options={"graph_frame_chunks": 2})
+    ec.check_inception_train_steps(lib, B=5, T=120, steps=1, grid=0, options={"graph_frame_chunks": 3})
+    ec.check_inception_train_steps(lib, B=4, T=194, steps=1, grid=0, options={"graph_frame_chunks": 1})
+    ec.check_inception_train_steps(lib, B=6, T=120, steps=1, grid=2, flags=ec.INC_VARIANT, options={"graph_frame_chunks": 4})
+    ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET, B=8, T=100, steps=2, grid=0, options={"graph_frame_chunks": 3})
+    ec.check_graph_mixednet(lib, ec.GRAPH_MIXEDNET_NOCONV1, B=4, T=60, steps=1, grid=1, graphs=True, options={"graph_frame_chunks": 2})
+    ec.check_graph_mixednet(lib, ec.DEF, B=64, T=194, steps=1, grid=0, options={"graph_frame_chunks": 0})   # the non-default setting for such graphs
+
+
 def test_assemble_overlap_is_schedule_only(lib):
     ec.check_assemble_overlap(lib, B=64, T=194, steps=6)
 
