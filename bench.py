@@ -481,12 +481,26 @@ def main():
                           "note": "cached window index -> one mww_evaluate_windows call per set: descriptor upload + HBM gather + inference "
                                   "forward + threshold metrics in batches of 1024, metric read-back included; best of %d" % reps}
 
+        # device settle: inference forwards on the last batch (no weights, statistics or RNG touched) until ~80 ms of GPU work
+        # have gone by in total, so that a run with a 2 ms warm-up starts its timed region at the same clocks as a long one
+        # (skipped with --profile-steps 0, the form the rocprofv3 passes use: their per-kernel averages then hold train steps only)
+        if args.profile_steps > 0:
+            next_batch()
+        eng.synchronize()
+        t_settle = time.perf_counter()
+        while args.profile_steps > 0 and time.perf_counter() - t_settle < float(os.environ.get("MWW_BENCH_SETTLE_S", "0.08")):
+            for _ in range(16):
+                eng.forward(B, training=False)
+            eng.synchronize()
+
         # ---- per-kernel durations with HIP events on the engine's stream (eager launches, separate pass)
         prof = {}
         if args.profile_steps > 0:   # every rank runs the pass (same pre-roll everywhere); rank 0's times are reported
             eng.set_option("graphs", 0)
             eng.set_option("profile", 1)
-            for _ in range(args.profile_steps):
+            for ps in range(args.profile_steps + 1):
+                if ps == 1:
+                    eng.profile_read()   # the first step's launches carry one-off costs (code object load): not reported
                 fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
                 if dp is not None and world == 1:
                     dp.train_step(B, lr)          # forced-DP on one GPU: the exchanges are degenerate but present
@@ -501,15 +515,6 @@ def main():
             eng.set_option("profile", 0)
             if args.graphs and not args.no_graphs:
                 eng.set_option("graphs", 1)
-        # device settle: inference forwards on the last batch (no weights, statistics or RNG touched) until ~80 ms of GPU work
-        # have gone by in total, so that a run with a 2 ms warm-up starts its timed region at the same clocks as a long one
-        # (skipped with --profile-steps 0, the form the rocprofv3 passes use: their per-kernel averages then hold train steps only)
-        eng.synchronize()
-        t_settle = time.perf_counter()
-        while args.profile_steps > 0 and time.perf_counter() - t_settle < float(os.environ.get("MWW_BENCH_SETTLE_S", "0.08")):
-            for _ in range(16):
-                eng.forward(B, training=False)
-            eng.synchronize()
 
         def fence():
             eng.synchronize()

@@ -306,227 +306,55 @@ __device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, in
 }
 
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB = false>
-__global__ __launch_bounds__(kThreads, 2) void bwd_block_kernel(BwdBlockArgs a) {
-  constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
-  constexpr int RA = TT + K - 1;
-  constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
-  constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
-  constexpr int QI = CIN / 4;
-  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
-  constexpr int OFF_P = 0, OFF_DP = OFF_P + RAP * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TTP * CPI;
-  constexpr int OFF_END = OFF_DU + RAP * CPI;
-  static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN && OFF_END >= NCH * 2 * CIN, "scratch aliasing");
-  static_assert(TT >= K - 1, "carry rows must not overlap");
+// LDS of the block / first-block backward stages as float offsets into a fused launch's LDS array
+template <int CIN, int COUT, int K>
+struct BwdBlockLds {
+  static constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
+  static constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
+  static constexpr int OFF_END = RAP * CPI + TT * CPO + TTP * CPI + RAP * CPI;
+  static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
+  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), DW = WT + COUT * CPI, ACT = DW + up4(K * CIN), END = ACT + 2 * CIN;
+};
+template <int K1, int C1, int COUT, int K, int S>
+struct BwdFirstLds {
+  static constexpr int CIN = C1, CPI = pitch(CIN), CPO = pitch(COUT);
+  static constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
+  static constexpr int OFF_END = RAP * CPI + TT * CPO + TTP * CPI + RAP * CPI + TTP * CPI;
+  static constexpr int XR = (TT - 1) * S + K1, PX = FBINS + 1;
+  static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
+  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), X = WT + COUT * CPI, XG = X + up4(XR * PX);
+  static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);
+};
 
-  __shared__ __attribute__((aligned(16))) float smem[OFF_END];
+// (64-wide blocks hold 93-107 KB of LDS per workgroup: one workgroup per CU whatever the register count, so they are compiled
+// for one - the bound of 2 they carried until round 3 could not be met and only produced "failed to meet occupancy target")
+template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB = false>
+__global__ __launch_bounds__(kThreads, (CIN > 48 ? 1 : 2)) void bwd_block_kernel(BwdBlockArgs a) {
+  typedef BwdBlockLds<CIN, COUT, K> Lds;
+  __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
-  __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
   __shared__ __attribute__((aligned(16))) float sDW[K * CIN];      // depthwise taps
   __shared__ __attribute__((aligned(16))) float sAct[2 * CIN];     // BN_{k-1} folded scale / shift (activation at commit)
-  float* sP = smem + OFF_P;
-  float* sDP = smem + OFF_DP;
-  float* sU = smem + OFF_U;
-  float* sDU = smem + OFF_DU;
+  constexpr bool FUSED = false;
+#define MWW_STAGE_SYNC
+#include "bwd_block_body.inc"
+#undef MWW_STAGE_SYNC
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int c = tid % CIN, chunk = tid / CIN;
-  const bool dw_active = chunk < NCH;
-  MWW_PC_DECL
-  MWW_PC_AT(0);   // kernel entry
-
-  // work items = (sample, input-row tile); the next item's rows travel HBM -> registers while the
-  // current one is computed
-  const int ntiles = (a.Tin + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  constexpr int NP = (RA * QI + kThreads - 1) / kThreads;
-  float4 pre_p[NP];
-  DpStage<COUT, LAST, SB> dps;
-  float pre_dz = 0.f;
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvp = min(RA, a.Tin - t0) * QI;
-    const BufRsrc src = tile_rsrc(elem_ptr<SB>(a.in, ((size_t)b * a.Tin + t0) * CIN), nvp * 4 * elem_bytes(SB));
-#pragma unroll
-    for (int j = 0; j < NP; ++j) pre_p[j] = tile_load4s<SB>(src, tid + j * kThreads);
-    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
-    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(elem_ptr<SB>(a.pk, koff), LAST ? a.wd + (size_t)t0 * COUT : elem_ptr<SB>(a.gk, koff), nvk, tid);
-    if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
-  };
-  if (nitems > 0) issue(0);
-
-  // every global load of the prologue first ...
-  WeightStage<CIN, COUT, K> wst;
-  wst.load(a.pw_w, a.dw_w, tid);
-  float accw[K];
-  float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
-  float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
-#pragma unroll
-  for (int i = 0; i < K; ++i) accw[i] = 0.f;
-  if (dw_active) {
-    dwb = a.dw_b[c];
-    sc_c = a.in_scale[c];
-    sh_c = a.in_shift[c];
-    mu_c = a.in_mean[c];
-    rs_c = a.in_rstd[c];
-  }
-  // ... then BN_k's backward coefficients (their loads are the last ones issued: when they have arrived, all have)
-  for (int i = tid; i < COUT; i += kThreads) {
-    const float krs = a.k_rstd[i];
-    const float kmean = a.k_mean[i];
-    const float ksc = LAST ? a.k_scale[i] : 0.f, ksh = LAST ? a.k_shift[i] : 0.f;
-    float c1, mg, mgx;
-    if (a.gfold.acc) {
-      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
-    } else {
-      c1 = a.k_c1[i];
-      mg = a.k_mg[i];
-      mgx = a.k_mgx[i];
-    }
-    const float kA = -c1 * krs * mgx;
-    sKp[0 * COUT + i] = c1;
-    sKp[1 * COUT + i] = kA;
-    sKp[2 * COUT + i] = -c1 * mg - kA * kmean;
-    sKp[5 * COUT + i] = ksc;
-    sKp[6 * COUT + i] = ksh;
-  }
-  wst.store(sWt, sDW, tid);
-  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {   // rows only the padded windows touch
-    sP[i] = 0.f;
-    sDU[i] = 0.f;
-  }
-  f32x4 dwacc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
-  // The block input is activated ONCE, while its rows are committed to LDS: sP holds a = relu(BN_{k-1}(p_{k-1})), so the
-  // depthwise recompute (P1) and the depthwise weight gradient (P4) read their windows as they are (before, each of the
-  // L + K - 1 window rows went through the fma + max twice per (channel, chunk): 2 x 66 of ~1150 VALU instructions per
-  // wave and tile at K = 21).  What P4 still needs of the raw tensor follows from a for the units it matters for (a > 0,
-  // i.e. a = gamma * xhat + beta):  the ReLU decision is a > 0, and xhat = (a - beta) / gamma = a * xk1 + xk0.
-  // (gamma = 0 gives xk1 = 0: such a channel passes no gradient to p_{k-1}; its own d gamma = sum g * xhat is then formed
-  // with xhat = 0 - the one deviation from the two-pass form, for a value of gamma training does not produce.)
-  if (chunk == 0) {
-    sAct[c] = sc_c;
-    sAct[CIN + c] = sh_c;
-  }
-  float xk1 = sc_c != 0.f ? rs_c / sc_c : 0.f;
-  float xk0 = -(sh_c + mu_c * sc_c) * xk1;
-  pin(dwb); pin(xk1); pin(xk0);
-  __syncthreads();
-
-  MWW_PC_AT(1);   // prologue done
-  MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
-  for (int it = 0; it < nitems; ++it) {
-    rotate_priority(it, 2);
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
-    const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
-    // ---- P0: commit raw p_{k-1} rows [t0, t0+RA) (zero past the sample), dp rows; roll the du ring
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int i = tid + j * kThreads;
-      if (i < RA * QI) {
-        const int r = i / QI, q = i - r * QI;
-        const float4 s4 = *reinterpret_cast<const float4*>(sAct + q * 4), h4 = *reinterpret_cast<const float4*>(sAct + CIN + q * 4);
-        float4 v = pre_p[j];
-        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f);
-        v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f);
-        v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
-        *reinterpret_cast<float4*>(sP + r * CPI + q * 4) = v;
-      }
-    }
-    dps.commit(sDP, sKp, pre_dz, nrows_new * (COUT / 4), tid);
-    carry_du<K, CPI>(sDU, t0 == 0, tid);
-    MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(1);   // barrier 1
-    if (it + 1 < nitems) issue(it + 1);
-    // ---- P1: recompute u = depthwise(relu(bn(p_{k-1}))) + bias for the tile's output rows
-    // (chunks / row tiles past the sample's last row only write their zero rows, see fwd_block_kernel)
-    if (dw_active && !MWW_ABLATE(a, 1)) {
-      if (chunk * L < nrows_new) {
-        float o[L], dww[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-        dw_chunk<K, L, false, false>(sP, CPI, chunk * L, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
-      }
-    }
-    MWW_PC_MARK(2);   // issue + P1 (u recompute)
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(3);   // barrier 2
-    // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
-    if (!MWW_ABLATE(a, 2)) pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc, wave * 16 < nrows_new);
-    MWW_PC_MARK(4);   // MFMA (dW_pw, du)
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(5);   // barrier 3
-    // ---- P4: depthwise backward, ReLU mask, stats, store g_{k-1}.  No divergent branch around the global stores (the
-    // wait-count pass would have to assume the skipped path at the next commit): the lanes past the last chunk shadow
-    // it, their stores are out of range and their sums are dropped by the epilogue.
-    if (!MWW_ABLATE(a, 4)) {
-      const int cch = dw_active ? chunk : NCH - 1;
-      // the tile's slice of g_{k-1}: rows past rows_da are dropped by the address unit
-      const BufRsrc gtile = tile_rsrc(elem_ptr<SB>(a.g_out, ((size_t)b * a.Tin + t0) * CIN), rows_da * CIN * elem_bytes(SB));
-      const int goff = (dw_active ? 0 : kOobOffset / 4) + cch * L * CIN + c;   // element index (out of range for the shadow lanes)
-      {
-        float da[L], raw[L];
-#pragma unroll
-        for (int t = 0; t < L; ++t) raw[t] = sP[(cch * L + t) * CPI + c];   // in flight under the da FMAs
-        if (cch * L < rows_da && !MWW_ABLATE(a, 128)) {   // chunks past the sample's last row: da = 0, nothing to compute
-          float dww[K];
-#pragma unroll
-          for (int i = 0; i < K; ++i) dww[i] = sDW[i * CIN + c];
-          depthwise_input_grad_chunk<K, L, CPI>(sDU, cch, c, dww, da);
-        } else {
-#pragma unroll
-          for (int t = 0; t < L; ++t) da[t] = 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int sl = cch * L + t;
-          // (row TT of the last chunk belongs to the next tile: its da is still partial)
-          const float gg = (sl < rows_da && raw[t] > 0.f) ? da[t] : 0.f;   // raw = the activated value here
-          if (!MWW_ABLATE(a, 32)) tile_store1s<SB>(gtile, goff + t * CIN, gg);
-          gs1 += gg;
-          gs2 = fmaf(gg, fmaf(raw[t], xk1, xk0), gs2);
-        }
-      }
-      if (cch * L < nrows_new && !MWW_ABLATE(a, 64))   // du = 0 past the sample's last output row
-        depthwise_weight_grad_chunk<K, L, CPI>(sDU, cch, c, accw, accb,
-                                               [&](int row) { return sP[row * CPI + c]; });
-    }
-    MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(7);   // barrier 4
-  }
-  MWW_PC_AT(2);   // tile loop done
-  float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * CIN + CIN * COUT);
-  write_block_grad_partials<CIN, COUT, K>(smem, gdst, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
-  if (dw_active) {
-    smem[(chunk * 2 + 0) * CIN + c] = gs1;
-    smem[(chunk * 2 + 1) * CIN + c] = gs2;
-  }
-  __syncthreads();
-  if (tid < 2 * CIN) {
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) v += smem[j * 2 * CIN + tid];
-    publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * CIN, 2 * CIN, tid, v);
-  }
-  MWW_PC_AT(3);   // epilogue done
-  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * kClkSlots : nullptr);
+template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB>
+__device__ __forceinline__ void bwd_block_stage(const BwdBlockArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
+  typedef BwdBlockLds<CIN, COUT, K> Lds;
+  float* smem = lds;
+  float* sKp = lds + Lds::KP;
+  float* sWt = lds + Lds::WT;
+  float* sDW = lds + Lds::DW;
+  float* sAct = lds + Lds::ACT;
+  constexpr bool FUSED = true;
+#undef MWW_STAGE_SYNC
+#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
+#include "bwd_block_body.inc"
+#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------
@@ -554,214 +382,34 @@ struct BwdFirstArgs {
   XGather xg;             // xg.win set: x rows are gathered from the feature stores (see kernels_fwd.hip.h)
 };
 
+// (stride-3 first convolutions stage 194 x rows per tile: 92-99 KB of LDS, one workgroup per CU)
 template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
-__global__ __launch_bounds__(kThreads, 2) void bwd_first_kernel(BwdFirstArgs a) {
-  constexpr int CIN = C1;
-  constexpr int CPI = pitch(CIN), CPO = pitch(COUT);
-  constexpr int RA = TT + K - 1;
-  constexpr int XR = (TT - 1) * S + K1;          // x rows the dW1 contraction of one tile reads
-  constexpr int NT1 = C1 / 16;
-  constexpr int M1 = K1 * FBINS;                 // rows of W1
-  constexpr int MT1 = (M1 + 15) / 16;            // m-tiles of dW1
-  constexpr int MPW = (MT1 + 3) / 4;             // m-tiles per wave
-  constexpr int MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
-  constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
-  constexpr int QI = CIN / 4;
-  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
-  constexpr int OFF_A = 0, OFF_DP = OFF_A + RAP * CPI, OFF_U = OFF_DP + TT * CPO, OFF_DU = OFF_U + TTP * CPI;
-  constexpr int OFF_G0 = OFF_DU + RAP * CPI, OFF_END = OFF_G0 + TTP * CPI;
-  constexpr int PX = FBINS + 1;                  // odd pitch of the staged x rows (see fwd_first_kernel)
-  static_assert(OFF_END >= 4 * CIN * COUT && OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
-  static_assert(TT >= K - 1, "shape");
-
-  __shared__ __attribute__((aligned(16))) float sX[XR * PX];
+__global__ __launch_bounds__(kThreads, (S > 1 ? 1 : 2)) void bwd_first_kernel(BwdFirstArgs a) {
+  typedef BwdFirstLds<K1, C1, COUT, K, S> Lds;
+  __shared__ __attribute__((aligned(16))) float sX[Lds::XR * Lds::PX];
   __shared__ XShared sXg;
-  __shared__ __attribute__((aligned(16))) float smem[OFF_END];
+  __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
-  __shared__ __attribute__((aligned(16))) float sWt[COUT * CPI];   // W_pw^T
-  float* sA = smem + OFF_A;
-  float* sDP = smem + OFF_DP;
-  float* sU = smem + OFF_U;
-  float* sDU = smem + OFF_DU;
-  float* sG0 = smem + OFF_G0;
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
+  constexpr bool FUSED = false;
+#define MWW_STAGE_SYNC
+#include "bwd_first_body.inc"
+#undef MWW_STAGE_SYNC
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int c = tid % CIN, chunk = tid / CIN;
-  const bool dw_active = chunk < NCH;
-  const int Ta = (a.T - K1) / S + 1;
-
-  const int ntiles = (Ta + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  XStage<XR, PX> xs;
-  DpStage<COUT, false, SB> dps;
-  constexpr int NA = (RA * QI + kThreads - 1) / kThreads;
-  float4 pre_a[NA];
-  auto issue = [&](int it) {
-    const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nrx = (min(TT, Ta - t0) - 1) * S + K1;
-    xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrx, tid);
-    const BufRsrc ra = tile_rsrc(a.a0 + ((size_t)b * Ta + t0) * CIN, min(RA, Ta - t0) * QI * 16);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) pre_a[j] = tile_load4(ra, (tid + j * kThreads) * 16);
-    const int nvk = max(0, min(TT, a.Tout - t0)) * (COUT / 4);
-    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
-    dps.issue(elem_ptr<SB>(a.pk, koff), elem_ptr<SB>(a.gk, koff), nvk, tid);
-  };
-  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s*S+j][f]
-  int offm[MPW];
-  bool okm[MPW];
-#pragma unroll
-  for (int mi = 0; mi < MPW; ++mi) {
-    const int m = (wave * MPW + mi) * 16 + r16;
-    okm[mi] = m < M1;
-    offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
-  }
-  if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
-  if (nitems > 0) issue(0);
-
-  // every global load of the prologue first (see WeightStage) ...
-  WeightStage<CIN, COUT, 0> wst;
-  wst.load(a.pw_w, nullptr, tid);
-  float dww[K], accw[K];
-  float accb = 0.f, dwb = 0.f;
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    dww[i] = dw_active ? a.dw_w[i * CIN + c] : 0.f;
-    accw[i] = 0.f;
-  }
-  if (dw_active) dwb = a.dw_b[c];
-  // ... then BN_1's backward coefficients
-  for (int i = tid; i < COUT; i += kThreads) {
-    const float krs = a.k_rstd[i];
-    const float kmean = a.k_mean[i];
-    float c1, mg, mgx;
-    if (a.gfold.acc) {
-      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
-    } else {
-      c1 = a.k_c1[i];
-      mg = a.k_mg[i];
-      mgx = a.k_mgx[i];
-    }
-    const float kA = -c1 * krs * mgx;
-    sKp[0 * COUT + i] = c1;
-    sKp[1 * COUT + i] = kA;
-    sKp[2 * COUT + i] = -c1 * mg - kA * kmean;
-    sKp[5 * COUT + i] = 0.f;
-    sKp[6 * COUT + i] = 0.f;
-  }
-  wst.store(sWt, nullptr, tid);
-  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) {
-    sA[i] = 0.f;
-    sDU[i] = 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < K; ++i) pin(dww[i]);
-  pin(dwb);
-  f32x4 dwacc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dwacc[mt][nt] = zero4();
-  f32x4 w1acc[MPW][NT1];
-#pragma unroll
-  for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = zero4();
-  __syncthreads();
-
-  for (int it = 0; it < nitems; ++it) {
-    rotate_priority(it, 2);
-    const int t0 = (it % ntiles) * TT;
-    const int nrows_new = max(0, min(TT, a.Tout - t0));
-    const int rows_da = min(TT, Ta - t0);
-    // ---- P0: commit x (odd pitch), a0 rows [t0, t0+RA) (zero past the sample), dp; roll the du ring
-    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int i = tid + j * kThreads;
-      if (i < RA * QI) {
-        const int r = i / QI, q = i - r * QI;
-        *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = pre_a[j];
-      }
-    }
-    dps.commit(sDP, sKp, 0.f, nrows_new * (COUT / 4), tid);
-    carry_du<K, CPI>(sDU, t0 == 0, tid);
-    __syncthreads();
-    if (it + 1 < nitems) issue(it + 1);
-    // ---- P1: u = depthwise(a0) + bias
-    if (dw_active) {
-      if (chunk * L < nrows_new) {
-        float o[L];
-        dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          sU[tl * CPI + c] = (tl < nrows_new) ? o[t] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
-      }
-    }
-    __syncthreads();
-    pointwise_backward_tile<CIN, COUT, K, BF>(sU, sDP, sDU, wave, r16, g, sWt, dwacc, wave * 16 < nrows_new);
-    __syncthreads();
-    // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS
-    if (dw_active) {
-      {
-        float da[L];
-        depthwise_input_grad_chunk<K, L, CPI>(sDU, chunk, c, dww, da);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int sl = chunk * L + t;
-          sG0[sl * CPI + c] = (sl < rows_da && sA[sl * CPI + c] > 0.f) ? da[t] : 0.f;
-        }
-      }
-      if (chunk * L < nrows_new)
-        depthwise_weight_grad_chunk<K, L, CPI>(sDU, chunk, c, accw, accb, [&](int row) { return sA[row * CPI + c]; });
-    }
-    __syncthreads();
-    // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s*S + m/40][m%40], B[k=s][n] = g0[s][n]
-    // (operands one k-step ahead of their MFMAs, schedule pinned: see pointwise_backward_tile)
-    {
-      float av[2][MPW], bv[2][NT1];
-      auto load_w1 = [&](int kk, int sl) {
-        const int s = kk * 4 + g;
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) bv[sl][nt] = sG0[s * CPI + nt * 16 + r16];
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi) {
-          const float v = sX[s * S * PX + offm[mi]];   // (rows past M1 read offset 0 and are zeroed: no conditional load)
-          av[sl][mi] = okm[mi] ? v : 0.f;
-        }
-      };
-      load_w1(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < TT / 4; ++kk) {
-        if (kk + 1 < TT / 4) load_w1(kk + 1, (kk + 1) & 1);
-#pragma unroll
-        for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-          for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[kk & 1][mi], bv[kk & 1][nt], w1acc[mi][nt]);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, MPW + NT1, 0);
-      sched_read_mfma_groups<TT / 4 - 1, MPW + NT1, MPW * NT1>();
-      sched_read_mfma_groups<1, 0, MPW * NT1>();
-    }
-    __syncthreads();
-  }
-  float* gdst = a.grad_part + (size_t)blockIdx.x * (M1 * C1 + (K + 1) * CIN + CIN * COUT);
-#pragma unroll
-  for (int mi = 0; mi < MPW; ++mi)
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (wave * MPW + mi) * 16 + g * 4 + r;
-        if (m < M1) gdst[m * C1 + nt * 16 + r16] = w1acc[mi][nt][r];
-      }
-  write_block_grad_partials<CIN, COUT, K>(smem, gdst + M1 * C1, dwacc, accw, accb, dw_active, c, chunk, tid, wave, r16, g);
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB>
+__device__ __forceinline__ void bwd_first_stage(const BwdFirstArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
+  typedef BwdFirstLds<K1, C1, COUT, K, S> Lds;
+  float* smem = lds;
+  float* sKp = lds + Lds::KP;
+  float* sWt = lds + Lds::WT;
+  float* sX = lds + Lds::X;
+  XShared& sXg = *reinterpret_cast<XShared*>(lds + Lds::XG);
+  constexpr bool FUSED = true;
+#undef MWW_STAGE_SYNC
+#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
+#include "bwd_first_body.inc"
+#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------

@@ -353,287 +353,78 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 // network), keeps them in an LDS ring behind the K-1 rows carried over from the previous tile, and stores them to
 // HBM for bwd_first_kernel.  The depthwise / pointwise part of the tile then produces the output rows
 // [64 i - (K-1), 64 i + 64 - (K-1)) that those ring rows complete.
+// LDS of the first-block / block stages as float offsets into a fused launch's LDS array
+template <int K1, int C1, int COUT, int K, int S>
+struct FwdFirstLds {
+  static constexpr int CP1 = pitch(C1), RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
+  static constexpr int XR = (TT - 1) * S + K1, PX = FBINS + 1;
+  static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
+  static constexpr int X = 0, A = X + up4(XR * PX), U = A + RAP * CP1, RED = U + TTP * CP1, XG = RED + 4 * 2 * COUT;
+  static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);
+};
+template <int CIN, int COUT, int K>
+struct FwdBlockLds {
+  static constexpr int CPI = pitch(CIN), RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
+  static constexpr int A = 0, U = A + RAP * CPI, RED = U + TTP * CPI, SCALE = RED + 4 * 2 * COUT, SHIFT = SCALE + CIN, END = SHIFT + CIN;
+};
+
 template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
-  constexpr int CP1 = pitch(C1);
-  constexpr int RA = TT + K - 1;               // ring rows: K-1 carried + TT new
-  constexpr int RT1 = TT / 16;                 // MFMA row tiles of the first conv
-  constexpr int XR = (TT - 1) * S + K1;        // x rows staged (zero filled past the valid ones); S = first-conv time stride
-  constexpr int KS1 = K1 * FBINS / 4;          // k-steps of the im2col GEMM
-  constexpr int NT1 = C1 / 16;
-  constexpr int KS = C1 / 4, NT = COUT / 16;
-  constexpr int NCH = nchunks(C1), L = chunk_len(C1);
-  constexpr int RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
-  constexpr int PX = FBINS + 1;                // odd LDS pitch of the staged x rows: conflict-free MFMA operand reads
-  static_assert(4 % NT1 == 0, "first-conv filters must be 16, 32 or 64");
-  static_assert((K1 * FBINS) % 4 == 0 && C1 % 16 == 0 && COUT % 16 == 0, "shape");
-  static_assert(TT >= K - 1, "carry rows must not overlap");
-
-  __shared__ __attribute__((aligned(16))) float sX[XR * PX];
-  __shared__ __attribute__((aligned(16))) float sA[RAP * CP1];
-  __shared__ __attribute__((aligned(16))) float sU[TTP * CP1];
+  typedef FwdFirstLds<K1, C1, COUT, K, S> Lds;
+  __shared__ __attribute__((aligned(16))) float sX[Lds::XR * Lds::PX];
+  __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CP1];
+  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CP1];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ XShared sXg;
+  constexpr bool FUSED = false;
+  (void)FUSED;
+#include "fwd_first_body.inc"
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int c = tid % C1, chunk = tid / C1;
-  const bool dw_active = chunk < NCH;
-  for (int i = RA * CP1 + tid; i < RAP * CP1; i += kThreads) sA[i] = 0.f;   // rows only the padded windows touch
-
-  // work items = (sample, time tile); the next item's rows are fetched into registers while the
-  // current one is computed (global->register early, register->LDS late)
-  const int Ta = (a.T - K1) / S + 1;
-  const int ntiles = (Ta + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  XStage<XR, PX> xs;
-  auto issue = [&](int it) {
-    const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nrows = (min(TT, Ta - t0) - 1) * S + K1;
-    xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrows, tid);
-  };
-  const bool gather = a.xg.win != nullptr;
-  if (!gather && nitems > 0) issue(0);
-
-  // register-resident weights
-  const int nt1 = wave % NT1;
-  float w1frag[KS1];
-#pragma unroll
-  for (int kk = 0; kk < KS1; ++kk) w1frag[kk] = a.w1[(kk * 4 + g) * C1 + nt1 * 16 + r16];
-  PwWeights<C1, NT, BF> pw;
-  pw.load(a.pw_w, COUT, g, r16);
-  float dww[K];
-  float dwb = 0.f;
-  if (dw_active) {
-#pragma unroll
-    for (int i = 0; i < K; ++i) dww[i] = a.dw_w[i * C1 + c];
-    dwb = a.dw_b[c];
-  } else {
-#pragma unroll
-    for (int i = 0; i < K; ++i) dww[i] = 0.f;
-  }
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
-  if (gather) {   // after the weight loads were issued: their latency covers the descriptor round trip
-    xgather_setup(a.xg, sXg, nsamp, tid);
-    if (nitems > 0) issue(0);
-  }
-
-#pragma unroll
-  for (int kk = 0; kk < KS1; ++kk) pin(w1frag[kk]);
-  pw.retire();
-#pragma unroll
-  for (int i = 0; i < K; ++i) pin(dww[i]);
-  pin(dwb);
-  for (int it = 0; it < nitems; ++it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int rows_a = min(TT, Ta - t0);                    // a0 rows this tile computes
-    const int tu0 = t0 - (K - 1);                           // output row of ring row 0
-    const int r_lo = t0 == 0 ? K - 1 : 0, r_hi = min(TT, a.Tout - tu0);   // tile rows [r_lo, r_hi) are output rows
-    // commit the staged x rows (zero filled past the valid ones) with an odd row pitch; roll the a0 ring
-    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
-    for (int i = tid; i < (K - 1) * CP1; i += kThreads) sA[i] = t0 == 0 ? 0.f : sA[TT * CP1 + i];
-    __syncthreads();
-    if (it + 1 < nitems) issue(it + 1);
-    // first conv as im2col GEMM: A[row][k] = x[row*S + k/40][k%40]; a0 rows past the sample are zero
-    {
-      const BufRsrc a0s = tile_rsrc(a.a0 ? a.a0 + (size_t)b * Ta * C1 : nullptr, a.a0 ? Ta * C1 * 4 : 0);
-      // the wave's row tiles advance together through the k-steps: independent accumulator chains (one chain is a
-      // sequence of MFMAs each waiting for the one before it) that share the weight fragment of the k-step
-      constexpr int RSTEP = 4 / NT1, RPW = RT1 / RSTEP;
-      static_assert(4 % NT1 == 0 && RT1 % RSTEP == 0, "row tiles must divide among the waves");
-      f32x4 acc[RPW];
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) acc[i] = zero4();
-      const float* xr = sX + ((wave / NT1) * 16 + r16) * S * PX + g;
-#pragma unroll
-      for (int kk = 0; kk < KS1; ++kk)
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-          acc[i] = mfma4(xr[i * RSTEP * 16 * S * PX + (kk / (FBINS / 4)) * PX + (kk % (FBINS / 4)) * 4], w1frag[kk], acc[i]);
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int rt = wave / NT1 + i * RSTEP;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + g * 4 + r;
-          const float v = (row < rows_a) ? fmaxf(acc[i][r], 0.f) : 0.f;
-          sA[(K - 1 + row) * CP1 + nt1 * 16 + r16] = v;
-          tile_store1(a0s, ((t0 + row) * C1 + nt1 * 16 + r16) * 4, v);
-        }
-      }
-    }
-    __syncthreads();
-    // depthwise over the ring: tile row r is output row tu0 + r
-    if (dw_active) {
-      if (chunk * L < r_hi && chunk * L + L > r_lo) {
-        float o[L];
-        dw_chunk<K, L>(sA, CP1, chunk * L, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          sU[tl * CP1 + c] = (tl >= r_lo && tl < r_hi) ? o[t] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CP1 + c] = 0.f;
-      }
-    }
-    __syncthreads();
-    // pointwise
-    {
-      f32x4 acc[NT];
-      if (wave * 16 < r_hi && wave * 16 + 16 > r_lo) pw.tile(sU, CP1, wave * 16, r16, g, acc);   // wave-uniform
-      else
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
-      store_tile_stats<NT, COUT, SB>(acc, tile_rsrc(elem_ptr<SB>(a.out, (size_t)b * a.Tout * COUT), a.Tout * COUT * elem_bytes(SB)), wave * 16, r16, g, s1, s2, tu0);
-    }
-    __syncthreads();
-  }
-  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
+// the same body as a stage of a fused launch (lds = the launch's LDS array)
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB>
+__device__ __forceinline__ void fwd_first_stage(const FwdFirstArgs& a, float* lds) {
+  typedef FwdFirstLds<K1, C1, COUT, K, S> Lds;
+  float* sX = lds + Lds::X;
+  float* sA = lds + Lds::A;
+  float* sU = lds + Lds::U;
+  float* sRed = lds + Lds::RED;
+  XShared& sXg = *reinterpret_cast<XShared*>(lds + Lds::XG);
+  constexpr bool FUSED = true;
+  (void)FUSED;
+#define MWW_STAGE_SYNC
+#include "fwd_first_body.inc"
+#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
-  constexpr int CPI = pitch(CIN);
-  constexpr int RA = TT + K - 1;
-  constexpr int KS = CIN / 4, NT = COUT / 16;
-  constexpr int NCH = nchunks(CIN), L = chunk_len(CIN);
-  constexpr int Q = CIN / 4;
-  constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
-  static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
-
-  __shared__ __attribute__((aligned(16))) float sA[RAP * CPI];
-  __shared__ __attribute__((aligned(16))) float sU[TTP * CPI];
+  typedef FwdBlockLds<CIN, COUT, K> Lds;
+  __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CPI];
+  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPI];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ __attribute__((aligned(16))) float sScale[CIN];
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
-  MWW_PC_DECL
-  MWW_PC_AT(0);   // kernel entry
+  constexpr bool FUSED = false;
+#define MWW_STAGE_SYNC
+#include "fwd_block_body.inc"
+#undef MWW_STAGE_SYNC
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int c = tid % CIN, chunk = tid / CIN;
-  const bool dw_active = chunk < NCH;
-
-  for (int i = RA * CPI + tid; i < RAP * CPI; i += kThreads) sA[i] = 0.f;
-
-  const int ntiles = (a.Tout + TT - 1) / TT;
-  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int nitems = nsamp * ntiles;
-  constexpr int NLD = (RA * Q + kThreads - 1) / kThreads;
-  float4 pre[NLD];
-  // rows of one sample are contiguous ([T][CIN]): float4 i of the tile sits at byte 16*i of the tile's slice;
-  // float4s past the valid rows come back as zeros
-  auto issue = [&](int it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int nvalid = (min(TT, a.Tout - t0) + K - 1) * Q;
-    const BufRsrc src = tile_rsrc(elem_ptr<SB>(a.in, ((size_t)b * a.Tin + t0) * CIN), nvalid * 4 * elem_bytes(SB));
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) pre[j] = tile_load4s<SB>(src, tid + j * kThreads);
-  };
-  if (nitems > 0) issue(0);
-  PwWeights<CIN, NT, BF> pw;
-  pw.load(a.pw_w, COUT, g, r16);
-  float dww[K];
-  float dwb = 0.f;
-  if (dw_active) {
-#pragma unroll
-    for (int i = 0; i < K; ++i) dww[i] = a.dw_w[i * CIN + c];
-    dwb = a.dw_b[c];
-  } else {
-#pragma unroll
-    for (int i = 0; i < K; ++i) dww[i] = 0.f;
-  }
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
-  // BN_{k-1}: folded after the tile / weight loads were issued, so that the prologue is one memory round trip deep
-  // (fold first cost a second, dependent one: 2.4k + 3.5-7k cycles per workgroup in the round-2 timeline)
-  if (tid < CIN) {
-    float sc, sh, mu, rs;
-    if (a.fold.acc) {
-      bn_fold_channel(a.fold, CIN, tid, sc, sh, mu, rs);
-    } else {
-      sc = a.in_scale[tid];
-      sh = a.in_shift[tid];
-    }
-    sScale[tid] = sc;
-    sShift[tid] = sh;
-  }
-  MWW_PC_AT(1);   // statistics folded (thread 0 is one of the folding threads)
-  pw.retire();
-#pragma unroll
-  for (int i = 0; i < K; ++i) pin(dww[i]);
-  pin(dwb);
-  MWW_PC_AT(2);   // weights (and the first tile's rows) have arrived
-  __syncthreads();
-
-  MWW_PC_AT(3);   // prologue done
-  MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
-  for (int it = 0; it < nitems; ++it) {
-    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
-    const int rows_out = min(TT, a.Tout - t0);
-    const int rows_in = rows_out + K - 1;
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int i = tid + j * kThreads;
-      if (i < RA * Q) {   // rows past the sample are written as zeros
-        const int r = i / Q, q = i - r * Q;
-        float4 v = pre[j];
-        const float4 sc = *reinterpret_cast<const float4*>(sScale + q * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(sShift + q * 4);
-        const bool ok = i < rows_in * Q;
-        v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
-        v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
-        v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
-        v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
-        *reinterpret_cast<float4*>(sA + r * CPI + q * 4) = v;
-      }
-    }
-    MWW_PC_MARK(0);   // commit (incl. wait for the prefetch)
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(1);   // barrier 1
-    if (it + 1 < nitems) issue(it + 1);
-    MWW_PC_MARK(2);   // prefetch issue
-    // chunks / row tiles past the sample's last row (short last tile) only write their zero rows: the issue slots
-    // they would burn go to the other workgroups of the CU
-    if (dw_active && !MWW_ABLATE(a, 1)) {
-      if (chunk * L < rows_out) {
-        float o[L];
-        dw_chunk<K, L>(sA, CPI, chunk * L, c, dww, dwb, o);
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-          const int tl = chunk * L + t;
-          sU[tl * CPI + c] = (tl < rows_out) ? o[t] : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * CPI + c] = 0.f;
-      }
-    }
-    MWW_PC_MARK(3);   // depthwise
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(4);   // barrier 2
-    {
-      // (the stores stay unconditional - a dead wave's are dropped by the address unit - so that the wait-count pass
-      // sees the same memory-op sequence on every path and the next commit waits for the prefetched rows only)
-      f32x4 acc[NT];
-      if (wave * 16 < rows_out && !MWW_ABLATE(a, 2)) pw.tile(sU, CPI, wave * 16, r16, g, acc);   // wave-uniform
-      else
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
-      MWW_PC_MARK(5);   // pointwise MFMA
-      store_tile_stats<NT, COUT, SB>(acc, tile_rsrc(elem_ptr<SB>(a.out, ((size_t)b * a.Tout + t0) * COUT), rows_out * COUT * elem_bytes(SB)), wave * 16, r16, g, s1, s2);
-    }
-    MWW_PC_MARK(6);   // stores + stats
-    if (!MWW_ABLATE(a, 8)) __syncthreads();
-    MWW_PC_MARK(7);   // barrier 3
-  }
-  write_stat_partials<NT, COUT>(s1, s2, sRed, a.stat_part + (size_t)blockIdx.x * 2 * COUT, tid, wave, r16, g, a.sacc);
-  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * kClkSlots : nullptr);
+template <int CIN, int COUT, int K, bool BF, bool SB>
+__device__ __forceinline__ void fwd_block_stage(const FwdBlockArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
+  typedef FwdBlockLds<CIN, COUT, K> Lds;
+  float* sA = lds + Lds::A;
+  float* sU = lds + Lds::U;
+  float* sRed = lds + Lds::RED;
+  float* sScale = lds + Lds::SCALE;
+  float* sShift = lds + Lds::SHIFT;
+  constexpr bool FUSED = true;
+#undef MWW_STAGE_SYNC
+#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
+#include "fwd_block_body.inc"
+#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------

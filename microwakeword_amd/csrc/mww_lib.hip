@@ -13,6 +13,7 @@
 
 #include "../../include/mww.h"
 #include "kernels_bwd.hip.h"
+#include "kernels_fused.hip.h"
 #include "kernels_data.hip.h"
 #include "kernels_fwd.hip.h"
 #include "kernels_graph.hip.h"
@@ -212,6 +213,14 @@ struct mww_ctx {
   bool st_bf16 = false;   // p_k / g_k stored as bf16 ("storage_bf16", implies pointwise_bf16: BASELINE configs[4])
   bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
   bool bn_eval_ready = false;   // inside mww_evaluate_windows: the moving statistics are folded once, not per batch
+  // "fused_stages" option (default on where it applies): the four forward blocks / the four backward blocks of a train step run
+  // as ONE launch each, persistent workgroups meeting at grid-wide rendezvous between the layers (kernels_fused.hip.h)
+  bool fused_stages = true;
+  bool fused_fwd = false, fused_bwd = true;   // "fused_stages": 0 none, 1 both, 2 forward only, 3 backward only (the default: what measured faster)
+  unsigned* sync_words = nullptr;   // [2 parities][kSyncWords] + fault word
+  int sync_par = 0;
+  bool sync_par_used = false;   // a fused launch was enqueued: mww_synchronize looks at the fault word
+  std::map<const void*, int> fused_occ;   // resident workgroups per CU of a fused kernel (occupancy query)
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
@@ -341,6 +350,94 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
   X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
+}
+
+// (conv1 kernel, conv1 filters, conv1 stride, block width, depthwise kernels of the four blocks): the topologies with fused
+// launches - the reference's argparse defaults and its training notebook's flags; exact fp32 only (the bf16 modes and every
+// other shape keep one launch per layer)
+#ifdef MWW_SLIM
+#define MWW_FUSED_TOPOLOGIES(X) X(3, 32, 1, 48, 5, 9, 13, 21)
+#else
+#define MWW_FUSED_TOPOLOGIES(X) X(3, 32, 1, 48, 5, 9, 13, 21) X(5, 32, 3, 64, 5, 11, 15, 23)
+#endif
+
+// a launch whose workgroups wait for each other.  On the device that is an ordinary launch of a grid the host has checked to be
+// resident as a whole; a host-side stand-in for the HIP runtime that runs workgroups one after the other (tests/hipemu) hooks in here.
+#ifndef MWW_LAUNCH_RESIDENT
+#define MWW_LAUNCH_RESIDENT hipLaunchKernelGGL
+#endif
+
+bool fused_topology(const mww_ctx* c) {
+  const mww_mixednet_desc& d = c->d;
+  if (c->generic || d.n_blocks != kFusedBlocks || c->pw_bf16 || c->st_bf16) return false;
+#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
+  if (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_filters[1] == CW && \
+      d.block_filters[2] == CW && d.block_filters[3] == CW && d.block_kernel[0] == KA && d.block_kernel[1] == KB &&          \
+      d.block_kernel[2] == KC && d.block_kernel[3] == KD)                                                                     \
+    return true;
+  MWW_FUSED_TOPOLOGIES(X)
+#undef X
+  return false;
+}
+
+// every workgroup of a fused launch waits for every other one: the grid must be resident as a whole
+int fused_resident(mww_ctx* c, const void* func, size_t lds, int grid, bool* ok) {
+  auto it = c->fused_occ.find(func);
+  if (it == c->fused_occ.end()) {
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, func, kThreads, lds) != hipSuccess) occ = 0;
+    it = c->fused_occ.emplace(func, occ).first;
+  }
+  *ok = grid <= it->second * c->n_cu;
+  return MWW_OK;
+}
+
+GridSync next_sync(mww_ctx* c) {
+  GridSync g;
+  g.words = c->sync_words + (size_t)c->sync_par * kSyncWords;
+  g.next = c->sync_words + (size_t)(c->sync_par ^ 1) * kSyncWords;
+  g.fault = c->sync_words + 2 * kSyncWords;
+  c->sync_par ^= 1;
+  c->sync_par_used = true;
+  return g;
+}
+
+// launches the fused kernel of this context's topology (launch = false: only answers whether `grid` workgroups of it are resident)
+int launch_fwd_fused(mww_ctx* c, FwdFusedArgs& a, int grid, bool launch, bool* ok) {
+  const mww_mixednet_desc& d = c->d;
+  *ok = false;
+#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
+  if (d.conv1_kernel == K1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_kernel[1] == KB) {                  \
+    const void* f = reinterpret_cast<const void*>(&fwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>);            \
+    const size_t lds = (size_t)FusedLds<K1, C1, S, CW, KA, KB, KC, KD>::FWD * sizeof(float);                                  \
+    int rc = fused_resident(c, f, lds, grid, ok);                                                                             \
+    if (rc || !*ok || !launch) return rc;                                                                                     \
+    a.sync = next_sync(c);                                                                                                    \
+    MWW_LAUNCH_RESIDENT((fwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>), dim3(grid), dim3(kThreads), lds, c->stream, a); \
+    return MWW_OK;                                                                                                            \
+  }
+  MWW_FUSED_TOPOLOGIES(X)
+#undef X
+  return MWW_OK;
+}
+
+int launch_bwd_fused(mww_ctx* c, BwdFusedArgs& a, int grid, bool launch, bool* ok) {
+  const mww_mixednet_desc& d = c->d;
+  *ok = false;
+#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
+  if (d.conv1_kernel == K1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_kernel[1] == KB) {                  \
+    const void* f = reinterpret_cast<const void*>(&bwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>);            \
+    const size_t lds = (size_t)FusedLds<K1, C1, S, CW, KA, KB, KC, KD>::BWD * sizeof(float);                                  \
+    int rc = fused_resident(c, f, lds, grid, ok);                                                                             \
+    if (rc || !*ok || !launch) return rc;                                                                                     \
+    a.sync = next_sync(c);                                                                                                    \
+    MWW_LAUNCH_RESIDENT((bwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>), dim3(grid), dim3(kThreads), lds, c->stream, a); \
+    return MWW_OK;                                                                                                            \
+  }
+  MWW_FUSED_TOPOLOGIES(X)
+#undef X
+  return MWW_OK;
 }
 
 bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
@@ -536,6 +633,14 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     f.rstd = bn_slot(pl, BN_RSTD);
     return f;
   };
+  // the four blocks of a training forward in one launch (kernels_fused.hip.h) where the topology has a fused kernel, the
+  // statistics travel in accumulator rows and the whole grid is resident; one launch per layer otherwise
+  bool fused = false;
+  FwdFusedArgs fa;
+  if (training && inl && c->fused_stages && c->fused_fwd && fused_topology(c)) {
+    int rcf = launch_fwd_fused(c, fa, std::min(B, c->grid_fwd), false, &fused);
+    if (rcf) return rcf;
+  }
   for (int i = 0; i < nb; ++i) {
     Layer& l = c->L[i];
     const int grid = std::min(B, c->grid_fwd);
@@ -548,6 +653,10 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
                      l.p, l.stat_part, B, d.frames, l.tout, 0, sacc, x_gather(c), training ? c->a0 : nullptr};
+      if (fused) {
+        fa.first = a;
+        continue;
+      }
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
@@ -557,6 +666,16 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * kClkSlots,
                      sacc, fold_of(pl)};
+      if (fused) {
+        fa.blk[i - 1] = a;
+        if (i == nb - 1) {
+          lp.begin("fwd_fused");
+          int rc = launch_fwd_fused(c, fa, grid, true, &fused);
+          lp.end();
+          if (rc) return rc;
+        }
+        continue;
+      }
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
@@ -771,6 +890,14 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   // gamma / beta gradients of a block are then written by that block's own backward kernel).
   const int split = nb >= 3 ? nb - 2 : 0;
   const bool bucketed = fuse_adam && c->hook && c->reduce_grads && !c->sync_bn && inl && c->tail_in_reduce && c->grad_buckets == 2 && split > 0;
+  // the four blocks' backward kernels as one launch (kernels_fused.hip.h): needs every BN layer's backward sums to arrive in
+  // accumulator rows (no finalize / head_tail launch in between) and no gradient bucket handed over half way
+  bool fused = false;
+  BwdFusedArgs fa;
+  if (inl && c->tail_in_reduce && !bucketed && c->fused_stages && c->fused_bwd && fused_topology(c)) {
+    int rcf = launch_bwd_fused(c, fa, gbwd, false, &fused);
+    if (rcf) return rcf;
+  }
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -858,6 +985,10 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
         pl.gacc_cur = a.gacc.acc;
       }
       a.gfold = gf;
+      if (fused) {
+        fa.blk[nb - 1 - i] = a;
+        continue;
+      }
       lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
@@ -873,6 +1004,14 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       BwdFirstArgs a{c->x, c->a0, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf, x_gather(c)};
+      if (fused) {
+        fa.first = a;
+        lp.begin("bwd_fused");
+        int rc = launch_bwd_fused(c, fa, gbwd, true, &fused);
+        lp.end();
+        if (rc) return rc;
+        continue;
+      }
       lp.begin("bwd_block", i);
       int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, gbwd);
       lp.end();
@@ -1763,6 +1902,8 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
   A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * kClkSlots));
+  A(dev_alloc(&c->sync_words, (size_t)2 * kSyncWords + kSyncStride));
+  HIPCHK(hipMemsetAsync(c->sync_words, 0, ((size_t)2 * kSyncWords + kSyncStride) * sizeof(unsigned), c->stream));
   c->mail_off_masks = mb * sizeof(mww_window);
   c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
   c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
@@ -1809,6 +1950,12 @@ int open_device(mww_ctx* c, int device, void* stream) {
   }
   c->grid_fwd = c->n_cu * 4;
   c->grid_bwd = c->n_cu * 2;
+  if (!c->generic && c->d.n_blocks > 0 && c->d.block_filters[0] > 48) {
+    // 64-wide blocks: the backward kernels fit once per CU (LDS), the forward kernels twice - grids of resident workgroups
+    // only, no second dispatch round (tools/gpu_r3g.sh: notebook topology grid sweep)
+    c->grid_fwd = c->n_cu * 2;
+    c->grid_bwd = c->n_cu;
+  }
   c->grid_head = c->n_cu * 2;   // one window per workgroup at a time, two resident per CU (177 VGPRs): measured 13.5 us vs 15.4 (x4) / 17.4 (x1)
   c->grid_g = c->n_cu * 3;   // measured on the Inception step: 3 workgroups per CU and launch (roles share them) beats 2 and 4
   return MWW_OK;
@@ -2334,6 +2481,7 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : op) if (p) (void)hipFree(p);
   }
   if (c->sync_buf) (void)hipFree(c->sync_buf);
+  if (c->sync_words) (void)hipFree(c->sync_words);
   if (c->hact) (void)hipFree(c->hact);
   if (c->watt_part) (void)hipFree(c->watt_part);
   if (c->ones) (void)hipFree(c->ones);
@@ -2360,6 +2508,11 @@ void mww_destroy(mww_ctx* c) {
 int mww_synchronize(mww_ctx* c) {
   if (!c) return fail(MWW_ERR_INVALID, "null context");
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->sync_words && c->sync_par_used) {
+    unsigned fault = 0;
+    HIPCHK(hipMemcpy(&fault, c->sync_words + 2 * kSyncWords, sizeof(fault), hipMemcpyDeviceToHost));
+    if (fault) return fail(MWW_ERR_STATE, "a fused launch gave up waiting for its other workgroups (grid not resident?): results since the last synchronize are invalid; set option fused_stages 0");
+  }
   return MWW_OK;
 }
 
@@ -2597,7 +2750,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | (c->sync_par << 27) | ((c->fused_stages ? (c->fused_fwd ? 1 : 0) | (c->fused_bwd ? 2 : 0) : 0) << 28);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2792,6 +2945,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
+  else if (!strcmp(name, "fused_stages")) { c->fused_stages = v != 0; c->fused_fwd = v == 1 || v == 2; c->fused_bwd = v == 1 || v == 3; }
   else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }
   else if (!strcmp(name, "graph_dgrad_share")) { if (v < 10 || v > 90) return fail(MWW_ERR_INVALID, "graph_dgrad_share must be 10..90"); c->g_dgrad_share = (int)v; }
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;

@@ -1047,6 +1047,51 @@ def check_assemble_overlap(lib, B=8, T=60, steps=5):
         np.testing.assert_array_equal(a, b)
 
 
+# ------------------------------------------------------------------------------------------ fused stages
+def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 3), flags=DEF, graphs=False, sizes=None):
+    """"fused_stages" (kernels_fused.hip.h: the four forward blocks / the four backward blocks as one launch each, persistent
+    workgroups meeting at grid-wide rendezvous between the layers) runs the same stage bodies on the same windows in the same
+    order as one launch per layer, so gradients, parameters, BN moving statistics and outputs are bit-identical - over several
+    steps (the rendezvous words alternate between two sets), with grids smaller than the batch (grid-stride windows), with
+    changing batch sizes, and through captured graphs.  Also checks that the fused launches were really taken."""
+    rng = np.random.default_rng(17)
+    sizes = list(sizes) if sizes else [B] * steps
+    xs = [synth_x(rng, b, T) for b in sizes]
+    ys = [(rng.random(b) < 0.5).astype(np.float32) for b in sizes]
+    ws = [rng.choice([0.5, 1.0, 2.0], size=b).astype(np.float32) for b in sizes]
+    om = perturbed_oracle(T, flags=flags)
+    outs = []
+    for fused in (1, 0):
+        lay, eng = make_engine(lib, T, max(sizes), om, flags=flags)
+        eng.set_option("fused_stages", fused)
+        if grids[0]:
+            eng.set_option("grid_fwd", grids[0])
+        if grids[1]:
+            eng.set_option("grid_bwd", grids[1])
+        if graphs:
+            eng.set_option("graphs", 1)
+        else:
+            eng.set_option("profile", 1)
+        got = []
+        for x, y, w in zip(xs, ys, ws):
+            eng.set_batch(x)
+            eng.set_targets(y, w)
+            eng.train_step(x.shape[0], 1e-3)
+            got.append(eng.read_outputs(x.shape[0])[0].copy())
+            got.append(eng.get_grads().copy())
+        if not graphs:
+            names = [n for n, _ in eng.profile_read()]
+            if not fused:
+                assert "fwd_fused" not in names and "bwd_fused" not in names, names
+            elif flags is DEF and lib.device_count() > 0 and (grids[1] or max(sizes)) <= 512:
+                assert "fwd_fused" in names and "bwd_fused" in names, names   # (wider topologies: only where the whole grid is resident)
+        got += [eng.get_params().copy(), eng.get_bn_state().copy()]
+        outs.append(got)
+        eng.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ prefetched batches
 def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
     """Batches drawn ahead by the prefetcher's worker thread (native.Prefetcher, csrc/sampler.cpp) against the synchronous

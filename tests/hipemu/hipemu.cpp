@@ -47,37 +47,37 @@ void yield(State s) {
 }
 }  // namespace
 
-int lane_id() { return cur & 63; }
+static int g_tpb();
+int lane_id() { return (cur % g_tpb()) & 63; }
+void* dyn_shared();
 
-static std::vector<float> g_dyn_shared;
-void* dyn_shared() { return g_dyn_shared.data(); }
-
+static int wave_of_cur();
 void sync_block() { yield(WAIT_BLOCK); }
 
 unsigned wave_exchange(unsigned v, int src_lane) {
-  WaveBuf& w = waves[cur >> 6];
+  WaveBuf& w = waves[wave_of_cur()];
   int g = w.gen & 1;
-  w.v[g][cur & 63] = v;
+  w.v[g][lane_id()] = v;
   yield(WAIT_WAVE);
   // after release the scheduler bumped w.gen; our data sits in buffer g
   return w.v[g][src_lane & 63];
 }
 
 void wave_exchange2(float a, float b, const float** A, const float** B) {
-  WaveBuf& w = waves[cur >> 6];
+  WaveBuf& w = waves[wave_of_cur()];
   int g = w.gen & 1;
-  w.a[g][cur & 63] = a;
-  w.b[g][cur & 63] = b;
+  w.a[g][lane_id()] = a;
+  w.b[g][lane_id()] = b;
   yield(WAIT_WAVE);
   *A = w.a[g];
   *B = w.b[g];
 }
 
 const unsigned long long* wave_publish2(unsigned long long a, unsigned long long b) {
-  WaveBuf& w = waves[cur >> 6];
+  WaveBuf& w = waves[wave_of_cur()];
   int g = w.gen & 1;
-  w.q[g][(cur & 63) * 2] = a;
-  w.q[g][(cur & 63) * 2 + 1] = b;
+  w.q[g][lane_id() * 2] = a;
+  w.q[g][lane_id() * 2 + 1] = b;
   yield(WAIT_WAVE);
   return w.q[g];
 }
@@ -87,20 +87,33 @@ static int sched_order() {
   return e ? atoi(e) : 0;
 }
 
-static void run_block(dim3 block, const std::function<void()>& body) {
+// Runs `nblk` blocks (block indices ids[0..nblk)) to completion with all their fibers alive: one block at a time for an
+// ordinary launch, the whole grid for a resident one.  Fiber i belongs to block i / n.
+static std::vector<uint3_emu> g_fiber_block;       // block index per resident block slot
+static std::vector<std::vector<float>> g_dyn_pool; // dynamic LDS per resident block slot
+static int g_threads_per_block = 0;
+
+static void run_blocks(dim3 block, const std::vector<uint3_emu>& ids, size_t shmem, const std::function<void()>& body) {
   const int n = block.x * block.y * block.z;
+  const int nblk = (int)ids.size();
   const int nw = (n + 63) / 64;
-  fibers.resize(n);
-  waves.assign(nw, WaveBuf());
-  while ((int)stack_pool.size() < n) stack_pool.push_back((char*)malloc(kStack));
+  const int total = n * nblk;
+  g_threads_per_block = n;
+  g_fiber_block = ids;
+  g_dyn_pool.resize(nblk);
+  for (auto& d : g_dyn_pool) d.assign(shmem / sizeof(float) + 4, NAN);   // poisoned: reads of unwritten LDS show up
+  fibers.resize(total);
+  waves.assign((size_t)nw * nblk, WaveBuf());
+  while ((int)stack_pool.size() < total) stack_pool.push_back((char*)malloc(kStack));
   cur_body = &body;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < total; ++i) {
     Fiber& f = fibers[i];
+    const int t = i % n;
     f.st = RUN;
     f.stack = stack_pool[i];
-    f.tid.x = i % block.x;
-    f.tid.y = (i / block.x) % block.y;
-    f.tid.z = i / (block.x * block.y);
+    f.tid.x = t % block.x;
+    f.tid.y = (t / block.x) % block.y;
+    f.tid.z = t / (block.x * block.y);
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
     f.ctx.uc_stack.ss_size = kStack;
@@ -117,39 +130,43 @@ static void run_block(dim3 block, const std::function<void()>& body) {
   for (;;) {
     bool progressed = false;
     int done = 0;
-    for (int k = 0; k < n; ++k) {
-      int i = seq[k];
-      if (fibers[i].st == DONE) { ++done; continue; }
-      if (fibers[i].st != RUN) continue;
-      cur = i;
-      g_threadIdx = fibers[i].tid;
-      swapcontext(&sched_ctx, &fibers[i].ctx);
-      progressed = true;
-      if (fibers[i].st == DONE) ++done;
-    }
-    if (done == n) break;
-    // release waves whose live lanes all wait at a wave op
-    for (int w = 0; w < nw; ++w) {
-      int lo = w * 64, hi = std::min(n, lo + 64), waiting = 0, live = 0;
-      for (int i = lo; i < hi; ++i) {
-        if (fibers[i].st != DONE) ++live;
-        if (fibers[i].st == WAIT_WAVE) ++waiting;
+    for (int b = 0; b < nblk; ++b)
+      for (int k = 0; k < n; ++k) {
+        const int i = b * n + seq[k];
+        if (fibers[i].st == DONE) { ++done; continue; }
+        if (fibers[i].st != RUN) continue;
+        cur = i;
+        g_threadIdx = fibers[i].tid;
+        g_blockIdx = ids[b];
+        swapcontext(&sched_ctx, &fibers[i].ctx);
+        progressed = true;
+        if (fibers[i].st == DONE) ++done;
       }
-      if (live && waiting == live) {
-        waves[w].gen++;
-        for (int i = lo; i < hi; ++i) if (fibers[i].st == WAIT_WAVE) fibers[i].st = RUN;
+    if (done == total) break;
+    for (int b = 0; b < nblk; ++b) {
+      // release waves whose live lanes all wait at a wave op
+      for (int w = 0; w < nw; ++w) {
+        int lo = b * n + w * 64, hi = std::min(b * n + n, lo + 64), waiting = 0, live = 0;
+        for (int i = lo; i < hi; ++i) {
+          if (fibers[i].st != DONE) ++live;
+          if (fibers[i].st == WAIT_WAVE) ++waiting;
+        }
+        if (live && waiting == live) {
+          waves[(size_t)b * nw + w].gen++;
+          for (int i = lo; i < hi; ++i) if (fibers[i].st == WAIT_WAVE) fibers[i].st = RUN;
+          progressed = true;
+        }
+      }
+      // release the block barrier when every live thread of the block waits on it
+      int live = 0, atbar = 0;
+      for (int i = b * n; i < b * n + n; ++i) {
+        if (fibers[i].st != DONE) ++live;
+        if (fibers[i].st == WAIT_BLOCK) ++atbar;
+      }
+      if (live && atbar == live) {
+        for (int i = b * n; i < b * n + n; ++i) if (fibers[i].st == WAIT_BLOCK) fibers[i].st = RUN;
         progressed = true;
       }
-    }
-    // release the block barrier when every live thread waits on it
-    int live = 0, atbar = 0;
-    for (int i = 0; i < n; ++i) {
-      if (fibers[i].st != DONE) ++live;
-      if (fibers[i].st == WAIT_BLOCK) ++atbar;
-    }
-    if (live && atbar == live) {
-      for (int i = 0; i < n; ++i) if (fibers[i].st == WAIT_BLOCK) fibers[i].st = RUN;
-      progressed = true;
     }
     if (!progressed) {
       fprintf(stderr, "hipemu: deadlock (divergent barrier / partial-wave shuffle) in block (%u,%u,%u)\n", g_blockIdx.x, g_blockIdx.y, g_blockIdx.z);
@@ -161,15 +178,30 @@ static void run_block(dim3 block, const std::function<void()>& body) {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   g_gridDim = grid;
   g_blockDim = block;
-  g_dyn_shared.assign(shmem / sizeof(float) + 4, NAN);   // poisoned: reads of unwritten LDS show up
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) {
-        g_blockIdx = {x, y, z};
-        std::fill(g_dyn_shared.begin(), g_dyn_shared.end(), NAN);
-        run_block(block, body);
-      }
+      for (unsigned x = 0; x < grid.x; ++x) run_blocks(block, {uint3_emu{x, y, z}}, shmem, body);
 }
+
+// every block of the grid alive at once: a polling thread (spin_yield) lets the other blocks run.  Kernels launched this
+// way must keep their LDS in the dynamic segment (a `static` stand-in for __shared__ is one object for all blocks).
+void launch_resident(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+  g_gridDim = grid;
+  g_blockDim = block;
+  std::vector<uint3_emu> ids;
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) ids.push_back(uint3_emu{x, y, z});
+  run_blocks(block, ids, shmem, body);
+}
+
+void spin_yield() { yield(RUN); }
+static int g_tpb() { return g_threads_per_block > 0 ? g_threads_per_block : 1; }
+static int wave_of_cur() {
+  const int n = g_tpb(), nw = (n + 63) / 64;
+  return (cur / n) * nw + ((cur % n) >> 6);
+}
+void* dyn_shared() { return g_dyn_pool[cur / g_tpb()].data(); }
 
 void enqueue(hipStream_t st, std::function<void()> fn) {
   if (st && st->capturing) st->g->nodes.push_back(std::move(fn));

@@ -426,6 +426,15 @@ def test_assemble_overlap_is_schedule_only(lib):
     ec.check_assemble_overlap(lib, B=64, T=194, steps=6)
 
 
+def test_fused_stages_match_one_launch_per_layer(lib):
+    """The fused launches on the device: full-size grids (every workgroup resident, one to four windows each), grids smaller
+    than the batch, changing batch sizes, captured graphs, the notebook topology - all bit-identical to one launch per layer."""
+    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=3, grids=(0, 0))
+    ec.check_fused_stages_match_layer_launches(lib, B=300, T=194, steps=4, grids=(128, 64))
+    ec.check_fused_stages_match_layer_launches(lib, T=130, grids=(0, 0), sizes=(700, 64, 1, 2048, 5), graphs=True)
+    ec.check_fused_stages_match_layer_launches(lib, B=512, T=204, steps=2, grids=(0, 0), flags=ec.NOTEBOOK)
+
+
 def test_prefetched_batches_train_like_the_synchronous_sampler(lib):
     ec.check_prefetched_training_matches_synchronous(lib, B=64, T=194, steps=7)
 

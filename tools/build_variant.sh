@@ -3,4 +3,4 @@
 # (-DMWW_SLIM: default-topology kernels only; add -DMWW_PROFILE for the ablation / phase-clock switches)
 R=$(cd $(dirname $0)/.. && pwd)
 N=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -pthread -DMWW_SLIM "$@" -I $R/include $R/microwakeword_amd/csrc/mww_lib.hip $R/microwakeword_amd/csrc/sampler.cpp -o $R/microwakeword_amd/libmww_$N.so -ldl 2>&1 | grep -E "error|Error" ; ls -la $R/microwakeword_amd/libmww_$N.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -pthread -DMWW_SLIM "$@" -I $R/include $R/microwakeword_amd/csrc/mww_lib.hip $R/microwakeword_amd/csrc/sampler.cpp -o $R/microwakeword_amd/libmww_$N.so -ldl 2>&1 | grep -E "error|Error" ; ls -la $R/microwakeword_amd/libmww_$N.so
