@@ -78,6 +78,12 @@ class _Counts:
 
 
 WEIGHT_BROADCAST_MODES = ("per_sample", "keras_last_axis", "keras_first_axis")
+# How the reference's [B,B] sample weight (train.py:288-293) is reduced to per-sample weights when nothing else is
+# configured.  "per_sample" is the evident intent; which reading Keras 3 really evaluates is settled by
+# tests/test_tf_golden.py as soon as tests/golden/tf_golden.npz exists (tools/make_tf_golden.py) - that test fails until
+# this constant names the reading the reference's numbers follow.  Equal for all readings while class weights (or penalty
+# weights) are uniform, which holds for every BASELINE configuration.
+DEFAULT_WEIGHT_BROADCAST = "per_sample"
 
 
 def combine_weights(penalty, labels, negative_class_weight, positive_class_weight, mode="per_sample"):
@@ -124,7 +130,7 @@ class Model:
         self.loss = None
         self.train_function = None
         self._compiled = False
-        self.sample_weight_broadcast = "per_sample"   # how a [B,B] sample_weight matrix is reduced (combine_weights)
+        self.sample_weight_broadcast = DEFAULT_WEIGHT_BROADCAST   # how a [B,B] sample_weight matrix is reduced (combine_weights)
 
     # ---- Keras surface
     def compile(self, optimizer=None, loss=None, metrics=None):

@@ -26,7 +26,7 @@ import os
 
 import numpy as np
 
-from .model import combine_weights
+from .model import DEFAULT_WEIGHT_BROADCAST, combine_weights
 
 log = logging.getLogger("microwakeword_amd.train")
 
@@ -167,6 +167,7 @@ def train(model, config, data_processor, verbose=True):
     train_writer = _JsonSummary(os.path.join(config["summaries_dir"], "train"), "scalars")
     val_writer = _JsonSummary(os.path.join(config["summaries_dir"], "validation"), "scalars")
 
+    warned_weights = False
     steps_max = int(np.sum(ph["training_steps"]))
     best_min, best_max, best_cutoff = 10000, 0.0, 1.0
     fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
@@ -197,16 +198,21 @@ def train(model, config, data_processor, verbose=True):
                   "time_mask_max_size": ph["time_mask_max_size"][i], "time_mask_count": ph["time_mask_count"][i],
                   "freq_mask_max_size": ph["freq_mask_max_size"][i], "freq_mask_count": ph["freq_mask_count"][i]}
         cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
+        if cw_neg != cw_pos and not warned_weights and config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST) == "per_sample":
+            warned_weights = True
+            log.warning("class weights %g / %g are not uniform: the loss weights are penalty_i x class_weight(y_i) (sample_weight_broadcast: "
+                        "per_sample).  The reference hands Keras a [B,B] matrix here (train.py:288-293); if its loss curves are to be "
+                        "followed to the digit, see INTEGRATION.md section 2 (sample_weight_broadcast: keras_last_axis).", cw_neg, cw_pos)
         if fast:
             data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy,
                                                          class_weights=(cw_neg, cw_pos),
-                                                         weight_broadcast=config.get("sample_weight_broadcast", "per_sample"))
+                                                         weight_broadcast=config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
             result = model.train_on_device_batch(config["batch_size"])
         else:
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",
                                               augmentation_policy=policy)
-            combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", "per_sample"))
+            combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
             result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
         if verbose:
             print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(

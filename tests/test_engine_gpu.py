@@ -426,6 +426,21 @@ def test_assemble_overlap_is_schedule_only(lib):
     ec.check_assemble_overlap(lib, B=64, T=194, steps=6)
 
 
+def test_tf_golden_vectors(lib, tmp_path):
+    """The engine against the reference's own TensorFlow numbers (tests/golden/tf_golden.npz, tools/make_tf_golden.py) when the
+    file exists; always against a file of the same schema synthesized from the oracle, so the consumer stays exercised."""
+    import os
+
+    import tf_golden as tg
+    z = np.load(tg.synthesize(str(tmp_path / "tf_like.npz"), cases=("mixednet_default", "inception_default")))
+    for case in z["cases"]:
+        tg.check_engine(lib, z, str(case))
+    if os.path.isfile(tg.GOLDEN):
+        z = np.load(tg.GOLDEN)
+        for case in z["cases"]:
+            tg.check_engine(lib, z, str(case))
+
+
 def test_fused_stages_match_one_launch_per_layer(lib):
     """The fused launches on the device: full-size grids (every workgroup resident, one to four windows each), grids smaller
     than the batch, changing batch sizes, captured graphs, the notebook topology - all bit-identical to one launch per layer."""
