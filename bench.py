@@ -53,6 +53,10 @@ KERNEL_ELEMS = {
     "bwd_block2": P_ELEMS[1] + P_ELEMS[2] + P_ELEMS[2] + P_ELEMS[1],
     "bwd_block1": X_READ + P_ELEMS[1] + P_ELEMS[1],                   # R x, R p1, R g1
 }
+# fused launches (kernels_fused.hip.h): the four layers' bytes (what travels between the stages of one launch is read
+# and written like between launches: the stages are the same bodies)
+KERNEL_ELEMS["bwd_fused"] = sum(KERNEL_ELEMS["bwd_block%d" % k] for k in (1, 2, 3, 4))
+KERNEL_ELEMS["fwd_fused"] = sum(KERNEL_ELEMS["fwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 
@@ -60,7 +64,7 @@ KERNEL_ELEMS = {
 def kernel_elems_stored_bf16():
     """The same accounting with p_k / g_k held as bf16 ("storage_bf16"): their elements cost 2 B, the input rows
     keep their cost.  Returned in the 4-byte units of KERNEL_ELEMS."""
-    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ}
+    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ, "fwd_fused": X_READ, "bwd_fused": X_READ}
     return {k: xpart.get(k, 0) + (v - xpart.get(k, 0)) / 2 for k, v in KERNEL_ELEMS.items()}
 
 
@@ -78,6 +82,8 @@ KERNEL_MFMA_FLOPS = {
     "bwd_block4": 2 * PW_FLOPS[4], "bwd_block3": 2 * PW_FLOPS[3], "bwd_block2": 2 * PW_FLOPS[2],
     "bwd_block1": CONV1_FLOPS + 2 * PW_FLOPS[1],
 }
+KERNEL_MFMA_FLOPS["bwd_fused"] = sum(KERNEL_MFMA_FLOPS["bwd_block%d" % k] for k in (1, 2, 3, 4))
+KERNEL_MFMA_FLOPS["fwd_fused"] = sum(KERNEL_MFMA_FLOPS["fwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 def inception_kernel_elems(layout):
@@ -126,11 +132,11 @@ def inception_kernel_elems(layout):
     return elems
 
 
-PMC_FILE = "round2_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
+PMC_FILE = "round3_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
 
 
 def pmc_traffic(kernel, model):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round2_*:
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round3_*:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run of `bench.py --no-graphs`), corrected
     as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE (KB) counts half the bytes of wide coalesced
     reads -> x2; WRITE_SIZE (KB) as reported.  Returns (bytes, source) or (None, None).  The counters cannot be
@@ -144,7 +150,8 @@ def pmc_traffic(kernel, model):
     want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
             "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
             "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
-            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}.get(kernel)
+            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<",
+            "bwd_fused": r"bwd_fused_kernel<3, 32, 1, 48,", "fwd_fused": r"fwd_fused_kernel<3, 32, 1, 48,"}.get(kernel)
     if not want:
         return None, None
     fetch = write = None
