@@ -341,12 +341,12 @@ __device__ __forceinline__ void publish_stat(const StatAcc& s, float* row, int C
 // workgroups' first tiles from HBM.  Every workgroup of the grid must be resident (grid <= CUs x blocks per CU of this
 // kernel): the host checks the occupancy query before it picks the fused launch, and every spin is bounded.
 struct GridSync {
-  unsigned* words;   // [kSyncWords]: arrival counters per dispatch class (blockIdx % 8), the top counter, release words; zero at launch
-  unsigned* next;    // the other parity's words: zeroed by workgroup 0 for the next fused launch
+  unsigned* words;   // [kSyncWords]: arrival counters per dispatch class (blockIdx % 8), the top counter, release words, the
+                     // count of finished workgroups; all zero at launch - the last workgroup to finish zeroes them again
   unsigned* fault;   // set when a spin gave up (the step's results are then garbage, the host reports it)
 };
 constexpr int kSyncStride = 32;                    // one 128-byte line per word
-constexpr int kSyncWords = (8 + 1 + 8) * kSyncStride;
+constexpr int kSyncWords = (8 + 1 + 8 + 1) * kSyncStride;
 #ifndef MWW_SYNC_SLEEP
 #define MWW_SYNC_SLEEP 1
 #endif
@@ -397,11 +397,17 @@ __device__ __forceinline__ void stage_end() {
   __syncthreads();
 }
 
-// last thing a fused launch does: the words of the other parity are zero for the next fused launch (plain stores: a
-// kernel boundary lies in between)
-__device__ __forceinline__ void grid_sync_reset_next(const GridSync& g) {
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < kSyncWords; i += kThreads) g.next[i] = 0u;
+// last thing a fused launch does: the last workgroup to finish - every other one has passed every rendezvous and polls
+// nothing any more - returns the words to zero, so that the next fused launch (a replay of the same captured graph node
+// included: the pointers are baked into it) starts from a clean set
+__device__ __forceinline__ void grid_sync_finish(const GridSync& g) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* done = g.words + 17 * kSyncStride;
+    const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == gridDim.x)
+      for (int i = 0; i < 18; ++i) __hip_atomic_store(g.words + i * kSyncStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // accumulator-row element as another workgroup's atomic add left it (FUSED), or a plain load (one launch per layer:

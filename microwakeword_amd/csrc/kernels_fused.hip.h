@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads, (FusedFwdWaves<K1, S, CW>::value)) void f
   fwd_block_stage<CW, CW, KC, BF, SB>(a.blk[1], lds, &a.sync, 2);
   stage_end();
   fwd_block_stage<CW, CW, KD, BF, SB>(a.blk[2], lds, &a.sync, 3);
-  grid_sync_reset_next(a.sync);
+  grid_sync_finish(a.sync);
 }
 
 template <int K1, int C1, int S, int CW, int KA, int KB, int KC, int KD, bool BF, bool SB>
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads, (CW > 48 || S > 1 ? 1 : 2)) void bwd_fuse
   bwd_block_stage<CW, CW, KB, false, BF, SB>(a.blk[2], lds, &a.sync, 2);
   stage_end();
   bwd_first_stage<K1, C1, CW, KA, S, BF, SB>(a.first, lds, &a.sync, 3);
-  grid_sync_reset_next(a.sync);
+  grid_sync_finish(a.sync);
 }
 
 }  // namespace mww

@@ -215,10 +215,9 @@ struct mww_ctx {
   bool bn_eval_ready = false;   // inside mww_evaluate_windows: the moving statistics are folded once, not per batch
   // "fused_stages" option (default on where it applies): the four forward blocks / the four backward blocks of a train step run
   // as ONE launch each, persistent workgroups meeting at grid-wide rendezvous between the layers (kernels_fused.hip.h)
-  bool fused_stages = true;
-  bool fused_fwd = false, fused_bwd = true;   // "fused_stages": 0 none, 1 both, 2 forward only, 3 backward only (the default: what measured faster)
-  unsigned* sync_words = nullptr;   // [2 parities][kSyncWords] + fault word
-  int sync_par = 0;
+  bool fused_stages = false;                 // default off: the backward variant gains 1 % of the step, not worth a launch whose
+  bool fused_fwd = false, fused_bwd = false;  // workgroups wait for each other; "fused_stages": 0 none, 1 both, 2 forward only, 3 backward only
+  unsigned* sync_words = nullptr;   // [kSyncWords] rendezvous words (self-resetting) + fault word
   bool sync_par_used = false;   // a fused launch was enqueued: mww_synchronize looks at the fault word
   std::map<const void*, int> fused_occ;   // resident workgroups per CU of a fused kernel (occupancy query)
   int ablate = 0;
@@ -395,10 +394,8 @@ int fused_resident(mww_ctx* c, const void* func, size_t lds, int grid, bool* ok)
 
 GridSync next_sync(mww_ctx* c) {
   GridSync g;
-  g.words = c->sync_words + (size_t)c->sync_par * kSyncWords;
-  g.next = c->sync_words + (size_t)(c->sync_par ^ 1) * kSyncWords;
-  g.fault = c->sync_words + 2 * kSyncWords;
-  c->sync_par ^= 1;
+  g.words = c->sync_words;
+  g.fault = c->sync_words + kSyncWords;
   c->sync_par_used = true;
   return g;
 }
@@ -1902,8 +1899,8 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
   A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * kClkSlots));
-  A(dev_alloc(&c->sync_words, (size_t)2 * kSyncWords + kSyncStride));
-  HIPCHK(hipMemsetAsync(c->sync_words, 0, ((size_t)2 * kSyncWords + kSyncStride) * sizeof(unsigned), c->stream));
+  A(dev_alloc(&c->sync_words, (size_t)kSyncWords + kSyncStride));
+  HIPCHK(hipMemsetAsync(c->sync_words, 0, ((size_t)kSyncWords + kSyncStride) * sizeof(unsigned), c->stream));
   c->mail_off_masks = mb * sizeof(mww_window);
   c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
   c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
@@ -2510,7 +2507,7 @@ int mww_synchronize(mww_ctx* c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->sync_words && c->sync_par_used) {
     unsigned fault = 0;
-    HIPCHK(hipMemcpy(&fault, c->sync_words + 2 * kSyncWords, sizeof(fault), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&fault, c->sync_words + kSyncWords, sizeof(fault), hipMemcpyDeviceToHost));
     if (fault) return fail(MWW_ERR_STATE, "a fused launch gave up waiting for its other workgroups (grid not resident?): results since the last synchronize are invalid; set option fused_stages 0");
   }
   return MWW_OK;
@@ -2750,7 +2747,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | (c->sync_par << 27) | ((c->fused_stages ? (c->fused_fwd ? 1 : 0) | (c->fused_bwd ? 2 : 0) : 0) << 28);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | ((c->fused_stages ? (c->fused_fwd ? 1 : 0) | (c->fused_bwd ? 2 : 0) : 0) << 27);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;

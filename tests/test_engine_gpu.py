@@ -448,6 +448,8 @@ def test_fused_stages_match_one_launch_per_layer(lib):
     ec.check_fused_stages_match_layer_launches(lib, B=300, T=194, steps=4, grids=(128, 64))
     ec.check_fused_stages_match_layer_launches(lib, T=130, grids=(0, 0), sizes=(700, 64, 1, 2048, 5), graphs=True)
     ec.check_fused_stages_match_layer_launches(lib, B=512, T=204, steps=2, grids=(0, 0), flags=ec.NOTEBOOK)
+    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=5, grids=(0, 0), graphs=True, mode=3)
+    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=3, grids=(0, 0), mode=3)
 
 
 def test_prefetched_batches_train_like_the_synchronous_sampler(lib):
