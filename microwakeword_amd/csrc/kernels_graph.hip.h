@@ -564,7 +564,6 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         for (int j = 0; j < a.k; ++j) {
           const float* ar = arow + j * a.dil * PI;
           const float* wr = wrow + j * cin4 * NCW;
-#pragma unroll 2
           for (int ci0 = 0; ci0 < cin4; ci0 += 4) {
             float av = ar[ci0];
             if (!kfull && ci0 + g >= a.cin) av = 0.f;   // the last k-step of a channel count that is no multiple of 4

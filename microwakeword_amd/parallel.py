@@ -90,7 +90,17 @@ class DataParallel:
             raise ValueError("sync_bn needs a wrap(ptr, n) function")
         self.engine_driven = wrap is not None or library_comm
         if library_comm:
-            self._join_library_communicator()
+            try:
+                self._join_library_communicator()
+            except native.NativeError as e:
+                # e.g. no librccl.so next to this process: every rank fails the same way (before the collective join), and every
+                # rank falls back to the callback form over the caller's process group
+                if wrap is None:
+                    raise
+                import warnings
+                warnings.warn("library-owned RCCL communicator unavailable (%s): using torch.distributed through the callback" % e)
+                self.library_comm = library_comm = False
+        if library_comm:
             engine.set_option("grad_buckets", int(grad_buckets))
         elif self.engine_driven:
             # the engine calls back for every BN layer (sync-BN) and for the gradient buckets: the complete DP step

@@ -195,26 +195,39 @@ def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
     return float(np.abs(pr - po).max())
 
 
-def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11):
+def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=None, kind="mixednet"):
     """One train step against the float64 oracle WITHOUT reading the engine's ReLU decisions back: the comparison the
     mask-imposing checks cannot give (a wrong mask would be copied into the oracle there).  A float32-vs-float64 flip
     of a near-zero unit may move a tensor's gradient by ~1/sqrt(units), hence the loose per-tensor L2 bound; a mask
-    bug moves it by O(1)."""
-    om = perturbed_oracle(T)
-    lay, eng = make_engine(lib, T, B, om)
+    bug moves it by O(1).  `kind` "inception" runs the conv/BN graph engine (dropout mask injected), `flags` any topology."""
     rng = np.random.default_rng(seed)
     x = synth_x(rng, B, T)
     y = (rng.random(B) < 0.5).astype(np.float32)
     w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
+    kw = {}
+    if kind == "inception":
+        flags = flags or INC
+        om = perturbed_inception_oracle(T, flags)
+        lay, eng = make_inception_engine(lib, T, B, om, flags)
+        keep = (rng.random((B, lay.t_last * lay.c_last)) >= flags["dropout"]).astype(np.float32)
+        eng.set_dropout_mask(keep)
+        kw = {"dropout_mask": keep}
+    else:
+        om = perturbed_oracle(T, flags=flags or DEF)
+        lay, eng = make_engine(lib, T, B, om, flags=flags or DEF)
     eng.set_batch(x)
     eng.set_targets(y, w)
     eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
     pr, z, loss = eng.read_outputs(B)
-    lo, po, grads, _ = om.loss_and_grads(x, y, w)
+    lo, po, grads, _ = om.loss_and_grads(x, y, w, **kw)
     assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
     assert np.abs(pr - po).max() <= FWD_TOL
     g = eng.get_grads()
-    gref = oracle_grads_native_order(lay, om, grads)
+    if kind == "inception":
+        gref = lay.pack([grads[n].numpy().astype(np.float32) if kd == "param" else np.zeros(sh, np.float32)
+                         for n, sh, kd in lay.keras_vars])[0]
+    else:
+        gref = oracle_grads_native_order(lay, om, grads)
     scale = max(1e-6, float(np.abs(gref).max()))
     off, worst = 0, 0.0
     for name, n in lay.segments():

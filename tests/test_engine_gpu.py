@@ -91,6 +91,16 @@ def test_train_step_at_the_baseline_size_vs_float64_oracle(lib):
 
 def test_inception_train_step_batch1024_vs_float64_oracle(lib):
     ec.check_inception_train_steps(lib, B=1024, T=194, steps=1, grid=0)
+    # ... and without imposing the engine's ReLU decisions on the oracle (a mask bug cannot hide)
+    assert ec.check_gradients_unimposed(lib, B=1024, T=194, bound=2e-2, kind="inception") <= 2e-2
+
+
+def test_notebook_topology_batch1024_gradients_without_imposed_masks(lib):
+    """The topology the reference's notebook trains (first conv 5x1 stride 3, 64 filters, MixConv groups, T = 204) at B = 1024 on the
+    kernels compiled for one workgroup per CU: train step vs the float64 oracle with and without the engine's ReLU decisions imposed."""
+    worst = ec.check_train_steps(lib, B=1024, T=204, steps=1, grid=0, flags=ec.NOTEBOOK)
+    assert worst["l2_max"] <= 1e-4
+    assert ec.check_gradients_unimposed(lib, B=1024, T=204, bound=2e-2, flags=ec.NOTEBOOK) <= 2e-2
 
 
 def test_training_reduces_loss(lib):
