@@ -275,35 +275,12 @@ __device__ __forceinline__ void write_block_grad_partials(float* scratch, float*
   __syncthreads();
 }
 
-// depthwise backward of one (channel, chunk) for one time tile, in two steps so that the input
-// gradient can be consumed (masked, stored) before the weight-gradient window is loaded:
+// depthwise backward of one (channel, chunk) for one time tile (phase P4 of the two backward bodies, written out there):
 //   da[sl]      = sum_j w[K-1-j] * du_ring[sl + j]                     (sl local input row)
 //   dW_dw[i]   += sum_t du[t] * a[t+i] ;  db += sum_t du[t]            (t local output row)
-// `a_at(row)` returns the activation of local input row `row` for channel c.
-template <int K, int L, int CPI>
-__device__ __forceinline__ void depthwise_input_grad_chunk(const float* sDU, int chunk, int c, const float (&dww)[K],
-                                                           float (&da)[L]) {
-  dw_chunk<K, L, true, false>(sDU, CPI, chunk * L, c, dww, 0.f, da);
-}
-
-template <int K, int L, int CPI, typename ActFn>
-__device__ __forceinline__ void depthwise_weight_grad_chunk(const float* sDU, int chunk, int c, float (&accw)[K],
-                                                            float& accb, ActFn a_at) {
-  // every LDS read of the phase is issued before the first FMA (read -> wait -> use per element exposes one LDS
-  // round trip per output row: the round-2 ISA of this phase was a chain of lgkmcnt(0) waits)
-  float win[L + K - 1], du[L];
-#pragma unroll
-  for (int t = 0; t < L; ++t) du[t] = sDU[(K - 1 + chunk * L + t) * CPI + c];   // ring rows past the tile are allocated and zero
-#pragma unroll
-  for (int j = 0; j < L + K - 1; ++j) win[j] = a_at(chunk * L + j);
-  lds_reads_first();
-#pragma unroll
-  for (int t = 0; t < L; ++t) {
-    accb += du[t];
-#pragma unroll
-    for (int i = 0; i < K; ++i) accw[i] = fmaf(du[t], win[t + i], accw[i]);
-  }
-}
+// Every LDS read of the phase is issued before the first FMA (read -> wait -> use per element exposes one LDS round trip
+// per output row: the round-2 ISA of this phase was a chain of lgkmcnt(0) waits), and the du-ring / activation windows
+// are read once and serve both sums.
 
 // ------------------------------------------------------------------------------------------
 // LDS of the block / first-block backward stages as float offsets into a fused launch's LDS array
