@@ -56,7 +56,6 @@ KERNEL_ELEMS = {
 # fused launches (kernels_fused.hip.h): the four layers' bytes (what travels between the stages of one launch is read
 # and written like between launches: the stages are the same bodies)
 KERNEL_ELEMS["bwd_fused"] = sum(KERNEL_ELEMS["bwd_block%d" % k] for k in (1, 2, 3, 4))
-KERNEL_ELEMS["fwd_fused"] = sum(KERNEL_ELEMS["fwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 
@@ -64,7 +63,7 @@ KERNEL_ELEMS["fwd_fused"] = sum(KERNEL_ELEMS["fwd_block%d" % k] for k in (1, 2, 
 def kernel_elems_stored_bf16():
     """The same accounting with p_k / g_k held as bf16 ("storage_bf16"): their elements cost 2 B, the input rows
     keep their cost.  Returned in the 4-byte units of KERNEL_ELEMS."""
-    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ, "fwd_fused": X_READ, "bwd_fused": X_READ}
+    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ, "bwd_fused": X_READ}
     return {k: xpart.get(k, 0) + (v - xpart.get(k, 0)) / 2 for k, v in KERNEL_ELEMS.items()}
 
 
@@ -83,7 +82,6 @@ KERNEL_MFMA_FLOPS = {
     "bwd_block1": CONV1_FLOPS + 2 * PW_FLOPS[1],
 }
 KERNEL_MFMA_FLOPS["bwd_fused"] = sum(KERNEL_MFMA_FLOPS["bwd_block%d" % k] for k in (1, 2, 3, 4))
-KERNEL_MFMA_FLOPS["fwd_fused"] = sum(KERNEL_MFMA_FLOPS["fwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 def inception_kernel_elems(layout):
@@ -151,7 +149,7 @@ def pmc_traffic(kernel, model):
             "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
             "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
             "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<",
-            "bwd_fused": r"bwd_fused_kernel<3, 32, 1, 48,", "fwd_fused": r"fwd_fused_kernel<3, 32, 1, 48,"}.get(kernel)
+            "bwd_fused": r"bwd_fused_kernel<3, 32, 1, 48,"}.get(kernel)
     if not want:
         return None, None
     fetch = write = None

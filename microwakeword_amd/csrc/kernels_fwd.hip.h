@@ -381,22 +381,6 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
 #include "fwd_first_body.inc"
 }
 
-// the same body as a stage of a fused launch (lds = the launch's LDS array)
-template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB>
-__device__ __forceinline__ void fwd_first_stage(const FwdFirstArgs& a, float* lds) {
-  typedef FwdFirstLds<K1, C1, COUT, K, S> Lds;
-  float* sX = lds + Lds::X;
-  float* sA = lds + Lds::A;
-  float* sU = lds + Lds::U;
-  float* sRed = lds + Lds::RED;
-  XShared& sXg = *reinterpret_cast<XShared*>(lds + Lds::XG);
-  constexpr bool FUSED = true;
-  (void)FUSED;
-#define MWW_STAGE_SYNC
-#include "fwd_first_body.inc"
-#undef MWW_STAGE_SYNC
-}
-
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
@@ -408,21 +392,6 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
   constexpr bool FUSED = false;
 #define MWW_STAGE_SYNC
-#include "fwd_block_body.inc"
-#undef MWW_STAGE_SYNC
-}
-
-template <int CIN, int COUT, int K, bool BF, bool SB>
-__device__ __forceinline__ void fwd_block_stage(const FwdBlockArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
-  typedef FwdBlockLds<CIN, COUT, K> Lds;
-  float* sA = lds + Lds::A;
-  float* sU = lds + Lds::U;
-  float* sRed = lds + Lds::RED;
-  float* sScale = lds + Lds::SCALE;
-  float* sShift = lds + Lds::SHIFT;
-  constexpr bool FUSED = true;
-#undef MWW_STAGE_SYNC
-#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
 #include "fwd_block_body.inc"
 #undef MWW_STAGE_SYNC
 }

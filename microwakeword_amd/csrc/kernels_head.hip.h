@@ -181,11 +181,27 @@ struct MetricsArgs {
 template <int NT>
 __device__ __forceinline__ void metrics_body(const MetricsArgs& a, unsigned (*sH101)[101], unsigned (*sH200)[200], unsigned* sCnt,
                                              double* sBce, int tid) {
+  // This workgroup is the only writer of the metric state while it runs (one stream, one workgroup): the cumulative counters
+  // are read at the start - beside the probabilities, one memory round trip for both - and stored back at the end, instead of
+  // ~150 64-bit atomics and a read-modify-write of the loss sum behind the LDS phase.
+  constexpr int N101 = (202 + NT - 1) / NT, N200 = (400 + NT - 1) / NT;
+  unsigned long long old101[N101], old200[N200], old_cnt = 0ull;
+  double old_bce = 0.0;
+#pragma unroll
+  for (int k = 0; k < N101; ++k) old101[k] = tid + k * NT < 202 ? (&a.m->hist101[0][0])[tid + k * NT] : 0ull;
+#pragma unroll
+  for (int k = 0; k < N200; ++k) old200[k] = tid + k * NT < 400 ? (&a.m->hist200[0][0])[tid + k * NT] : 0ull;
+  if (tid < 7) old_cnt = (&a.m->n)[tid];
+  if (tid == 0) old_bce = a.m->bce_sum;
   for (int i = tid; i < 202; i += NT) (&sH101[0][0])[i] = 0u;
   for (int i = tid; i < 400; i += NT) (&sH200[0][0])[i] = 0u;
   if (tid < 8) sCnt[tid] = 0u;
   __syncthreads();
+  // counters and the loss sum per thread, then per wave (shuffles), then one LDS add per wave: the first version sent every
+  // window's seven counter updates to the same LDS words and let thread 0 add the NT loss partials one after the other -
+  // ~8 us of the gradient-assembly launch this workgroup rides in, which was that launch's critical path
   double bce = 0.0;
+  int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int b = tid; b < a.B; b += NT) {
     const float pr = a.prob[b], yy = a.y[b];
     const int lab = yy > 0.5f ? 1 : 0;
@@ -196,29 +212,49 @@ __device__ __forceinline__ void metrics_body(const MetricsArgs& a, unsigned (*sH
     if (b101 >= 0) atomicAdd(&sH101[lab][b101], 1u);   // p == 0 exceeds no threshold (0.0 included): strict '>' of train.py's metrics
     atomicAdd(&sH200[lab][b200], 1u);
     const bool ppos = pr > 0.5f;
-    atomicAdd(&sCnt[0], 1u);
-    if (ppos == (lab == 1)) atomicAdd(&sCnt[1], 1u);
-    if (ppos && lab) atomicAdd(&sCnt[2], 1u);
-    if (ppos && !lab) atomicAdd(&sCnt[3], 1u);
-    if (!ppos && lab) atomicAdd(&sCnt[4], 1u);
-    atomicAdd(&sCnt[lab ? 5 : 6], 1u);
+    cnt[0] += 1;
+    cnt[1] += (ppos == (lab == 1)) ? 1 : 0;
+    cnt[2] += (ppos && lab) ? 1 : 0;
+    cnt[3] += (ppos && !lab) ? 1 : 0;
+    cnt[4] += (!ppos && lab) ? 1 : 0;
+    cnt[5] += lab ? 1 : 0;
+    cnt[6] += lab ? 0 : 1;
     bce += (double)bce_value(a.z ? a.z[b] : 0.f, pr, yy, a.z == nullptr);
   }
-  sBce[tid] = bce;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int v = cnt[k];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    if ((tid & 63) == 0 && v) atomicAdd(&sCnt[k], (unsigned)v);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    union { double d; int i[2]; } u;
+    u.d = bce;
+    u.i[0] = __shfl_xor(u.i[0], m);
+    u.i[1] = __shfl_xor(u.i[1], m);
+    bce += u.d;
+  }
+  if ((tid & 63) == 0) sBce[tid >> 6] = bce;
   __syncthreads();
-  for (int i = tid; i < 202; i += NT) {
-    const unsigned v = (&sH101[0][0])[i];
-    if (v) atomicAdd(&a.m->hist101[0][0] + i, (unsigned long long)v);
+#pragma unroll
+  for (int k = 0; k < N101; ++k) {
+    const int i = tid + k * NT;
+    const unsigned v = i < 202 ? (&sH101[0][0])[i] : 0u;
+    if (v) (&a.m->hist101[0][0])[i] = old101[k] + v;
   }
-  for (int i = tid; i < 400; i += NT) {
-    const unsigned v = (&sH200[0][0])[i];
-    if (v) atomicAdd(&a.m->hist200[0][0] + i, (unsigned long long)v);
+#pragma unroll
+  for (int k = 0; k < N200; ++k) {
+    const int i = tid + k * NT;
+    const unsigned v = i < 400 ? (&sH200[0][0])[i] : 0u;
+    if (v) (&a.m->hist200[0][0])[i] = old200[k] + v;
   }
-  if (tid < 7 && sCnt[tid]) atomicAdd(&a.m->n + tid, (unsigned long long)sCnt[tid]);
+  if (tid < 7 && sCnt[tid]) (&a.m->n)[tid] = old_cnt + sCnt[tid];
   if (tid == 0) {
     double s = 0.0;
-    for (int i = 0; i < NT; ++i) s += sBce[i];
-    a.m->bce_sum += s;   // single workgroup, single writer
+    for (int i = 0; i < NT / 64; ++i) s += sBce[i];
+    a.m->bce_sum = old_bce + s;
   }
 }
 

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kThreads) void head_tail_kernel(HeadTailArgs a) {
     const int i = bid - a.n_fin;
     dense_grad_body(a.dense, i % a.ndx, i / a.ndx, tid);
   } else if (a.do_metrics) {
-    metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-thread BCE partials
+    metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-wave BCE partials
   }
 }
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
   __shared__ unsigned sCnt[8];
   const int bid = blockIdx.x, tid = threadIdx.x;
   if (bid >= a.nblocks) {
-    if (a.do_metrics) metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-thread BCE partials
+    if (a.do_metrics) metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-wave BCE partials
     return;
   }
   int si = 0;

@@ -213,10 +213,10 @@ struct mww_ctx {
   bool st_bf16 = false;   // p_k / g_k stored as bf16 ("storage_bf16", implies pointwise_bf16: BASELINE configs[4])
   bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
   bool bn_eval_ready = false;   // inside mww_evaluate_windows: the moving statistics are folded once, not per batch
-  // "fused_stages" option (default on where it applies): the four forward blocks / the four backward blocks of a train step run
-  // as ONE launch each, persistent workgroups meeting at grid-wide rendezvous between the layers (kernels_fused.hip.h)
-  bool fused_stages = false;                 // default off: the backward variant gains 1 % of the step, not worth a launch whose
-  bool fused_fwd = false, fused_bwd = false;  // workgroups wait for each other; "fused_stages": 0 none, 1 both, 2 forward only, 3 backward only
+  // "fused_stages" option: the four backward blocks of a train step run as ONE launch, persistent workgroups meeting at
+  // grid-wide rendezvous between the layers (kernels_fused.hip.h).  Default off: it gains 1 % of the step, not
+  // worth a launch whose workgroups wait for each other.  (The forward counterpart measured slower and was removed.)
+  bool fused_stages = false;
   unsigned* sync_words = nullptr;   // [kSyncWords] rendezvous words (self-resetting) + fault word
   bool sync_par_used = false;   // a fused launch was enqueued: mww_synchronize looks at the fault word
   std::map<const void*, int> fused_occ;   // resident workgroups per CU of a fused kernel (occupancy query)
@@ -401,24 +401,6 @@ GridSync next_sync(mww_ctx* c) {
 }
 
 // launches the fused kernel of this context's topology (launch = false: only answers whether `grid` workgroups of it are resident)
-int launch_fwd_fused(mww_ctx* c, FwdFusedArgs& a, int grid, bool launch, bool* ok) {
-  const mww_mixednet_desc& d = c->d;
-  *ok = false;
-#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
-  if (d.conv1_kernel == K1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_kernel[1] == KB) {                  \
-    const void* f = reinterpret_cast<const void*>(&fwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>);            \
-    const size_t lds = (size_t)FusedLds<K1, C1, S, CW, KA, KB, KC, KD>::FWD * sizeof(float);                                  \
-    int rc = fused_resident(c, f, lds, grid, ok);                                                                             \
-    if (rc || !*ok || !launch) return rc;                                                                                     \
-    a.sync = next_sync(c);                                                                                                    \
-    MWW_LAUNCH_RESIDENT((fwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>), dim3(grid), dim3(kThreads), lds, c->stream, a); \
-    return MWW_OK;                                                                                                            \
-  }
-  MWW_FUSED_TOPOLOGIES(X)
-#undef X
-  return MWW_OK;
-}
-
 int launch_bwd_fused(mww_ctx* c, BwdFusedArgs& a, int grid, bool launch, bool* ok) {
   const mww_mixednet_desc& d = c->d;
   *ok = false;
@@ -596,6 +578,14 @@ int exchange_stats(mww_ctx* c, Launcher& lp, const char* what, int layer, const 
 int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics);
 int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam);
 
+// Workgroups of one forward block launch: its (window, time tile) items over at most the workgroups the instantiation
+// keeps resident (the __launch_bounds__ of fwd_block_kernel), so that no launch runs a partial second dispatch round.
+int fwd_block_grid(const mww_ctx* c, const Layer& l, int B) {
+  const int per_cu = l.cin > 48 ? 2 : (l.k > 13 ? 3 : 4);
+  const long long items = (long long)B * ((l.tout + TT - 1) / TT);
+  return (int)std::min<long long>(items, std::min(c->grid_fwd, c->n_cu * per_cu));
+}
+
 int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
   if (c->generic) return g_enqueue_forward(c, B, training, update_moving, loss, metrics);
   Launcher lp{c};
@@ -630,17 +620,9 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     f.rstd = bn_slot(pl, BN_RSTD);
     return f;
   };
-  // the four blocks of a training forward in one launch (kernels_fused.hip.h) where the topology has a fused kernel, the
-  // statistics travel in accumulator rows and the whole grid is resident; one launch per layer otherwise
-  bool fused = false;
-  FwdFusedArgs fa;
-  if (training && inl && c->fused_stages && c->fused_fwd && fused_topology(c)) {
-    int rcf = launch_fwd_fused(c, fa, std::min(B, c->grid_fwd), false, &fused);
-    if (rcf) return rcf;
-  }
   for (int i = 0; i < nb; ++i) {
     Layer& l = c->L[i];
-    const int grid = std::min(B, c->grid_fwd);
+    const int grid = i == 0 ? std::min(B, c->grid_fwd) : fwd_block_grid(c, l, B);
     StatAcc sacc{nullptr, nullptr};
     if (inl) {
       sacc.acc = l.facc[c->fpar];
@@ -650,10 +632,6 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
     if (i == 0) {
       FwdFirstArgs a{c->x, c->params + c->o_conv1, c->params + l.o_dw_w, c->params + l.o_dw_b, c->params + l.o_pw_w,
                      l.p, l.stat_part, B, d.frames, l.tout, 0, sacc, x_gather(c), training ? c->a0 : nullptr};
-      if (fused) {
-        fa.first = a;
-        continue;
-      }
       lp.begin("fwd_block", i);
       int rc = launch_fwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, grid);
       lp.end();
@@ -663,16 +641,6 @@ int enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool l
       FwdBlockArgs a{pl.p, bn_slot(pl, BN_SCALE), bn_slot(pl, BN_SHIFT), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.p, l.stat_part, B, l.tin, l.tout, c->ablate, c->phase_clk + (size_t)(2 * i) * 2048 * kClkSlots,
                      sacc, fold_of(pl)};
-      if (fused) {
-        fa.blk[i - 1] = a;
-        if (i == nb - 1) {
-          lp.begin("fwd_fused");
-          int rc = launch_fwd_fused(c, fa, grid, true, &fused);
-          lp.end();
-          if (rc) return rc;
-        }
-        continue;
-      }
       lp.begin("fwd_block", i);
       int rc = launch_fwd_block(c, l.cin, l.cout, l.k, a, grid);
       lp.end();
@@ -891,7 +859,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   // accumulator rows (no finalize / head_tail launch in between) and no gradient bucket handed over half way
   bool fused = false;
   BwdFusedArgs fa;
-  if (inl && c->tail_in_reduce && !bucketed && c->fused_stages && c->fused_bwd && fused_topology(c)) {
+  if (inl && c->tail_in_reduce && !bucketed && c->fused_stages && fused_topology(c)) {
     int rcf = launch_bwd_fused(c, fa, gbwd, false, &fused);
     if (rcf) return rcf;
   }
@@ -2019,7 +1987,10 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
   c->S = soff;
   c->dwd_stride = t * ch + 4;
   const size_t mb = (size_t)d.max_batch;
-  const int gmax_f = c->grid_fwd, gmax_b = c->grid_bwd, gmax_h = c->grid_head;
+  // partial rows are sized for the largest grids the "grid_fwd" / "grid_bwd" / "grid_head" options accept, not for this
+  // topology's defaults (until round 3 a 64-wide context - defaults 2 / 1 workgroups per CU - overran them when the options
+  // asked for more: found by the shape fuzz on the emulator)
+  const int gmax_f = c->n_cu * 4, gmax_b = c->n_cu * 2;
   int rc = 0;
 #define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
   A(alloc_common(c));
@@ -2747,7 +2718,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | ((c->fused_stages ? (c->fused_fwd ? 1 : 0) | (c->fused_bwd ? 2 : 0) : 0) << 27);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | ((c->fused_stages ? 1 : 0) << 27);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2942,7 +2913,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
-  else if (!strcmp(name, "fused_stages")) { c->fused_stages = v != 0; c->fused_fwd = v == 1 || v == 2; c->fused_bwd = v == 1 || v == 3; }
+  else if (!strcmp(name, "fused_stages")) c->fused_stages = v != 0;
   else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }
   else if (!strcmp(name, "graph_dgrad_share")) { if (v < 10 || v > 90) return fail(MWW_ERR_INVALID, "graph_dgrad_share must be 10..90"); c->g_dgrad_share = (int)v; }
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;

@@ -1061,8 +1061,8 @@ def check_assemble_overlap(lib, B=8, T=60, steps=5):
 
 
 # ------------------------------------------------------------------------------------------ fused stages
-def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 3), flags=DEF, graphs=False, sizes=None, mode=1):
-    """"fused_stages" (kernels_fused.hip.h: the four forward blocks / the four backward blocks as one launch each, persistent
+def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 3), flags=DEF, graphs=False, sizes=None):
+    """"fused_stages" (kernels_fused.hip.h: the four backward blocks as one launch, persistent
     workgroups meeting at grid-wide rendezvous between the layers) runs the same stage bodies on the same windows in the same
     order as one launch per layer, so gradients, parameters, BN moving statistics and outputs are bit-identical - over several
     steps (the rendezvous words alternate between two sets), with grids smaller than the batch (grid-stride windows), with
@@ -1074,9 +1074,9 @@ def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 
     ws = [rng.choice([0.5, 1.0, 2.0], size=b).astype(np.float32) for b in sizes]
     om = perturbed_oracle(T, flags=flags)
     outs = []
-    for fused in (mode, 0):
+    for fused in (1, 0):
         lay, eng = make_engine(lib, T, max(sizes), om, flags=flags)
-        eng.set_option("fused_stages", fused)   # 1 = forward and backward fused, 3 = backward only, 0 = one launch per layer (the default)
+        eng.set_option("fused_stages", fused)   # 1 = the backward blocks in one launch, 0 = one launch per layer (the default)
         if grids[0]:
             eng.set_option("grid_fwd", grids[0])
         if grids[1]:
@@ -1095,9 +1095,9 @@ def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 
         if not graphs:
             names = [n for n, _ in eng.profile_read()]
             if not fused:
-                assert "fwd_fused" not in names and "bwd_fused" not in names, names
+                assert "bwd_fused" not in names, names
             elif flags is DEF and lib.device_count() > 0 and (grids[1] or max(sizes)) <= 512:
-                assert ("fwd_fused" in names or mode == 3) and "bwd_fused" in names, names   # (wider topologies: only where the whole grid is resident)
+                assert "bwd_fused" in names, names   # (wider topologies: only where the whole grid is resident)
         got += [eng.get_params().copy(), eng.get_bn_state().copy()]
         outs.append(got)
         eng.close()

@@ -127,6 +127,7 @@ def test_notebook_topology_stride3_mixconv_groups(lib):
     ec.check_forward_parity(lib, B=4, T=204, training=False, flags=ec.NOTEBOOK)
     ec.check_forward_parity(lib, B=9, T=204, training=True, flags=ec.NOTEBOOK)
     ec.check_train_steps(lib, B=8, T=204, steps=2, grid=0, flags=ec.NOTEBOOK)
+    ec.check_train_steps(lib, B=600, T=204, steps=1, grid=512, flags=ec.NOTEBOOK)   # grids above the topology's defaults
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -458,8 +459,7 @@ def test_fused_stages_match_one_launch_per_layer(lib):
     ec.check_fused_stages_match_layer_launches(lib, B=300, T=194, steps=4, grids=(128, 64))
     ec.check_fused_stages_match_layer_launches(lib, T=130, grids=(0, 0), sizes=(700, 64, 1, 2048, 5), graphs=True)
     ec.check_fused_stages_match_layer_launches(lib, B=512, T=204, steps=2, grids=(0, 0), flags=ec.NOTEBOOK)
-    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=5, grids=(0, 0), graphs=True, mode=3)
-    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=3, grids=(0, 0), mode=3)
+    ec.check_fused_stages_match_layer_launches(lib, B=1024, T=194, steps=5, grids=(0, 0), graphs=True)
 
 
 def test_prefetched_batches_train_like_the_synchronous_sampler(lib):

@@ -12,8 +12,8 @@ print('$1', 'ms/step', d['ms_per_step'], 'gpu', d['gpu_stream_ms_per_step'], 'ho
 for rep in 1 2 3; do
   timeout 300 python bench.py --steps 200 --warmup 20 $Q 2>/dev/null | line eager
   timeout 300 python bench.py --steps 200 --warmup 20 $Q --graphs 2>/dev/null | line graphs
-  MWW_BENCH_OPTIONS=fused_stages=3 timeout 300 python bench.py --steps 200 --warmup 20 $Q 2>/dev/null | line eager_fused_bwd
-  MWW_BENCH_OPTIONS=fused_stages=3 timeout 300 python bench.py --steps 200 --warmup 20 $Q --graphs 2>/dev/null | line graphs_fused_bwd
+  MWW_BENCH_OPTIONS=fused_stages=1 timeout 300 python bench.py --steps 200 --warmup 20 $Q 2>/dev/null | line eager_fused_bwd
+  MWW_BENCH_OPTIONS=fused_stages=1 timeout 300 python bench.py --steps 200 --warmup 20 $Q --graphs 2>/dev/null | line graphs_fused_bwd
   timeout 300 python bench.py --steps 20 --warmup 5 $Q 2>/dev/null | line eager_driver_form
   timeout 300 python bench.py --steps 20 --warmup 5 $Q --graphs 2>/dev/null | line graphs_driver_form
 done 2>&1 | tee $OUT/host_ab.txt
