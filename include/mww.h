@@ -265,7 +265,8 @@ int mww_metrics_reset(mww_ctx* ctx);
 void* mww_device_ptr(mww_ctx* ctx, int which);
 
 /* named internal tensors for parity tests ("p1".."p8" pre-BN block outputs, "g1".. gradients at
- * the BN outputs, "bn_mean<k>", "bn_rstd<k>"); returns the element count or a negative error */
+ * the BN outputs, "bn<k>" the folded BN rows of block k, "a0" = relu(conv1(x)) as the first block stored it, "dz", "x");
+ * returns the element count or a negative error */
 int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64_t capacity);
 
 /* options: "graphs" (0/1 replay the step from a hipGraph), "grid_fwd", "grid_bwd", "grid_head", "grid_graph",

@@ -97,43 +97,104 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
   const int n = __builtin_amdgcn_readfirstlane(bytes > 0 ? bytes : 0);
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, n, 0x00020000);
 }
+// ---- cache policies of the activation / gradient streams (round 3) --------------------------------------------
+// A train step moves ~300 MB of activations and gradients through 8 x 4 MB of L2 and 256 MB of memory-side cache (MALL).
+// With the default policy every store leaves a dirty L2 line (written back in a burst when the kernel ends and its release
+// fence runs) and every load allocates in the MALL, so tensors that are dead after the read push out the ones the backward
+// pass comes back for.  Per stream (tools/gpu_variants.sh sweeps r3t-r3w, same session, +-0.0015 ms):
+//   stores of p_k (forward) and g_k (backward): sc1 = written through to memory as they are produced      -1.5 us per launch
+//   store of a0 (read again only by the very last backward launch): nt                                     -0.5 us
+//   backward loads of p_k / g_k / a0 (last use of each): nt = no allocation                                -1...2 us per launch,
+//                                                  and the NEXT step's forward launches find their inputs: -1.5 us each
+//   forward loads (p_{k-1}: the backward pass reads it again) and the head's read of p_L: default (nt: +2.5 us per launch);
+//   sc1|nt on the forward stores: +2 us per forward launch.
+// 0.329 -> 0.314 ms per step in total.  The macros exist for the sweeps (tools/build_variant.sh -DMWW_AUX_...=n).
+// Conv/BN graph kernels (Inception, 1.2 GB of traffic per step - nothing survives in the MALL): forward stores written
+// through -1.2 % (0.889 -> 0.879 ms); written-through gradient stores +1 %, nt loads of (g, p) +1.7 %: left at the default.
+#ifndef MWW_AUX_ST_P
+#define MWW_AUX_ST_P 16
+#endif
+#ifndef MWW_AUX_ST_G
+#define MWW_AUX_ST_G 16
+#endif
+#ifndef MWW_AUX_ST_A0
+#define MWW_AUX_ST_A0 2
+#endif
+#ifndef MWW_AUX_LD_FP
+#define MWW_AUX_LD_FP 0
+#endif
+#ifndef MWW_AUX_LD_BP
+#define MWW_AUX_LD_BP 2
+#endif
+#ifndef MWW_AUX_LD_A0
+#define MWW_AUX_LD_A0 2
+#endif
+#ifndef MWW_AUX_LD_PK
+#define MWW_AUX_LD_PK 2
+#endif
+#ifndef MWW_AUX_LD_GK
+#define MWW_AUX_LD_GK 2
+#endif
+#ifndef MWW_AUX_LD_HP
+#define MWW_AUX_LD_HP 0
+#endif
+#ifndef MWW_AUX_GR_ST_P
+#define MWW_AUX_GR_ST_P 1
+#endif
+#ifndef MWW_AUX_GR_ST_G
+#define MWW_AUX_GR_ST_G 0
+#endif
+#ifndef MWW_AUX_GR_LD_DP
+#define MWW_AUX_GR_LD_DP 0
+#endif
+// a plain store written through to memory (sc1) when WT, for the epilogues that address with pointers
+template <int WT>
+__device__ __forceinline__ void store_stream(float* p, float v) {
+  if constexpr (WT != 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// AUX = cache policy of the access (gfx940+ buffer instructions: 1 = sc0, 2 = nt, 16 = sc1; see "cache policies" below)
+template <int AUX = 0>
 __device__ __forceinline__ float4 tile_load4(BufRsrc r, int byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint2 tile_load2(BufRsrc r, int byte_off) {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, AUX);
   uint2 o;
   o.x = v.x;
   o.y = v.y;
   return o;
 }
+template <int AUX = 0>
 __device__ __forceinline__ float tile_load1(BufRsrc r, int byte_off) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void tile_store1(BufRsrc r, int byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, AUX);
 }
 // ---- bf16 storage of the block outputs p_k and the stashed gradients g_k ("storage_bf16", BASELINE configs[4]) ----
 // SB = true: the tensor holds bf16 (RNE on store, exact widening on load); arithmetic, accumulation and the BN sums
 // stay fp32.  Element / float4-group indices are the same in both modes, only the byte offsets differ.
-template <bool SB>
+template <bool SB, int AUX = 0>
 __device__ __forceinline__ float4 tile_load4s(BufRsrc r, int group) {   // group = index of a 4-channel group in the slice
   if constexpr (!SB) {
-    return tile_load4(r, group * 16);
+    return tile_load4<AUX>(r, group * 16);
   } else {
-    const uint2 v = tile_load2(r, group * 8);
+    const uint2 v = tile_load2<AUX>(r, group * 8);
     return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                        __uint_as_float(v.y & 0xffff0000u));
   }
 }
-template <bool SB>
+template <bool SB, int AUX = 0>
 __device__ __forceinline__ void tile_store1s(BufRsrc r, int elem, float v) {   // elem = element index in the slice
   if constexpr (!SB) {
-    tile_store1(r, elem * 4, v);
+    tile_store1<AUX>(r, elem * 4, v);
   } else {
     const __bf16 h = (__bf16)v;
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, elem * 2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, elem * 2, 0, AUX);
   }
 }
 template <bool SB>

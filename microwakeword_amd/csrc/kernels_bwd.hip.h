@@ -65,8 +65,8 @@ struct DpStage {
     const BufRsrc rp = tile_rsrc(pk_base, nvalid * 4 * elem_bytes(SB)), rg = tile_rsrc(g_base, nvalid * 4 * elem_bytes(SG));
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      pk[j] = tile_load4s<SB>(rp, tid + j * kThreads);
-      gg[j] = tile_load4s<SG>(rg, tid + j * kThreads);
+      pk[j] = tile_load4s<SB, MWW_AUX_LD_PK>(rp, tid + j * kThreads);
+      gg[j] = tile_load4s<SG, MWW_AUX_LD_GK>(rg, tid + j * kThreads);
     }
   }
 

@@ -320,7 +320,7 @@ __device__ __forceinline__ void store_tile_stats(const f32x4 (&acc)[NT], BufRsrc
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[nt][r];
-      tile_store1s<SB>(out, off + r * COUT + nt * 16, v);
+      tile_store1s<SB, MWW_AUX_ST_P>(out, off + r * COUT + nt * 16, v);
       s1[nt] += v;
       s2[nt] = fmaf(v, v, s2[nt]);
     }

@@ -224,17 +224,17 @@ template <int V>
 struct GVec {
   float f[V];
 };
-template <int V>
+template <int V, int AUX = 0>
 __device__ __forceinline__ GVec<V> gvec_bload(BufRsrc r, int elem) {
   GVec<V> o;
   if constexpr (V == 4) {
-    const float4 t = tile_load4(r, elem * 4);
+    const float4 t = tile_load4<AUX>(r, elem * 4);
     o.f[0] = t.x; o.f[1] = t.y; o.f[2] = t.z; o.f[3] = t.w;
   } else if constexpr (V == 2) {
-    const uint2 t = tile_load2(r, elem * 4);
+    const uint2 t = tile_load2<AUX>(r, elem * 4);
     o.f[0] = __uint_as_float(t.x); o.f[1] = __uint_as_float(t.y);
   } else {
-    o.f[0] = tile_load1(r, elem * 4);
+    o.f[0] = tile_load1<AUX>(r, elem * 4);
   }
   return o;
 }
@@ -352,8 +352,8 @@ __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int 
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int off = (t0 + u * nrg) * C + q * V;
-      g[u] = gvec_bload<V>(gslab, off);
-      p[u] = gvec_bload<V>(pslab, off);
+      g[u] = gvec_bload<V, MWW_AUX_GR_LD_DP>(gslab, off);
+      p[u] = gvec_bload<V, MWW_AUX_GR_LD_DP>(pslab, off);
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -587,7 +587,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         float* dst = a.out + ((size_t)b * Ttot + f0) * NC + c;
         for (int t = rg; t < Tout; t += nrg) {
           const float v = sOut[t * PO + c];
-          dst[(size_t)t * NC] = v;
+          store_stream<MWW_AUX_GR_ST_P>(dst + (size_t)t * NC, v);
           s1o += v;
           s2o = fmaf(v, v, s2o);
         }
@@ -632,7 +632,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
                     const float p = pv[u];
                     const int r = t - s.toff - f0;   // row of the output tile
                     const float gv = ((r >= 0 && (!CH || r < Tout) && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f) + gold[u];
-                    tile_store1(gr, (t * s.ld + c) * 4, gv);
+                    tile_store1<MWW_AUX_GR_ST_G>(gr, (t * s.ld + c) * 4, gv);
                     t1 += gv;
                     t2 = fmaf(gv, (p - mu) * rs, t2);
                   }
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
           gdw_block(sW + c, C, sIn + t0 * PI + c, PI, njb, o);
 #pragma unroll
           for (int i = 0; i < kGDwJ; ++i)
-            if (t0 + i < a.Tout) dst[(size_t)(t0 + i) * C] = o[i];
+            if (t0 + i < a.Tout) store_stream<MWW_AUX_GR_ST_P>(dst + (size_t)(t0 + i) * C, o[i]);
         }
       } else {
         const GSrc& s = a.src;
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
         if (t < a.T) {
           const float raw = pvf[u];
           const float gv = (fmaf(raw, sc, sh) > 0.f ? dzz * wvf[u] : 0.f) * kvf[u];
-          tile_store1(grs, (t * C + c) * 4, gv);
+          tile_store1<MWW_AUX_GR_ST_G>(grs, (t * C + c) * 4, gv);
           g1 += gv;
           g2 = fmaf(gv, (raw - mu) * rs, g2);
         }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
     const bool ok = b < a.B;
     const BufRsrc pr = tile_rsrc(elem_ptr<SB>(a.p, (size_t)(ok ? b : 0) * a.T * C), (ok && active) ? a.T * C * elem_bytes(SB) : 0);
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) dst[j] = tile_load4s<SB>(pr, (rg + NRG * j) * Q + q);
+    for (int j = 0; j < JMAX; ++j) dst[j] = tile_load4s<SB, MWW_AUX_LD_HP>(pr, (rg + NRG * j) * Q + q);
     yy = (ok && a.y != nullptr) ? a.y[b] : 0.f;
     ww = (ok && a.y != nullptr && (a.training & kHeadTraining)) ? a.sw[b] : 0.f;
   };

@@ -59,7 +59,7 @@ struct FinalSegment {
 };
 struct GradFinalArgs {
   FinalSegment seg[kMaxFinalSegments];
-  int nseg, nblocks;       // nblocks = workgroups of all segments (the metric workgroup, if any, follows)
+  int nseg, nblocks;       // nblocks = workgroups of all segments (the metric workgroup, if any, is block 0 in front of them)
   DenseGradArgs dense;     // kind 1: p, scale, shift, dz, B, n, C, keep, residual (part / stride / chunk unused)
   MetricsArgs met;
   int do_metrics;
@@ -123,9 +123,12 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
   __shared__ unsigned sH101[2][101];
   __shared__ unsigned sH200[2][200];
   __shared__ unsigned sCnt[8];
-  const int bid = blockIdx.x, tid = threadIdx.x;
-  if (bid >= a.nblocks) {
-    if (a.do_metrics) metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-wave BCE partials
+  const int tid = threadIdx.x;
+  // (the metric workgroup, if any, is block 0: its chain - probabilities in, histograms, counters out - is the longest
+  // after the dense role's)
+  const int bid = (int)blockIdx.x - a.do_metrics;
+  if (bid < 0) {
+    metrics_body<kThreads>(a.met, sH101, sH200, sCnt, sAcc, tid);   // sAcc doubles as the per-wave BCE partials
     return;
   }
   int si = 0;

@@ -763,12 +763,18 @@ int assemble_range(mww_ctx* c, int B, const GradReduceArgs& ga, int64_t lo, int6
   a.apply_adam = apply_adam ? 1 : 0;
   for (size_t first = 0; first < all.size() || (metrics && first == 0); first += kMaxFinalSegments) {
     const int n = (int)std::min<size_t>(kMaxFinalSegments, all.size() - first);
-    int nb = 0;
-    for (int i = 0; i < n; ++i) {
-      a.seg[i] = all[first + i];
-      a.seg[i].block0 = nb;
-      nb += (a.seg[i].n + kFinalCols - 1) / kFinalCols;
-    }
+    // workgroups are dispatched in block order: the longest role (the dense kernel's gradient: B strided rows of p_L per
+    // parameter) takes the first blocks, so that it starts first
+    int nb = 0, ns = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int i = 0; i < n; ++i) {
+        const FinalSegment& sg = all[first + i];
+        if ((sg.kind == kSegDense) != (pass == 0)) continue;
+        a.seg[ns] = sg;
+        a.seg[ns].block0 = nb;
+        nb += (sg.n + kFinalCols - 1) / kFinalCols;
+        ++ns;
+      }
     a.nseg = n;
     a.nblocks = nb;
     a.do_metrics = (metrics && first == 0) ? 1 : 0;
@@ -2874,6 +2880,7 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
   else if ((k = idx("g")) >= 0) { src = c->L[k].g; n = (int64_t)B * c->L[k].tout * c->L[k].cout; stored = true; }
   else if ((k = idx("bn")) >= 0) { src = c->L[k].bn; n = (int64_t)9 * c->L[k].cout; }
   else if (!strcmp(name, "dz")) { src = c->dz; n = B; }
+  else if (!strcmp(name, "a0")) { src = c->a0; n = (int64_t)B * c->L[0].tin * c->d.conv1_filters; }   // relu(conv1(x)) as the first block stored it
   else if (!strncmp(name, "clkf", 4) || !strncmp(name, "clkb", 4)) {
     // phase clocks of layer k (1-based) as raw 64-bit counters viewed as floats: 2048 x 8 x 2 words
     const int kk = atoi(name + 4);

@@ -314,7 +314,13 @@ def mixednet_logits(flags, tensors, x, training, taps=None, relu_masks=None):
     net = x.transpose(1, 2)  # [B,40,T]
     f0, stride = _get(flags, "first_conv_filters"), _get(flags, "stride")
     if f0 > 0:
-        net = torch.relu(cur.conv(net, "conv1", stride=stride))
+        net = cur.conv(net, "conv1", stride=stride)
+        if taps is not None:
+            taps["conv1.pre"] = net.transpose(1, 2)
+        if relu_masks is not None and "conv1" in relu_masks:
+            net = net * relu_masks["conv1"].to(net.dtype)   # (test aid, as for the block outputs below)
+        else:
+            net = torch.relu(net)
         if taps is not None:
             taps["conv1"] = net.transpose(1, 2)
     pf, rep = parse(_get(flags, "pointwise_filters")), parse(_get(flags, "repeat_in_block"))

@@ -16,6 +16,5 @@ template __global__ void head_kernel<48, 8>(HeadArgs);
 }
 #include "../../microwakeword_amd/csrc/kernels_fused.hip.h"
 namespace mww {
-template __global__ void fwd_fused_kernel<3, 32, 1, 48, 5, 9, 13, 21, false, false>(FwdFusedArgs);
 template __global__ void bwd_fused_kernel<3, 32, 1, 48, 5, 9, 13, 21, false, false>(BwdFusedArgs);
 }
