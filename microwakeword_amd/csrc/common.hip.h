@@ -104,11 +104,12 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
 // pass comes back for.  Per stream (tools/gpu_variants.sh sweeps r3t-r3w, same session, +-0.0015 ms):
 //   stores of p_k (forward) and g_k (backward): sc1 = written through to memory as they are produced      -1.5 us per launch
 //   store of a0 (read again only by the very last backward launch): nt                                     -0.5 us
+//   the weight-gradient partial rows a backward launch writes in its last microsecond: written through     -0.5 us per launch
 //   backward loads of p_k / g_k / a0 (last use of each): nt = no allocation                                -1...2 us per launch,
 //                                                  and the NEXT step's forward launches find their inputs: -1.5 us each
 //   forward loads (p_{k-1}: the backward pass reads it again) and the head's read of p_L: default (nt: +2.5 us per launch);
 //   sc1|nt on the forward stores: +2 us per forward launch.
-// 0.329 -> 0.314 ms per step in total.  The macros exist for the sweeps (tools/build_variant.sh -DMWW_AUX_...=n).
+// 0.329 -> 0.312 ms per step in total.  The macros exist for the sweeps (tools/build_variant.sh -DMWW_AUX_...=n).
 // Conv/BN graph kernels (Inception, 1.2 GB of traffic per step - nothing survives in the MALL): forward stores written
 // through -1.2 % (0.889 -> 0.879 ms); written-through gradient stores +1 %, nt loads of (g, p) +1.7 %: left at the default.
 #ifndef MWW_AUX_ST_P
@@ -137,6 +138,9 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
 #endif
 #ifndef MWW_AUX_LD_HP
 #define MWW_AUX_LD_HP 0
+#endif
+#ifndef MWW_AUX_ST_GP
+#define MWW_AUX_ST_GP 1
 #endif
 #ifndef MWW_AUX_GR_ST_P
 #define MWW_AUX_GR_ST_P 1

@@ -258,7 +258,7 @@ __device__ __forceinline__ void write_block_grad_partials(float* scratch, float*
         scratch[(wave * CIN + mt * 16 + g * 4 + r) * COUT + nt * 16 + r16] = dwacc[mt][nt][r];
   __syncthreads();
   for (int e = tid; e < CIN * COUT; e += kThreads)
-    dst[(K + 1) * CIN + e] = (scratch[e] + scratch[CIN * COUT + e]) + (scratch[2 * CIN * COUT + e] + scratch[3 * CIN * COUT + e]);
+    store_stream<MWW_AUX_ST_GP>(dst + (K + 1) * CIN + e, (scratch[e] + scratch[CIN * COUT + e]) + (scratch[2 * CIN * COUT + e] + scratch[3 * CIN * COUT + e]));
   __syncthreads();
   if (dw_active) {
 #pragma unroll
@@ -270,7 +270,7 @@ __device__ __forceinline__ void write_block_grad_partials(float* scratch, float*
     float v = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) v += scratch[j * (K + 1) * CIN + e];
-    dst[e] = v;
+    store_stream<MWW_AUX_ST_GP>(dst + e, v);
   }
   __syncthreads();
 }
