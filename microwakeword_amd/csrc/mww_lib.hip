@@ -151,6 +151,7 @@ struct mww_ctx {
   float* bn_state = nullptr;
   float *x = nullptr, *y = nullptr, *sw = nullptr, *z = nullptr, *prob = nullptr, *dz = nullptr, *loss_part = nullptr;
   float* a0 = nullptr;     // relu(conv1(x)) [max_batch][Ta][conv1_filters]: written by the training forward, read by bwd_first_kernel
+  float* gbuf[2] = {nullptr, nullptr};   // the two buffers the blocks' g_k take in turn (block k uses gbuf[k & 1])
   float* dwd_part = nullptr;
   MetricState* metrics = nullptr;
   // "mailboxes": pinned host memory mapped into the device address space.  The host writes one
@@ -2001,10 +2002,23 @@ int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx*
 #define A(call) if ((rc = (call)) != 0) { mww_destroy(c); return rc; }
   A(alloc_common(c));
   A(dev_alloc(&c->a0, mb * c->L[0].tin * d.conv1_filters));
+#ifndef MWW_G_PINGPONG
+#define MWW_G_PINGPONG 1
+#endif
+  // g_k (the gradient at block k's BN output) is written by the backward launch of block k+1 and read by block k's, once: two
+  // buffers taken in turn hold them all (35 MB each at the headline batch instead of one per block - address space the
+  // memory-side cache does not have to give up activations for)
+  if (MWW_G_PINGPONG) {
+    size_t need[2] = {0, 0};
+    for (int i = 0; i < d.n_blocks; ++i) need[i & 1] = std::max(need[i & 1], mb * c->L[i].tout * c->L[i].cout);
+    for (int par = 0; par < 2; ++par)
+      if (need[par]) A(dev_alloc(&c->gbuf[par], need[par]));
+  }
   for (int i = 0; i < d.n_blocks; ++i) {
     Layer& l = c->L[i];
     A(dev_alloc(&l.p, mb * l.tout * l.cout));
-    A(dev_alloc(&l.g, mb * l.tout * l.cout));
+    if (MWW_G_PINGPONG) l.g = c->gbuf[i & 1];
+    else A(dev_alloc(&l.g, mb * l.tout * l.cout));
     A(dev_alloc(&l.stat_part, (size_t)gmax_f * 2 * l.cout));
     A(dev_alloc(&l.gstat_part, (size_t)std::max(gmax_b, c->n_cu * 4) * 2 * l.cout));
     for (int par = 0; par < 2; ++par) {
@@ -2447,9 +2461,10 @@ void mww_destroy(mww_ctx* c) {
                   c->z, c->prob, c->dz, c->loss_part, c->dwd_part, c->metrics, c->phase_clk, c->a0};
   for (void* p : flat) if (p) (void)hipFree(p);
   for (auto& l : c->L) {
-    void* lp[] = {l.p, l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn, l.facc[0], l.facc[1], l.gacc[0], l.gacc[1]};
+    void* lp[] = {l.p, (c->gbuf[0] || c->gbuf[1]) ? nullptr : l.g, l.stat_part, l.gstat_part, l.grad_part, l.bn, l.facc[0], l.facc[1], l.gacc[0], l.gacc[1]};
     for (void* p : lp) if (p) (void)hipFree(p);
   }
+  for (float* p : c->gbuf) if (p) (void)hipFree(p);
   for (auto& o : c->G) {
     void* op[] = {o.p, o.g, o.stat_part, o.gstat_part, o.grad_part, o.bn, o.facc[0], o.facc[1], o.gacc[0], o.gacc[1]};
     for (void* p : op) if (p) (void)hipFree(p);
