@@ -148,6 +148,12 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
 #ifndef MWW_AUX_GR_ST_G
 #define MWW_AUX_GR_ST_G 0
 #endif
+#ifndef MWW_AUX_GR_LD_GOLD
+#define MWW_AUX_GR_LD_GOLD 0
+#endif
+#ifndef MWW_AUX_GR_ST_GP
+#define MWW_AUX_GR_ST_GP 0
+#endif
 #ifndef MWW_AUX_GR_LD_DP
 #define MWW_AUX_GR_LD_DP 0
 #endif

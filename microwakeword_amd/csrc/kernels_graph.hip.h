@@ -623,7 +623,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
                 for (int u = 0; u < kGE; ++u) {
                   const int off = ((tb + u * nrg) * s.ld + c) * 4;
                   pv[u] = tile_load1(pr, off);
-                  gold[u] = tile_load1(go, off);
+                  gold[u] = tile_load1<MWW_AUX_GR_LD_GOLD>(go, off);
                 }
 #pragma unroll
                 for (int u = 0; u < kGE; ++u) {
@@ -828,7 +828,7 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + g * 4 + r, co = nt * 16 + r16;
-            if (m < tasks && co < NC) dst[(size_t)m * NC + co] = acc[u][nt][r];
+            if (m < tasks && co < NC) store_stream<MWW_AUX_GR_ST_GP>(dst + (size_t)m * NC + co, acc[u][nt][r]);
           }
       }
     }
