@@ -108,7 +108,7 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
 //   backward loads of p_k / g_k / a0 (last use of each): nt = no allocation                                -1...2 us per launch,
 //                                                  and the NEXT step's forward launches find their inputs: -1.5 us each
 //   forward loads (p_{k-1}: the backward pass reads it again) and the head's read of p_L: default (nt: +2.5 us per launch);
-//   sc1|nt on the forward stores: +2 us per forward launch.
+//   sc1|nt on the forward stores: +2 us per forward launch; nt on the first block's gathers from the feature stores: no effect.
 // 0.329 -> 0.312 ms per step in total.  The macros exist for the sweeps (tools/build_variant.sh -DMWW_AUX_...=n).
 // Conv/BN graph kernels (Inception, 1.2 GB of traffic per step - nothing survives in the MALL): forward stores written
 // through -1.2 % (0.889 -> 0.879 ms); written-through gradient stores +1 %, nt loads of (g, p) +1.7 %: left at the default.
@@ -135,6 +135,12 @@ __device__ __forceinline__ BufRsrc tile_rsrc(const void* base, int bytes) {
 #endif
 #ifndef MWW_AUX_LD_GK
 #define MWW_AUX_LD_GK 2
+#endif
+#ifndef MWW_AUX_LD_XF
+#define MWW_AUX_LD_XF 0
+#endif
+#ifndef MWW_AUX_LD_XB
+#define MWW_AUX_LD_XB 0
 #endif
 #ifndef MWW_AUX_LD_HP
 #define MWW_AUX_LD_HP 0

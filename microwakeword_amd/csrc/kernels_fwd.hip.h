@@ -95,7 +95,7 @@ __device__ __forceinline__ void xgather_setup(const XGather& g, XShared& sh, int
 // from a per-thread base, in HBM (float4 index tid + 250 j of the tile) and in LDS (odd row pitch PX).
 // issue() fetches rows [row0, row0 + nrows) of the sample (dense) or gathers them (store rows row0 - pad_rows ...);
 // commit() writes them to LDS, converting / masking in gather mode.
-template <int XROWS, int PX>
+template <int XROWS, int PX, int AUX = 0>
 struct XStage {
   static constexpr int QX = FBINS / 4, RPP = kThreads / QX, ACT = RPP * QX, NJ = (XROWS + RPP - 1) / RPP;
   float4 pre[NJ];
@@ -123,7 +123,7 @@ struct XStage {
     const int off0 = tid < ACT ? (tid - r_lo * QX) * gb : kOobOffset;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const uint2 a = tile_load2(lo, off0 + ACT * j * gb), c = tile_load2(hi, off0 + ACT * j * gb);
+      const uint2 a = tile_load2<AUX>(lo, off0 + ACT * j * gb), c = tile_load2<AUX>(hi, off0 + ACT * j * gb);
       pre[j] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(c.x), __uint_as_float(c.y));
     }
   }
