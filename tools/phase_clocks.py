@@ -10,7 +10,7 @@ from microwakeword_amd.model import Model
 
 import subprocess
 from microwakeword_amd import native
-LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_hip_prof.so")   # tools/build_prof.sh (-DMWW_PROFILE), built in the container
+LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_prof.so")   # FULL=1 bash tools/build_variant.sh prof -DMWW_PROFILE, built in the container
 if not os.path.isfile(LIB):
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PROFILE",
                     "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
