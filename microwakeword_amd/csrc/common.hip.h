@@ -314,17 +314,6 @@ struct PhaseClock {
   }
 };
 
-// stores of the big activation / gradient tensors: consumed by the NEXT launch, usually on another XCD.  With
-// -DMWW_NT_STORES they are streaming stores (no dirty lines left for the end-of-kernel L2 write-back); measured
-// neutral on the default step (0.398 vs 0.395-0.398 ms), so plain stores stay the default.
-__device__ __forceinline__ void store_stream(float* p, float v) {
-#ifdef MWW_NT_STORES
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-
 // q = a / b, r = a % b for 0 <= a < 2^22 and b > 0 known only at run time: a reciprocal, a multiply and a one-step
 // correction (~10 VALU) instead of the ~35-instruction integer division the compiler emits; the conv/BN graph kernels
 // decompose thread / element indices by run-time channel counts dozens of times per window.
