@@ -58,6 +58,10 @@ struct FinalSegment {
   int block0;          // first workgroup of this segment
 };
 struct GradFinalArgs {
+  // first workgroup of every segment, ascending, INT_MAX past nseg: a workgroup finds its segment by counting - 56 scalar
+  // compares on four wide scalar loads - instead of walking seg[].block0 (one dependent scalar-cache round trip per two
+  // segments in the round-2 ISA: ~14 of them in front of every workgroup's first vector load)
+  int block0[kMaxFinalSegments];
   FinalSegment seg[kMaxFinalSegments];
   int nseg, nblocks;       // nblocks = workgroups of all segments (the metric workgroup, if any, is block 0 in front of them)
   DenseGradArgs dense;     // kind 1: p, scale, shift, dz, B, n, C, keep, residual (part / stride / chunk unused)
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(kThreads) void grad_final_kernel(GradFinalArgs a) {
     return;
   }
   int si = 0;
-  for (int i = 1; i < a.nseg; ++i)
-    if (bid >= a.seg[i].block0) si = i;
+#pragma unroll
+  for (int i = 1; i < kMaxFinalSegments; ++i) si += (int)((unsigned)(a.block0[i] - 1 - bid) >> 31);   // bid >= block0[i], as sign arithmetic
   const FinalSegment s = a.seg[si];
   const int pl = tid % kFinalCols, sl = tid / kFinalCols;
   const int e = (bid - s.block0) * kFinalCols + pl;

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <map>
 #include <string>
@@ -773,9 +774,11 @@ int assemble_range(mww_ctx* c, int B, const GradReduceArgs& ga, int64_t lo, int6
         if ((sg.kind == kSegDense) != (pass == 0)) continue;
         a.seg[ns] = sg;
         a.seg[ns].block0 = nb;
+        a.block0[ns] = nb;
         nb += (sg.n + kFinalCols - 1) / kFinalCols;
         ++ns;
       }
+    for (int i = ns; i < kMaxFinalSegments; ++i) a.block0[i] = INT_MAX;
     a.nseg = n;
     a.nblocks = nb;
     a.do_metrics = (metrics && first == 0) ? 1 : 0;
