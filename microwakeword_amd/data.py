@@ -128,6 +128,7 @@ class FeatureHandler:
         self._private_rng = None
         self._prefetch_depth = 0
         self._pf = None
+        self.eval_shard = (0, 1)   # (rank, world): evaluate_on_device scores windows rank, rank + W, ... (parallel.shard_feature_handler)
         if engine is not None:
             self.attach(engine)
 
@@ -215,6 +216,19 @@ class FeatureHandler:
         py, npst, _, _ = self._export_global_rng()
         self._private_rng = (py, npst)
         self._prefetch_depth = int(prefetch)
+
+    def release_private_rng(self):
+        """Hand the private streams back: the global ``random`` / ``numpy.random`` generators continue from where the last
+        batch HANDED OUT left the private copies, and later draws use the global generators again.  The train loop
+        brackets every validation pass with this and ``use_private_rng``: the reference's validation shuffles
+        (data.py:593-595, on the global numpy stream) then advance the same stream the next training draws continue
+        from, exactly as they do without private streams."""
+        self._drop_prefetcher()
+        if self._private_rng is not None:
+            py, npst = self._private_rng
+            _, _, ps, ns = self._export_global_rng()
+            self._import_global_rng(py, npst, ps, ns)
+            self._private_rng = None
 
     def _drop_prefetcher(self, keep_streams=True):
         """Stop the worker; the private streams continue from the last batch it HANDED OUT (what it drew ahead is discarded)."""
@@ -327,7 +341,7 @@ class FeatureHandler:
     def _eval_windows(self, mode, features_length, truncation_strategy):
         """Window descriptors, labels and weights of a whole evaluation mode.  Deterministic strategies are
         indexed once and cached (validation runs every eval_step_interval steps on the same windows)."""
-        key = (mode, int(features_length), truncation_strategy)
+        key = (mode, int(features_length), truncation_strategy, self.eval_shard[1] > 1)
         cache = self.__dict__.setdefault("_eval_cache", {})
         if key in cache:
             return cache[key]
@@ -340,7 +354,10 @@ class FeatureHandler:
         win, labels, weights, split_blocks = [], [], [], []
         for p in self.feature_providers:
             strat = p.strategy(truncation_strategy)
-            for fi, sub in p.feature_sets[mode]:
+            # data-parallel ranks index the samples in canonical (store, sample) order: the per-mode shuffle of
+            # MmapFeatureProvider (global ``random`` stream) need not agree between processes, the shards must
+            samples = sorted(p.feature_sets[mode]) if self.eval_shard[1] > 1 else p.feature_sets[mode]
+            for fi, sub in samples:
                 length = p.sample_len[fi][sub]
                 base = p.sample_start[fi][sub]
                 sid = p.store_id[p.feature_dtype[fi]]
@@ -392,7 +409,8 @@ class FeatureHandler:
         host round trip of the spectrograms: the windows are gathered from the HBM-resident stores
         straight into the engine's batch buffer, the inference-mode forward runs on them and the
         threshold counters accumulate on the device.  Consumes the same ``np.random.shuffle`` draw as
-        ``get_data`` so the global RNG stream stays where the reference would leave it.  Like Keras'
+        ``get_data`` so the global RNG stream stays where the reference would leave it (single process; a data-parallel
+        rank shuffles its own shard of the windows, ``eval_shard``, and ``labels`` are that shard's).  Like Keras'
         ``evaluate`` it starts by calling ``model.reset_metrics()`` (looked up at call time, so the
         reference's no-op swap still works).  Returns ``(n_windows, labels, model metric results)``."""
         self._need_engine()
@@ -402,12 +420,18 @@ class FeatureHandler:
             raise NotImplementedError("variable-length ('none') evaluation is outside the MI355X path")
         win, labels, _ = self._eval_windows(mode, features_length, truncation_strategy)
         n = win.shape[0]
-        indices = np.arange(n)
+        rank, world = self.eval_shard
+        if world > 1:
+            # data-parallel validation: the window list is the same on every rank, rank r scores windows
+            # r, r + W, ...; the counters are summed over the ranks when the results are read (Model.evaluation_results)
+            mine = np.arange(rank, n, world)
+            win, labels = win[mine], labels[mine]
+        indices = np.arange(win.shape[0])
         np.random.shuffle(indices)
         win, labels = win[indices], labels[indices].astype(np.float32)
         model.reset_metrics()
         bs = min(int(batch_size), self.engine.max_batch)
-        if n:
+        if win.shape[0]:
             self.engine.evaluate_windows(win, labels, bs)   # one native call: the batches are walked inside the library
         return n, labels, model.evaluation_results()
 

@@ -130,6 +130,7 @@ class Model:
         self.loss = None
         self.train_function = None
         self._compiled = False
+        self.data_parallel = None   # parallel.DataParallel once join_data_parallel() was called
         self.sample_weight_broadcast = DEFAULT_WEIGHT_BROADCAST   # how a [B,B] sample_weight matrix is reduced (combine_weights)
 
     # ---- Keras surface
@@ -166,8 +167,25 @@ class Model:
         self.engine.metrics_reset()
         self._loss_sum, self._loss_n = 0.0, 0
 
-    def _metric_results(self):
-        return native.metrics_from_raw(self.engine.metrics_raw())
+    def join_data_parallel(self, group=None, sync_bn=False, grad_buckets=1, library_comm=True):
+        """One process per GPU (``torch.distributed`` initialised by the caller): from here on ``train_on_batch`` /
+        ``train_on_device_batch`` are data-parallel steps - local forward / backward on this rank's batch, one all-reduce
+        of the flat gradient inside the engine's step, Adam on the average (parallel.DataParallel) - and
+        ``evaluation_results`` reports the counters summed over the ranks (validation is sharded by
+        ``FeatureHandler.evaluate_on_device``).  Collective: every rank calls it."""
+        from .parallel import DataParallel
+        self.data_parallel = DataParallel.for_engine(self.engine, group=group, sync_bn=sync_bn, grad_buckets=grad_buckets,
+                                                     library_comm=library_comm)
+        return self.data_parallel
+
+    def _metric_results(self, reduce=False):
+        """``reduce``: the counters of every rank's context summed by ONE all-reduce of the raw state (collective; the
+        device counters themselves stay rank-local, so accumulation across calls keeps working)."""
+        raw = self.engine.metrics_raw()
+        dp = self.data_parallel
+        if reduce and dp is not None and dp.world > 1:
+            raw = native.metrics_from_vector(dp.allreduce_host(native.metrics_to_vector(raw)))
+        return native.metrics_from_raw(raw)
 
     def _per_sample_weights(self, sample_weight, n):
         if sample_weight is None:
@@ -247,15 +265,16 @@ class Model:
             self.engine.set_batch(x[s:e])
             self.engine.set_targets(y[s:e], np.ones(e - s, np.float32))
             self.engine.forward(e - s, training=False, update_metrics=True)
-        res = self.evaluation_results()
+        res = self.evaluation_results(reduce=False)   # host arrays are not sharded: every rank scored all of x
         if return_dict:
             return res
         return [res["loss"], res["accuracy"], res["recall"], res["precision"], res["tp"], res["fp"], res["tn"], res["fn"],
                 res["auc"], res["loss"]]
 
-    def evaluation_results(self):
-        """The ``return_dict=True`` result of ``evaluate`` from the counters accumulated so far."""
-        m = self._metric_results()
+    def evaluation_results(self, reduce=True):
+        """The ``return_dict=True`` result of ``evaluate`` from the counters accumulated so far (data-parallel: over all
+        ranks - a collective call)."""
+        m = self._metric_results(reduce=reduce)
         return dict(accuracy=m["accuracy"], recall=m["recall"], precision=m["precision"], auc=m["auc"], loss=m["loss"],
                     tp=_Counts(m["tp"]), fp=_Counts(m["fp"]), tn=_Counts(m["tn"]), fn=_Counts(m["fn"]))
 

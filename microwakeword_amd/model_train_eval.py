@@ -7,6 +7,13 @@ Mirrors microwakeword/model_train_eval.py:
   * ``train_model(config, model, data_processor, restore_checkpoint)``   :99-128
   * argparse surface                          :277-389 (the ``--test_*`` export flags are accepted; TFLite
     export / streaming evaluation stay with the reference and raise here if requested)
+
+Data-parallel over the GPUs of one node (no reference equivalent): launched as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m
+microwakeword_amd.model_train_eval --training_config cfg.yaml mixednet ...`` every process reads ``RANK`` / ``LOCAL_RANK`` /
+``WORLD_SIZE``, takes GPU ``LOCAL_RANK``, joins an RCCL process group and ``train.train`` does the rest (sharded providers,
+gradient all-reduce inside the step, sharded validation, rank 0 writes the files).  ``batch_size`` of the YAML stays the
+global batch.
 """
 from __future__ import annotations
 
@@ -54,18 +61,59 @@ def save_model_summary(model, path, file_name="model_summary.txt"):
         model.summary(print_fn=lambda x: fd.write(x + "\n"))
 
 
+def claim_train_dir(config, restore_checkpoint):
+    """model_train_eval.py:99-120: the run owns a fresh ``train_dir`` unless it restores a checkpoint.  In a data-parallel
+    job rank 0 creates the directory and every rank learns the outcome (one object broadcast), so that all of them raise
+    - or none."""
+    rank, world = train_mod.process_group()
+    exists = False
+    if rank == 0:
+        try:
+            os.makedirs(config["train_dir"])
+            os.mkdir(config["summaries_dir"])
+        except OSError:
+            exists = True
+    if world > 1:
+        import torch.distributed as dist
+        box = [exists]
+        dist.broadcast_object_list(box, src=0)
+        exists = box[0]
+    if exists and not restore_checkpoint:
+        raise ValueError("model already exists in folder %s" % config["train_dir"]) from None
+
+
 def train_model(config, model, data_processor, restore_checkpoint):
-    try:
-        os.makedirs(config["train_dir"])
-        os.mkdir(config["summaries_dir"])
-    except OSError:
-        if not restore_checkpoint:
-            raise ValueError("model already exists in folder %s" % config["train_dir"]) from None
-    with open(os.path.join(config["train_dir"], "training_config.yaml"), "w") as outfile:
-        yaml.dump({k: v for k, v in config.items() if k != "features" or all("stores" not in f for f in v)}, outfile,
-                  default_flow_style=False)
-    save_model_summary(model, config["train_dir"])
+    if train_mod.process_group()[0] == 0:
+        with open(os.path.join(config["train_dir"], "training_config.yaml"), "w") as outfile:
+            yaml.dump({k: v for k, v in config.items() if k != "features" or all("stores" not in f for f in v)}, outfile,
+                      default_flow_style=False)
+        save_model_summary(model, config["train_dir"])
     return train_mod.train(model, config, data_processor)
+
+
+def init_process_group_from_env():
+    """One process per GPU: ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT`` as
+    ``torch.distributed.run`` exports them.  Returns (rank, local_rank, world); (0, None, 1) outside such a launch - torch is
+    not imported then.  The backend is RCCL (``"nccl"``); ``MWW_DIST_BACKEND=gloo`` serves host-emulated builds of the
+    library (tests)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, None, 1
+    import torch
+    import torch.distributed as dist
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    backend = os.environ.get("MWW_DIST_BACKEND", "nccl")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            # 88 KB of gradient per step: latency-bound, one or two channels move it as fast as many (DESIGN 6)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
 
 
 def build_parser():
@@ -98,16 +146,23 @@ def main(argv=None):
         model_module = inception
     else:
         raise ValueError("Unknown model type: {}".format(flags.model_name))
-    logging.basicConfig(level=getattr(logging, flags.verbosity.upper(), logging.INFO))
+    rank, local_rank, world = init_process_group_from_env()
+    logging.basicConfig(level=getattr(logging, flags.verbosity.upper(), logging.INFO) if rank == 0 else logging.WARNING)
     if any((flags.test_tf_nonstreaming, flags.test_tflite_nonstreaming, flags.test_tflite_nonstreaming_quantized,
             flags.test_tflite_streaming, flags.test_tflite_streaming_quantized)):
         raise NotImplementedError("model export / TFLite evaluation stays with the reference (microwakeword.utils / .test); "
                                   "train here, then load the saved weights there (INTEGRATION.md)")
     config = load_config(flags, model_module)
     if flags.train:
-        model = model_module.model(flags, config["training_input_shape"], config["batch_size"], device=flags.device)
+        claim_train_dir(config, flags.restore_checkpoint)
+        device = flags.device if local_rank is None else local_rank
+        if world > 1 and config["batch_size"] % world:
+            raise ValueError("batch_size %d (the global batch) is not divisible by the %d ranks" % (config["batch_size"], world))
+        # every rank's engine holds batch_size / W windows per step
+        model = model_module.model(flags, config["training_input_shape"], config["batch_size"] // world, device=device)
         data_processor = FeatureHandler(config, engine=model.engine)
-        model.summary(print_fn=logging.getLogger("microwakeword_amd").info)
+        if rank == 0:
+            model.summary(print_fn=logging.getLogger("microwakeword_amd").info)
         return train_model(config, model, data_processor, flags.restore_checkpoint)
     if not os.path.isdir(config["train_dir"]):
         raise ValueError('model is not trained set "--train 1" and retrain it')

@@ -120,6 +120,9 @@ class NativeLib:
         except OSError as e:
             raise NativeError("cannot load %s: %s" % (self.path, e)) from None
         L = self.lib
+        # a host-emulated build of the product sources (tests/hipemu): its "device" memory is host memory, so process groups
+        # without device support (gloo) can reduce it in place - parallel.DataParallel.for_engine asks
+        self.host_emulated = hasattr(L, "hipemu_host_memory")
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise NativeError("%s does not export %s (stale build?)" % (self.path, name))
@@ -271,6 +274,7 @@ class Engine:
         self.nl = lib or NativeLib.get()
         self.max_batch = int(max_batch)
         self.frames = int(frames)
+        self.device = int(device)
         if conv_ops is not None:
             d = ConvNetDesc()
             d.frames, d.n_ops, d.dropout, d.max_batch = int(frames), len(conv_ops), float(dropout), int(max_batch)
@@ -517,7 +521,35 @@ class Engine:
         return list(zip(nm, ms[:n].tolist()))
 
 
-def metrics_from_raw(m: MetricsRaw) -> dict:
+_METRIC_SCALARS = ("n", "correct", "tp5", "fp5", "fn5", "pos", "neg", "bce_sum")
+
+
+class MetricsSum:
+    """The fields of ``MetricsRaw`` as float64 (a sum of several contexts' counters)."""
+
+
+def metrics_to_vector(m) -> np.ndarray:
+    """The raw cumulative counters as one float64 vector (610 entries; the integer counters are exact below 2**53), the
+    unit of the data-parallel validation's one all-reduce."""
+    h101 = np.array([[m.hist101[l][i] for i in range(101)] for l in range(2)], np.float64)
+    h200 = np.array([[m.hist200[l][i] for i in range(200)] for l in range(2)], np.float64)
+    v = np.concatenate([h101.reshape(-1), h200.reshape(-1), [float(getattr(m, k)) for k in _METRIC_SCALARS]])
+    if v[:-1].max(initial=0.0) >= 2.0 ** 53:
+        raise OverflowError("metric counters beyond 2**53")
+    return v
+
+
+def metrics_from_vector(v: np.ndarray) -> MetricsSum:
+    v = np.asarray(v, np.float64)
+    m = MetricsSum()
+    m.hist101 = v[:202].reshape(2, 101)
+    m.hist200 = v[202:602].reshape(2, 200)
+    for k, x in zip(_METRIC_SCALARS, v[602:]):
+        setattr(m, k, float(x))
+    return m
+
+
+def metrics_from_raw(m) -> dict:
     """Derives the reference's nine compiled metrics (train.py:209-221) from the raw counters."""
     h101 = np.array([[m.hist101[l][i] for i in range(101)] for l in range(2)], np.float64)
     h200 = np.array([[m.hist200[l][i] for i in range(200)] for l in range(2)], np.float64)

@@ -23,6 +23,7 @@ barriers of the caller.  The callback form (``mww_set_allreduce_hook`` -> ``Data
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import random
 from typing import Optional
 
@@ -43,17 +44,30 @@ def wrap_device_floats(ptr: int, n: int, device) -> torch.Tensor:
     return torch.as_tensor(_DeviceArray(ptr, n), device=device)
 
 
-def shard_feature_handler(handler, rank: int, world: int, seed: int):
-    """Per provider keep training samples ``rank, rank+W, ...`` of the (identically shuffled) list and
-    give the rank its own RNG streams."""
+def host_floats(ptr: int, n: int) -> torch.Tensor:
+    """A torch view of ``n`` floats of HOST memory (the "device" memory of a host-emulated build of the library, which a
+    gloo group can reduce in place)."""
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr)))
+
+
+def shard_feature_handler(handler, rank: int, world: int, seed: int, prefetch: int = 2):
+    """Per provider keep training samples ``rank, rank+W, ...`` of the provider's list in CANONICAL (store, sample) order -
+    a partition whatever per-rank shuffle produced the list (``MmapFeatureProvider`` shuffles with the global ``random``
+    stream, which need not stand at the same point on every rank) - and give the rank its own RNG streams
+    (``seed * W + rank``).  Validation windows are sharded by index in ``FeatureHandler.evaluate_on_device``
+    (``handler.eval_shard``).  SURVEY 8(e)."""
     for p in handler.feature_providers:
-        p.feature_sets["training"] = p.feature_sets["training"][rank::world]
+        p.feature_sets["training"] = sorted(p.feature_sets["training"])[rank::world]
         if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:
             raise ValueError("provider has fewer training samples than ranks")
     handler._sampler = None
+    handler.eval_shard = (int(rank), int(world))
     random.seed(seed * world + rank)
     np.random.seed(seed * world + rank)
-    handler.use_private_rng()
+    try:
+        handler.use_private_rng(prefetch=prefetch)
+    except TypeError:   # duck-typed handlers without the prefetch argument
+        handler.use_private_rng()
 
 
 class DataParallel:
@@ -90,15 +104,15 @@ class DataParallel:
             raise ValueError("sync_bn needs a wrap(ptr, n) function")
         self.engine_driven = wrap is not None or library_comm
         if library_comm:
-            try:
-                self._join_library_communicator()
-            except native.NativeError as e:
-                # e.g. no librccl.so next to this process: every rank fails the same way (before the collective join), and every
-                # rank falls back to the callback form over the caller's process group
+            # the ranks decide TOGETHER whether the library-owned communicator is used (every step of the join is followed by
+            # an all_reduce(MIN) of its success flag): a rank that cannot load librccl, or whose ncclCommInitRank fails, takes
+            # every rank to the callback form over the caller's process group - or every rank raises
+            err = self._join_library_communicator()
+            if err is not None:
                 if wrap is None:
-                    raise
+                    raise err
                 import warnings
-                warnings.warn("library-owned RCCL communicator unavailable (%s): using torch.distributed through the callback" % e)
+                warnings.warn("library-owned RCCL communicator unavailable (%s): using torch.distributed through the callback" % err)
                 self.library_comm = library_comm = False
         if library_comm:
             engine.set_option("grad_buckets", int(grad_buckets))
@@ -108,25 +122,84 @@ class DataParallel:
             engine.set_option("grad_buckets", int(grad_buckets))
 
     @classmethod
-    def for_engine(cls, engine: native.Engine, device, group=None, sync_bn: bool = False, grad_buckets: int = 1,
+    def for_engine(cls, engine: native.Engine, device=None, group=None, sync_bn: bool = False, grad_buckets: int = 1,
                    library_comm: bool = True):
-        g = wrap_device_floats(engine.device_ptr(native.BUF_GRADS), engine.n_params, device)
-        p = wrap_device_floats(engine.device_ptr(native.BUF_PARAMS), engine.n_params, device)
-        s = wrap_device_floats(engine.device_ptr(native.BUF_BN_STATE), engine.n_state, device)
-        return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=lambda ptr, n: wrap_device_floats(ptr, n, device),
-                   grad_buckets=grad_buckets, library_comm=library_comm)
+        """The engine's own flat vectors as the views.  On the GPU (NCCL = RCCL process group) they are zero-copy views of HBM
+        and the library joins its own communicator; a host-emulated build of the library (its "device" memory is host
+        memory) is served by the callback over whatever group the caller initialised (gloo)."""
+        if getattr(engine.nl, "host_emulated", False):
+            wrap, library_comm = host_floats, False
+        else:
+            if dist.is_initialized() and dist.get_backend(group) != "nccl":
+                raise ValueError("data-parallel training on the GPU needs an NCCL (RCCL) process group, not %r" % dist.get_backend(group))
+            if device is None:
+                device = torch.device("cuda", engine.device)
+
+            def wrap(ptr, n):
+                return wrap_device_floats(ptr, n, device)
+        g = wrap(engine.device_ptr(native.BUF_GRADS), engine.n_params)
+        p = wrap(engine.device_ptr(native.BUF_PARAMS), engine.n_params)
+        s = wrap(engine.device_ptr(native.BUF_BN_STATE), engine.n_state)
+        return cls(engine, g, p, s, group, sync_bn=sync_bn, wrap=wrap, grad_buckets=grad_buckets, library_comm=library_comm)
+
+    # ---- small host-side collectives of the train loop (start-up, validation counters): never inside a step
+    def agree(self, ok: bool) -> bool:
+        """True iff ``ok`` on every rank (all_reduce(MIN) of the flag)."""
+        if not dist.is_initialized() or self.world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.grad_view.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def allreduce_host(self, a: np.ndarray) -> np.ndarray:
+        """Sum of a small float64 host vector over the ranks (every rank receives the same bits)."""
+        a = np.ascontiguousarray(a, np.float64)
+        if not dist.is_initialized() or self.world == 1:
+            return a
+        t = torch.from_numpy(a.copy()).to(self.grad_view.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def broadcast_host(self, a: np.ndarray, src: int = 0) -> np.ndarray:
+        a = np.ascontiguousarray(a)
+        if not dist.is_initialized() or self.world == 1:
+            return a
+        t = torch.from_numpy(a.copy()).to(self.grad_view.device)
+        dist.broadcast(t, src=src, group=self.group)
+        return t.cpu().numpy()
+
+    def barrier(self):
+        if dist.is_initialized() and self.world > 1:
+            self.agree(True)
 
     def _join_library_communicator(self):
-        """rank 0 asks the library for an RCCL unique id, the process group carries its 128 bytes to the other
-        ranks, every rank joins (``mww_allreduce_init`` is collective)."""
+        """Every rank probes the library's RCCL binding (``mww_allreduce_unique_id`` loads librccl; only rank 0's id is
+        used), the process group carries rank 0's 128 bytes to the other ranks, every rank joins (``mww_allreduce_init`` is
+        collective).  Returns None, or the error every rank reports after the ranks agreed that one of them failed."""
         dev = self.grad_view.device
+        err, mine = None, None
+        try:
+            mine = self.engine.nl.allreduce_unique_id()
+        except native.NativeError as e:
+            err = e
+        if not self.agree(err is None):
+            return err or native.NativeError("another rank could not load librccl")
         uid = torch.zeros(native.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
         if self.rank == 0:
-            uid.copy_(torch.from_numpy(self.engine.nl.allreduce_unique_id()))
+            uid.copy_(torch.from_numpy(mine))
         if dist.is_initialized() and self.world > 1:
             dist.broadcast(uid, src=0, group=self.group)
-            torch.cuda.synchronize(dev)
-        self.engine.allreduce_init(self.rank, self.world, uid.cpu().numpy(), sync_bn=self.sync_bn)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+        try:
+            self.engine.allreduce_init(self.rank, self.world, uid.cpu().numpy(), sync_bn=self.sync_bn)
+        except native.NativeError as e:
+            err = e
+        if not self.agree(err is None):
+            if err is None:
+                self.engine.allreduce_destroy()
+            return err or native.NativeError("another rank could not join the RCCL communicator")
+        return None
 
     def _engine_stream(self):
         """The callback's collectives are ordered against torch's CURRENT stream; the engine's kernels run on the engine's
@@ -163,7 +236,9 @@ class DataParallel:
                 else:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def broadcast_parameters(self, src=0):
+    def broadcast_parameters(self, src=0, optimizer_state=False):
+        """Weights and BN moving statistics of rank ``src`` to every rank; with ``optimizer_state`` also the Adam slots and
+        the step counter (a resumed run: every rank continues from the checkpoint rank ``src`` restored)."""
         if dist.is_initialized():
             self.engine.synchronize()
             dist.broadcast(self.param_view, src=src, group=self.group)
@@ -171,6 +246,24 @@ class DataParallel:
                 dist.broadcast(self.state_view, src=src, group=self.group)
             if self.grad_view.is_cuda:
                 torch.cuda.synchronize(self.grad_view.device)   # the engine's stream is not torch's: order by completion
+            if optimizer_state and hasattr(self.engine, "get_opt_state"):
+                m, v, step = self.engine.get_opt_state()
+                packed = np.concatenate([np.asarray(m, np.float64).reshape(-1), np.asarray(v, np.float64).reshape(-1), [float(step)]])
+                packed = self.broadcast_host(packed, src=src)
+                n = (packed.size - 1) // 2
+                self.engine.set_opt_state(packed[:n].astype(np.float32), packed[n:2 * n].astype(np.float32), int(packed[-1]))
+
+    def average_bn_state(self):
+        """Rank-local BatchNorm (throughput mode) leaves every rank with its own moving statistics.  Before the model is
+        validated or saved the ranks take their mean (one all-reduce of the small state vector), so that every rank scores -
+        and rank 0 writes - the same model.  A no-op with sync-BN (identical already) and on one rank."""
+        if self.state_view is None or self.sync_bn or not dist.is_initialized() or self.world == 1:
+            return
+        self.engine.synchronize()
+        dist.all_reduce(self.state_view, op=dist.ReduceOp.SUM, group=self.group)
+        self.state_view.mul_(1.0 / self.world)
+        if self.grad_view.is_cuda:
+            torch.cuda.synchronize(self.grad_view.device)
 
     def train_step(self, B, lr, flags=0, prefetch=None):
         """Local forward/backward, gradient all-reduce, Adam on the averaged gradient.  ``prefetch`` (optional

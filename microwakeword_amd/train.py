@@ -16,6 +16,15 @@ When both objects come from this package the spectrogram batch never leaves HBM
 (``FeatureHandler.next_training_batch_on_device`` + ``Model.train_on_device_batch``); with any other
 duck-typed pair it falls back to the reference's host-array calls.  TensorBoard summaries
 (train.py:236-241,328-334,361-389) are written as JSON lines under ``<summaries_dir>``.
+
+Data-parallel (the reference has no distributed code, this wraps its loop train.py:249-299,315-458): when the
+process is one rank of an initialised ``torch.distributed`` job (``python -m torch.distributed.run --nproc-per-node N -m
+microwakeword_amd.model_train_eval ...``), ``train`` shards every provider's training samples over the ranks, joins the
+engines into one gradient exchange (``Model.join_data_parallel``), starts every rank from rank 0's weights and optimizer
+state, and runs ``batch_size // W`` windows per rank and step - ``batch_size`` stays the GLOBAL batch of the YAML config.
+Validation is sharded by window index and the raw metric counters are summed by one all-reduce per result, so every rank
+computes the same validation metrics and takes the same best-weights decision; ONLY RANK 0 writes weights, checkpoints,
+summaries and log lines.
 """
 from __future__ import annotations
 
@@ -23,6 +32,7 @@ import contextlib
 import json
 import logging
 import os
+import sys
 
 import numpy as np
 
@@ -154,33 +164,75 @@ class _JsonSummary:
         self.f.flush()
 
 
+def process_group():
+    """(rank, world) of the ``torch.distributed`` job this process is a rank of; (0, 1) outside one.  torch is not imported
+    for the question: a process that never imported ``torch.distributed`` cannot have initialised a group."""
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class _NoSummary:
+    def scalars(self, step, **kv):
+        pass
+
+
 def train(model, config, data_processor, verbose=True):
     ph = _phase_lists(config)
     model.compile()
     model.make_train_function()
+    rank, world = process_group()
+    chief = rank == 0
+    fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
+        and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
+    prefetch = int(config.get("prefetch_batches", 2))
     ckpt_dir = os.path.join(config["train_dir"], "restore")
     ckpt = os.path.join(ckpt_dir, "ckpt")
-    if os.path.isfile(ckpt + ".weights.npz") and hasattr(model, "load_optimizer_state"):
-        # restore is unconditional in the reference (train.py:232-233)
+    if chief and os.path.isfile(ckpt + ".weights.npz") and hasattr(model, "load_optimizer_state"):
+        # restore is unconditional in the reference (train.py:232-233); data-parallel: rank 0 restores, the broadcast below
+        # hands weights, moving statistics and Adam state to the other ranks
         model.load_weights(ckpt + ".weights")
         model.load_optimizer_state(ckpt + ".opt.npz")
-    train_writer = _JsonSummary(os.path.join(config["summaries_dir"], "train"), "scalars")
-    val_writer = _JsonSummary(os.path.join(config["summaries_dir"], "validation"), "scalars")
+
+    dp = None
+    if world > 1 or config.get("data_parallel"):
+        if not fast:
+            raise ValueError("data-parallel training needs this package's Model and FeatureHandler on one engine "
+                             "(the spectrogram batches are assembled per rank in HBM)")
+        if config["batch_size"] % world:
+            raise ValueError("batch_size %d (the global batch) is not divisible by the %d ranks" % (config["batch_size"], world))
+        from .parallel import shard_feature_handler
+        dp = model.data_parallel or model.join_data_parallel(sync_bn=bool(config.get("sync_bn", False)),
+                                                             grad_buckets=int(config.get("grad_buckets", 1)))
+        shard_feature_handler(data_processor, rank, world, seed=int(config.get("data_parallel_seed", 0)), prefetch=prefetch)
+        dp.broadcast_parameters(0, optimizer_state=True)
+        log.info("data-parallel: rank %d of %d, %d windows per rank and step (global batch %d), %s BatchNorm", rank, world,
+                 config["batch_size"] // world, config["batch_size"], "synchronised" if dp.sync_bn else "rank-local")
+    elif fast and hasattr(data_processor, "use_private_rng") and prefetch > 0:
+        # the draws of get_data("training") (data.py:540-569) continue the global random / numpy.random streams from where
+        # they stand now, on a worker thread that runs `prefetch_batches` batches ahead of the step being enqueued
+        # (native.Prefetcher).  The streams are handed back around every validation pass (below), whose shuffles advance
+        # the global numpy stream in the reference too.  prefetch_batches: 0 keeps every draw on this thread and in the
+        # global generators, as the reference does.
+        data_processor.use_private_rng(prefetch=prefetch)
+    private_streams = fast and hasattr(data_processor, "release_private_rng") and (dp is not None or prefetch > 0)
+    local_batch = config["batch_size"] // world
+
+    train_writer = _JsonSummary(os.path.join(config["summaries_dir"], "train"), "scalars") if chief else _NoSummary()
+    val_writer = _JsonSummary(os.path.join(config["summaries_dir"], "validation"), "scalars") if chief else _NoSummary()
 
     warned_weights = False
     steps_max = int(np.sum(ph["training_steps"]))
     best_min, best_max, best_cutoff = 10000, 0.0, 1.0
-    fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
-        and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
 
-    if fast and hasattr(data_processor, "use_private_rng") and int(config.get("prefetch_batches", 2)) > 0:
-        # the draws of get_data("training") (data.py:540-569) continue the global random / numpy.random streams from where
-        # they stand now, on a worker thread that runs `prefetch_batches` batches ahead of the step being enqueued
-        # (native.Prefetcher); nothing else in this loop consumes those streams.  prefetch_batches: 0 keeps every draw on
-        # this thread and in the global generators, as the reference does.
-        data_processor.use_private_rng(prefetch=int(config.get("prefetch_batches", 2)))
+    def save_weights(path):
+        if chief:
+            model.save_weights(path)
 
     def save_ckpt():
+        if not chief:
+            return
         os.makedirs(ckpt_dir, exist_ok=True)
         model.save_weights(ckpt + ".weights")
         if hasattr(model, "save_optimizer_state"):
@@ -204,46 +256,59 @@ def train(model, config, data_processor, verbose=True):
                         "per_sample).  The reference hands Keras a [B,B] matrix here (train.py:288-293); if its loss curves are to be "
                         "followed to the digit, see INTEGRATION.md section 2 (sample_weight_broadcast: keras_last_axis).", cw_neg, cw_pos)
         if fast:
-            data_processor.next_training_batch_on_device(config["batch_size"], config["spectrogram_length"], "default", policy,
+            data_processor.next_training_batch_on_device(local_batch, config["spectrogram_length"], "default", policy,
                                                          class_weights=(cw_neg, cw_pos),
                                                          weight_broadcast=config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
-            result = model.train_on_device_batch(config["batch_size"])
+            result = model.train_on_device_batch(local_batch)
         else:
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",
                                               augmentation_policy=policy)
             combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
             result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
-        if verbose:
+        if verbose and chief:
             print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(
                 (step // config["eval_step_interval"] + 1), result[1], result[2], result[3], result[9],
                 (step % config["eval_step_interval"])), end="\r")
 
         is_last = step == steps_max
         if (step % config["eval_step_interval"]) == 0 or is_last:
-            log.info("Step #%d: rate %f, accuracy %.2f%%, recall %.2f%%, precision %.2f%%, cross entropy %f",
-                     step, lr, result[1] * 100, result[2] * 100, result[3] * 100, result[9])
+            if dp is not None:
+                dp.average_bn_state()   # rank-local BatchNorm: validate and save ONE model (the mean of the ranks' moving statistics)
+                # the running train metrics over every rank's windows (each rank's counters cover its own batches)
+                tm = model._metric_results(reduce=True)
+                result = [result[0], tm["accuracy"], tm["recall"], tm["precision"], tm["tp"], tm["fp"], tm["tn"], tm["fn"], tm["auc"], tm["loss"]]
+            info = log.info if chief else log.debug
+            info("Step #%d: rate %f, accuracy %.2f%%, recall %.2f%%, precision %.2f%%, cross entropy %f",
+                 step, lr, result[1] * 100, result[2] * 100, result[3] * 100, result[9])
             train_writer.scalars(step, loss=result[9], accuracy=result[1], recall=result[2], precision=result[3], auc=result[8])
-            model.save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+            save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+            if private_streams:
+                data_processor.release_private_rng()   # validation shuffles on the global numpy stream (data.py:593-595) ...
             nm = validate_nonstreaming(config, data_processor, model, "validation")
+            if private_streams:
+                data_processor.use_private_rng(prefetch=prefetch)   # ... and the training draws continue behind them
             model.reset_metrics()
-            log.info("Step %d (nonstreaming): Validation: recall at no faph = %.3f with cutoff %.2f, accuracy = %.2f%%, recall = %.2f%%, "
+            info("Step %d (nonstreaming): Validation: recall at no faph = %.3f with cutoff %.2f, accuracy = %.2f%%, recall = %.2f%%, "
                      "precision = %.2f%%, ambient false positives = %d, estimated false positives per hour = %.5f, loss = %.5f, "
                      "auc = %.5f, average viable recall = %.9f", step, nm["recall_at_no_faph"] * 100, nm["cutoff_for_no_faph"],
-                     nm["accuracy"] * 100, nm["recall"] * 100, nm["precision"] * 100, nm["ambient_false_positives"],
-                     nm["ambient_false_positives_per_hour"], nm["loss"], nm["auc"], nm["average_viable_recall"])
+                 nm["accuracy"] * 100, nm["recall"] * 100, nm["precision"] * 100, nm["ambient_false_positives"],
+                 nm["ambient_false_positives_per_hour"], nm["loss"], nm["auc"], nm["average_viable_recall"])
             val_writer.scalars(step, loss=nm["loss"], accuracy=nm["accuracy"], recall=nm["recall"], precision=nm["precision"],
                                recall_at_no_faph=nm["recall_at_no_faph"], auc=nm["auc"], average_viable_recall=nm["average_viable_recall"])
-            os.makedirs(os.path.join(config["train_dir"], "train"), exist_ok=True)
-            model.save_weights(os.path.join(config["train_dir"], "train", f"{int(best_min * 10000)}_weights_{step}.weights.h5"))
+            if chief:
+                os.makedirs(os.path.join(config["train_dir"], "train"), exist_ok=True)
+            save_weights(os.path.join(config["train_dir"], "train", f"{int(best_min * 10000)}_weights_{step}.weights.h5"))
             cur_min = 0.0 if config["minimization_metric"] is None else nm[config["minimization_metric"]]
             cur_max = nm[config["maximization_metric"]]
             if _is_better(cur_min, cur_max, best_min, best_max, config["target_minimization"]):
                 best_min, best_max, best_cutoff = cur_min, cur_max, nm["cutoff_for_no_faph"]
-                model.save_weights(os.path.join(config["train_dir"], "best_weights.weights.h5"))
+                save_weights(os.path.join(config["train_dir"], "best_weights.weights.h5"))
                 save_ckpt()
-            log.info("So far the best minimization quantity is %.3f with best maximization quantity of %.5f%%; no faph cutoff is %.2f",
-                     best_min, best_max * 100, best_cutoff)
+            info("So far the best minimization quantity is %.3f with best maximization quantity of %.5f%%; no faph cutoff is %.2f",
+                 best_min, best_max * 100, best_cutoff)
     save_ckpt()
-    model.save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+    save_weights(os.path.join(config["train_dir"], "last_weights.weights.h5"))
+    if dp is not None:
+        dp.barrier()   # rank 0's files are complete before any rank returns (and tears the process group down)
     return dict(best_minimization=best_min, best_maximization=best_max, best_no_faph_cutoff=best_cutoff)

@@ -1158,6 +1158,90 @@ def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
         np.testing.assert_array_equal(a, b)
 
 
+def check_train_loop_prefetch_is_schedule_only(lib, tmp_path, B=8, T=60):
+    """train.train with the batches drawn on a worker thread from private RNG streams (prefetch_batches 2, the default)
+    against prefetch_batches 0 (every draw on the launching thread, in the global generators, as the reference does):
+    bit-identical weights ACROSS validation passes, whose shuffles (data.py:593-595) advance the global numpy stream the
+    next training draws continue from, and with a provider whose 'random' truncation draws from that stream - the loop
+    hands the streams back around every validation.  The global generators end at the same point too."""
+    from microwakeword_amd import mixednet
+    from microwakeword_amd import train as tr
+    outs = []
+    for depth in (0, 2):
+        cfg = learnable_config(T=T)
+        cfg["features"][1]["truncation_strategy"] = "random"   # consumes numpy.random per drawn sample
+        cfg = dict(cfg, train_dir=str(tmp_path / ("run%d" % depth)), summaries_dir=str(tmp_path / ("run%d" % depth) / "logs"),
+                   batch_size=B, spectrogram_length=T, training_steps=[7], learning_rates=[0.01], time_mask_max_size=[4],
+                   time_mask_count=[2], freq_mask_max_size=[4], freq_mask_count=[1], positive_class_weight=[1.0],
+                   negative_class_weight=[1.0], eval_step_interval=3, target_minimization=0.9, minimization_metric=None,
+                   maximization_metric="accuracy", prefetch_batches=depth)
+        random.seed(2)
+        np.random.seed(2)
+        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=5, max_batch=64)
+        fh = FeatureHandler(cfg, engine=model.engine)
+        tr.train(model, cfg, fh, verbose=False)
+        if depth:
+            fh.release_private_rng()
+        outs.append((model.engine.get_params().copy(), model.engine.get_bn_state().copy(), random.random(), float(np.random.random())))
+        model.engine.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2:] == outs[1][2:]
+
+
+def check_train_loop_data_parallel_world1(lib, tmp_path, backend):
+    """microwakeword_amd.train.train as the single rank of a ``torch.distributed`` job (config ``data_parallel``): sharding,
+    the communicator (the library's own RCCL one on the GPU), the weight / optimizer-state broadcast, the gradient
+    exchange in every step, the sharded validation's counter all-reduce and the BN-state averaging all run through the
+    collective path; with one rank the run must equal the plain loop bit for bit."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from microwakeword_amd import mixednet
+    from microwakeword_amd import train as tr
+    T, B = 60, 16
+
+    def run(tag, **extra):
+        cfg = dict(learnable_config(T=T), train_dir=str(tmp_path / tag), summaries_dir=str(tmp_path / tag / "logs"), batch_size=B,
+                   spectrogram_length=T, training_steps=[6], learning_rates=[0.01], time_mask_max_size=[3], time_mask_count=[1],
+                   freq_mask_max_size=[3], freq_mask_count=[1], positive_class_weight=[1.0], negative_class_weight=[1.0],
+                   eval_step_interval=3, target_minimization=0.9, minimization_metric=None, maximization_metric="accuracy", **extra)
+        random.seed(9)
+        np.random.seed(9)
+        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=3, max_batch=64)
+        fh = FeatureHandler(cfg, engine=model.engine)
+        if not extra:
+            # the plain loop on what rank 0 of a one-rank job draws from: canonical sample order, streams seeded seed * W + rank = 0
+            for p in fh.feature_providers:
+                p.feature_sets["training"] = sorted(p.feature_sets["training"])
+            random.seed(0)
+            np.random.seed(0)
+        out = tr.train(model, cfg, fh, verbose=False)
+        res = (model.engine.get_params().copy(), model.engine.get_bn_state().copy(), out, model.data_parallel)
+        fh._drop_prefetcher()
+        model.engine.close()
+        return res
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+    try:
+        p1, s1, o1, dp = run("dp", data_parallel=True)
+        assert dp is not None and dp.world == 1
+    finally:
+        dist.destroy_process_group()
+    p0, s0, o0, none = run("plain")
+    assert none is None
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(s0, s1)
+    assert o0 == o1
+    return dp
+
+
 # ------------------------------------------------------------------------------------------ statistics hand-over
 def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
     """"bn_inline" (BN sums in replicated fp64 accumulator rows, folded by their first consumer) against the

@@ -257,6 +257,8 @@ hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// marker export: "device" memory of this build is host memory (native.NativeLib.host_emulated)
+extern "C" int hipemu_host_memory(void) { return 1; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p));
   strcpy(p->name, "hipemu (host fibers)");

@@ -264,6 +264,15 @@ def test_prefetched_batches_train_like_the_synchronous_sampler(emu_lib):
     ec.check_prefetched_training_matches_synchronous(emu_lib)
 
 
+def test_train_loop_prefetch_is_schedule_only(emu_lib, tmp_path):
+    ec.check_train_loop_prefetch_is_schedule_only(emu_lib, tmp_path)
+
+
+def test_train_loop_data_parallel_world1(emu_lib, tmp_path):
+    dp = ec.check_train_loop_data_parallel_world1(emu_lib, tmp_path, "gloo")
+    assert not dp.library_comm and dp.engine_driven
+
+
 def test_bn_inline_matches_finalize(emu_lib):
     ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)
 

@@ -242,6 +242,12 @@ def test_exchange_through_the_library_s_own_rccl_communicator_world1(lib):
     _dp_world1_step(lib, library_comm=True, sync_bn=True, buckets=1)
 
 
+def test_train_loop_data_parallel_world1_rccl(lib, tmp_path):
+    """microwakeword_amd.train.train as the single rank of an RCCL job: see engine_checks."""
+    dp = ec.check_train_loop_data_parallel_world1(lib, tmp_path, "nccl")
+    assert dp.library_comm
+
+
 def test_bf16_pointwise_mode(lib):
     """BASELINE configs[4] "default mixednet bf16 with MFMA pointwise": forward and train step against the
     oracle that rounds the same operands to bf16; and within the 1e-3 forward tolerance of the fp32 oracle."""
@@ -464,6 +470,10 @@ def test_fused_stages_match_one_launch_per_layer(lib):
 
 def test_prefetched_batches_train_like_the_synchronous_sampler(lib):
     ec.check_prefetched_training_matches_synchronous(lib, B=64, T=194, steps=7)
+
+
+def test_train_loop_prefetch_is_schedule_only(lib, tmp_path):
+    ec.check_train_loop_prefetch_is_schedule_only(lib, tmp_path)
 
 
 def test_bn_inline_matches_finalize(lib):

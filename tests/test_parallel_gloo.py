@@ -374,3 +374,155 @@ def test_local_bn_two_ranks_mixednet_graph_kernels(tmp_path):
         assert np.abs(outs[r]["state"] - s_ref).max() <= 1e-5 * max(1.0, np.abs(s_ref).max())
     g = outs[0]["grads"].astype(np.float64)
     assert np.linalg.norm(g - gsum) <= 2e-3 * np.linalg.norm(gsum)
+
+
+# ------------------------------------------------------------------------------------------ the product train loop
+# microwakeword_amd.train.train as one rank of a two-rank job: providers sharded, one gradient exchange per
+# step inside the engine, validation sharded by window index with one all-reduce of the raw counters per result,
+# rank 0 the only writer.  Product kernels (host-emulated) on both ranks.
+_LOOP_T, _LOOP_B, _LOOP_STEPS = 60, 8, 6
+
+
+def _loop_config(run_dir):
+    import engine_checks as ec
+    return dict(ec.learnable_config(n=24, T=_LOOP_T), train_dir=str(run_dir), summaries_dir=os.path.join(str(run_dir), "logs"),
+                batch_size=_LOOP_B, spectrogram_length=_LOOP_T, training_steps=[3, 3], learning_rates=[0.01, 0.003],
+                time_mask_max_size=[3], time_mask_count=[1], freq_mask_max_size=[3], freq_mask_count=[1],
+                positive_class_weight=[1.0], negative_class_weight=[1.0], eval_step_interval=2, target_minimization=0.9,
+                minimization_metric=None, maximization_metric="accuracy")
+
+
+def _final_validation(tr, cfg, fh, model):
+    nm = tr.validate_nonstreaming(cfg, fh, model, "validation")
+    res = model.evaluation_results()   # validation + ambient windows accumulated (the reference's no-op reset swap)
+    counts = {k: res[k].numpy().copy() for k in ("tp", "fp", "tn", "fn")}
+    return nm, counts
+
+
+def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn):
+    import engine_checks as ec
+    from microwakeword_amd import mixednet, native
+    from microwakeword_amd import train as tr
+    from microwakeword_amd.data import FeatureHandler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    lib = native.NativeLib(emu_path)
+    cfg = dict(_loop_config(os.path.join(out_dir, "run")), sync_bn=sync_bn)
+    os.makedirs(cfg["train_dir"], exist_ok=True)
+    # the ranks deliberately disagree on everything a single process would get from its seeds: initial weights and the
+    # per-mode shuffles of the providers - the loop has to make them agree (broadcast, canonical shards)
+    random.seed(100 + rank)
+    np.random.seed(100 + rank)
+    model = mixednet.model(ec.DEF, (_LOOP_T, 40), _LOOP_B // world, lib=lib, seed=7 + rank, max_batch=64)
+    fh = FeatureHandler(cfg, engine=model.engine)
+    n_train = [len(p.feature_sets["training"]) for p in fh.feature_providers]
+    out = tr.train(model, cfg, fh, verbose=False)
+    shard = [sorted(p.feature_sets["training"]) for p in fh.feature_providers]
+    assert all(len(s) * world >= n and len(s) <= -(-n // world) for s, n in zip(shard, n_train))
+    nm, counts = _final_validation(tr, cfg, fh, model)
+    m, v, step = model.engine.get_opt_state()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), params=model.engine.get_params(), state=model.engine.get_bn_state(), m=m, v=v,
+             step=step, best=np.array([out["best_minimization"], out["best_maximization"], out["best_no_faph_cutoff"]]),
+             nm=np.array([nm[k] for k in sorted(nm)], np.float64), shard0=np.array(shard[0]), **counts)
+    model.engine.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_train_loop_two_ranks_end_to_end(tmp_path, sync_bn):
+    import conftest
+    import engine_checks as ec
+    from microwakeword_amd import mixednet, native
+    from microwakeword_amd import train as tr
+    from microwakeword_amd.data import FeatureHandler
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W = 2
+    mp.spawn(_train_loop_worker, args=(W, _free_port(), str(tmp_path), emu, sync_bn), nprocs=W, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(W)]
+    # identical model, optimizer state, decisions and validation metrics on both ranks
+    for k in ("params", "state", "m", "v", "step", "best", "nm", "tp", "fp", "tn", "fn"):
+        np.testing.assert_array_equal(r[0][k], r[1][k], err_msg=k)
+    assert int(r[0]["step"]) == _LOOP_STEPS
+    # the shards partition the provider
+    assert not set(map(tuple, r[0]["shard0"])) & set(map(tuple, r[1]["shard0"]))
+    assert len(r[0]["shard0"]) + len(r[1]["shard0"]) == 24
+    # ONE set of files, written once: three validation passes -> three summary lines (two writers would leave six)
+    run = tmp_path / "run"
+    for f in ("best_weights.weights.h5.npz", "last_weights.weights.h5.npz", "restore/ckpt.weights.npz", "restore/ckpt.opt.npz"):
+        assert (run / f).exists(), f
+    assert len((run / "logs" / "validation" / "scalars.jsonl").read_text().splitlines()) == 3
+    assert len((run / "logs" / "train" / "scalars.jsonl").read_text().splitlines()) == 3
+    assert sorted(os.listdir(run / "train")) == sorted("%d_weights_%d.weights.h5.npz" % (b, s) for b, s in ((100000000, 2), (0, 4), (0, 6)))
+    # the sharded validation's summed counters are the single-process counters of the same model
+    lib = native.NativeLib(emu)
+    cfg = _loop_config(tmp_path / "single")
+    random.seed(5)
+    np.random.seed(5)
+    model = mixednet.model(ec.DEF, (_LOOP_T, 40), _LOOP_B, lib=lib, seed=1, max_batch=64)
+    model.load_weights(str(run / "last_weights.weights.h5"))
+    np.testing.assert_array_equal(model.engine.get_params(), r[0]["params"])
+    np.testing.assert_array_equal(model.engine.get_bn_state(), r[0]["state"])
+    fh = FeatureHandler(cfg, engine=model.engine)
+    nm, counts = _final_validation(tr, cfg, fh, model)
+    for k in ("tp", "fp", "tn", "fn"):
+        np.testing.assert_array_equal(counts[k], r[0][k], err_msg=k)
+    np.testing.assert_allclose(np.array([nm[k] for k in sorted(nm)], np.float64), r[0]["nm"], rtol=1e-6, atol=1e-9)
+    model.engine.close()
+
+
+def _cli_worker(rank, world, port, emu_path, argv, expect_exists):
+    from microwakeword_amd import model_train_eval
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),   # the emulator has one "device"
+                      MWW_DIST_BACKEND="gloo", MWW_HIP_LIB=emu_path)
+    torch.set_num_threads(1)
+    if expect_exists:
+        with pytest.raises(ValueError, match="already exists"):   # every rank raises, none hangs in a collective
+            model_train_eval.main(argv)
+    else:
+        out = model_train_eval.main(argv)
+        assert set(out) == {"best_minimization", "best_maximization", "best_no_faph_cutoff"}
+    dist.destroy_process_group()
+
+
+def test_cli_two_ranks_from_disk(tmp_path):
+    """``python -m torch.distributed.run --nproc-per-node 2 -m microwakeword_amd.model_train_eval ...`` as the launcher
+    sees it: two processes with RANK / LOCAL_RANK / WORLD_SIZE in the environment run ``main`` on stores read from disk;
+    rank 0 owns train_dir; a second launch into the same folder raises on BOTH ranks; a third restores the checkpoint."""
+    import yaml
+
+    import conftest
+    from microwakeword_amd import ragged
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    rng = np.random.default_rng(0)
+    for prov, positive in (("wake", True), ("background", False)):
+        for mode, n in (("training", 12), ("validation", 6), ("validation_ambient", 2)):
+            if mode == "validation_ambient" and positive:
+                continue
+            lo, hi = (200, 260) if mode == "validation_ambient" else (62, 90)
+            samples = [rng.integers(0, 200, size=(int(rng.integers(lo, hi)), 40)).astype(np.uint16) for _ in range(n)]
+            ragged.write_ragged_store(str(tmp_path / prov / mode / ("%s_mmap" % mode)), samples)
+    cfg = dict(window_step_ms=10, train_dir=str(tmp_path / "trained"), clip_duration_ms=160, batch_size=4, training_steps=[4],
+               learning_rates=[0.001], eval_step_interval=2, target_minimization=0.9, minimization_metric=None,
+               maximization_metric="average_viable_recall", time_mask_max_size=[3], time_mask_count=[1], freq_mask_max_size=[3],
+               freq_mask_count=[1], positive_class_weight=[1], negative_class_weight=[1],
+               features=[dict(features_dir=str(tmp_path / "wake"), sampling_weight=1.0, penalty_weight=1.0, truth=True,
+                              truncation_strategy="truncate_start", type="mmap"),
+                         dict(features_dir=str(tmp_path / "background"), sampling_weight=2.0, penalty_weight=1.0, truth=False,
+                              truncation_strategy="random", type="mmap")])
+    (tmp_path / "cfg.yaml").write_text(yaml.dump(cfg))
+    argv = ["--training_config", str(tmp_path / "cfg.yaml"), "--verbosity", "ERROR", "mixednet", "--residual_connection", "0,0,0,0"]
+    mp.spawn(_cli_worker, args=(2, _free_port(), emu, argv, False), nprocs=2, join=True)
+    run = tmp_path / "trained"
+    for f in ("training_config.yaml", "model_summary.txt", "best_weights.weights.h5.npz", "last_weights.weights.h5.npz",
+              "restore/ckpt.weights.npz", "restore/ckpt.opt.npz", "logs/train/scalars.jsonl", "logs/validation/scalars.jsonl"):
+        assert (run / f).exists(), f
+    assert len((run / "logs" / "validation" / "scalars.jsonl").read_text().splitlines()) == 2
+    assert int(np.load(run / "restore" / "ckpt.opt.npz")["step"]) == 4
+    mp.spawn(_cli_worker, args=(2, _free_port(), emu, argv, True), nprocs=2, join=True)
+    mp.spawn(_cli_worker, args=(2, _free_port(), emu, argv[:2] + ["--restore_checkpoint", "1"] + argv[2:], False), nprocs=2, join=True)
+    assert int(np.load(run / "restore" / "ckpt.opt.npz")["step"]) == 8   # 4 restored (rank 0, broadcast) + 4 new steps
