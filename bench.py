@@ -53,9 +53,6 @@ KERNEL_ELEMS = {
     "bwd_block2": P_ELEMS[1] + P_ELEMS[2] + P_ELEMS[2] + P_ELEMS[1],
     "bwd_block1": X_READ + P_ELEMS[1] + P_ELEMS[1],                   # R x, R p1, R g1
 }
-# fused launches (kernels_fused.hip.h): the four layers' bytes (what travels between the stages of one launch is read
-# and written like between launches: the stages are the same bodies)
-KERNEL_ELEMS["bwd_fused"] = sum(KERNEL_ELEMS["bwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 
@@ -63,7 +60,7 @@ KERNEL_ELEMS["bwd_fused"] = sum(KERNEL_ELEMS["bwd_block%d" % k] for k in (1, 2, 
 def kernel_elems_stored_bf16():
     """The same accounting with p_k / g_k held as bf16 ("storage_bf16"): their elements cost 2 B, the input rows
     keep their cost.  Returned in the 4-byte units of KERNEL_ELEMS."""
-    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ, "bwd_fused": X_READ}
+    xpart = {"assemble": KERNEL_ELEMS["assemble"], "fwd_block1": X_READ, "bwd_block1": X_READ}
     return {k: xpart.get(k, 0) + (v - xpart.get(k, 0)) / 2 for k, v in KERNEL_ELEMS.items()}
 
 
@@ -81,7 +78,6 @@ KERNEL_MFMA_FLOPS = {
     "bwd_block4": 2 * PW_FLOPS[4], "bwd_block3": 2 * PW_FLOPS[3], "bwd_block2": 2 * PW_FLOPS[2],
     "bwd_block1": CONV1_FLOPS + 2 * PW_FLOPS[1],
 }
-KERNEL_MFMA_FLOPS["bwd_fused"] = sum(KERNEL_MFMA_FLOPS["bwd_block%d" % k] for k in (1, 2, 3, 4))
 
 
 def inception_kernel_elems(layout):
@@ -130,26 +126,52 @@ def inception_kernel_elems(layout):
     return elems
 
 
-PMC_FILE = "round3_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
+PMC_FILE = "round4_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
+LIBRARY = os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")
 
 
-def pmc_traffic(kernel, model):
+def library_sha16(path=LIBRARY):
+    import hashlib
+    try:
+        with open(path, "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_profile_sha16(path):
+    """tools/pmc_summary.py stamps the library it profiled into the first line of its summary (`# library sha256_16=...`)."""
+    import re
+    try:
+        with open(path) as fh:
+            m = re.match(r"#\s*library sha256_16=([0-9a-f]{16})", fh.readline())
+        return m.group(1) if m else None
+    except OSError:
+        return None
+
+
+def pmc_traffic(kernel, model, path=None, library=LIBRARY):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this round (profiles/round3_*:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in its own run of `bench.py --no-graphs`), corrected
     as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE (KB) counts half the bytes of wide coalesced
     reads -> x2; WRITE_SIZE (KB) as reported.  Returns (bytes, source) or (None, None).  The counters cannot be
     read from inside this process; the figure belongs to the kernel binary profiled at the end of the round (it includes
     the 24.6 KB/window of a0 = relu(conv1(x)) that fwd_block1 stores and bwd_block1 reads back, which SURVEY 8(d)'s
-    algorithmic bytes do not count)."""
+    algorithmic bytes do not count).  The summary carries the sha256 of the library it was measured on; when that is not the
+    library this process loaded, the figure is NOT reported (traffic null, the source says why)."""
     import re
-    path = os.path.join(ROOT, "profiles", PMC_FILE)
-    if model != "mixednet" or not os.path.isfile(path):
+    path = path or os.path.join(ROOT, "profiles", PMC_FILE)
+    if model != "mixednet":
         return None, None
+    if not os.path.isfile(path):
+        return None, "missing: no PMC summary of this round's library yet (%s)" % os.path.basename(path)
+    prof_sha, lib_sha = pmc_profile_sha16(path), library_sha16(library)
+    if prof_sha is None or prof_sha != lib_sha:
+        return None, "stale: profile sha %s != library sha %s (%s)" % (prof_sha, lib_sha, os.path.basename(path))
     want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
             "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
             "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
-            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<",
-            "bwd_fused": r"bwd_fused_kernel<3, 32, 1, 48,"}.get(kernel)
+            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}.get(kernel)
     if not want:
         return None, None
     fetch = write = None
@@ -161,7 +183,7 @@ def pmc_traffic(kernel, model):
             write = float(m.group(1)) if m else write
     if fetch is None or write is None:
         return None, None
-    return int(2 * fetch * 1024 + write * 1024), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB)" % PMC_FILE
+    return int(2 * fetch * 1024 + write * 1024), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB; library sha %s)" % (os.path.basename(path), lib_sha)
 
 
 def parse_args():
@@ -187,6 +209,7 @@ def parse_args():
     ap.add_argument("--no-graphs", action="store_true", help="accepted for older scripts: eager launches are the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true", help="skip the (untimed-for-value) validation-throughput leg")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the extra batch-4096 point (`batch_sweep`, after the timed region)")
     ap.add_argument("--store-samples", type=int, default=4096)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--grid-fwd", type=int, default=0)
@@ -288,11 +311,14 @@ def cpu_baseline(batch, budget_s=24.0, model="mixednet"):
     small = run(32, 0.15 * budget_s, 40)
     big = small if batch == 32 else run(batch, 0.45 * budget_s, 8)
     return {"value": big["windows_per_s"], "unit": "windows/s", "cores": cores, "kind": "port",
+            "loader_kind": "reference" if ref_get is not None else "port",
             "loader": "reference data.py (unmodified, via oracle/ref_data_shim)" if ref_get is not None else "oracle/data_oracle.py (restatement; /root/reference is not on this box)",
             "model": "oracle/model_oracle.py torch-CPU fp32 fwd/bwd/Keras-Adam",
             "sample": "%d train steps of batch %d (loader %.2fs + model %.2fs) and %d of batch 32, %d torch threads of %d host threads"
                       % (big["steps"], batch, big["loader_s"], big["model_s"], small["steps"], cores, os.cpu_count() or 1),
             "loader_windows_per_s": big["loader_windows_per_s"], "model_windows_per_s": big["model_windows_per_s"],
+            "loader_note": None if ref_get is not None else "loader_windows_per_s is the ORACLE'S restatement of get_data (vectorised numpy), not the "
+                           "reference's loader: the reference's own data.py measured 7.2 k windows/s at batch 1024 in the build container (BASELINE.md section 2)",
             "by_batch": {"32": small, str(batch): big}}
 
 
@@ -365,7 +391,7 @@ def main():
             step_bytes = 1222208   # algorithmic bytes per window of the default Inception train step (fp32, T = 194)
         elif args.model == "notebook":
             from microwakeword_amd import mixednet
-            T_FRAMES = 204
+            T_FRAMES = int(os.environ.get("MWW_BENCH_T", "204"))   # (204 = the notebook's clip length; the override is for tile-shape experiments)
             model = mixednet.model(synthetic.NOTEBOOK_MIXEDNET_FLAGS, (T_FRAMES, 40), B, device=local_rank, stream=stream.cuda_stream,
                                    seed=42, max_batch=B)
             lay = model.layout
@@ -429,8 +455,6 @@ def main():
             eng.set_option("fused_input", int(os.environ["MWW_BENCH_FUSED_INPUT"]))
         if os.environ.get("MWW_BENCH_ASM_SPLIT") is not None:
             eng.set_option("assemble_split", int(os.environ["MWW_BENCH_ASM_SPLIT"]))
-        if os.environ.get("MWW_BENCH_ASM_OVERLAP") is not None:
-            eng.set_option("assemble_overlap", int(os.environ["MWW_BENCH_ASM_OVERLAP"]))
         if args.graphs and not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY
@@ -464,6 +488,8 @@ def main():
         # 5 + 20-step run against 0.342 in a 20 + 200-step run (profiles/round3_*: the per-kernel event times are 2-3 %
         # longer, the rest is the pipeline fill of the first step).  K and W themselves are exactly what was asked for.
         validation = None
+        eng.synchronize()
+        t_pre_roll = time.perf_counter()
         if n_val and rank == 0:
             for mode, strat in (("validation", "truncate_start"), ("validation_ambient", "split")):   # warm-up: index build, caches
                 fh.evaluate_on_device(model, mode, T_FRAMES, strat, 1024)
@@ -528,6 +554,8 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(device)
 
+        eng.synchronize()
+        pre_roll_s = time.perf_counter() - t_pre_roll
         for _ in range(args.warmup):
             one_step()
         fence()
@@ -547,6 +575,31 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         _, _, last_loss = eng.read_outputs(B)
+
+        # ---- one more point of the batch sweep in the driver's own line (after the timed region, not part of `value`): the
+        # same step at batch 4096 on a second context.  ~118 us of the step do not scale with the batch, so the
+        # roofline fraction of the step is a function of the batch; this is the point the 40 % claim refers to.
+        batch_sweep = None
+        if (world == 1 and not force_dp and args.model == "mixednet" and B == 1024 and not args.no_batch_sweep and not args.force_generic
+                and not (args.pointwise_bf16 or args.storage_bf16) and args.profile_steps > 0):
+            # (the context is new and the device idled while it was built: ~80 steps = 80 ms of warm-up bring the clocks back)
+            Bs, Ks, Ws = 4096, 40, 80
+            m2 = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T_FRAMES, 40), Bs, device=local_rank, stream=stream.cuda_stream, seed=42, max_batch=Bs)
+            fh._drop_prefetcher()
+            fh2 = FeatureHandler(cfg, engine=m2.engine)
+            fh2.use_private_rng()
+            for k in range(Ws + Ks):
+                if k == Ws:
+                    m2.engine.synchronize()
+                    ts0 = time.perf_counter()
+                fh2.next_training_batch_on_device(Bs, T_FRAMES, "default", policy)
+                m2.engine.train_step(Bs, lr)
+            m2.engine.synchronize()
+            dts = (time.perf_counter() - ts0) / Ks
+            batch_sweep = {str(Bs): {"value": round(Bs / dts, 1), "ms_per_step": round(1e3 * dts, 4), "steps": Ks, "warmup": Ws,
+                                     "step_frac": round(Bs / dts * step_bytes / HBM_PEAK, 4)}}
+            fh2._drop_prefetcher()
+            m2.engine.close()
 
         if world > 1:
             dist.barrier()
@@ -605,7 +658,13 @@ def main():
                      "step_frac_note": "whole step, per GPU: windows/s x SURVEY 8(d) algorithmic bytes per window / 8.0 TB/s",
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4), "final_loss": round(float(last_loss), 5),
+        "pre_roll_s": round(pre_roll_s, 3),
+        "pre_roll_note": "GPU work of this process BEFORE the W warm-up steps, outside the timed region: validation leg (3 x both sets), ~80 ms of "
+                         "inference forwards (device settle) and the per-kernel HIP-event pass (%d train steps).  It brings the device to its steady "
+                         "clocks; without it (--no-validation --profile-steps 0) a 5 + 20-step run reads ~0.36 ms/step instead" % args.profile_steps,
     }
+    if batch_sweep is not None:
+        out["batch_sweep"] = batch_sweep
     if validation is not None:
         out["validation"] = validation
     if world == 1 and not args.no_cpu_baseline:

@@ -291,14 +291,9 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops - and the forward convolution of any op - process
  * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, 1 = automatic, 2..4 = that many; default 1 for graphs
  * with depthwise ops (MixedNet flag sets: -7 % step time measured), 0 for pure convolution graphs (Inception: +0.5 ... +8 %)),
- * "fused_stages" (specialised MixedNet kernels, four-block topologies with a fused kernel, fp32: 0 = one launch per layer, the default;
- * 1 = the four backward blocks run as ONE launch of persistent workgroups that meet at grid-wide rendezvous between the layers - the whole
- * grid must be resident, the library checks the occupancy query and falls back otherwise; -1 % step time measured.  A spin that gives
- * up makes the next mww_synchronize return MWW_ERR_STATE),
  * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
  * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
- * assembly kernel), "assemble_overlap" (0: assembly of the next batch on its own stream next to the previous step's
- * gradient reduction — measured slower), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
+ * assembly kernel), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */
 int mww_set_option(mww_ctx* ctx, const char* name, int64_t value);
 
 /* per-kernel timing of the last N steps measured with HIP events on the context's stream:

@@ -391,99 +391,6 @@ __device__ __forceinline__ void publish_stat(const StatAcc& s, float* row, int C
   }
 }
 
-// ---- several layers in one launch ("fused_stages") ------------------------------------------------------
-// The layers of the network are separated by BatchNorm statistics over the whole batch: a device-wide dependency, but a
-// tiny one (2C sums).  Everything bulky a layer hands to the next one - the pre-BN tensor p_k, the stashed gradient g_k -
-// is produced and consumed per window, and a workgroup owns the same windows in every layer.  A launch that runs the
-// layers back to back in persistent workgroups therefore needs, between two layers, only
-//   * its own global stores to have completed (stage_drain: s_waitcnt vmcnt(0) in every wave; a CU's later loads of
-//     lines it stored itself are served by its XCD's L2, no fence involved),
-//   * a grid-wide rendezvous (grid_sync: counters moved by agent-scope atomics), and
-//   * the accumulator rows of the statistics hand-over read with agent-scope atomic loads (they were written by
-//     agent-scope atomic adds of workgroups on other XCDs: "8-byte agent atomics on both sides" needs no release /
-//     acquire pair - no L2 write-back, no L1 invalidate; MI355X_MICROARCH.md, inter-workgroup visibility).
-// What it buys over one launch per layer: no kernel boundary, no L2 write-back / cold start in between, and the first
-// rows a workgroup reads in the next layer are the rows it has just written (L2-resident) instead of a burst of 1024
-// workgroups' first tiles from HBM.  Every workgroup of the grid must be resident (grid <= CUs x blocks per CU of this
-// kernel): the host checks the occupancy query before it picks the fused launch, and every spin is bounded.
-struct GridSync {
-  unsigned* words;   // [kSyncWords]: arrival counters per dispatch class (blockIdx % 8), the top counter, release words, the
-                     // count of finished workgroups; all zero at launch - the last workgroup to finish zeroes them again
-  unsigned* fault;   // set when a spin gave up (the step's results are then garbage, the host reports it)
-};
-constexpr int kSyncStride = 32;                    // one 128-byte line per word
-constexpr int kSyncWords = (8 + 1 + 8 + 1) * kSyncStride;
-#ifndef MWW_SYNC_SLEEP
-#define MWW_SYNC_SLEEP 1
-#endif
-constexpr int kSyncSleep = MWW_SYNC_SLEEP;         // x 64 cycles between two polls of the release word
-constexpr unsigned kSpinLimit = 1u << 22;          // x ~100 cycles of sleep: tens of milliseconds, far beyond any real skew
-
-__device__ __forceinline__ void stage_drain() {
-  // vmcnt(0) (stores and atomics of this wave have been acknowledged), lgkmcnt / expcnt untouched (gfx9 encoding of the immediate)
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-}
-
-// every thread of every workgroup calls it; `epoch` = 1, 2, ... counts the rendezvous of this launch
-// (the caller has drained its own stores / atomics - stage_end - BEFORE it issued the loads that are in flight across this wait)
-__device__ __forceinline__ void grid_sync(const GridSync& g, unsigned epoch) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned x = blockIdx.x & 7u, ncls = gridDim.x < 8u ? gridDim.x : 8u;
-    const unsigned nx = (gridDim.x - x + 7u) / 8u;   // workgroups of this dispatch class
-    unsigned* cnt = g.words + x * kSyncStride;
-    unsigned* top = g.words + 8 * kSyncStride;
-    unsigned* rel = g.words + (9 + x) * kSyncStride;
-    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == nx * epoch) {
-      const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == ncls * epoch)
-        for (unsigned i = 0; i < ncls; ++i)
-          __hip_atomic_store(g.words + (9 + i) * kSyncStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned spins = 0;
-#ifdef MWW_SYNC_NOWAIT   // tuning builds only: arrive but do not wait (results invalid) - what the rendezvous itself costs
-    if (false)
-#endif
-    while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-      __builtin_amdgcn_s_sleep(kSyncSleep);
-      if (++spins > kSpinLimit) {
-        *g.fault = epoch;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// end of a stage: this workgroup's stores (its rows of p_k / g_k) and statistics atomics have been performed, and every wave is done
-// with the LDS tiles - the next stage may start loading (its first rows are rows this workgroup has just written)
-__device__ __forceinline__ void stage_end() {
-  stage_drain();
-  __syncthreads();
-}
-
-// last thing a fused launch does: the last workgroup to finish - every other one has passed every rendezvous and polls
-// nothing any more - returns the words to zero, so that the next fused launch (a replay of the same captured graph node
-// included: the pointers are baked into it) starts from a clean set
-__device__ __forceinline__ void grid_sync_finish(const GridSync& g) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* done = g.words + 17 * kSyncStride;
-    const unsigned old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == gridDim.x)
-      for (int i = 0; i < 18; ++i) __hip_atomic_store(g.words + i * kSyncStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// accumulator-row element as another workgroup's atomic add left it (FUSED), or a plain load (one launch per layer:
-// the kernel boundary has published it)
-template <bool FUSED>
-__device__ __forceinline__ double acc_load(const double* p) {
-  if constexpr (FUSED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-
 struct BnFoldArgs {      // forward statistics of a BN layer, folded by the first kernel that consumes them
   const double* acc;     // [kStatRows][2][C] sums of x, x^2 (null: scale / shift were written by a finalize / eval-prepare launch)
   float inv_n;           // 1 / (B*T)
@@ -499,14 +406,13 @@ struct BnFoldArgs {      // forward statistics of a BN layer, folded by the firs
 };
 
 // one thread per channel; same arithmetic as bn_fwd_finalize_kernel
-template <bool FUSED = false>
 __device__ __forceinline__ void bn_fold_channel(const BnFoldArgs& f, int C, int ch, float& sc, float& sh, float& meanf, float& rstd) {
   double s1 = 0.0, s2 = 0.0;
   double v1[kStatRows], v2[kStatRows];
 #pragma unroll
   for (int j = 0; j < kStatRows; ++j) {
-    v1[j] = acc_load<FUSED>(f.acc + (size_t)j * 2 * C + ch);
-    v2[j] = acc_load<FUSED>(f.acc + (size_t)j * 2 * C + C + ch);
+    v1[j] = f.acc[(size_t)j * 2 * C + ch];
+    v2[j] = f.acc[(size_t)j * 2 * C + C + ch];
   }
   const float gam = f.gamma[ch], bet = f.beta[ch];
   // workgroup 0 also updates the moving statistics: their old values travel with the sums (a load behind the stores
@@ -553,14 +459,13 @@ struct BnGradFoldArgs {  // backward statistics (sum g, sum g*xhat) of a BN laye
   float* dbeta;
 };
 
-template <bool FUSED = false>
 __device__ __forceinline__ void bn_grad_fold_channel(const BnGradFoldArgs& f, int C, int ch, float rstd, float& c1, float& mg, float& mgx) {
   double s1 = 0.0, s2 = 0.0;
   double v1[kStatRows], v2[kStatRows];
 #pragma unroll
   for (int j = 0; j < kStatRows; ++j) {
-    v1[j] = acc_load<FUSED>(f.acc + (size_t)j * 2 * C + ch);
-    v2[j] = acc_load<FUSED>(f.acc + (size_t)j * 2 * C + C + ch);
+    v1[j] = f.acc[(size_t)j * 2 * C + ch];
+    v2[j] = f.acc[(size_t)j * 2 * C + C + ch];
   }
   const float gam = f.gamma[ch];
 #pragma unroll

@@ -313,25 +313,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 1 : 2)) void bwd_block_kernel
   __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
   __shared__ __attribute__((aligned(16))) float sDW[K * CIN];      // depthwise taps
   __shared__ __attribute__((aligned(16))) float sAct[2 * CIN];     // BN_{k-1} folded scale / shift (activation at commit)
-  constexpr bool FUSED = false;
-#define MWW_STAGE_SYNC
 #include "bwd_block_body.inc"
-#undef MWW_STAGE_SYNC
-}
-
-template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB>
-__device__ __forceinline__ void bwd_block_stage(const BwdBlockArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
-  typedef BwdBlockLds<CIN, COUT, K> Lds;
-  float* smem = lds;
-  float* sKp = lds + Lds::KP;
-  float* sWt = lds + Lds::WT;
-  float* sDW = lds + Lds::DW;
-  float* sAct = lds + Lds::ACT;
-  constexpr bool FUSED = true;
-#undef MWW_STAGE_SYNC
-#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
-#include "bwd_block_body.inc"
-#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------
@@ -368,25 +350,7 @@ __global__ __launch_bounds__(kThreads, (S > 1 ? 1 : 2)) void bwd_first_kernel(Bw
   __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
-  constexpr bool FUSED = false;
-#define MWW_STAGE_SYNC
 #include "bwd_first_body.inc"
-#undef MWW_STAGE_SYNC
-}
-
-template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB>
-__device__ __forceinline__ void bwd_first_stage(const BwdFirstArgs& a, float* lds, const GridSync* sync, unsigned epoch) {
-  typedef BwdFirstLds<K1, C1, COUT, K, S> Lds;
-  float* smem = lds;
-  float* sKp = lds + Lds::KP;
-  float* sWt = lds + Lds::WT;
-  float* sX = lds + Lds::X;
-  XShared& sXg = *reinterpret_cast<XShared*>(lds + Lds::XG);
-  constexpr bool FUSED = true;
-#undef MWW_STAGE_SYNC
-#define MWW_STAGE_SYNC if (sync) grid_sync(*sync, epoch);
-#include "bwd_first_body.inc"
-#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------

@@ -376,8 +376,6 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
   __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CP1];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ XShared sXg;
-  constexpr bool FUSED = false;
-  (void)FUSED;
 #include "fwd_first_body.inc"
 }
 
@@ -390,10 +388,7 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ __attribute__((aligned(16))) float sScale[CIN];
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
-  constexpr bool FUSED = false;
-#define MWW_STAGE_SYNC
 #include "fwd_block_body.inc"
-#undef MWW_STAGE_SYNC
 }
 
 // ------------------------------------------------------------------------------------------

@@ -14,7 +14,6 @@
 
 #include "../../include/mww.h"
 #include "kernels_bwd.hip.h"
-#include "kernels_fused.hip.h"
 #include "kernels_data.hip.h"
 #include "kernels_fwd.hip.h"
 #include "kernels_graph.hip.h"
@@ -176,11 +175,6 @@ struct mww_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
-  // "assemble_overlap" option: the batch assembly of step k+1 runs on its own stream next to the gradient
-  // reduction / Adam launches of step k (tiny launch-bound kernels), never next to the block kernels
-  hipStream_t asm_stream = nullptr;
-  hipEvent_t ev_xfree = nullptr, ev_asm = nullptr;
-  bool asm_overlap = false, xfree_valid = false;
   int asm_split = 2;        // workgroups per window of the assembly kernel ("assemble_split" option)
   // "fused_input" option (default on, specialised MixedNet kernels only): mww_assemble_batch only uploads the window
   // descriptors; the first block's forward / backward kernels gather their rows from the stores themselves
@@ -215,13 +209,6 @@ struct mww_ctx {
   bool st_bf16 = false;   // p_k / g_k stored as bf16 ("storage_bf16", implies pointwise_bf16: BASELINE configs[4])
   bool bce_clipped = false;   // "bce_from_logits" 0: probability-form BCE with the Keras clip instead of the logits form (common.hip.h)
   bool bn_eval_ready = false;   // inside mww_evaluate_windows: the moving statistics are folded once, not per batch
-  // "fused_stages" option: the four backward blocks of a train step run as ONE launch, persistent workgroups meeting at
-  // grid-wide rendezvous between the layers (kernels_fused.hip.h).  Default off: it gains 1 % of the step, not
-  // worth a launch whose workgroups wait for each other.  (The forward counterpart measured slower and was removed.)
-  bool fused_stages = false;
-  unsigned* sync_words = nullptr;   // [kSyncWords] rendezvous words (self-resetting) + fault word
-  bool sync_par_used = false;   // a fused launch was enqueued: mww_synchronize looks at the fault word
-  std::map<const void*, int> fused_occ;   // resident workgroups per CU of a fused kernel (occupancy query)
   int ablate = 0;
   unsigned long long* phase_clk = nullptr;   // profiling: [2*layers][2048 workgroups][8 phases]
   std::vector<ProfileEntry> prof;
@@ -351,74 +338,6 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
   X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
-}
-
-// (conv1 kernel, conv1 filters, conv1 stride, block width, depthwise kernels of the four blocks): the topologies with fused
-// launches - the reference's argparse defaults and its training notebook's flags; exact fp32 only (the bf16 modes and every
-// other shape keep one launch per layer)
-#ifdef MWW_SLIM
-#define MWW_FUSED_TOPOLOGIES(X) X(3, 32, 1, 48, 5, 9, 13, 21)
-#else
-#define MWW_FUSED_TOPOLOGIES(X) X(3, 32, 1, 48, 5, 9, 13, 21) X(5, 32, 3, 64, 5, 11, 15, 23)
-#endif
-
-// a launch whose workgroups wait for each other.  On the device that is an ordinary launch of a grid the host has checked to be
-// resident as a whole; a host-side stand-in for the HIP runtime that runs workgroups one after the other (tests/hipemu) hooks in here.
-#ifndef MWW_LAUNCH_RESIDENT
-#define MWW_LAUNCH_RESIDENT hipLaunchKernelGGL
-#endif
-
-bool fused_topology(const mww_ctx* c) {
-  const mww_mixednet_desc& d = c->d;
-  if (c->generic || d.n_blocks != kFusedBlocks || c->pw_bf16 || c->st_bf16) return false;
-#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
-  if (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_filters[1] == CW && \
-      d.block_filters[2] == CW && d.block_filters[3] == CW && d.block_kernel[0] == KA && d.block_kernel[1] == KB &&          \
-      d.block_kernel[2] == KC && d.block_kernel[3] == KD)                                                                     \
-    return true;
-  MWW_FUSED_TOPOLOGIES(X)
-#undef X
-  return false;
-}
-
-// every workgroup of a fused launch waits for every other one: the grid must be resident as a whole
-int fused_resident(mww_ctx* c, const void* func, size_t lds, int grid, bool* ok) {
-  auto it = c->fused_occ.find(func);
-  if (it == c->fused_occ.end()) {
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, func, kThreads, lds) != hipSuccess) occ = 0;
-    it = c->fused_occ.emplace(func, occ).first;
-  }
-  *ok = grid <= it->second * c->n_cu;
-  return MWW_OK;
-}
-
-GridSync next_sync(mww_ctx* c) {
-  GridSync g;
-  g.words = c->sync_words;
-  g.fault = c->sync_words + kSyncWords;
-  c->sync_par_used = true;
-  return g;
-}
-
-// launches the fused kernel of this context's topology (launch = false: only answers whether `grid` workgroups of it are resident)
-int launch_bwd_fused(mww_ctx* c, BwdFusedArgs& a, int grid, bool launch, bool* ok) {
-  const mww_mixednet_desc& d = c->d;
-  *ok = false;
-#define X(K1, C1, S, CW, KA, KB, KC, KD)                                                                                      \
-  if (d.conv1_kernel == K1 && d.conv1_stride == S && d.block_filters[0] == CW && d.block_kernel[1] == KB) {                  \
-    const void* f = reinterpret_cast<const void*>(&bwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>);            \
-    const size_t lds = (size_t)FusedLds<K1, C1, S, CW, KA, KB, KC, KD>::BWD * sizeof(float);                                  \
-    int rc = fused_resident(c, f, lds, grid, ok);                                                                             \
-    if (rc || !*ok || !launch) return rc;                                                                                     \
-    a.sync = next_sync(c);                                                                                                    \
-    MWW_LAUNCH_RESIDENT((bwd_fused_kernel<K1, C1, S, CW, KA, KB, KC, KD, false, false>), dim3(grid), dim3(kThreads), lds, c->stream, a); \
-    return MWW_OK;                                                                                                            \
-  }
-  MWW_FUSED_TOPOLOGIES(X)
-#undef X
-  return MWW_OK;
 }
 
 bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
@@ -802,11 +721,6 @@ int enqueue_grad_assembly(mww_ctx* c, int B, GradReduceArgs& ga, bool fuse_adam,
   if (hi < 0) hi = c->P;
   int rcj = join_side(c);
   if (rcj) return rcj;
-  if (last_range && c->asm_overlap && !c->use_graphs && !c->profile) {
-    // x, y and the sample weights were last read by the launches above: the next batch may be assembled from here on
-    HIPCHK(hipEventRecord(c->ev_xfree, c->stream));
-    c->xfree_valid = true;
-  }
   const bool tail_here = c->tail_in_reduce && c->o_dense_w >= lo && c->o_dense_w < hi;
   if (tail_here) c->tail_in_reduce = false;
   if (!tail_here && c->o_dense_w >= lo && c->o_dense_w < hi) {
@@ -865,14 +779,6 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
   // gamma / beta gradients of a block are then written by that block's own backward kernel).
   const int split = nb >= 3 ? nb - 2 : 0;
   const bool bucketed = fuse_adam && c->hook && c->reduce_grads && !c->sync_bn && inl && c->tail_in_reduce && c->grad_buckets == 2 && split > 0;
-  // the four blocks' backward kernels as one launch (kernels_fused.hip.h): needs every BN layer's backward sums to arrive in
-  // accumulator rows (no finalize / head_tail launch in between) and no gradient bucket handed over half way
-  bool fused = false;
-  BwdFusedArgs fa;
-  if (inl && c->tail_in_reduce && !bucketed && c->fused_stages && fused_topology(c)) {
-    int rcf = launch_bwd_fused(c, fa, gbwd, false, &fused);
-    if (rcf) return rcf;
-  }
   for (int i = nb - 1; i >= 0; --i) {
     Layer& l = c->L[i];
     const bool last = (i == nb - 1);
@@ -960,10 +866,6 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
         pl.gacc_cur = a.gacc.acc;
       }
       a.gfold = gf;
-      if (fused) {
-        fa.blk[nb - 1 - i] = a;
-        continue;
-      }
       lp.begin("bwd_block", i);
       int rc = launch_bwd_block(c, l.cin, l.cout, l.k, last, a, gbwd);
       lp.end();
@@ -979,14 +881,6 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       BwdFirstArgs a{c->x, c->a0, l.p, l.g, bn_slot(l, BN_MEAN), bn_slot(l, BN_RSTD), bn_slot(l, BN_C1),
                      bn_slot(l, BN_MG), bn_slot(l, BN_MGX), c->params + l.o_dw_w, c->params + l.o_dw_b,
                      c->params + l.o_pw_w, l.grad_part, B, d.frames, l.tout, gf, x_gather(c)};
-      if (fused) {
-        fa.first = a;
-        lp.begin("bwd_fused");
-        int rc = launch_bwd_fused(c, fa, gbwd, true, &fused);
-        lp.end();
-        if (rc) return rc;
-        continue;
-      }
       lp.begin("bwd_block", i);
       int rc = launch_bwd_first(c, d.conv1_kernel, d.conv1_filters, l.cout, l.k, d.conv1_stride, a, gbwd);
       lp.end();
@@ -1877,8 +1771,6 @@ int alloc_common(mww_ctx* c) {
   A(dev_alloc(&c->dwd_part, (size_t)kDenseChunks * c->dwd_stride));
   A(dev_alloc(&c->metrics, 1));
   A(dev_alloc(&c->phase_clk, (size_t)2 * MWW_MAX_BLOCKS * 2048 * kClkSlots));
-  A(dev_alloc(&c->sync_words, (size_t)kSyncWords + kSyncStride));
-  HIPCHK(hipMemsetAsync(c->sync_words, 0, ((size_t)kSyncWords + kSyncStride) * sizeof(unsigned), c->stream));
   c->mail_off_masks = mb * sizeof(mww_window);
   c->mail_off_y = c->mail_off_masks + mb * kMaxMasks * 2 * sizeof(int);
   c->mail_off_sw = c->mail_off_y + mb * sizeof(float);
@@ -1898,9 +1790,6 @@ int alloc_common(mww_ctx* c) {
   H(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   H(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   H(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  H(hipStreamCreateWithFlags(&c->asm_stream, hipStreamNonBlocking));
-  H(hipEventCreateWithFlags(&c->ev_xfree, hipEventDisableTiming));
-  H(hipEventCreateWithFlags(&c->ev_asm, hipEventDisableTiming));
 #undef A
 #undef H
   return MWW_OK;
@@ -2473,7 +2362,6 @@ void mww_destroy(mww_ctx* c) {
     for (void* p : op) if (p) (void)hipFree(p);
   }
   if (c->sync_buf) (void)hipFree(c->sync_buf);
-  if (c->sync_words) (void)hipFree(c->sync_words);
   if (c->hact) (void)hipFree(c->hact);
   if (c->watt_part) (void)hipFree(c->watt_part);
   if (c->ones) (void)hipFree(c->ones);
@@ -2488,9 +2376,6 @@ void mww_destroy(mww_ctx* c) {
     if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
   }
   if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-  if (c->asm_stream) { (void)hipStreamSynchronize(c->asm_stream); (void)hipStreamDestroy(c->asm_stream); }
-  if (c->ev_xfree) (void)hipEventDestroy(c->ev_xfree);
-  if (c->ev_asm) (void)hipEventDestroy(c->ev_asm);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -2500,11 +2385,6 @@ void mww_destroy(mww_ctx* c) {
 int mww_synchronize(mww_ctx* c) {
   if (!c) return fail(MWW_ERR_INVALID, "null context");
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->sync_words && c->sync_par_used) {
-    unsigned fault = 0;
-    HIPCHK(hipMemcpy(&fault, c->sync_words + kSyncWords, sizeof(fault), hipMemcpyDeviceToHost));
-    if (fault) return fail(MWW_ERR_STATE, "a fused launch gave up waiting for its other workgroups (grid not resident?): results since the last synchronize are invalid; set option fused_stages 0");
-  }
   return MWW_OK;
 }
 
@@ -2631,7 +2511,6 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
       c->lazy_a = a;
       c->x_lazy = true;
       c->lazy_slot = c->mail_cur;
-      c->xfree_valid = false;
       c->have_batch = B;
       return MWW_OK;
     }
@@ -2644,14 +2523,7 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
     }
     c->x_lazy = false;
   }
-  if (c->xfree_valid && c->asm_overlap && !c->profile) {
-    c->xfree_valid = false;
-    HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_copy[c->mail_cur], 0));
-    HIPCHK(hipStreamWaitEvent(c->asm_stream, c->ev_xfree, 0));
-    hipLaunchKernelGGL(assemble_kernel, dim3(B * a.split), dim3(kThreads), 0, c->asm_stream, a);
-    HIPCHK(hipEventRecord(c->ev_asm, c->asm_stream));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_asm, 0));
-  } else {
+  {
     Launcher lp{c};
     lp.begin("assemble");
     hipLaunchKernelGGL(assemble_kernel, dim3(B * a.split), dim3(kThreads), 0, c->stream, a);
@@ -2665,7 +2537,6 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
 int mww_set_batch(mww_ctx* c, const float* hx, int B) {
   if (!c || !hx || B <= 0 || B > c->d.max_batch) return fail(MWW_ERR_INVALID, "bad batch size");
   HIPCHK(hipSetDevice(c->device));
-  c->xfree_valid = false;
   int rc = bring_targets(c);
   if (rc) return rc;
   c->x_lazy = false;
@@ -2742,7 +2613,7 @@ int mww_train_step(mww_ctx* c, int B, float lr, int flags) {
     const int mail = (apply || gen_dropout || c->x_lazy) ? c->mail_cur : -1;
     // the accumulator parities of the statistics hand-over are baked into the captured kernel arguments
     const bool flips = c->bn_inline && (!c->generic || (c->g_inline_ok && !c->profile_split));
-    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24) | ((c->fused_stages ? 1 : 0) << 27);
+    const int par = (flips ? (4 | c->fpar | (c->gpar << 1)) : 0) | (c->x_lazy ? 8 : 0) | (c->y_cur != c->y ? 16 : 0) | (c->tail_roles ? 32 : 0) | (c->g_role_split ? 64 : 0) | (c->grid_g_auto ? 128 : 0) | (c->g_dgrad_share << 8) | (c->g_cap_fwd << 16) | (c->g_cap_bwd << 20) | (c->g_chunks << 24);
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->graphs)
       if (g.B == B && g.flags == flags && g.mail == mail && g.par == par) exec = g.exec;
@@ -2787,7 +2658,6 @@ int mww_forward(mww_ctx* c, int B, int training, int update_metrics) {
   if (c->have_batch < B) return fail(MWW_ERR_STATE, "forward needs a batch of at least B rows");
   if (update_metrics && c->have_targets < B) return fail(MWW_ERR_STATE, "metric update needs targets");
   HIPCHK(hipSetDevice(c->device));
-  c->xfree_valid = false;   // this forward reads x on the main stream: the next assembly must queue behind it
   int rc = flush_targets(c);
   if (rc) return rc;
   if (c->lazy_slot != c->mail_cur) {
@@ -2933,12 +2803,10 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   }
   else if (!strcmp(name, "ablate")) c->ablate = (int)v;
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
-  else if (!strcmp(name, "assemble_overlap")) { c->asm_overlap = v != 0; c->xfree_valid = false; }
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
-  else if (!strcmp(name, "fused_stages")) c->fused_stages = v != 0;
   else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }
   else if (!strcmp(name, "graph_dgrad_share")) { if (v < 10 || v > 90) return fail(MWW_ERR_INVALID, "graph_dgrad_share must be 10..90"); c->g_dgrad_share = (int)v; }
   else if (!strcmp(name, "tail_roles")) c->tail_roles = v != 0;

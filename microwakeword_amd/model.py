@@ -84,6 +84,14 @@ WEIGHT_BROADCAST_MODES = ("per_sample", "keras_last_axis", "keras_first_axis")
 # this constant names the reading the reference's numbers follow.  Equal for all readings while class weights (or penalty
 # weights) are uniform, which holds for every BASELINE configuration.
 DEFAULT_WEIGHT_BROADCAST = "per_sample"
+# ... and how a [B,B] MATRIX handed to the drop-in ``train_on_batch`` is reduced: the caller that builds such a matrix is the
+# reference's own train.py (:288-293) and wants the reference's arithmetic, which by our reading of Keras 3
+# (keras/src/losses/loss.py: ``Loss.__call__`` -> ``reduce_weighted_values``: ``squeeze_or_expand_to_same_rank`` leaves a [B]
+# loss vector and a [B,B] weight as they are, ``values * sample_weight`` broadcasts the losses along the LAST axis,
+# ``reduce_values`` divides the sum by ``prod(shape(values))`` = B*B) is w_j = penalty_j * mean_i cw(y_i).  The vector-form
+# fast path of this package's own loop (train.train, config key ``sample_weight_broadcast``) keeps the evident intent
+# ``per_sample`` and says so in its log.  tests/test_tf_golden.py is the arbiter of both once TensorFlow numbers exist.
+MATRIX_WEIGHT_BROADCAST = "keras_last_axis"
 
 
 def combine_weights(penalty, labels, negative_class_weight, positive_class_weight, mode="per_sample"):
@@ -131,7 +139,7 @@ class Model:
         self.train_function = None
         self._compiled = False
         self.data_parallel = None   # parallel.DataParallel once join_data_parallel() was called
-        self.sample_weight_broadcast = DEFAULT_WEIGHT_BROADCAST   # how a [B,B] sample_weight matrix is reduced (combine_weights)
+        self.sample_weight_broadcast = MATRIX_WEIGHT_BROADCAST   # how a [B,B] sample_weight matrix is reduced (combine_weights)
 
     # ---- Keras surface
     def compile(self, optimizer=None, loss=None, metrics=None):
@@ -193,8 +201,9 @@ class Model:
         sw = np.asarray(sample_weight, np.float64)
         if sw.ndim == 2 and sw.shape == (n, n) and n > 1:
             # train.py:291-293 broadcasts penalty[B] * class_weight(y)[B,1] to [B,B] with W[i,j] = penalty_j * cw(y_i).
-            # Default: the intended per-sample weight, i.e. the diagonal; the two readings of Keras' reduction of the
-            # matrix (combine_weights) are the column / row means.  All agree when either factor is uniform.
+            # Default (MATRIX_WEIGHT_BROADCAST): what Keras 3 evaluates for the matrix by our reading, the column means;
+            # "per_sample" is the diagonal (the evident intent), "keras_first_axis" the row means.  All agree when either
+            # factor is uniform.
             mode = self.sample_weight_broadcast
             if mode == "per_sample":
                 sw = np.diagonal(sw)

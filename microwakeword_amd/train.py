@@ -252,9 +252,12 @@ def train(model, config, data_processor, verbose=True):
         cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
         if cw_neg != cw_pos and not warned_weights and config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST) == "per_sample":
             warned_weights = True
-            log.warning("class weights %g / %g are not uniform: the loss weights are penalty_i x class_weight(y_i) (sample_weight_broadcast: "
-                        "per_sample).  The reference hands Keras a [B,B] matrix here (train.py:288-293); if its loss curves are to be "
-                        "followed to the digit, see INTEGRATION.md section 2 (sample_weight_broadcast: keras_last_axis).", cw_neg, cw_pos)
+            log.warning("class weights %g / %g are not uniform.  THIS RUN optimises mean_i(penalty_i x class_weight(y_i) x bce_i) "
+                        "(sample_weight_broadcast: per_sample - every sample carries its own class weight).  The reference hands Keras a "
+                        "[B,B] matrix here (train.py:288-293), which Keras 3 reduces - by our reading of keras/src/losses/loss.py - to "
+                        "mean_j(penalty_j x bce_j) x mean_i(class_weight(y_i)): the class weights only rescale the whole batch loss.  Set "
+                        "sample_weight_broadcast: keras_last_axis in the training config to follow the reference's loss curve instead "
+                        "(INTEGRATION.md section 2).", cw_neg, cw_pos)
         if fast:
             data_processor.next_training_batch_on_device(local_batch, config["spectrogram_length"], "default", policy,
                                                          class_weights=(cw_neg, cw_pos),

@@ -166,7 +166,7 @@ CROSSED = (dict(DEF, mixconv_kernel_sizes="[5],[7,11],[9,15],[23]"),
            dict(NOTEBOOK, stride=1))
 
 
-def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
+def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF, lowp_tap_tol=5e-3):
     om = perturbed_oracle(T, flags=flags)
     lay, eng = make_engine(lib, T, max(B, 2), om, flags=flags)
     if grid:
@@ -189,17 +189,25 @@ def check_forward_parity(lib, B=5, T=194, training=False, grid=None, flags=DEF):
         ref = taps["b%d.r0.pre_bn" % k].detach().numpy()
         # bf16 mode: an engine fp32 operand and its oracle fp64 twin ~1e-6 apart round to different bf16
         # values with probability ~3e-4, each a 0.4 % operand error
-        tap_tol = 5e-3 if _lowp(flags) else 2e-5
-        assert np.abs(got - ref).max() <= tap_tol * max(1.0, np.abs(ref).max()), (k, np.abs(got - ref).max())
+        # (the bound is on the MAXIMUM over B * T_k * C elements of a heavy-tailed flip noise: a batch four times the size
+        # needs `lowp_tap_tol` raised - the 99.99th percentile keeps the small-batch bound)
+        tap_tol = lowp_tap_tol if _lowp(flags) else 2e-5
+        err = np.abs(got - ref)
+        assert err.max() <= tap_tol * max(1.0, np.abs(ref).max()), (k, err.max())
+        if _lowp(flags):
+            assert np.quantile(err, 0.9999) <= 5e-3 * max(1.0, np.abs(ref).max()), (k, np.quantile(err, 0.9999))
     eng.close()
     return float(np.abs(pr - po).max())
 
 
-def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=None, kind="mixednet"):
+def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=None, kind="mixednet", noise_factor=None):
     """One train step against the float64 oracle WITHOUT reading the engine's ReLU decisions back: the comparison the
     mask-imposing checks cannot give (a wrong mask would be copied into the oracle there).  A float32-vs-float64 flip
     of a near-zero unit may move a tensor's gradient by ~1/sqrt(units), hence the loose per-tensor L2 bound; a mask
-    bug moves it by O(1).  `kind` "inception" runs the conv/BN graph engine (dropout mask injected), `flags` any topology."""
+    bug moves it by O(1).  `kind` "inception" runs the conv/BN graph engine (dropout mask injected), "graph_mixednet" a
+    MixedNet flag set on the generic graph kernels, `flags` any topology.  `noise_factor` (the bf16 modes): the bound of a
+    tensor is that factor times the distance between the float32 and the float64 ORACLE on the same batch - the mode's own
+    rounding / decision-flip noise, measured here - but never below `bound`."""
     rng = np.random.default_rng(seed)
     x = synth_x(rng, B, T)
     y = (rng.random(B) < 0.5).astype(np.float32)
@@ -212,6 +220,16 @@ def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=Non
         keep = (rng.random((B, lay.t_last * lay.c_last)) >= flags["dropout"]).astype(np.float32)
         eng.set_dropout_mask(keep)
         kw = {"dropout_mask": keep}
+    elif kind == "graph_mixednet":
+        from microwakeword_amd.layout import GraphMixedNetLayout
+        flags = flags or GRAPH_MIXEDNET
+        om = perturbed_oracle(T, flags=flags)
+        lay = GraphMixedNetLayout(flags, T)
+        eng = native.Engine(lib=lib, **lay.engine_args(B))
+        eng.set_grad_mask(lay.grad_mask())
+        p0, s0 = lay.pack(om.get_weights())
+        eng.set_params(p0)
+        eng.set_bn_state(s0)
     else:
         om = perturbed_oracle(T, flags=flags or DEF)
         lay, eng = make_engine(lib, T, B, om, flags=flags or DEF)
@@ -220,24 +238,40 @@ def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=Non
     eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
     pr, z, loss = eng.read_outputs(B)
     lo, po, grads, _ = om.loss_and_grads(x, y, w, **kw)
-    assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
-    assert np.abs(pr - po).max() <= FWD_TOL
-    g = eng.get_grads()
-    if kind == "inception":
-        gref = lay.pack([grads[n].numpy().astype(np.float32) if kd == "param" else np.zeros(sh, np.float32)
-                         for n, sh, kd in lay.keras_vars])[0]
+    lowp = noise_factor is not None
+
+    def flat(grads):
+        if kind in ("inception", "graph_mixednet"):
+            return lay.pack([grads[n].numpy().astype(np.float32) if kd == "param" else np.zeros(sh, np.float32)
+                             for n, sh, kd in lay.keras_vars])[0]
+        return oracle_grads_native_order(lay, om, grads)
+
+    gref = flat(grads)
+    gnoise = None
+    if lowp:
+        om32 = perturbed_oracle(T, flags=flags or DEF, dtype=torch.float32)
+        lo32, po32, grads32, _ = om32.loss_and_grads(x, y, w, **kw)
+        gnoise = flat(grads32)
+        assert abs(loss - lo) <= max(1e-3, noise_factor * abs(lo32 - lo)) * max(1.0, abs(lo)), (loss, lo, lo32)
+        assert np.abs(pr - po).max() <= max(5e-3, noise_factor * float(np.abs(po32 - po).max()))
     else:
-        gref = oracle_grads_native_order(lay, om, grads)
+        assert abs(loss - lo) <= 1e-5 * max(1.0, abs(lo)), (loss, lo)
+        assert np.abs(pr - po).max() <= FWD_TOL
+    g = eng.get_grads()
     scale = max(1e-6, float(np.abs(gref).max()))
     off, worst = 0, 0.0
     for name, n in lay.segments():
         a, r = g[off:off + n], gref[off:off + n]
-        off += n
         if name.endswith("dw.bias"):     # true gradient exactly zero (cancelled by the BatchNorm): noise, bounded absolutely
-            assert np.abs(a - r).max() <= 2e-3 * scale, (name, np.abs(a - r).max())
+            tol = 2e-3 * scale if not lowp else max(2e-3 * scale, noise_factor * float(np.abs(gnoise[off:off + n] - r).max()))
+            assert np.abs(a - r).max() <= tol, (name, np.abs(a - r).max())
+            off += n
             continue
-        l2 = float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n)))
-        assert l2 <= bound, (name, l2)
+        den = max(np.linalg.norm(r), 1e-3 * scale * np.sqrt(n))
+        l2 = float(np.linalg.norm(a - r) / den)
+        lim = bound if not lowp else max(bound, noise_factor * float(np.linalg.norm(gnoise[off:off + n] - r) / den))
+        off += n
+        assert l2 <= lim, (name, l2, lim)
         worst = max(worst, l2)
     eng.close()
     return worst
@@ -352,9 +386,13 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
     m = native.metrics_from_raw(eng.metrics_raw())
     r = om.metrics.result()
     if lowp:
-        # a probability 1e-4 away from one of the 101 cutoffs may be bucketed on the other side
+        # a probability 1e-4 away from one of the 101 cutoffs may be bucketed on the other side; at thousands of windows
+        # (probabilities up to 5e-3 apart against a bucket width of 1e-2) every cutoff sees a few crossings in both directions:
+        # the counts are then bounded per cutoff
+        n_win = B * steps
+        slack, nz = (1, 2) if n_win <= 64 else (1 + n_win // 512, 101)
         for k in ("tp", "fp", "tn", "fn"):
-            assert np.abs(m[k] - r[k]).max() <= 1 and np.count_nonzero(m[k] != r[k]) <= 2, k
+            assert np.abs(m[k] - r[k]).max() <= slack and np.count_nonzero(m[k] != r[k]) <= nz, (k, np.abs(m[k] - r[k]).max())
     else:
         for k in ("accuracy", "recall", "precision", "auc"):
             assert abs(m[k] - r[k]) < 1e-6, (k, m[k], r[k])
@@ -1034,88 +1072,6 @@ def check_against_frozen_oracle(lib, golden_dir):
         eng.close()
 
 
-# ------------------------------------------------------------------------------------------ overlapped assembly
-def check_assemble_overlap(lib, B=8, T=60, steps=5):
-    """"assemble_overlap" (the next batch is gathered on its own stream next to the previous step's gradient
-    reduction / Adam launches) changes the schedule only: parameters after a few steps, with an evaluation forward
-    and a host-provided batch in between, are bit-identical to the serial schedule."""
-    from microwakeword_amd import mixednet
-    policy = dict(time_mask_max_size=4, time_mask_count=2, freq_mask_max_size=4, freq_mask_count=2)
-    results = []
-    for overlap in (0, 1):
-        random.seed(3)
-        np.random.seed(3)
-        model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=11, max_batch=B)
-        eng = model.engine
-        eng.set_option("assemble_overlap", overlap)
-        fh = FeatureHandler(learnable_config(T=T), engine=eng)
-        probs = []
-        for k in range(steps):
-            fh.next_training_batch_on_device(B, T, "default", policy)
-            eng.train_step(B, 1e-2)
-            if k == 1:   # an evaluation pass reads x on the main stream between two steps
-                fh.next_training_batch_on_device(B, T, "default", policy)
-                eng.forward(B, training=False)
-                probs.append(eng.read_outputs(B, want_loss=False)[0].copy())
-            if k == 2:   # a host batch overwrites x between two steps
-                eng.set_batch(np.full((B, T, 40), 0.5, np.float32))
-                eng.set_targets(np.ones(B, np.float32), np.ones(B, np.float32))
-                eng.train_step(B, 1e-2)
-        probs.append(eng.read_outputs(B)[0].copy())
-        results.append((eng.get_params().copy(), probs, eng.get_batch(B).copy()))
-        eng.close()
-    np.testing.assert_array_equal(results[0][0], results[1][0])
-    np.testing.assert_array_equal(results[0][2], results[1][2])
-    for a, b in zip(results[0][1], results[1][1]):
-        np.testing.assert_array_equal(a, b)
-
-
-# ------------------------------------------------------------------------------------------ fused stages
-def check_fused_stages_match_layer_launches(lib, B=4, T=194, steps=3, grids=(3, 3), flags=DEF, graphs=False, sizes=None):
-    """"fused_stages" (kernels_fused.hip.h: the four backward blocks as one launch, persistent
-    workgroups meeting at grid-wide rendezvous between the layers) runs the same stage bodies on the same windows in the same
-    order as one launch per layer, so gradients, parameters, BN moving statistics and outputs are bit-identical - over several
-    steps (the rendezvous words alternate between two sets), with grids smaller than the batch (grid-stride windows), with
-    changing batch sizes, and through captured graphs.  Also checks that the fused launches were really taken."""
-    rng = np.random.default_rng(17)
-    sizes = list(sizes) if sizes else [B] * steps
-    xs = [synth_x(rng, b, T) for b in sizes]
-    ys = [(rng.random(b) < 0.5).astype(np.float32) for b in sizes]
-    ws = [rng.choice([0.5, 1.0, 2.0], size=b).astype(np.float32) for b in sizes]
-    om = perturbed_oracle(T, flags=flags)
-    outs = []
-    for fused in (1, 0):
-        lay, eng = make_engine(lib, T, max(sizes), om, flags=flags)
-        eng.set_option("fused_stages", fused)   # 1 = the backward blocks in one launch, 0 = one launch per layer (the default)
-        if grids[0]:
-            eng.set_option("grid_fwd", grids[0])
-        if grids[1]:
-            eng.set_option("grid_bwd", grids[1])
-        if graphs:
-            eng.set_option("graphs", 1)
-        else:
-            eng.set_option("profile", 1)
-        got = []
-        for x, y, w in zip(xs, ys, ws):
-            eng.set_batch(x)
-            eng.set_targets(y, w)
-            eng.train_step(x.shape[0], 1e-3)
-            got.append(eng.read_outputs(x.shape[0])[0].copy())
-            got.append(eng.get_grads().copy())
-        if not graphs:
-            names = [n for n, _ in eng.profile_read()]
-            if not fused:
-                assert "bwd_fused" not in names, names
-            elif flags is DEF and lib.device_count() > 0 and (grids[1] or max(sizes)) <= 512:
-                assert "bwd_fused" in names, names   # (wider topologies: only where the whole grid is resident)
-        got += [eng.get_params().copy(), eng.get_bn_state().copy()]
-        outs.append(got)
-        eng.close()
-    for a, b in zip(*outs):
-        np.testing.assert_array_equal(a, b)
-
-
-# ------------------------------------------------------------------------------------------ prefetched batches
 def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
     """Batches drawn ahead by the prefetcher's worker thread (native.Prefetcher, csrc/sampler.cpp) against the synchronous
     sampler on the launching thread: the same private streams give the same windows / masks / labels / weights in the same

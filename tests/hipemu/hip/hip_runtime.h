@@ -58,7 +58,6 @@ unsigned wave_exchange(unsigned v, int src_lane);                 // 32-bit shuf
 void wave_exchange2(float a, float b, const float** A, const float** B);  // publish 2 floats, get arrays
 const unsigned long long* wave_publish2(unsigned long long a, unsigned long long b);  // publish 2 x 64 bit, get [64][2]
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
-void launch_resident(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);   // all blocks alive at once (grid-wide waits)
 void spin_yield();                                                // a thread polling memory lets every other fiber run
 int lane_id();
 void* dyn_shared();                                               // dynamic LDS of the running block
@@ -262,12 +261,6 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, co
 }
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::dyn_shared());
-// a launch whose workgroups wait for each other (kernels_fused.hip.h): the emulator keeps every block's fibers alive at once
-#define MWW_LAUNCH_RESIDENT(kernel, grid, block, shmem, stream, ...)                                 \
-  do {                                                                                               \
-    dim3 hipemu_g = (grid), hipemu_b = (block);                                                      \
-    hipemu::enqueue((stream), [=]() { hipemu::launch_resident(hipemu_g, hipemu_b, (shmem), [=]() { kernel(__VA_ARGS__); }); }); \
-  } while (0)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                  \
   do {                                                                                               \
     dim3 hipemu_g = (grid), hipemu_b = (block);                                                      \

@@ -183,18 +183,6 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
       for (unsigned x = 0; x < grid.x; ++x) run_blocks(block, {uint3_emu{x, y, z}}, shmem, body);
 }
 
-// every block of the grid alive at once: a polling thread (spin_yield) lets the other blocks run.  Kernels launched this
-// way must keep their LDS in the dynamic segment (a `static` stand-in for __shared__ is one object for all blocks).
-void launch_resident(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
-  g_gridDim = grid;
-  g_blockDim = block;
-  std::vector<uint3_emu> ids;
-  for (unsigned z = 0; z < grid.z; ++z)
-    for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) ids.push_back(uint3_emu{x, y, z});
-  run_blocks(block, ids, shmem, body);
-}
-
 void spin_yield() { yield(RUN); }
 static int g_tpb() { return g_threads_per_block > 0 ? g_threads_per_block : 1; }
 static int wave_of_cur() {

@@ -248,18 +248,6 @@ def test_against_frozen_oracle_outputs(emu_lib, golden_dir):
     ec.check_against_frozen_oracle(emu_lib, golden_dir)
 
 
-def test_assemble_overlap_is_schedule_only(emu_lib):
-    ec.check_assemble_overlap(emu_lib)
-
-
-def test_fused_stages_match_one_launch_per_layer(emu_lib):
-    ec.check_fused_stages_match_layer_launches(emu_lib, B=4, T=194, steps=3, grids=(3, 3))
-    ec.check_fused_stages_match_layer_launches(emu_lib, T=130, grids=(2, 2), sizes=(4, 2, 1, 3), graphs=True)
-    ec.check_fused_stages_match_layer_launches(emu_lib, B=2, T=204, steps=2, grids=(2, 2), flags=ec.NOTEBOOK)
-    # one fused launch per captured step: the rendezvous words have to come back to zero by themselves between two replays
-    ec.check_fused_stages_match_layer_launches(emu_lib, B=3, T=130, steps=4, grids=(2, 2), graphs=True)
-
-
 def test_prefetched_batches_train_like_the_synchronous_sampler(emu_lib):
     ec.check_prefetched_training_matches_synchronous(emu_lib)
 

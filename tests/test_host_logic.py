@@ -189,6 +189,13 @@ def test_sample_weight_broadcast_modes():
     np.testing.assert_allclose(combine_weights(np.ones(B), y, 0.25, 3.0, "keras_first_axis"), combine_weights(np.ones(B), y, 0.25, 3.0, "per_sample"))
     with pytest.raises(ValueError):
         combine_weights(pen, y, 1.0, 1.0, "diagonal")
+    # the two defaults: a [B,B] matrix through the drop-in train_on_batch (its caller is the reference's train.py) follows
+    # the reference's arithmetic as Keras 3 reduces it; the vector-form fast path keeps the per-sample product
+    from microwakeword_amd import model as model_mod
+    assert model_mod.MATRIX_WEIGHT_BROADCAST == "keras_last_axis" and model_mod.DEFAULT_WEIGHT_BROADCAST == "per_sample"
+    m.sample_weight_broadcast = model_mod.MATRIX_WEIGHT_BROADCAST
+    np.testing.assert_allclose(m._per_sample_weights(W, B), pen * cw.mean(), rtol=1e-6)
+    np.testing.assert_allclose(m._per_sample_weights(pen * cw, B), pen * cw, rtol=1e-6)   # a plain vector is taken as it is
 
 
 def test_best_model_rule():
@@ -334,3 +341,37 @@ def test_bench_refuses_to_report_a_smaller_job_under_a_bigger_label():
     assert r.returncode != 0
     assert "GPU(s) are visible" in (r.stderr + r.stdout)
     assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_traffic_figure_is_tied_to_the_library_it_was_measured_on(tmp_path):
+    """roofline.traffic comes from a committed PMC summary; bench.py reports it only when the summary's stamp
+    (`# library sha256_16=...`, written by tools/pmc_summary.py) is the sha of the library this process loads."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lib = tmp_path / "libfake.so"
+    lib.write_bytes(b"library build A")
+    sha = bench.library_sha16(str(lib))
+    body = ("## counters pmc3\nbwd_block_kernel<48, 48, 21, true>   n=8   us=52.0 FETCH_SIZE=3.2e+04\n"
+            "## counters pmc4\nbwd_block_kernel<48, 48, 21, true>   n=8   us=52.0 WRITE_SIZE=4e+04\n")
+    good = tmp_path / "good.txt"
+    good.write_text("# library sha256_16=%s\n%s" % (sha, body))
+    nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(good), library=str(lib))
+    assert nbytes == int(2 * 3.2e4 * 1024 + 4e4 * 1024) and sha in src
+    lib.write_bytes(b"library build B")                       # the library moved on, the profile did not
+    nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(good), library=str(lib))
+    assert nbytes is None and src.startswith("stale: profile sha %s != library sha" % sha)
+    unstamped = tmp_path / "old.txt"
+    unstamped.write_text(body)                                 # a summary from before the stamp existed
+    nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(unstamped), library=str(lib))
+    assert nbytes is None and src.startswith("stale: profile sha None")
+    # the summariser writes the stamp of the library in the tree as its first line
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py")], capture_output=True, text=True)
+    first = r.stdout.splitlines()[0]
+    assert first.startswith("# library sha256_16=")
+    if os.path.isfile(bench.LIBRARY):
+        assert first.endswith(bench.library_sha16())

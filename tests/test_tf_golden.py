@@ -22,6 +22,6 @@ def test_oracle_matches_the_reference_tensorflow_model():
     z = np.load(tg.GOLDEN)
     for case in z["cases"]:
         modes = tg.check_oracle(z, str(case))
-        # the package's default reading of the [B,B] sample weight has to be the one Keras follows
-        assert model.DEFAULT_WEIGHT_BROADCAST in modes, (
-            "the reference's weighted loss follows %s; set microwakeword_amd.model.DEFAULT_WEIGHT_BROADCAST accordingly" % modes)
+        # the package's reading of the [B,B] sample weight matrix has to be the one Keras follows
+        assert model.MATRIX_WEIGHT_BROADCAST in modes, (
+            "the reference's weighted loss follows %s; set microwakeword_amd.model.MATRIX_WEIGHT_BROADCAST accordingly" % modes)

@@ -16,8 +16,6 @@ Q="--no-cpu-baseline --no-validation"
 echo "== bench default (as the driver runs it: 5 + 20 steps; then 20 + 200 steps)"
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench.err; tail -c 2600 $OUT/bench_driver_form.json; tail -2 $OUT/bench.err
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 300 $OUT/bench.json; echo
-echo "== fused backward stages"
-MWW_BENCH_OPTIONS=fused_stages=1 timeout 600 python bench.py $Q > $OUT/bench_fused_backward.json 2>/dev/null; head -c 200 $OUT/bench_fused_backward.json; echo
 echo "== synchronous sampler"
 timeout 600 python bench.py $Q --no-prefetch > $OUT/bench_sync_sampler.json 2>/dev/null; head -c 200 $OUT/bench_sync_sampler.json; echo
 echo "== bench inception / notebook / generic"
@@ -48,15 +46,10 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- $B > /dev/null 2> $OUT/pmc2.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $B > /dev/null 2> $OUT/pmc3.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $B > /dev/null 2> $OUT/pmc4.err
-# kernel trace of the fused-backward option
-export MWW_BENCH_OPTIONS=fused_stages=1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fused -o t -- $B > /dev/null 2> $OUT/trace_fused.err
-unset MWW_BENCH_OPTIONS
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inc -o t -- $B --model inception > /dev/null 2> $OUT/trace_inc.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nb -o t -- $B --model notebook > /dev/null 2> $OUT/trace_nb.err
 cd $R
 python tools/pmc_summary.py $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 > $OUT/kernel_stats_and_pmc.txt 2>&1
-python tools/pmc_summary.py $OUT/trace_fused > $OUT/kernel_stats_fused_backward.txt 2>&1
 python tools/pmc_summary.py $OUT/trace_inc > $OUT/kernel_stats_inception.txt 2>&1
 python tools/pmc_summary.py $OUT/trace_nb > $OUT/kernel_stats_notebook.txt 2>&1
 head -14 $OUT/kernel_stats_and_pmc.txt | cut -c1-200

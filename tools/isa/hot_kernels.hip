@@ -14,7 +14,3 @@ template __global__ void bwd_block_kernel<48, 48, 21, true, false>(BwdBlockArgs)
 template __global__ void bwd_first_kernel<3, 32, 48, 5, 1, false>(BwdFirstArgs);
 template __global__ void head_kernel<48, 8>(HeadArgs);
 }
-#include "../../microwakeword_amd/csrc/kernels_fused.hip.h"
-namespace mww {
-template __global__ void bwd_fused_kernel<3, 32, 1, 48, 5, 9, 13, 21, false, false>(BwdFusedArgs);
-}

@@ -13,7 +13,20 @@ def short(name):
     return name
 
 
+def library_stamp():
+    """First line of every summary: the library the profile was measured on (bench.py refuses a summary whose stamp is not
+    the library it loaded)."""
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microwakeword_amd", "libmww_hip.so")
+    try:
+        with open(lib, "rb") as fh:
+            return "# library sha256_16=%s" % hashlib.sha256(fh.read()).hexdigest()[:16]
+    except OSError:
+        return "# library sha256_16=unknown"
+
+
 def main():
+    print(library_stamp())
     for d in sys.argv[1:]:
         for f in glob.glob(os.path.join(d, "*kernel_stats.csv")):
             print("## kernel stats", f)
