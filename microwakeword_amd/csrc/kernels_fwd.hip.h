@@ -357,7 +357,8 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 template <int K1, int C1, int COUT, int K, int S>
 struct FwdFirstLds {
   static constexpr int CP1 = pitch(C1), RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
-  static constexpr int XR = (TT - 1) * S + K1, PX = FBINS + 1;
+  static constexpr int TAIL = S > 1 ? K - 1 : 0;   // extra a0 rows of a single-tile window (fwd_first_body.inc "tail rows")
+  static constexpr int XR = (TT + TAIL - 1) * S + K1, PX = FBINS + 1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
   static constexpr int X = 0, A = X + up4(XR * PX), U = A + RAP * CP1, RED = U + TTP * CP1, XG = RED + 4 * 2 * COUT;
   static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);

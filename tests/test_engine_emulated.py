@@ -261,6 +261,10 @@ def test_train_loop_data_parallel_world1(emu_lib, tmp_path):
     assert not dp.library_comm and dp.engine_driven
 
 
+def test_first_conv_tail_rows(emu_lib):
+    ec.check_first_conv_tail_rows(emu_lib, B=3, lengths=(203, 206, 209))
+
+
 def test_bn_inline_matches_finalize(emu_lib):
     ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)
 

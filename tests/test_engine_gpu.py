@@ -479,6 +479,10 @@ def test_train_loop_prefetch_is_schedule_only(lib, tmp_path):
     ec.check_train_loop_prefetch_is_schedule_only(lib, tmp_path)
 
 
+def test_first_conv_tail_rows(lib):
+    ec.check_first_conv_tail_rows(lib, B=37, grid=0)
+
+
 def test_bn_inline_matches_finalize(lib):
     ec.check_bn_inline_matches_finalize(lib, B=96, T=194, steps=4)
     ec.check_bn_inline_matches_finalize(lib, B=5, T=194, steps=2)   # fewer workgroups than accumulator rows
