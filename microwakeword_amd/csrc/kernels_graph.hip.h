@@ -63,6 +63,25 @@ struct GSrc {
   StatAcc gacc;         // backward sums of this slice go to the producer's accumulator rows ([kStatRows][2][ld]) instead of gstat_part
 };
 
+// ---- compile-time shapes ---------------------------------------------------------------------------------------
+// The graph kernels take every shape at run time: kernel length, dilation, channel counts, the sources' widths and row
+// lengths.  Their launches turned out to be bound by instruction issue, not by memory latency (round-2 counters of the
+// default Inception step: 2 800 VALU + 2 400 SALU instructions per wave around 180 MFMAs - index arithmetic, loop control,
+// run-time divisions - with four waves per SIMD each active 20-30 % of its time: the SIMDs are saturated).  GShape names
+// what the instantiations for a known topology (mww_lib.hip MWW_G_SHAPES: the ops of the reference's default Inception
+// flags, inception.py:146-209) know at compile time: kernel length K (dilation and stride 1), the number of sources and
+// each one's (width, row length of the tensor it is a channel slice of).  Everything derived from them - LDS pitches, the
+// thread <-> (channel group, frame group) maps, trip counts of the MFMA loops - folds to constants, LDS reads take
+// immediate offsets.  GShapeDyn (all zero) = the run-time path, for every other topology.
+template <int K_, int NSRC_, int C0_, int L0_, int C1_ = 0, int L1_ = 0, int C2_ = 0, int L2_ = 0>
+struct GShape {
+  static constexpr int K = K_, NSRC = NSRC_, CIN = C0_ + C1_ + C2_;
+  static constexpr int srcC(int i) { return i == 0 ? C0_ : (i == 1 ? C1_ : C2_); }
+  static constexpr int srcLD(int i) { return i == 0 ? L0_ : (i == 1 ? L1_ : L2_); }
+  static constexpr int srcC0(int i) { return i == 0 ? 0 : (i == 1 ? C0_ : C0_ + C1_); }   // first channel in the concatenation
+};
+typedef GShape<0, 0, 0, 0> GShapeDyn;
+
 // ---- BN statistics hand-over (common.hip.h) in the graph kernels -------------------------------------------
 // The producer of a BN'd tensor adds its per-workgroup sums to kStatRows replicated fp64 rows; the FIRST launch that
 // consumes the tensor folds them in every workgroup's prologue into an LDS table (its workgroup 0 also publishes the
@@ -244,12 +263,22 @@ __device__ __forceinline__ int gvec_width(int C, int ld, int c0) {
 
 // one source without a residual branch; coef = [2][...] scale / shift indexed by producer channel (global or LDS)
 // f0: first frame of the staged rows within the (aligned) window - frame chunks of 1x1 ops, else 0
-template <int V>
+// (SC, SLD > 0: the slice width and the producer's row length as the instantiation knows them - GShape)
+template <int V, int SC = 0, int SLD = 0>
 __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows, float* sIn, int PI, int c0out, int tid,
                                                  const float* cscale, const float* cshift, int f0 = 0) {
-  const int NQ = s.C / V, nrg = fast_div(kThreads, NQ);
-  int q, rg;
-  fast_divmod(tid, NQ, rg, q);
+  const int sC = SC > 0 ? SC : s.C, sLD = SLD > 0 ? SLD : s.ld;
+  int q, rg, nrg;
+  if constexpr (SC > 0) {
+    constexpr int NQ = SC / V;
+    nrg = kThreads / NQ;
+    rg = tid / NQ;
+    q = tid - rg * NQ;
+  } else {
+    const int NQ = sC / V;
+    nrg = fast_div(kThreads, NQ);
+    fast_divmod(tid, NQ, rg, q);
+  }
   if (rg >= nrg) return;
   const bool ident = (s.flags & GSRC_IDENTITY) != 0;
   float sc[V], sh[V];
@@ -259,14 +288,14 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
     sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
   }
   const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
-  const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff + f0) * s.ld + s.c0, ((rows - 1) * s.ld + s.C) * 4);
+  const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff + f0) * sLD + s.c0, ((rows - 1) * sLD + sC) * 4);
   float* dst = sIn + c0out + q * V;
   constexpr int NB = kGB;   // rows in flight (these kernels live on
                                                // the number of resident workgroups: registers are occupancy)
   for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
     GVec<V> v[NB];
 #pragma unroll
-    for (int u = 0; u < NB; ++u) v[u] = gvec_bload<V>(slab, (t0 + u * nrg) * s.ld + q * V);
+    for (int u = 0; u < NB; ++u) v[u] = gvec_bload<V>(slab, (t0 + u * nrg) * sLD + q * V);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
       const int t = t0 + u * nrg;
@@ -278,9 +307,29 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
   }
 }
 
+// the sources of a static shape: the loop over them is unrolled, every source with its own compile-time width / row length
+template <class SH, int I = 0>
+__device__ __forceinline__ void stage_sources_static(const GSrc* src, int b, int rows, float* sIn, int PI, int tid, const GFoldFwd* fold,
+                                                     const float* ftab, int f0) {
+  if constexpr (I < SH::NSRC) {
+    constexpr int C = SH::srcC(I), LD = SH::srcLD(I);
+    constexpr int V = ((C | LD) & 3) == 0 ? 4 : (((C | LD) & 1) == 0 ? 2 : 1);   // (the host checks that the slice offset is a multiple of it)
+    const GSrc& s = src[I];
+    const bool folded = fold != nullptr && ftab != nullptr && fold[I].acc != nullptr;
+    const float* tab = ftab + I * 4 * kGFoldC;
+    stage_source_vec<V, C, LD>(s, b, rows, sIn, PI, SH::srcC0(I), tid, folded ? tab : s.scale, folded ? tab + kGFoldC : s.shift, f0);
+    stage_sources_static<SH, I + 1>(src, b, rows, sIn, PI, tid, fold, ftab, f0);
+  }
+}
+
 // ftab: null, or [kGMaxSrc][4][kGFoldC] with the folded (scale, shift, ..) of the sources whose fold[i].acc is set
+template <class SH = GShapeDyn>
 __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b, int rows, float* sIn, int PI, int tid,
                                               const GFoldFwd* fold = nullptr, const float* ftab = nullptr, int f0 = 0) {
+  if constexpr (SH::NSRC > 0) {
+    stage_sources_static<SH>(src, b, rows, sIn, PI, tid, fold, ftab, f0);
+    return;
+  }
   int c0 = 0;
   for (int i = 0; i < n_src; ++i) {
     const GSrc& s = src[i];
@@ -326,12 +375,22 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
 
 // dp = BN backward of the op's output gradient, rows [0, rows) of window b -> dst[t * ld + c]
 // (f0, Ttot: rows [f0, f0 + rows) of a window of Ttot frames - frame chunks of 1x1 ops; Ttot < 0: the whole window)
-template <int V>
-__device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab,
+// (CC > 0: the channel count as the instantiation knows it)
+template <int V, int CC = 0>
+__device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C_, int b, int rows, float* dst, int ld, int tid, const float* btab,
                                              int f0 = 0, int Ttot = -1) {
-  const int NQ = C / V, nrg = fast_div(kThreads, NQ);
-  int q, rg;
-  fast_divmod(tid, NQ, rg, q);
+  const int C = CC > 0 ? CC : C_;
+  int q, rg, nrg;
+  if constexpr (CC > 0) {
+    constexpr int NQ = CC / V;
+    nrg = kThreads / NQ;
+    rg = tid / NQ;
+    q = tid - rg * NQ;
+  } else {
+    const int NQ = C / V;
+    nrg = fast_div(kThreads, NQ);
+    fast_divmod(tid, NQ, rg, q);
+  }
   if (rg >= nrg) return;
   const bool folded = btab != nullptr && y.fold.acc != nullptr;
   float mu[V], rs[V], c1[V], mg[V], mgx[V];
@@ -373,7 +432,7 @@ template <int CW>
 __device__ __forceinline__ void stage_dp(const GBnBwd& y, int C, int b, int rows, float* dst, int ld, int tid, const float* btab = nullptr,
                                          int f0 = 0, int Ttot = -1) {
   constexpr int V = CW == 0 ? 1 : (CW % 4 == 0 ? 4 : (CW % 2 == 0 ? 2 : 1));
-  stage_dp_vec<V>(y, C, b, rows, dst, ld, tid, btab, f0, Ttot);
+  stage_dp_vec<V, CW>(y, C, b, rows, dst, ld, tid, btab, f0, Ttot);
 }
 
 // per-thread (s1, s2) of channel c = tid % C, frame group tid / C  ->  part[2][ld] of this workgroup
@@ -448,8 +507,71 @@ struct GConvArgs {
 // (window, chunk) pairs.  The forward convolution and the weight gradient also take k > 1 (a chunk stages its input frames
 // plus halo: the 5 x 40 -> 24 stem); the data gradient only k = 1.  Separate instantiations: the whole-window kernels are
 // unchanged by it.
-template <int NC, int MODE, int CDP = 0, bool CH = false>
+// Data-gradient epilogue of a static shape (whole windows, no residual branches): source I's slice of the gradient tile goes
+// to g (first consumer: stored, later ones: accumulated) through the ReLU mask of the source, with the slice's backward sums.
+// Same arithmetic and order as the run-time loop in gconv_body; the slice width / row length are constants here.
+template <class SH, int I = 0>
+__device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, const float* sOut, int PO, int tid, float& s1o, float& s2o,
+                                                     float* sSrcAcc) {
+  if constexpr (I < SH::NSRC) {
+    constexpr int C = SH::srcC(I), LD = SH::srcLD(I), c0 = SH::srcC0(I);
+    const GSrc& s = src[I];
+    if (s.flags & GSRC_GRAD) {
+      constexpr int nrg = kThreads / C;
+      const int rg = tid / C, c = tid - rg * C;
+      if (rg < nrg) {
+        const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
+        const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
+        const bool linear = (s.flags & GSRC_LINEAR) != 0;
+        const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
+        float t1 = 0.f, t2 = 0.f;
+        const size_t woff = (size_t)b * s.T * LD + s.c0;
+        const int wbytes = ((s.T - 1) * LD + C) * 4;
+        const BufRsrc pr = tile_rsrc(s.p + woff, wbytes), gr = tile_rsrc(s.g + woff, wbytes), go = tile_rsrc(s.g + woff, accum ? wbytes : 0);
+        for (int tb = rg; tb < s.T; tb += kGE * nrg) {
+          float pv[kGE], gold[kGE];
+#pragma unroll
+          for (int u = 0; u < kGE; ++u) {
+            const int off = ((tb + u * nrg) * LD + c) * 4;
+            pv[u] = tile_load1(pr, off);
+            gold[u] = tile_load1<MWW_AUX_GR_LD_GOLD>(go, off);
+          }
+#pragma unroll
+          for (int u = 0; u < kGE; ++u) {
+            const int t = tb + u * nrg;
+            if (t < s.T) {
+              const float p = pv[u];
+              const int r = t - s.toff;   // row of the output tile
+              const float gv = ((r >= 0 && (linear || fmaf(p, sc, sh) > 0.f)) ? sOut[r * PO + c0 + c] : 0.f) + gold[u];
+              tile_store1<MWW_AUX_GR_ST_G>(gr, (t * LD + c) * 4, gv);
+              t1 += gv;
+              t2 = fmaf(gv, (p - mu) * rs, t2);
+            }
+          }
+        }
+        if constexpr (I == 0) {
+          s1o += t1;
+          s2o += t2;
+        } else {
+          sSrcAcc[(I * 2 - 2) * kThreads + tid] += t1;
+          sSrcAcc[(I * 2 - 1) * kThreads + tid] += t2;
+        }
+      }
+    }
+    dgrad_sources_static<SH, I + 1>(src, b, sOut, PO, tid, s1o, s2o, sSrcAcc);
+  }
+}
+
+// SH: the op's shape where the instantiation knows it (GShape; static shapes have dilation = stride = 1 and whole windows)
+template <int NC, int MODE, int CDP = 0, bool CH = false, class SH = GShapeDyn>
 __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
+  constexpr bool ST = SH::NSRC > 0;
+  static_assert(!ST || !CH, "static shapes run whole windows");
+  static_assert(!ST || MODE == 0 || CDP > 0, "the data gradient of a static shape knows its filter count");
+  // kernel length, dilation, stride, channels reduced over, number of sources: constants of a static shape
+  const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride;
+  const int kCin = ST ? (MODE == 0 ? SH::CIN : CDP) : a.cin;
+  const int kNsrc = ST ? SH::NSRC : a.n_src;
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   // The convolution runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): per tap j a [16 frames] x [4 channels]
@@ -457,15 +579,15 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // k-steps (cin4) and whole filter tiles (NCW) with zeros, so the inner loop carries no predicate on B.
   constexpr int NT = (NC + 15) / 16, NCW = NT * 16;
   const int tid = threadIdx.x;
-  const int PI = a.cin | 1, PO = NC | 1;
-  const int cin4 = (a.cin + 3) & ~3;
-  const int pad = MODE == 1 ? (a.k - 1) * a.dil : 0;
+  const int PI = kCin | 1, PO = NC | 1;
+  const int cin4 = (kCin + 3) & ~3;
+  const int pad = MODE == 1 ? (kK - 1) * kDil : 0;
   // rows of the input tile / of the output tile.  CH: a chunk of Tc output frames; the forward convolution stages the
   // chunk's input frames with their halo, the data gradient is only chunked for k = 1 (no halo, no zero frames)
-  const int rows_in = CH ? (MODE == 0 ? (a.Tc - 1) * a.stride + (a.k - 1) * a.dil + 1 : a.Tc) : a.Tin + 2 * pad;
+  const int rows_in = CH ? (MODE == 0 ? (a.Tc - 1) * kStride + (kK - 1) * kDil + 1 : a.Tc) : a.Tin + 2 * pad;
   const int rows_o = CH ? a.Tc : a.Tout;
   float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
-  float* sIn = sW + a.k * cin4 * NCW;
+  float* sIn = sW + kK * cin4 * NCW;
   float* sOut = sIn + rows_in * PI;
   // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source - the first
   // source's in registers, the others' in LDS so that the sources can be walked by a real loop (their descriptors stay
@@ -474,10 +596,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // live behind the tiles only for the sources that exist and the reduction scratch of the final publish reuses the
   // weight tile (the host sizes the dynamic segment to match: mww_lib.hip, lds_fwd / lds_dx).
   float s1o = 0.f, s2o = 0.f;
-  float* sSrcAcc = g_smem + max(a.k * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
+  float* sSrcAcc = g_smem + max(kK * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
   float* sRed = g_smem;   // [2 * kThreads], after the window loop
   if (MODE == 1)
-    for (int i = 0; i < (a.n_src - 1) * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
+    for (int i = 0; i < (kNsrc - 1) * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
 
   // statistics hand-over: fold what this launch is the first to consume.  The loads go out before the weights are staged,
   // the table is written after (visible to the other waves after the loop's first barrier).
@@ -487,9 +609,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   const int fsrc = tid >> 6, ftid = tid & 63;
   static_assert(kGFoldC <= 64 && kGMaxSrc <= kThreads / 64, "one wave folds one source");
   if (MODE == 0) {
-    if (fsrc < a.n_src && a.fold[fsrc].acc) gfold_forward_load(a.fold[fsrc], bid, ftid, fr);
+    if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_load(a.fold[fsrc], bid, ftid, fr);
   } else if (a.y.fold.acc) {
-    gfold_backward_load(a.y.fold, a.cin, a.y.rstd, tid, fr);
+    gfold_backward_load(a.y.fold, kCin, a.y.rstd, tid, fr);
   }
   {
     // (four elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
@@ -497,7 +619,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     // wider batch still pays its index arithmetic: 16 / 8 / 4 / 2 / 1 per batch = 1.090 / 1.074 / 1.064 / 1.068 / 1.065 ms
     // per Inception step in same-session A/B)
     constexpr int kWB = 4;
-    const int nw = a.k * cin4 * NCW, nreal = a.k * a.cin * NC;
+    const int nw = kK * cin4 * NCW, nreal = kK * kCin * NC;
     for (int i0 = tid; i0 < nw; i0 += kWB * kThreads) {
       float wv[kWB];
 #pragma unroll
@@ -506,10 +628,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         const int co = i % NCW, rest = i / NCW;   // (compile-time divisor)
         int ci, j;
         fast_divmod(rest, cin4, j, ci);
-        const bool real = i < nw && co < NC && ci < a.cin;
+        const bool real = i < nw && co < NC && ci < kCin;
         // MODE 1 reads the forward weights [k][fwd cin = NC][fwd cout = cin] as its transposed, tap-reversed operand in
         // place (a separate transpose launch per step used to prepare a copy)
-        const int src = min(MODE == 0 ? (j * a.cin + ci) * NC + co : ((a.k - 1 - j) * NC + co) * a.cin + ci, nreal - 1);
+        const int src = min(MODE == 0 ? (j * kCin + ci) * NC + co : ((kK - 1 - j) * NC + co) * kCin + ci, nreal - 1);
         wv[u] = a.w[real ? src : 0];
         if (!real) wv[u] = 0.f;
       }
@@ -521,9 +643,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     }
   }
   if (MODE == 0) {
-    if (fsrc < a.n_src && a.fold[fsrc].acc) gfold_forward_finish(a.fold[fsrc], sFold + fsrc * 4 * kGFoldC, bid, ftid, fr);
+    if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_finish(a.fold[fsrc], sFold + fsrc * 4 * kGFoldC, bid, ftid, fr);
   } else if (a.y.fold.acc) {
-    gfold_backward_finish(a.y.fold, a.cin, sFold, bid, tid, fr);
+    gfold_backward_finish(a.y.fold, kCin, sFold, bid, tid, fr);
   }
   if (MODE == 1) {
     // the zero frames around dp are written once: staging only touches the middle
@@ -541,17 +663,17 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       fast_divmod(v, a.S, b, chunk);
       f0 = chunk * a.Tc;
       Tout = min(a.Tc, Ttot - f0);
-      Tin = MODE == 0 ? (Tout - 1) * a.stride + (a.k - 1) * a.dil + 1 : Tout;
+      Tin = MODE == 0 ? (Tout - 1) * kStride + (kK - 1) * kDil + 1 : Tout;
     }
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if (MODE == 0) stage_sources(a.src, a.n_src, b, Tin, sIn, PI, tid, a.fold, sFold, CH ? f0 * a.stride : 0);
-    else if (CH) stage_dp<CDP>(a.y, a.cin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
-    else stage_dp<CDP>(a.y, a.cin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
+    if (MODE == 0) stage_sources<SH>(a.src, kNsrc, b, Tin, sIn, PI, tid, a.fold, sFold, CH ? f0 * kStride : 0);
+    else if (CH) stage_dp<CDP>(a.y, kCin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
+    else stage_dp<CDP>(a.y, kCin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
     __syncthreads();
     {
       const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
       const int ntile = (Tout + 15) >> 4;
-      const bool kfull = (a.cin & 3) == 0;
+      const bool kfull = (kCin & 3) == 0;
       for (int rt = wave; rt < ntile; rt += kThreads / 64) {
         f32x4 acc[NT];
 #pragma unroll
@@ -559,17 +681,31 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         // A: lane (r16, g) holds frame rt*16 + r16 (frames past the window repeat its last one: their rows are not
         // stored), channel ci0 + g;  B: lane holds W[ci0 + g][nt*16 + r16]
         const int t = min(rt * 16 + r16, Tout - 1);
-        const float* arow = sIn + (MODE == 0 ? t * a.stride : t) * PI + g;
+        const float* arow = sIn + (MODE == 0 ? t * kStride : t) * PI + g;
         const float* wrow = sW + g * NCW + r16;
-        for (int j = 0; j < a.k; ++j) {
-          const float* ar = arow + j * a.dil * PI;
+        if constexpr (ST) {
+          // constant trip counts: every LDS read is one instruction with an immediate offset off two base registers
+#pragma unroll
+          for (int j = 0; j < SH::K; ++j) {
+#pragma unroll
+            for (int ci0 = 0; ci0 < ((MODE == 0 ? SH::CIN : CDP) + 3) / 4 * 4; ci0 += 4) {
+              float av = arow[j * PI + ci0];
+              if (!kfull && ci0 + 4 > kCin && ci0 + g >= kCin) av = 0.f;   // (only the last k-step carries the select)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(av, wrow[(j * cin4 + ci0) * NCW + nt * 16], acc[nt]);
+            }
+          }
+        } else {
+        for (int j = 0; j < kK; ++j) {
+          const float* ar = arow + j * kDil * PI;
           const float* wr = wrow + j * cin4 * NCW;
           for (int ci0 = 0; ci0 < cin4; ci0 += 4) {
             float av = ar[ci0];
-            if (!kfull && ci0 + g >= a.cin) av = 0.f;   // the last k-step of a channel count that is no multiple of 4
+            if (!kfull && ci0 + g >= kCin) av = 0.f;   // the last k-step of a channel count that is no multiple of 4
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(av, wr[ci0 * NCW + nt * 16], acc[nt]);
           }
+        }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -592,9 +728,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
           s2o = fmaf(v, v, s2o);
         }
       }
+    } else if constexpr (ST) {
+      dgrad_sources_static<SH>(a.src, b, sOut, PO, tid, s1o, s2o, sSrcAcc);
     } else {
       int c0 = 0;
-      for (int i = 0; i < a.n_src; ++i) {
+      for (int i = 0; i < kNsrc; ++i) {
         const GSrc& s = a.src[i];
         const int C = s.C;
         if (s.flags & GSRC_GRAD) {
@@ -686,7 +824,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   if (MODE == 0) {
     if (a.stat_part) publish_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)bid * 2 * NC, tid, NC, a.sacc, 0, bid, nb);
   } else {
-    for (int i = 0; i < a.n_src; ++i) {
+    for (int i = 0; i < kNsrc; ++i) {
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
         publish_channel_partials(i == 0 ? s1o : sSrcAcc[(i * 2 - 2) * kThreads + tid], i == 0 ? s2o : sSrcAcc[(i * 2 - 1) * kThreads + tid],
@@ -695,9 +833,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   }
 }
 
-template <int NC, int MODE>
+template <int NC, int MODE, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
-  gconv_body<NC, MODE>(a, blockIdx.x, gridDim.x);
+  gconv_body<NC, MODE, 0, false, SH>(a, blockIdx.x, gridDim.x);
 }
 template <int NC, int MODE>
 __global__ __launch_bounds__(kThreads) void gconv_chunk_kernel(GConvArgs a) {
@@ -708,10 +846,10 @@ __global__ __launch_bounds__(kThreads) void gconv_chunk_kernel(GConvArgs a) {
 // halves of one launch: workgroups [0, nb) run op a0, [nb, 2 nb) op a1.
 // (the twin's descriptors are picked by a run-time index into the kernel-argument segment: one copy of the body's code)
 struct GConv2Args { GConvArgs op[2]; };
-template <int NC>
+template <int NC, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_fwd2_kernel(GConv2Args a, int nb) {
   const int op = (int)blockIdx.x >= nb ? 1 : 0;
-  gconv_body<NC, 0>(a.op[op], blockIdx.x - op * nb, nb);
+  gconv_body<NC, 0, 0, false, SH>(a.op[op], blockIdx.x - op * nb, nb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -741,19 +879,23 @@ __host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (
 // columns that are never stored - puts the stem's weight gradient at three per CU too, but measured 0.891 against 0.887.)
 __host__ __device__ inline int gwg_dp_pitch(int nc) { return (nc + 15) / 16 * 16; }
 
-template <int NC, bool CH = false>
+template <int NC, bool CH = false, class SH = GShapeDyn>
 __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
+  constexpr bool ST = SH::NSRC > 0;
+  static_assert(!ST || !CH, "static shapes run whole windows");
+  const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride, kCin = ST ? SH::CIN : a.cin;
+  const int kNsrc = ST ? SH::NSRC : a.n_src;
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   constexpr int NT = (NC + 15) / 16;
   const int PO = gwg_dp_pitch(NC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int PI = a.cin | 1;
+  const int PI = kCin | 1;
   const int cap = CH ? a.Tc : a.Tout;                   // frames of the dp tile (CH: a chunk; the A tile holds its input frames + halo)
   const int Tout4 = (cap + 3) & ~3;
   float* sA = g_smem;
-  float* sDP = g_smem + ((CH ? (a.Tc - 1) * a.stride + (a.k - 1) * a.dil + 1 : a.Tin) * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
-  const int tasks = a.k * a.cin, MT = (tasks + 15) >> 4;
+  float* sDP = g_smem + ((CH ? (a.Tc - 1) * kStride + (kK - 1) * kDil + 1 : a.Tin) * PI + 3 + 3) / 4 * 4;   // (+3: the clamped A reads of a short last k-step stay in front of it)
+  const int tasks = kK * kCin, MT = (tasks + 15) >> 4;
   const int KS = gwg_kparts(tasks), nslot = (kThreads / 64) / KS;
   const int kp = wave % KS, slot = wave / KS;
   // this wave's task tiles: mt = slot, slot + nslot, ...;  lane r16 <-> task m of the tile (tasks past the end repeat the
@@ -763,8 +905,8 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   for (int u = 0; u < kGWgTilesPerWave; ++u) {
     const int m = min((slot + u * nslot) * 16 + r16, tasks - 1);
     int mj, mc;
-    fast_divmod(m, a.cin, mj, mc);
-    offA[u] = mj * a.dil * PI + mc;
+    fast_divmod(m, kCin, mj, mc);
+    offA[u] = mj * kDil * PI + mc;
   }
   f32x4 acc[kGWgTilesPerWave][NT];
 #pragma unroll
@@ -787,10 +929,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       fast_divmod(v, a.S, b, chunk);
       f0 = chunk * a.Tc;
       Tout = min(a.Tc, a.Tout - f0);
-      Tin = (Tout - 1) * a.stride + (a.k - 1) * a.dil + 1;
+      Tin = (Tout - 1) * kStride + (kK - 1) * kDil + 1;
     }
     __syncthreads();
-    stage_sources(a.src, a.n_src, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * a.stride : 0);
+    stage_sources<SH>(a.src, kNsrc, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * kStride : 0);
     if (CH) {
       stage_dp<NC>(a.y, NC, b, Tout, sDP, PO, tid, sFoldB, f0, a.Tout);
       // a shorter last chunk leaves the previous item's rows behind its own: the k-step that straddles the end reads them
@@ -802,7 +944,7 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
     for (int t0 = kp * 4; t0 < Tout; t0 += 4 * KS) {
       // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
       const int tf = min(t0 + g, Tout - 1);
-      const float* arow = sA + tf * a.stride * PI;
+      const float* arow = sA + tf * kStride * PI;
       float bv[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bv[nt] = sDP[(t0 + g) * PO + nt * 16 + r16];
@@ -859,9 +1001,9 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   }
 }
 
-template <int NC>
+template <int NC, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
-  gconv_wgrad_body<NC>(a, blockIdx.x, gridDim.x);
+  gconv_wgrad_body<NC, false, SH>(a, blockIdx.x, gridDim.x);
 }
 template <int NC>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_chunk_kernel(GWgradArgs a) {
@@ -871,10 +1013,10 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_chunk_kernel(GWgradArgs 
 // Both halves of an op's backward in one launch: workgroups [0, nb) form the weight gradient, [nb, 2 nb) the data
 // gradient.  They are independent (both only read the op's output gradient) and each is latency-bound on its
 // own, so sharing the launch hides one of the two.
-template <int NCO, int NCI>
+template <int NCO, int NCI, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
-  if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO>(w, blockIdx.x, nbw);
-  else gconv_body<NCI, 1, NCO>(d, blockIdx.x - nbw, nbd);
+  if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO, false, SH>(w, blockIdx.x, nbw);
+  else gconv_body<NCI, 1, NCO, false, SH>(d, blockIdx.x - nbw, nbd);
 }
 template <int NCO, int NCI>
 __global__ __launch_bounds__(kThreads, 3) void gconv_bwd_chunk_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
@@ -884,11 +1026,11 @@ __global__ __launch_bounds__(kThreads, 3) void gconv_bwd_chunk_kernel(GWgradArgs
 
 // ... and of twin ops: four roles
 struct GBwd2Args { GWgradArgs w[2]; GConvArgs d[2]; };
-template <int NCO, int NCI>
+template <int NCO, int NCI, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GBwd2Args a, int nbw, int nbd) {
   const int pair = nbw + nbd, op = (int)blockIdx.x >= pair ? 1 : 0, bid = blockIdx.x - op * pair;
-  if (bid < nbw) gconv_wgrad_body<NCO>(a.w[op], bid, nbw);
-  else gconv_body<NCI, 1, NCO>(a.d[op], bid - nbw, nbd);
+  if (bid < nbw) gconv_wgrad_body<NCO, false, SH>(a.w[op], bid, nbw);
+  else gconv_body<NCI, 1, NCO, false, SH>(a.d[op], bid - nbw, nbd);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -130,6 +130,7 @@ struct mww_ctx {
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   int grid_g = 0;
   int g_cap_fwd = 4, g_cap_bwd = 4;   // "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" (g_role_grid)
+  bool g_static = true;   // "graph_static_shapes": ops whose shape has a compile-time instantiation (MWW_G_SHAPES) use it
   int g_chunks = 0;   // "graph_frame_chunks" (g_chunks())
   int g_dgrad_share = 50;   // "graph_dgrad_share"
   bool grid_g_auto = true;   // per-launch grids from the kernel's occupancy (g_role_grid); "grid_graph" > 0 fixes one grid
@@ -1002,9 +1003,75 @@ void g_share_roles(mww_ctx* c, const GridPick& pk, int* nbw, int* nbd) {
   if (pk.used) *pk.used = *nbw;
 }
 
+// Static shapes (kernels_graph.hip.h GShape): the ops of the reference's default Inception flags (inception.py:146-209:
+// 5x1 stem over the 40 spectrogram bins; per block a fused 1x1 head, 5x1 convolutions over channel slices of it and over
+// each other, and the 1x1 convolution over the aligned concatenation).  (id, K, sources, C0, LD0, C1, LD1, C2, LD2); dilation
+// and stride 1, no residual branches, whole windows.  Any other op takes the run-time kernels.
+#ifdef MWW_SLIM
+#define MWW_G_SHAPES(X)
+#else
+#define MWW_G_SHAPES(X)                                                                                                   \
+  X(1, 5, 1, 40, 40, 0, 0, 0, 0) X(2, 1, 1, 24, 24, 0, 0, 0, 0) X(3, 5, 1, 10, 30, 0, 0, 0, 0) X(4, 5, 1, 10, 10, 0, 0, 0, 0)    \
+  X(5, 1, 3, 10, 30, 10, 10, 10, 10) X(6, 1, 1, 10, 10, 0, 0, 0, 0) X(7, 5, 1, 16, 48, 0, 0, 0, 0) X(8, 5, 1, 16, 16, 0, 0, 0, 0) \
+  X(9, 1, 3, 16, 48, 16, 16, 16, 16)
+#endif
+#define X(ID, K, N, C0, L0, C1, L1, C2, L2) typedef GShape<K, N, C0, L0, C1, L1, C2, L2> GSh##ID;
+MWW_G_SHAPES(X)
+#undef X
+// (shape id, filters) of the forward / weight-gradient instantiations, (id, filters, input channels) of the backward pairs
+#ifdef MWW_SLIM
+#define MWW_G_SHAPE_FWD(X)
+#define MWW_G_SHAPE_FWD2(X)
+#define MWW_G_SHAPE_WG(X)
+#define MWW_G_SHAPE_BWD(X)
+#define MWW_G_SHAPE_BWD2(X)
+#else
+#define MWW_G_SHAPE_FWD(X) X(1, 24) X(2, 30) X(3, 10) X(4, 10) X(5, 10) X(6, 30) X(6, 48) X(7, 16) X(8, 16) X(9, 16)
+#define MWW_G_SHAPE_FWD2(X) X(3, 10) X(7, 16)
+#define MWW_G_SHAPE_WG(X) X(1, 24)
+#define MWW_G_SHAPE_BWD(X) X(2, 30, 24) X(3, 10, 10) X(4, 10, 10) X(5, 10, 30) X(6, 30, 10) X(6, 48, 10) X(7, 16, 16) X(8, 16, 16) X(9, 16, 48)
+#define MWW_G_SHAPE_BWD2(X) X(3, 10) X(7, 16)
+#endif
+
+// the static shape of op `o`, or 0
+int g_shape_id(const mww_ctx* c, const GOp& o) {
+  if (!c->g_static || o.kind != MWW_OP_CONV || o.dil != 1 || o.stride != 1 || o.res_src >= 0 || o.n_src < 1) return 0;
+  int C[kGMaxSrc] = {0, 0, 0}, L[kGMaxSrc] = {0, 0, 0};
+  for (int i = 0; i < o.n_src; ++i) {
+    if (o.src[i] < 0) {
+      C[i] = L[i] = MWW_FEATURE_BINS;
+    } else {
+      const GOp& pr = c->G[o.src[i]];
+      if (pr.res_src >= 0) return 0;
+      C[i] = o.scn[i];
+      L[i] = pr.cout;
+    }
+    const int v = ((C[i] | L[i]) & 3) == 0 ? 4 : (((C[i] | L[i]) & 1) == 0 ? 2 : 1);
+    if (o.src[i] >= 0 && o.sc0[i] % v) return 0;   // the slice must start on the vector width the static staging uses
+  }
+#define X(ID, K, N, C0, L0, C1, L1, C2, L2)                                                                     \
+  if (o.k == K && o.n_src == N && C[0] == C0 && L[0] == L0 && C[1] == C1 && L[1] == L1 && C[2] == C2 && L[2] == L2) return ID;
+  MWW_G_SHAPES(X)
+#undef X
+  return 0;
+}
+
 // (CH: the frame-chunk instantiations, a.S > 1)
 template <int MODE, bool CH = false>
-int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, size_t lds) {
+int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, size_t lds, int shape = 0) {
+  if constexpr (MODE == 0 && !CH) {
+#define XS(ID, N)                                                                                              \
+    if (shape == ID && nc == N) {                                                                              \
+      auto k = &gconv_kernel<N, 0, GSh##ID>;                                                                   \
+      const void* f = reinterpret_cast<const void*>(k);                                                        \
+      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      const int grid = g_role_grid(c, f, lds, pk);                                                             \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, c->stream, a);                                    \
+      return MWW_OK;                                                                                           \
+    }
+    MWW_G_SHAPE_FWD(XS)
+#undef XS
+  }
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
     auto k = CH ? &gconv_chunk_kernel<N, MODE> : &gconv_kernel<N, MODE>;                                       \
@@ -1020,7 +1087,20 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, siz
 }
 
 template <bool CH = false>
-int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, size_t lds) {
+int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, size_t lds, int shape = 0) {
+  if constexpr (!CH) {
+#define XS(ID, N)                                                                                              \
+    if (shape == ID && nc == N) {                                                                              \
+      auto k = &gconv_wgrad_kernel<N, GSh##ID>;                                                                \
+      const void* f = reinterpret_cast<const void*>(k);                                                        \
+      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      const int grid = g_role_grid(c, f, lds, pk);                                                             \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, c->stream, a);                                    \
+      return MWW_OK;                                                                                           \
+    }
+    MWW_G_SHAPE_WG(XS)
+#undef XS
+  }
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
     auto k = CH ? &gconv_wgrad_chunk_kernel<N> : &gconv_wgrad_kernel<N>;                                       \
@@ -1043,7 +1123,21 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, s
 #endif
 
 template <bool CH = false>
-bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, const GridPick& pk, size_t lds) {
+bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const GConvArgs& d, const GridPick& pk, size_t lds, int shape = 0) {
+  if constexpr (!CH) {
+#define XS(ID, NCO, NCI)                                                                                       \
+    if (shape == ID && nco == NCO && nci == NCI) {                                                             \
+      auto k = &gconv_bwd_kernel<NCO, NCI, GSh##ID>;                                                           \
+      const void* f = reinterpret_cast<const void*>(k);                                                        \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      int nbw = g_role_grid(c, f, lds, pk), nbd = nbw;                                                         \
+      g_share_roles(c, pk, &nbw, &nbd);                                                                        \
+      hipLaunchKernelGGL(k, dim3(nbw + nbd), dim3(kThreads), lds, c->stream, w, d, nbw, nbd);                  \
+      return true;                                                                                             \
+    }
+    MWW_G_SHAPE_BWD(XS)
+#undef XS
+  }
 #define X(NCO, NCI)                                                                                            \
   if (nco == NCO && nci == NCI) {                                                                              \
     auto k = CH ? &gconv_bwd_chunk_kernel<NCO, NCI> : &gconv_bwd_kernel<NCO, NCI>;                             \
@@ -1064,7 +1158,17 @@ bool launch_gbwd_fused(mww_ctx* c, int nco, int nci, const GWgradArgs& w, const 
 #else
 #define MWW_G_TWIN_WIDTHS(X) X(8) X(10) X(12) X(16) X(20) X(24) X(32)
 #endif
-bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, const GridPick& pk, size_t lds) {
+bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, const GridPick& pk, size_t lds, int shape = 0) {
+#define XS(ID, N)                                                                                              \
+  if (shape == ID && nc == N) {                                                                                \
+    const void* f = reinterpret_cast<const void*>(&gconv_fwd2_kernel<N, GSh##ID>);                             \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    const int grid = g_role_grid(c, f, lds, pk);                                                               \
+    hipLaunchKernelGGL((gconv_fwd2_kernel<N, GSh##ID>), dim3(2 * grid), dim3(kThreads), lds, c->stream, GConv2Args{{a0, a1}}, grid); \
+    return true;                                                                                               \
+  }
+  MWW_G_SHAPE_FWD2(XS)
+#undef XS
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
     const void* f = reinterpret_cast<const void*>(&gconv_fwd2_kernel<N>);                                      \
@@ -1078,7 +1182,18 @@ bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, 
   return false;
 }
 bool launch_gbwd2(mww_ctx* c, int nc, const GWgradArgs& w0, const GConvArgs& d0, const GWgradArgs& w1, const GConvArgs& d1,
-                  const GridPick& pk, size_t lds) {
+                  const GridPick& pk, size_t lds, int shape = 0) {
+#define XS(ID, N)                                                                                              \
+  if (shape == ID && nc == N) {                                                                                \
+    const void* f = reinterpret_cast<const void*>(&gconv_bwd2_kernel<N, N, GSh##ID>);                          \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    int nbw = g_role_grid(c, f, lds, pk), nbd = nbw;                                                           \
+    g_share_roles(c, pk, &nbw, &nbd);                                                                          \
+    hipLaunchKernelGGL((gconv_bwd2_kernel<N, N, GSh##ID>), dim3(2 * (nbw + nbd)), dim3(kThreads), lds, c->stream, GBwd2Args{{w0, w1}, {d0, d1}}, nbw, nbd); \
+    return true;                                                                                               \
+  }
+  MWW_G_SHAPE_BWD2(XS)
+#undef XS
 #define X(N)                                                                                                   \
   if (nc == N) {                                                                                               \
     const void* f = reinterpret_cast<const void*>(&gconv_bwd2_kernel<N, N>);                                   \
@@ -1268,7 +1383,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       lp.begin("conv_fwd2_", i);
       const bool split2 = inl && c->g_role_split;
       const bool ok = launch_gfwd2(c, o.cout, fa0, fa1, GridPick{pick ? 0 : (split2 ? std::max(1, gg / 2) : gg), B, split2 ? 2 : 1, c->g_cap_fwd, nullptr},
-                                   std::max(o.lds_fwd, o2.lds_fwd));
+                                   std::max(o.lds_fwd, o2.lds_fwd), g_shape_id(c, o) == g_shape_id(c, o2) ? g_shape_id(c, o) : 0);
       lp.end();
       if (ok) {
         if (training && !inl) {
@@ -1299,7 +1414,7 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       fa.Tc = Tc;
       rc = launch_gconv<0, true>(c, o.cout, fa, GridPick{pick ? 0 : gg, B * S, 1, c->g_cap_fwd, nullptr}, g_lds_fwd(o, g_chunk_in(o, Tc), Tc));
     } else {
-      rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd);
+      rc = launch_gconv<0>(c, o.cout, fa, GridPick{pick ? 0 : gg, B, 1, c->g_cap_fwd, nullptr}, o.lds_fwd, g_shape_id(c, o));
     }
     lp.end();
     if (rc) return rc;
@@ -1492,7 +1607,8 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       if (!inl) hipLaunchKernelGGL(gbn_bwd_finalize2_kernel, dim3(o.slots + o1.slots), dim3(kThreads), 0, c->stream, bf0, bf1, n0);
       int rows = gg4;
       const bool ok = launch_gbwd2(c, o.cout, w0, d0, w1, d1, GridPick{pick ? 0 : gg4, B, split ? 4 : 1, c->g_cap_bwd, &rows},
-                                   std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)));
+                                   std::max(std::max(o.lds_wg, o.lds_dx), std::max(o1.lds_wg, o1.lds_dx)),
+                                   g_shape_id(c, o) == g_shape_id(c, o1) ? g_shape_id(c, o) : 0);
       lp.end();
       if (!ok) return fail(MWW_ERR_UNSUPPORTED, "twin ops without a fused backward instantiation");
       add_segment(i, rows);
@@ -1615,7 +1731,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       lp.begin("conv_bwd", i);
       const GridPick pkf{pick ? 0 : gg2, items, split ? 2 : 1, c->g_cap_bwd, &rows};
       fused = S > 1 ? launch_gbwd_fused<true>(c, o.cout, o.cin, w, a, pkf, std::max(lds_wg, lds_dx))
-                    : launch_gbwd_fused(c, o.cout, o.cin, w, a, pkf, std::max(lds_wg, lds_dx));
+                    : launch_gbwd_fused(c, o.cout, o.cin, w, a, pkf, std::max(lds_wg, lds_dx), g_shape_id(c, o));
       lp.end();
       if (!fused && c->profile) {   // nothing was launched: drop the empty profile entry
         (void)hipEventDestroy(c->prof.back().a);
@@ -1626,7 +1742,7 @@ int g_enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
     if (!fused) {
       lp.begin("conv_wgrad", i);
       const GridPick pkw{pick ? 0 : gg, items, 1, c->g_cap_bwd, &rows};
-      int rc = S > 1 ? launch_gwgrad<true>(c, o.cout, w, pkw, lds_wg) : launch_gwgrad(c, o.cout, w, pkw, lds_wg);
+      int rc = S > 1 ? launch_gwgrad<true>(c, o.cout, w, pkw, lds_wg) : launch_gwgrad(c, o.cout, w, pkw, lds_wg, g_shape_id(c, o));
       lp.end();
       if (rc) return rc;
       if (o.needs_dx) {
@@ -2805,6 +2921,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "side_stream")) c->use_side = v != 0;
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
+  else if (!strcmp(name, "graph_static_shapes")) c->g_static = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
   else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }
