@@ -32,6 +32,7 @@
 // holds: static LDS is kept to the fold tables, every launch takes the grid its own occupancy allows (g_role_grid in
 // mww_lib.hip: 1.030 -> 0.884 ms per Inception step), and the depthwise ops of MixedNet graphs are register-blocked.
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 namespace mww {
@@ -307,6 +308,150 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
   }
 }
 
+// ---- a window's rows in registers (static shapes) ----------------------------------------------------------------
+// With the widths known at compile time a thread's share of a window's slab is a fixed set of registers: ALL its rows are
+// requested at once (one memory round trip per window instead of one per kGB rows), the request for the NEXT window
+// goes out before this window's contraction (a backward role walks four windows per workgroup at the headline batch),
+// and the first window's before the weights are staged and the statistics folded.  A window may have at most kGTmax
+// frames for that (the host checks); slices whose share would take more than kGPipeRegs registers keep the direct
+// staging (registers are occupancy here).
+constexpr int kGTmax = 208;
+constexpr int kGPipeRegs = 40;
+
+template <int V, int C, int LD>
+struct GSliceRegs {
+  static constexpr int NQ = C / V, NRG = kThreads / NQ, NS = (kGTmax + NRG - 1) / NRG, REGS = NS * V;
+  GVec<V> v[NS];
+  // rows [0, rows) x channels [0, C) of the slab whose first element is `base` (row length LD)
+  __device__ __forceinline__ void issue(const float* base, int rows, int tid) {
+    const int rg = tid / NQ, q = tid - rg * NQ;
+    const BufRsrc slab = tile_rsrc(base, ((rows - 1) * LD + C) * 4);
+    const int e0 = rg < NRG ? rg * LD + q * V : kOobOffset / 4;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) v[u] = gvec_bload<V>(slab, e0 + u * NRG * LD);
+  }
+};
+
+// per-channel affine (+ clamp) of a source slice as this thread's channels see it
+template <int V>
+struct GSliceAffine {
+  float sc[V], sh[V], lo;
+};
+
+template <int V, int C, int LD>
+__device__ __forceinline__ void gslice_affine_load(const GSrc& s, const float* cscale, const float* cshift, int tid, GSliceAffine<V>& f) {
+  constexpr int NQ = C / V;
+  const int q = tid % NQ;
+  const bool ident = (s.flags & GSRC_IDENTITY) != 0;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    f.sc[e] = ident ? 1.f : cscale[s.c0 + q * V + e];
+    f.sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
+  }
+  f.lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;
+}
+
+template <int V, int C, int LD>
+__device__ __forceinline__ void gslice_commit(const GSliceRegs<V, C, LD>& r, const GSliceAffine<V>& f, float* dst, int PI, int rows, int tid) {
+  typedef GSliceRegs<V, C, LD> R;
+  const int rg = tid / R::NQ, q = tid - rg * R::NQ;
+  if (rg >= R::NRG) return;
+#pragma unroll
+  for (int u = 0; u < R::NS; ++u) {
+    const int t = rg + u * R::NRG;
+    if (t < rows) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) dst[t * PI + q * V + e] = fmaxf(fmaf(r.v[u].f[e], f.sc[e], f.sh[e]), f.lo);
+    }
+  }
+}
+
+// the (up to three) sources of a static shape
+template <class SH, int I>
+struct GSrcTraits {
+  static constexpr bool ON = I < SH::NSRC;
+  static constexpr int C = ON ? SH::srcC(I) : 4, LD = ON ? SH::srcLD(I) : 4;
+  static constexpr int V = ((C | LD) & 3) == 0 ? 4 : (((C | LD) & 1) == 0 ? 2 : 1);
+  typedef GSliceRegs<V, C, LD> Regs;
+  static constexpr int REGS = ON ? Regs::REGS : 0;
+};
+template <class SH>
+struct GSrcPipe {
+  typedef GSrcTraits<SH, 0> T0;
+  typedef GSrcTraits<SH, 1> T1;
+  typedef GSrcTraits<SH, 2> T2;
+  static constexpr int REGS = T0::REGS + T1::REGS + T2::REGS;
+  typename T0::Regs r0;
+  typename T1::Regs r1;
+  typename T2::Regs r2;
+  GSliceAffine<T0::V> f0;
+  GSliceAffine<T1::V> f1;
+  GSliceAffine<T2::V> f2;
+  // fold / ftab as in stage_sources: the affine comes from the folded LDS table where this launch folded the source
+  __device__ __forceinline__ void load_affine(const GSrc* src, const GFoldFwd* fold, const float* ftab, int tid) {
+    auto one = [&](auto tr, int i, auto& f) {
+      typedef decltype(tr) T;
+      const bool folded = fold != nullptr && ftab != nullptr && fold[i].acc != nullptr;
+      const float* tab = ftab + i * 4 * kGFoldC;
+      gslice_affine_load<T::V, T::C, T::LD>(src[i], folded ? tab : src[i].scale, folded ? tab + kGFoldC : src[i].shift, tid, f);
+    };
+    if constexpr (T0::ON) one(T0{}, 0, f0);
+    if constexpr (T1::ON) one(T1{}, 1, f1);
+    if constexpr (T2::ON) one(T2{}, 2, f2);
+  }
+  __device__ __forceinline__ void issue(const GSrc* src, int b, int rows, int tid) {
+    if constexpr (T0::ON) r0.issue(src[0].p + ((size_t)b * src[0].T + src[0].toff) * T0::LD + src[0].c0, rows, tid);
+    if constexpr (T1::ON) r1.issue(src[1].p + ((size_t)b * src[1].T + src[1].toff) * T1::LD + src[1].c0, rows, tid);
+    if constexpr (T2::ON) r2.issue(src[2].p + ((size_t)b * src[2].T + src[2].toff) * T2::LD + src[2].c0, rows, tid);
+  }
+  __device__ __forceinline__ void commit(float* sIn, int PI, int rows, int tid) const {
+    if constexpr (T0::ON) gslice_commit(r0, f0, sIn + SH::srcC0(0), PI, rows, tid);
+    if constexpr (T1::ON) gslice_commit(r1, f1, sIn + SH::srcC0(1), PI, rows, tid);
+    if constexpr (T2::ON) gslice_commit(r2, f2, sIn + SH::srcC0(2), PI, rows, tid);
+  }
+};
+
+// ... and the op's own output gradient on its way to dp = BN backward (g, p of the op: two slabs of C channels)
+template <int C>
+struct GDpPipe {
+  static constexpr int V = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);
+  typedef GSliceRegs<V, C, C> Regs;
+  static constexpr int REGS = 2 * Regs::REGS;
+  Regs g, p;
+  float mu[V], rs[V], c1[V], mg[V], mgx[V];
+  __device__ __forceinline__ void load_coeffs(const GBnBwd& y, const float* btab, int tid) {
+    const int q = tid % Regs::NQ;
+    const bool folded = btab != nullptr && y.fold.acc != nullptr;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = q * V + e;
+      mu[e] = y.mean[c];
+      rs[e] = y.rstd[c];
+      c1[e] = folded ? btab[c] : y.c1[c];
+      mg[e] = folded ? btab[kGFoldC + c] : y.mg[c];
+      mgx[e] = folded ? btab[2 * kGFoldC + c] : y.mgx[c];
+    }
+  }
+  __device__ __forceinline__ void issue(const GBnBwd& y, int b, int rows, int tid) {
+    const size_t w0 = (size_t)b * rows * C;
+    g.issue(y.g + w0, rows, tid);
+    p.issue(y.p + w0, rows, tid);
+  }
+  // same arithmetic as stage_dp_vec
+  __device__ __forceinline__ void commit(float* dst, int ld, int rows, int tid) const {
+    const int rg = tid / Regs::NQ, q = tid - rg * Regs::NQ;
+    if (rg >= Regs::NRG) return;
+#pragma unroll
+    for (int u = 0; u < Regs::NS; ++u) {
+      const int t = rg + u * Regs::NRG;
+      if (t < rows) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) dst[t * ld + q * V + e] = c1[e] * (g.v[u].f[e] - mg[e] - (p.v[u].f[e] - mu[e]) * rs[e] * mgx[e]);
+      }
+    }
+  }
+};
+
 // the sources of a static shape: the loop over them is unrolled, every source with its own compile-time width / row length
 template <class SH, int I = 0>
 __device__ __forceinline__ void stage_sources_static(const GSrc* src, int b, int rows, float* sIn, int PI, int tid, const GFoldFwd* fold,
@@ -572,6 +717,19 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride;
   const int kCin = ST ? (MODE == 0 ? SH::CIN : CDP) : a.cin;
   const int kNsrc = ST ? SH::NSRC : a.n_src;
+  // static shapes: the window's rows travel in registers, one window ahead (GSrcPipe / GDpPipe), if they fit
+  typedef typename std::conditional<ST, SH, GShape<1, 1, 4, 4> >::type SHX;
+  typedef GSrcPipe<SHX> SrcPipe;
+  typedef GDpPipe<(CDP > 0 ? CDP : 4)> DpPipe;
+  constexpr bool PIPE = ST && (MODE == 0 ? SrcPipe::REGS <= kGPipeRegs : DpPipe::REGS <= kGPipeRegs);
+  SrcPipe spipe;
+  DpPipe dpipe;
+  if constexpr (PIPE) {
+    if (bid < a.B) {
+      if constexpr (MODE == 0) spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
+      else dpipe.issue(a.y, bid, a.Tin, (int)threadIdx.x);
+    }
+  }
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   // The convolution runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): per tap j a [16 frames] x [4 channels]
@@ -654,6 +812,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       sIn[(pad + a.Tin) * PI + i] = 0.f;
     }
   }
+  if constexpr (PIPE) {
+    __syncthreads();   // the folded table is complete
+    if constexpr (MODE == 0) spipe.load_affine(a.src, a.fold, sFold, tid);
+    else dpipe.load_coeffs(a.y, sFold, tid);
+  }
   for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
     // work item v = window b, frames [f0, f0 + Tout) of its Ttot (whole-window kernels: f0 = 0, Tout = Ttot)
     int b = v, f0 = 0, chunk = 0;
@@ -666,10 +829,21 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       Tin = MODE == 0 ? (Tout - 1) * kStride + (kK - 1) * kDil + 1 : Tout;
     }
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if (MODE == 0) stage_sources<SH>(a.src, kNsrc, b, Tin, sIn, PI, tid, a.fold, sFold, CH ? f0 * kStride : 0);
-    else if (CH) stage_dp<CDP>(a.y, kCin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
-    else stage_dp<CDP>(a.y, kCin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
+    if constexpr (PIPE) {
+      if constexpr (MODE == 0) spipe.commit(sIn, PI, a.Tin, tid);
+      else dpipe.commit(sIn + pad * PI, PI, a.Tin, tid);
+    } else {
+      if (MODE == 0) stage_sources<SH>(a.src, kNsrc, b, Tin, sIn, PI, tid, a.fold, sFold, CH ? f0 * kStride : 0);
+      else if (CH) stage_dp<CDP>(a.y, kCin, b, Tin, sIn, PI, tid, sFold, f0, Ttot);
+      else stage_dp<CDP>(a.y, kCin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
+    }
     __syncthreads();
+    if constexpr (PIPE) {
+      if (v + nb < a.B) {   // the next window's rows travel while this one is contracted and written out
+        if constexpr (MODE == 0) spipe.issue(a.src, v + nb, a.Tin, tid);
+        else dpipe.issue(a.y, v + nb, a.Tin, tid);
+      }
+    }
     {
       const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
       const int ntile = (Tout + 15) >> 4;
@@ -885,6 +1059,20 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   static_assert(!ST || !CH, "static shapes run whole windows");
   const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride, kCin = ST ? SH::CIN : a.cin;
   const int kNsrc = ST ? SH::NSRC : a.n_src;
+  // static shapes: the window's rows travel in registers, one window ahead (see gconv_body)
+  typedef typename std::conditional<ST, SH, GShape<1, 1, 4, 4> >::type SHX;
+  typedef GSrcPipe<SHX> SrcPipe;
+  typedef GDpPipe<NC> DpPipe;
+  constexpr bool PIPE_S = ST && SrcPipe::REGS <= kGPipeRegs;
+  constexpr bool PIPE_D = PIPE_S && SrcPipe::REGS + DpPipe::REGS <= 32;   // (the 16-filter backward kernels passed 128 registers with it: three workgroups per CU instead of four)
+  SrcPipe spipe;
+  DpPipe dpipe;
+  if constexpr (PIPE_S) {
+    if (bid < a.B) {
+      spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
+      if constexpr (PIPE_D) dpipe.issue(a.y, bid, a.Tout, (int)threadIdx.x);
+    }
+  }
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   constexpr int NT = (NC + 15) / 16;
@@ -922,6 +1110,13 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
     gfold_backward_load(a.y.fold, NC, a.y.rstd, tid, fr);
     gfold_backward_finish(a.y.fold, NC, sFoldB, bid, tid, fr);
   }
+  if constexpr (PIPE_S) {
+    spipe.load_affine(a.src, nullptr, nullptr, tid);
+    if constexpr (PIPE_D) {
+      __syncthreads();   // the folded coefficients are complete
+      dpipe.load_coeffs(a.y, sFoldB, tid);
+    }
+  }
   for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
     int b = v, f0 = 0, Tin = a.Tin, Tout = a.Tout;
     if (CH) {
@@ -932,8 +1127,11 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       Tin = (Tout - 1) * kStride + (kK - 1) * kDil + 1;
     }
     __syncthreads();
-    stage_sources<SH>(a.src, kNsrc, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * kStride : 0);
-    if (CH) {
+    if constexpr (PIPE_S) spipe.commit(sA, PI, a.Tin, tid);
+    else stage_sources<SH>(a.src, kNsrc, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * kStride : 0);
+    if constexpr (PIPE_D) {
+      dpipe.commit(sDP, PO, a.Tout, tid);
+    } else if (CH) {
       stage_dp<NC>(a.y, NC, b, Tout, sDP, PO, tid, sFoldB, f0, a.Tout);
       // a shorter last chunk leaves the previous item's rows behind its own: the k-step that straddles the end reads them
       for (int i = tid; i < (((Tout + 3) & ~3) - Tout) * PO; i += kThreads) sDP[Tout * PO + i] = 0.f;
@@ -941,6 +1139,12 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       stage_dp<NC>(a.y, NC, b, a.Tout, sDP, PO, tid, sFoldB);
     }
     __syncthreads();
+    if constexpr (PIPE_S) {
+      if (v + nb < a.B) {
+        spipe.issue(a.src, v + nb, a.Tin, tid);
+        if constexpr (PIPE_D) dpipe.issue(a.y, v + nb, a.Tout, tid);
+      }
+    }
     for (int t0 = kp * 4; t0 < Tout; t0 += 4 * KS) {
       // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
       const int tf = min(t0 + g, Tout - 1);

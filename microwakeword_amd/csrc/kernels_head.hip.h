@@ -15,6 +15,11 @@
 
 namespace mww {
 
+// INVARIANT: the cumulative state has ONE writer at a time - a single metric workgroup per launch (metrics_kernel, or the
+// metric role of head_tail_kernel / grad_final_kernel), launches ordered on the context's stream.  metrics_body reads the
+// counters at its start and stores them back at its end with plain accesses (no atomics): two metric workgroups in flight
+// - a second stream, two launches of a step carrying do_metrics - would lose counts silently.  The host asserts the
+// per-step half (mww_lib.hip: at most one launch of a step carries the metric role).
 struct MetricState {            // device-resident cumulative metric counters (train.py:209-221)
   unsigned long long hist101[2][101];
   unsigned long long hist200[2][200];

@@ -130,6 +130,7 @@ struct mww_ctx {
   float *ones = nullptr, *zeros = nullptr;   // [256] constants standing in for the BN arrays of ops without a BN
   int grid_g = 0;
   int g_cap_fwd = 4, g_cap_bwd = 4;   // "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" (g_role_grid)
+  int metric_launches = 0;   // launches of the step being enqueued that carry the metric role (kernels_head.hip.h MetricState: one writer)
   bool g_static = true;   // "graph_static_shapes": ops whose shape has a compile-time instantiation (MWW_G_SHAPES) use it
   int g_chunks = 0;   // "graph_frame_chunks" (g_chunks())
   int g_dgrad_share = 50;   // "graph_dgrad_share"
@@ -431,6 +432,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
       MetricsArgs ma{c->prob, c->y_cur, c->metrics, B, c->bce_clipped ? nullptr : c->z};
       lp.begin("metrics");
       hipLaunchKernelGGL(metrics_kernel, dim3(1), dim3(1024), 0, ss, ma);
+      c->metric_launches += 1;
       lp.end();
     }
     if (loss) {
@@ -455,6 +457,7 @@ int enqueue_side_work(mww_ctx* c, int B, bool metrics, bool loss, const float* p
         ht.ndx = (dg.n + 1 + kThreads - 1) / kThreads;
         ht.ndy = ndchunks;
         ht.do_metrics = 1;
+        c->metric_launches += 1;
         lp.begin("dense_grad+metrics");
         hipLaunchKernelGGL(head_tail_kernel, dim3(ht.ndx * ht.ndy + 1), dim3(kThreads), 0, ss, ht);
         lp.end();
@@ -703,6 +706,7 @@ int assemble_range(mww_ctx* c, int B, const GradReduceArgs& ga, int64_t lo, int6
     a.nblocks = nb;
     a.do_metrics = (metrics && first == 0) ? 1 : 0;
     if (nb + a.do_metrics == 0) break;
+    c->metric_launches += a.do_metrics;
     lp.begin(apply_adam ? "grad_final+adam" : "grad_final");
     hipLaunchKernelGGL(grad_final_kernel, dim3(nb + a.do_metrics), dim3(kThreads), 0, c->stream, a);
     lp.end();
@@ -822,6 +826,7 @@ int enqueue_backward(mww_ctx* c, int B, bool fuse_adam) {
       ht.ndx = (ht.dense.n + 1 + kThreads - 1) / kThreads;
       ht.ndy = (B + dchunk - 1) / dchunk;
       ht.do_metrics = c->tail_metrics ? 1 : 0;
+      c->metric_launches += ht.do_metrics;
       lp.begin("head_tail");
       hipLaunchKernelGGL(head_tail_kernel, dim3(ht.n_fin + ht.ndx * ht.ndy + ht.do_metrics), dim3(kThreads), 0, c->stream, ht);
       lp.end();
@@ -1829,9 +1834,14 @@ float adam_alpha(float lr, int64_t t) {
 }
 
 int step_sequence(mww_ctx* c, int B, int flags) {
+  c->metric_launches = 0;
   int rc = enqueue_forward(c, B, true, true, true, !(flags & MWW_STEP_NO_METRICS));
   if (rc) return rc;
-  return enqueue_backward(c, B, !(flags & MWW_STEP_NO_APPLY));
+  rc = enqueue_backward(c, B, !(flags & MWW_STEP_NO_APPLY));
+  if (rc) return rc;
+  // the metric state has one writer per step (kernels_head.hip.h MetricState): a second launch with the role would lose counts
+  if (c->metric_launches > 1) return fail(MWW_ERR_STATE, "internal: more than one launch of this step carries the metric update");
+  return MWW_OK;
 }
 
 template <typename T>

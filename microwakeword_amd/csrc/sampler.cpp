@@ -279,7 +279,8 @@ extern "C" int mww_prefetch_create(const mww_sampler_desc* d, const float* provi
   p->set_len.assign(d->set_len, d->set_len + ns);
   p->cutoff_offsets.assign(d->cutoff_offsets, d->cutoff_offsets + n + 1);
   const int nc = p->cutoff_offsets[n];
-  p->cutoffs.assign(d->cutoffs, d->cutoffs + (nc > 0 ? nc : 1));
+  p->cutoffs.assign(d->cutoffs, d->cutoffs + (nc > 0 ? nc : 0));   // (no provider with fixed_right_cutoffs: the array may be empty or null)
+  if (p->cutoffs.empty()) p->cutoffs.push_back(0);                  // data() stays non-null
   p->label.assign(provider_label, provider_label + n);
   p->weight.assign(provider_weight, provider_weight + n);
   p->d.n_providers = n;
