@@ -291,6 +291,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * "graph_frame_chunks" (conv/BN graph contexts with bn_inline: the 1x1 ops - and the forward convolution of any op - process
  * a window as up to 4 frame chunks with correspondingly smaller LDS tiles; 0 = off, 1 = automatic, 2..4 = that many; default 1 for graphs
  * with depthwise ops (MixedNet flag sets: -7 % step time measured), 0 for pure convolution graphs (Inception: +0.5 ... +8 %)),
+ * "graph_static_shapes" (conv/BN graph contexts: 1 = ops whose shape - kernel length, sources' widths and row lengths - has a
+ * compile-time instantiation use it, the default; 0 = the run-time-shape kernels for every op),
  * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
  * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
  * assembly kernel), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */

@@ -20,7 +20,9 @@ echo "== synchronous sampler"
 timeout 600 python bench.py $Q --no-prefetch > $OUT/bench_sync_sampler.json 2>/dev/null; head -c 200 $OUT/bench_sync_sampler.json; echo
 echo "== bench inception / notebook / generic"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; head -c 300 $OUT/bench_inception.json; echo
+MWW_BENCH_OPTIONS=graph_static_shapes=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_runtime_shapes.json 2>/dev/null; head -c 200 $OUT/bench_inception_runtime_shapes.json; echo
 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook.json 2> $OUT/bench_notebook.err; head -c 300 $OUT/bench_notebook.json; echo
+MWW_BENCH_T=194 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook_T194_one_full_tile.json 2>/dev/null; head -c 200 $OUT/bench_notebook_T194_one_full_tile.json; echo
 timeout 900 python bench.py --force-generic $Q --steps 100 --warmup 10 > $OUT/bench_mixednet_on_graph_kernels.json 2>/dev/null; head -c 200 $OUT/bench_mixednet_on_graph_kernels.json; echo
 echo "== bf16 modes (configs[4]), batch 1024 and 4096; fp32 at 4096"
 timeout 900 python bench.py --pointwise-bf16 $Q > $OUT/bench_pointwise_bf16.json 2>/dev/null; head -c 200 $OUT/bench_pointwise_bf16.json; echo
@@ -46,12 +48,18 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- $B > /dev/null 2> $OUT/pmc2.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $B > /dev/null 2> $OUT/pmc3.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $B > /dev/null 2> $OUT/pmc4.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inc -o t -- $B --model inception > /dev/null 2> $OUT/trace_inc.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nb -o t -- $B --model notebook > /dev/null 2> $OUT/trace_nb.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inc -o t -- $BS --model inception > /dev/null 2> $OUT/trace_inc.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nb -o t -- $BS --model notebook > /dev/null 2> $OUT/trace_nb.err
+# counter passes of the other two topologies (SQ set, FETCH_SIZE, WRITE_SIZE: each in its own run)
+for m in inception notebook; do
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1_$m -o p -- $B --model $m > /dev/null 2> $OUT/pmc1_$m.err
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3_$m -o p -- $B --model $m > /dev/null 2> $OUT/pmc3_$m.err
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc4_$m -o p -- $B --model $m > /dev/null 2> $OUT/pmc4_$m.err
+done
 cd $R
 python tools/pmc_summary.py $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 > $OUT/kernel_stats_and_pmc.txt 2>&1
-python tools/pmc_summary.py $OUT/trace_inc > $OUT/kernel_stats_inception.txt 2>&1
-python tools/pmc_summary.py $OUT/trace_nb > $OUT/kernel_stats_notebook.txt 2>&1
+python tools/pmc_summary.py $OUT/trace_inc $OUT/pmc1_inception $OUT/pmc3_inception $OUT/pmc4_inception > $OUT/kernel_stats_and_pmc_inception.txt 2>&1
+python tools/pmc_summary.py $OUT/trace_nb $OUT/pmc1_notebook $OUT/pmc3_notebook $OUT/pmc4_notebook > $OUT/kernel_stats_and_pmc_notebook.txt 2>&1
 head -14 $OUT/kernel_stats_and_pmc.txt | cut -c1-200
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 find $OUT -name "*counter_collection.csv" -size +12M -delete
