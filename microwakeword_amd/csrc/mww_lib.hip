@@ -1041,6 +1041,7 @@ MWW_G_SHAPES(X)
 // the static shape of op `o`, or 0
 int g_shape_id(const mww_ctx* c, const GOp& o) {
   if (!c->g_static || o.kind != MWW_OP_CONV || o.dil != 1 || o.stride != 1 || o.res_src >= 0 || o.n_src < 1) return 0;
+  if (o.tin > kGTmax || o.tout > kGTmax) return 0;   // a window's rows travel in a fixed set of registers (GSliceRegs)
   int C[kGMaxSrc] = {0, 0, 0}, L[kGMaxSrc] = {0, 0, 0};
   for (int i = 0; i < o.n_src; ++i) {
     if (o.src[i] < 0) {

@@ -218,6 +218,11 @@ def train(model, config, data_processor, verbose=True):
         data_processor.use_private_rng(prefetch=prefetch)
     private_streams = fast and hasattr(data_processor, "release_private_rng") and (dp is not None or prefetch > 0)
     local_batch = config["batch_size"] // world
+    # The reference prints the running metrics after every step (train.py:302-312), which costs a host-device synchronisation
+    # per step (0.50 instead of 0.31 ms per step at batch 1024).  On the device path the numbers are read back every
+    # `progress_interval_steps` steps (and at every evaluation boundary); the counters themselves accumulate on the device
+    # every step, so what is printed is what the reference would print at that step.  1 = the reference's cadence.
+    progress = max(1, int(config.get("progress_interval_steps", 25)))
 
     train_writer = _JsonSummary(os.path.join(config["summaries_dir"], "train"), "scalars") if chief else _NoSummary()
     val_writer = _JsonSummary(os.path.join(config["summaries_dir"], "validation"), "scalars") if chief else _NoSummary()
@@ -262,14 +267,16 @@ def train(model, config, data_processor, verbose=True):
             data_processor.next_training_batch_on_device(local_batch, config["spectrogram_length"], "default", policy,
                                                          class_weights=(cw_neg, cw_pos),
                                                          weight_broadcast=config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
-            result = model.train_on_device_batch(local_batch)
+            boundary = (step % config["eval_step_interval"]) == 0 or step == steps_max
+            want = boundary or (verbose and chief and (step % progress == 0 or step == 1))
+            result = model.train_on_device_batch(local_batch, want_results=want)
         else:
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",
                                               augmentation_policy=policy)
             combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
             result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
-        if verbose and chief:
+        if verbose and chief and result is not None:
             print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(
                 (step // config["eval_step_interval"] + 1), result[1], result[2], result[3], result[9],
                 (step % config["eval_step_interval"])), end="\r")

@@ -1259,6 +1259,42 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
             np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)
 
 
+def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194, 208, 212), steps=3, grid=0):
+    """The static-shape instantiations of the graph kernels (kernels_graph.hip.h GShape: the default Inception ops) against
+    the run-time-shape kernels ("graph_static_shapes" 0): same arithmetic in the same order - the shapes only fold index
+    computations - so parameters, moving statistics, probabilities and gradients are bit-identical over several steps;
+    window lengths on both sides of the static path's limit (208 frames), a batch smaller than the grid in between, eager
+    and through captured graphs."""
+    rng = np.random.default_rng(17)
+    for T in lengths:
+        om = perturbed_inception_oracle(T, INC)
+        x = (rng.integers(0, 667, size=(steps, B, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
+        y = (rng.random((steps, B)) < 0.4).astype(np.float32)
+        w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
+        outs = []
+        for static, graphs in ((0, 0), (1, 0), (1, 1)):
+            lay, eng = make_inception_engine(lib, T, B, om, INC)
+            eng.set_option("graph_static_shapes", static)
+            eng.set_option("graphs", graphs)
+            if grid:
+                eng.set_option("grid_graph", grid)
+            got = []
+            for k in range(steps):
+                nb = B if k != 1 else min(B, 2)
+                eng.set_batch(x[k][:nb])
+                eng.set_targets(y[k][:nb], w[:nb])
+                eng.set_dropout_mask(np.ones((nb, eng_dense_inputs(lay)), np.uint8))
+                eng.train_step(nb, 1e-2)
+                got.append(eng.read_outputs(nb)[0].copy())
+                got.append(eng.get_grads().copy())
+            got += [eng.get_params().copy(), eng.get_bn_state().copy()]
+            outs.append(got)
+            eng.close()
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                np.testing.assert_array_equal(a, b)
+
+
 def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=INC, fuse_heads=True):
     """The statistics hand-over of the conv/BN graph kernels (accumulator rows folded by the first consumer launch, no
     finalize launches) against the finalize-launch path on the Inception graph: same sums, same arithmetic, so parameters,

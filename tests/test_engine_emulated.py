@@ -265,6 +265,10 @@ def test_first_conv_tail_rows(emu_lib):
     ec.check_first_conv_tail_rows(emu_lib, B=3, lengths=(203, 206, 209))
 
 
+def test_inception_static_shapes_are_schedule_only(emu_lib):
+    ec.check_inception_static_shapes_are_schedule_only(emu_lib, B=5, lengths=(100, 208, 212, 236), steps=2, grid=2)
+
+
 def test_bn_inline_matches_finalize(emu_lib):
     ec.check_bn_inline_matches_finalize(emu_lib, B=5, T=100, steps=3)
 

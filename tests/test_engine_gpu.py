@@ -483,6 +483,10 @@ def test_first_conv_tail_rows(lib):
     ec.check_first_conv_tail_rows(lib, B=37, grid=0)
 
 
+def test_inception_static_shapes_are_schedule_only(lib):
+    ec.check_inception_static_shapes_are_schedule_only(lib, B=67, lengths=(100, 194, 208, 212, 236))
+
+
 def test_bn_inline_matches_finalize(lib):
     ec.check_bn_inline_matches_finalize(lib, B=96, T=194, steps=4)
     ec.check_bn_inline_matches_finalize(lib, B=5, T=194, steps=2)   # fewer workgroups than accumulator rows
