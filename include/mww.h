@@ -293,6 +293,8 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * with depthwise ops (MixedNet flag sets: -7 % step time measured), 0 for pure convolution graphs (Inception: +0.5 ... +8 %)),
  * "graph_static_shapes" (conv/BN graph contexts: 1 = ops whose shape - kernel length, sources' widths and row lengths - has a
  * compile-time instantiation use it, the default; 0 = the run-time-shape kernels for every op),
+ * "graph_planar" (conv/BN graph contexts: 1 = a 30- / 48-filter op whose consumers all read one of its equal channel slices keeps its
+ * tensors one plane per slice, the default; 0 = interleaved),
  * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
  * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
  * assembly kernel), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */

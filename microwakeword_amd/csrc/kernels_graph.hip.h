@@ -54,6 +54,13 @@ struct GSrc {
   float* gstat_part;    // [grid][2][ld]
   int T, C, toff, flags;
   int ld, c0;           // the source is channels [c0, c0+C) of a producer tensor with ld channels per frame
+  // Planar producers (GConvArgs::out_planes): a tensor whose consumers all read equal channel slices is stored as one plane
+  // per slice, [plane][B][T][C], so that a consumer reads whole rows instead of 40 bytes out of every 120 (the counters of
+  // the default Inception step showed FETCH_SIZE at three times the operand bytes).  Such a source arrives with p / g and
+  // the BN arrays already pointing at its plane, ld = C and c0 = 0; what still refers to the producer's channel axis -
+  // the folded statistics table, the backward statistics rows - uses scb (the slice's first producer channel) and sld
+  // (the producer's channel count).  Interleaved sources: scb = c0, sld = ld.
+  int sld, scb;
   // residual branch added to the producer's normalised output before its activation (mixednet.py:340-358:
   // residual = BN(conv1x1(block input)); net = relu(BN(...) + StridedDrop(residual))): frame t of the producer
   // pairs with frame t + rdrop of the residual op's pre-BN tensor rp [B][rT][C]; null = none
@@ -229,6 +236,8 @@ struct GBnBwd {           // BN backward of the op itself: dp = c1 * (g - mg - x
   const float* p;
   const float *mean, *rstd, *c1, *mg, *mgx;
   GFoldBwd fold;          // fold.acc set: c1 / mg / mgx come from the accumulator rows (folded in the prologue)
+  int planes, pc;         // the op's own tensors g / p are planar (see GSrc): planes of pc channels, pstride floats apart
+  long long pstride;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -285,8 +294,8 @@ __device__ __forceinline__ void stage_source_vec(const GSrc& s, int b, int rows,
   float sc[V], sh[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    sc[e] = ident ? 1.f : cscale[s.c0 + q * V + e];
-    sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
+    sc[e] = ident ? 1.f : cscale[q * V + e];   // (cscale / cshift: the slice's first channel, see stage_sources)
+    sh[e] = ident ? 0.f : cshift[q * V + e];
   }
   const float lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;   // ReLU as a clamp from below
   const BufRsrc slab = tile_rsrc(s.p + ((size_t)b * s.T + s.toff + f0) * sLD + s.c0, ((rows - 1) * sLD + sC) * 4);
@@ -345,8 +354,8 @@ __device__ __forceinline__ void gslice_affine_load(const GSrc& s, const float* c
   const bool ident = (s.flags & GSRC_IDENTITY) != 0;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    f.sc[e] = ident ? 1.f : cscale[s.c0 + q * V + e];
-    f.sh[e] = ident ? 0.f : cshift[s.c0 + q * V + e];
+    f.sc[e] = ident ? 1.f : cscale[q * V + e];
+    f.sh[e] = ident ? 0.f : cshift[q * V + e];
   }
   f.lo = (s.flags & (GSRC_IDENTITY | GSRC_LINEAR)) ? -3.0e38f : 0.f;
 }
@@ -393,7 +402,8 @@ struct GSrcPipe {
       typedef decltype(tr) T;
       const bool folded = fold != nullptr && ftab != nullptr && fold[i].acc != nullptr;
       const float* tab = ftab + i * 4 * kGFoldC;
-      gslice_affine_load<T::V, T::C, T::LD>(src[i], folded ? tab : src[i].scale, folded ? tab + kGFoldC : src[i].shift, tid, f);
+      gslice_affine_load<T::V, T::C, T::LD>(src[i], folded ? tab + src[i].scb : src[i].scale + src[i].c0,
+                                            folded ? tab + kGFoldC + src[i].scb : src[i].shift + src[i].c0, tid, f);
     };
     if constexpr (T0::ON) one(T0{}, 0, f0);
     if constexpr (T1::ON) one(T1{}, 1, f1);
@@ -462,7 +472,8 @@ __device__ __forceinline__ void stage_sources_static(const GSrc* src, int b, int
     const GSrc& s = src[I];
     const bool folded = fold != nullptr && ftab != nullptr && fold[I].acc != nullptr;
     const float* tab = ftab + I * 4 * kGFoldC;
-    stage_source_vec<V, C, LD>(s, b, rows, sIn, PI, SH::srcC0(I), tid, folded ? tab : s.scale, folded ? tab + kGFoldC : s.shift, f0);
+    stage_source_vec<V, C, LD>(s, b, rows, sIn, PI, SH::srcC0(I), tid, folded ? tab + s.scb : s.scale + s.c0,
+                               folded ? tab + kGFoldC + s.scb : s.shift + s.c0, f0);
     stage_sources_static<SH, I + 1>(src, b, rows, sIn, PI, tid, fold, ftab, f0);
   }
 }
@@ -481,8 +492,8 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
     const bool folded = fold != nullptr && ftab != nullptr && fold[i].acc != nullptr;
     const float* tab = ftab + i * 4 * kGFoldC;
     if (!s.rp) {
-      const float* cscale = folded ? tab : s.scale;
-      const float* cshift = folded ? tab + kGFoldC : s.shift;
+      const float* cscale = folded ? tab + s.scb : s.scale + s.c0;
+      const float* cshift = folded ? tab + kGFoldC + s.scb : s.shift + s.c0;
       const int V = gvec_width(s.C, s.ld, s.c0);
       if (V == 4) stage_source_vec<4>(s, b, rows, sIn, PI, c0, tid, cscale, cshift, f0);
       else if (V == 2) stage_source_vec<2>(s, b, rows, sIn, PI, c0, tid, cscale, cshift, f0);
@@ -493,8 +504,8 @@ __device__ __forceinline__ void stage_sources(const GSrc* src, int n_src, int b,
     // sources with a residual branch (MixedNet residual_connection): one channel per thread, two tensors
     const int C = s.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
     if (rg < nrg) {
-      const float sc = folded ? tab[s.c0 + c] : s.scale[s.c0 + c];
-      const float sh = folded ? tab[kGFoldC + s.c0 + c] : s.shift[s.c0 + c];
+      const float sc = folded ? tab[s.scb + c] : s.scale[s.c0 + c];
+      const float sh = folded ? tab[kGFoldC + s.scb + c] : s.shift[s.c0 + c];
       const float lo = (s.flags & GSRC_LINEAR) ? -3.0e38f : 0.f;
       const float* base = s.p + ((size_t)b * s.T + s.toff + f0) * s.ld + s.c0 + c;
       const float rsc = s.rscale[c], rsh = s.rshift[c];
@@ -549,13 +560,24 @@ __device__ __forceinline__ void stage_dp_vec(const GBnBwd& y, int C_, int b, int
     mgx[e] = folded ? btab[2 * kGFoldC + c] : y.mgx[c];
   }
   const size_t w0 = ((size_t)b * (Ttot < 0 ? rows : Ttot) + f0) * C;
-  const BufRsrc gslab = tile_rsrc(y.g + w0, rows * C * 4), pslab = tile_rsrc(y.p + w0, rows * C * 4);
+  // planar tensors (GSrc): this thread's channel group lies in plane (q V) / pc; its rows are pc floats long.  One resource
+  // over the whole tensor then (the offsets stay below 2^31 bytes for every batch the context holds), rows past the window
+  // are not committed
+  // (the host makes only 30- and 48-channel tensors planar - mww_create_convnet - so the instantiations that know another
+  // width carry none of this: the 16-filter twin backward launch lost 10 us to the extra scalar pressure before)
+  constexpr bool kMaybePlanar = CC == 0 || CC == 30 || CC == 48;
+  const bool planar = kMaybePlanar && y.planes > 1;
+  const int pl = planar ? (q * V) / y.pc : 0, rowc = planar ? y.pc : C;
+  const size_t wp = (size_t)pl * (size_t)y.pstride + ((size_t)b * (Ttot < 0 ? rows : Ttot) + f0) * rowc;
+  const int tbytes = planar ? (int)((size_t)y.planes * (size_t)y.pstride * 4) : rows * C * 4;
+  const BufRsrc gslab = tile_rsrc(planar ? y.g : y.g + w0, tbytes), pslab = tile_rsrc(planar ? y.p : y.p + w0, tbytes);
+  const int e0 = planar ? (int)wp + (q * V - pl * rowc) : q * V;
   constexpr int NB = kGB;
   for (int t0 = rg; t0 < rows; t0 += NB * nrg) {
     GVec<V> g[NB], p[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int off = (t0 + u * nrg) * C + q * V;
+      const int off = (t0 + u * nrg) * rowc + e0;
       g[u] = gvec_bload<V, MWW_AUX_GR_LD_DP>(gslab, off);
       p[u] = gvec_bload<V, MWW_AUX_GR_LD_DP>(pslab, off);
     }
@@ -643,6 +665,10 @@ struct GConvArgs {
   GFoldFwd fold[kGMaxSrc];   // MODE 0: sources whose producer statistics this launch is the first to consume
   StatAcc sacc;         // MODE 0: the output statistics go to these accumulator rows instead of stat_part
   int S, Tc;            // frame chunks (the CH instantiations, 1x1 ops only): a window is S work items of Tc frames (the last one shorter)
+  // MODE 0: planar output (see GSrc): channel c goes to plane c / out_pc of `out`, planes out_pstride floats apart, rows of
+  // out_pc channels; out_planes <= 1: interleaved [B][Tout][NC]
+  int out_planes, out_pc;
+  long long out_pstride;
 };
 
 // bid / nb: this workgroup's index and the number of workgroups sharing the batch (a launch may hold several roles)
@@ -894,10 +920,12 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     if (MODE == 0) {
       const int nrg = kThreads / NC, c = tid % NC, rg = tid / NC;
       if (rg < nrg) {
-        float* dst = a.out + ((size_t)b * Ttot + f0) * NC + c;
+        const bool planar = a.out_planes > 1;
+        const int pl = planar ? c / a.out_pc : 0, rowc = planar ? a.out_pc : NC;
+        float* dst = a.out + (size_t)pl * a.out_pstride + ((size_t)b * Ttot + f0) * rowc + (c - pl * rowc);
         for (int t = rg; t < Tout; t += nrg) {
           const float v = sOut[t * PO + c];
-          store_stream<MWW_AUX_GR_ST_P>(dst + (size_t)t * NC, v);
+          store_stream<MWW_AUX_GR_ST_P>(dst + (size_t)t * rowc, v);
           s1o += v;
           s2o = fmaf(v, v, s2o);
         }
@@ -1002,7 +1030,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       const GSrc& s = a.src[i];
       if ((s.flags & GSRC_GRAD) && (s.flags & GSRC_STATS))
         publish_channel_partials(i == 0 ? s1o : sSrcAcc[(i * 2 - 2) * kThreads + tid], i == 0 ? s2o : sSrcAcc[(i * 2 - 1) * kThreads + tid],
-                                 s.C, sRed, s.gstat_part + (size_t)bid * 2 * s.ld + s.c0, tid, s.ld, s.gacc, s.c0, bid, nb);
+                                 s.C, sRed, s.gstat_part + (size_t)bid * 2 * s.sld + s.scb, tid, s.sld, s.gacc, s.scb, bid, nb);
     }
   }
 }
@@ -1408,8 +1436,8 @@ __global__ __launch_bounds__(kThreads) void gdw_kernel(GDwArgs a) {
     }
   }
   if (MODE == 1 && (a.src.flags & GSRC_STATS))
-    publish_channel_partials(s1, s2, C, sRed, a.src.gstat_part + (size_t)blockIdx.x * 2 * a.src.ld + a.src.c0, tid, a.src.ld, a.src.gacc,
-                             a.src.c0, blockIdx.x, gridDim.x);
+    publish_channel_partials(s1, s2, C, sRed, a.src.gstat_part + (size_t)blockIdx.x * 2 * a.src.sld + a.src.scb, tid, a.src.sld, a.src.gacc,
+                             a.src.scb, blockIdx.x, gridDim.x);
 }
 
 // dw[j][c] = sum_{b,t} act[b][t+j][c] * dp[b][t][c].  thread <-> (channel, tap block, frame part): the 8 taps of a block

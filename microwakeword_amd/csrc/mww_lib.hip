@@ -71,6 +71,8 @@ struct GOp {
   float *p = nullptr, *g = nullptr, *stat_part = nullptr, *gstat_part = nullptr, *grad_part = nullptr, *bn = nullptr;
   bool needs_dx = false;
   bool twin_next = false;     // op i+1 is an independent op of the same shape: the pair shares its launches
+  int planes = 1, pc = 0;     // > 1: every consumer reads one of `planes` equal channel slices of pc channels: the tensors p / g may be
+                              // stored one plane per slice (kernels_graph.hip.h GSrc; "graph_planar")
   size_t lds_fwd = 0, lds_dx = 0, lds_wg = 0;
   // statistics hand-over (kernels_graph.hip.h): [parity][kStatRows][2][cout] accumulator rows of the forward / backward sums,
   // *_cur = the rows the latest producer launch added to; first_consumer = the lowest op index that reads this op
@@ -131,6 +133,7 @@ struct mww_ctx {
   int grid_g = 0;
   int g_cap_fwd = 4, g_cap_bwd = 4;   // "graph_fwd_wg_per_cu" / "graph_bwd_wg_per_cu" (g_role_grid)
   int metric_launches = 0;   // launches of the step being enqueued that carry the metric role (kernels_head.hip.h MetricState: one writer)
+  bool g_planar = true;   // "graph_planar": tensors read only as equal channel slices are stored one plane per slice
   bool g_static = true;   // "graph_static_shapes": ops whose shape has a compile-time instantiation (MWW_G_SHAPES) use it
   int g_chunks = 0;   // "graph_frame_chunks" (g_chunks())
   int g_dgrad_share = 50;   // "graph_dgrad_share"
@@ -1018,7 +1021,7 @@ void g_share_roles(mww_ctx* c, const GridPick& pk, int* nbw, int* nbd) {
 #define MWW_G_SHAPES(X)                                                                                                   \
   X(1, 5, 1, 40, 40, 0, 0, 0, 0) X(2, 1, 1, 24, 24, 0, 0, 0, 0) X(3, 5, 1, 10, 30, 0, 0, 0, 0) X(4, 5, 1, 10, 10, 0, 0, 0, 0)    \
   X(5, 1, 3, 10, 30, 10, 10, 10, 10) X(6, 1, 1, 10, 10, 0, 0, 0, 0) X(7, 5, 1, 16, 48, 0, 0, 0, 0) X(8, 5, 1, 16, 16, 0, 0, 0, 0) \
-  X(9, 1, 3, 16, 48, 16, 16, 16, 16)
+  X(9, 1, 3, 16, 48, 16, 16, 16, 16) X(10, 1, 3, 10, 10, 10, 10, 10, 10) X(11, 1, 3, 16, 16, 16, 16, 16, 16)
 #endif
 #define X(ID, K, N, C0, L0, C1, L1, C2, L2) typedef GShape<K, N, C0, L0, C1, L1, C2, L2> GSh##ID;
 MWW_G_SHAPES(X)
@@ -1031,12 +1034,19 @@ MWW_G_SHAPES(X)
 #define MWW_G_SHAPE_BWD(X)
 #define MWW_G_SHAPE_BWD2(X)
 #else
-#define MWW_G_SHAPE_FWD(X) X(1, 24) X(2, 30) X(3, 10) X(4, 10) X(5, 10) X(6, 30) X(6, 48) X(7, 16) X(8, 16) X(9, 16)
-#define MWW_G_SHAPE_FWD2(X) X(3, 10) X(7, 16)
+#define MWW_G_SHAPE_FWD(X) X(1, 24) X(2, 30) X(3, 10) X(4, 10) X(5, 10) X(6, 30) X(6, 48) X(7, 16) X(8, 16) X(9, 16) X(10, 10) X(11, 16)
+#define MWW_G_SHAPE_FWD2(X) X(3, 10) X(7, 16) X(4, 10) X(8, 16)
 #define MWW_G_SHAPE_WG(X) X(1, 24)
-#define MWW_G_SHAPE_BWD(X) X(2, 30, 24) X(3, 10, 10) X(4, 10, 10) X(5, 10, 30) X(6, 30, 10) X(6, 48, 10) X(7, 16, 16) X(8, 16, 16) X(9, 16, 48)
-#define MWW_G_SHAPE_BWD2(X) X(3, 10) X(7, 16)
+#define MWW_G_SHAPE_BWD(X) X(2, 30, 24) X(3, 10, 10) X(4, 10, 10) X(5, 10, 30) X(6, 30, 10) X(6, 48, 10) X(7, 16, 16) X(8, 16, 16) X(9, 16, 48) X(10, 10, 30) X(11, 16, 48)
+#define MWW_G_SHAPE_BWD2(X) X(3, 10) X(7, 16) X(4, 10) X(8, 16)
 #endif
+
+// planes of op `o`'s tensors in effect (1 = interleaved) and the distance between two planes in floats
+int g_planes(const mww_ctx* c, const GOp& o) { return (c->g_planar && o.planes > 1) ? o.planes : 1; }
+// (+ kPlanePad floats: without it two planes lie a multiple of 4-8 KB apart - max_batch x T x pc x 4 bytes - and twin ops that
+// walk their planes in step hit the same HBM channels: the 16-channel twin backward launch went 45 -> 55 us)
+constexpr long long kPlanePad = 1088;   // 17 x 256 bytes
+long long g_pstride(const mww_ctx* c, const GOp& o) { return (long long)c->d.max_batch * o.tout * o.pc + kPlanePad; }
 
 // the static shape of op `o`, or 0
 int g_shape_id(const mww_ctx* c, const GOp& o) {
@@ -1050,10 +1060,10 @@ int g_shape_id(const mww_ctx* c, const GOp& o) {
       const GOp& pr = c->G[o.src[i]];
       if (pr.res_src >= 0) return 0;
       C[i] = o.scn[i];
-      L[i] = pr.cout;
+      L[i] = g_planes(c, pr) > 1 ? o.scn[i] : pr.cout;   // (a plane of a planar producer is a whole tensor of its own)
     }
     const int v = ((C[i] | L[i]) & 3) == 0 ? 4 : (((C[i] | L[i]) & 1) == 0 ? 2 : 1);
-    if (o.src[i] >= 0 && o.sc0[i] % v) return 0;   // the slice must start on the vector width the static staging uses
+    if (o.src[i] >= 0 && L[i] != C[i] && o.sc0[i] % v) return 0;   // the slice must start on the vector width the static staging uses
   }
 #define X(ID, K, N, C0, L0, C1, L1, C2, L2)                                                                     \
   if (o.k == K && o.n_src == N && C[0] == C0 && L[0] == L0 && C[1] == C1 && L[1] == L1 && C[2] == C2 && L[2] == L2) return ID;
@@ -1225,7 +1235,7 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward, bool inl = false) {
   if (o.src[i] < 0) {
     s.p = c->x;
     s.T = c->d.frames;
-    s.C = s.ld = MWW_FEATURE_BINS;
+    s.C = s.ld = s.sld = MWW_FEATURE_BINS;
     s.flags = GSRC_IDENTITY;
     return s;
   }
@@ -1246,8 +1256,20 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward, bool inl = false) {
   s.gstat_part = pr.gstat_part;
   s.T = pr.tout;
   s.C = o.scn[i];
-  s.ld = pr.cout;
-  s.c0 = o.sc0[i];
+  s.ld = s.sld = pr.cout;
+  s.c0 = s.scb = o.sc0[i];
+  if (g_planes(c, pr) > 1) {
+    // the producer's tensors are planar and this slice is one of the planes: whole rows of C channels, BN arrays at the plane
+    const long long off = (long long)(o.sc0[i] / pr.pc) * g_pstride(c, pr);
+    s.p += off;
+    s.g += off;
+    s.scale += s.c0;
+    s.shift += s.c0;
+    s.mean += s.c0;
+    s.rstd += s.c0;
+    s.ld = s.C;
+    s.c0 = 0;
+  }
   if (pr.act == MWW_ACT_LINEAR) s.flags |= GSRC_LINEAR;
   if (pr.res_src >= 0) {
     GOp& rr = c->G[pr.res_src];
@@ -1267,8 +1289,19 @@ GSrc g_make_src(mww_ctx* c, int oi, int i, bool backward, bool inl = false) {
 }
 
 GBnBwd g_make_bnbwd(mww_ctx* c, GOp& o) {
-  if (o.norm != MWW_NORM_BN) return GBnBwd{o.g, o.p, c->zeros, c->ones, c->ones, c->zeros, c->zeros};   // dp = g
-  return GBnBwd{o.g, o.p, gbn_slot(o, BN_MEAN), gbn_slot(o, BN_RSTD), gbn_slot(o, BN_C1), gbn_slot(o, BN_MG), gbn_slot(o, BN_MGX)};
+  GBnBwd y;
+  memset(&y, 0, sizeof(y));
+  y.g = o.g;
+  y.p = o.p;
+  if (o.norm != MWW_NORM_BN) {   // dp = g
+    y.mean = c->zeros; y.rstd = c->ones; y.c1 = c->ones; y.mg = c->zeros; y.mgx = c->zeros;
+  } else {
+    y.mean = gbn_slot(o, BN_MEAN); y.rstd = gbn_slot(o, BN_RSTD); y.c1 = gbn_slot(o, BN_C1); y.mg = gbn_slot(o, BN_MG); y.mgx = gbn_slot(o, BN_MGX);
+  }
+  y.planes = g_planes(c, o);
+  y.pc = o.pc;
+  y.pstride = g_pstride(c, o);
+  return y;
 }
 
 GDwArgs g_make_dw(mww_ctx* c, int oi, int B, bool backward, bool inl = false) {
@@ -1353,6 +1386,9 @@ int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool
       a.Tin = q.tin;
       a.Tout = q.tout;
       a.out = q.p;
+      a.out_planes = g_planes(c, q);
+      a.out_pc = q.pc;
+      a.out_pstride = g_pstride(c, q);
       a.stat_part = (training && q.norm == MWW_NORM_BN) ? q.stat_part : nullptr;
       if (inl) {
         a.sacc.acc = q.facc[c->fpar];
@@ -2212,6 +2248,26 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
     for (int cc = 0; cc < ops[pi].cout; ++cc)
       if (!covered[cc]) return fail(MWW_ERR_UNSUPPORTED, "op " + std::to_string(pi) + ": channel " + std::to_string(cc) + " has no consumer");
   }
+  // planar tensors: a convolution + BatchNorm op whose consumers are all convolutions that read one of `planes` equal slices
+  // each (the fused 1x1 branch heads of an Inception block: 30 = 3 x 10, 48 = 3 x 16 channels).  Only for the widths whose
+  // own backward staging is the direct one (kernels_graph.hip.h GDpPipe is not planar-aware: 30 and 48 exceed its registers).
+  for (int pi = 0; pi + 1 < d.n_ops; ++pi) {
+    GOp& pr = ops[pi];
+    if (pr.kind != MWW_OP_CONV || pr.norm != MWW_NORM_BN || pr.res_src >= 0 || !pr.adders.empty() || (pr.cout != 30 && pr.cout != 48)) continue;
+    int cn = 0;
+    bool ok = true;
+    for (int i = pi + 1; i < d.n_ops && ok; ++i)
+      for (int j = 0; j < ops[i].n_src; ++j) {
+        if (ops[i].src[j] != pi) continue;
+        if (ops[i].kind != MWW_OP_CONV || ops[i].res_src >= 0 || ops[i].stride != 1) ok = false;
+        if (cn == 0) cn = ops[i].scn[j];
+        if (ops[i].scn[j] != cn || ops[i].scn[j] >= pr.cout || ops[i].sc0[j] % cn) ok = false;
+      }
+    if (ok && cn > 0 && pr.cout % cn == 0 && (cn % 2) == 0) {
+      pr.planes = pr.cout / cn;
+      pr.pc = cn;
+    }
+  }
   if (n_consumers[d.n_ops - 1] != 0) return fail(MWW_ERR_INVALID, "the last op feeds the classifier head and cannot have other consumers");
   {
     const GOp& lo = ops[d.n_ops - 1];
@@ -2284,8 +2340,8 @@ int mww_create_convnet(const mww_convnet_desc* desc, int device, void* stream, m
   }
   std::vector<BnSlots> bn;
   for (GOp& o : c->G) {
-    A(dev_alloc(&o.p, mb * o.tout * o.cout));
-    A(dev_alloc(&o.g, mb * o.tout * o.cout));
+    A(dev_alloc(&o.p, mb * o.tout * o.cout + (size_t)o.planes * kPlanePad));
+    A(dev_alloc(&o.g, mb * o.tout * o.cout + (size_t)o.planes * kPlanePad));
     A(dev_alloc(&o.stat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.gstat_part, (size_t)gmax * 2 * o.cout));
     A(dev_alloc(&o.grad_part, (size_t)gmax * o.k * (o.kind == MWW_OP_DEPTHWISE ? 1 : o.cin) * o.cout));   // ("grid_graph" may be raised to gmax)
@@ -2887,6 +2943,20 @@ int64_t mww_debug_read(mww_ctx* c, const char* name, int B, float* host, int64_t
     }
     else return fail(MWW_ERR_INVALID, std::string("unknown tensor name: ") + name);
     if (n > cap) return fail(MWW_ERR_INVALID, "host buffer too small");
+    const int kpl = gidx("p") >= 0 ? gidx("p") : gidx("g");
+    if (kpl >= 0 && g_planes(c, c->G[kpl]) > 1) {
+      // a planar tensor is handed out interleaved [B][T][C], as the caller expects it
+      const GOp& o = c->G[kpl];
+      const int planes = g_planes(c, o);
+      std::vector<float> tmp((size_t)B * o.tout * o.pc);
+      for (int pl = 0; pl < planes; ++pl) {
+        int rcp = copy_out(c, tmp.data(), src + (size_t)pl * g_pstride(c, o), tmp.size() * sizeof(float));
+        if (rcp) return rcp;
+        for (int64_t r = 0; r < (int64_t)B * o.tout; ++r)
+          for (int cc = 0; cc < o.pc; ++cc) host[r * o.cout + pl * o.pc + cc] = tmp[(size_t)r * o.pc + cc];
+      }
+      return n;
+    }
     int rcg = copy_out(c, host, src, (size_t)n * sizeof(float));
     return rcg ? rcg : n;
   }
@@ -2933,6 +3003,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "bn_inline")) c->bn_inline = v != 0;
   else if (!strcmp(name, "graph_role_split")) c->g_role_split = v != 0;
   else if (!strcmp(name, "graph_static_shapes")) c->g_static = v != 0;
+  else if (!strcmp(name, "graph_planar")) c->g_planar = v != 0;
   else if (!strcmp(name, "graph_fwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_fwd_wg_per_cu must be 1..8"); c->g_cap_fwd = (int)v; }
   else if (!strcmp(name, "graph_bwd_wg_per_cu")) { if (v < 1 || v > 8) return fail(MWW_ERR_INVALID, "graph_bwd_wg_per_cu must be 1..8"); c->g_cap_bwd = (int)v; }
   else if (!strcmp(name, "graph_frame_chunks")) { if (v < 0 || v > 4) return fail(MWW_ERR_INVALID, "graph_frame_chunks must be 0..4"); c->g_chunks = (int)v; }

@@ -1272,9 +1272,11 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
         y = (rng.random((steps, B)) < 0.4).astype(np.float32)
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
         outs = []
-        for static, graphs in ((0, 0), (1, 0), (1, 1)):
+        # ... and so is the planar layout of the fused branch heads' tensors ("graph_planar": one plane per consumer slice)
+        for static, planar, graphs in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1)):
             lay, eng = make_inception_engine(lib, T, B, om, INC)
             eng.set_option("graph_static_shapes", static)
+            eng.set_option("graph_planar", planar)
             eng.set_option("graphs", graphs)
             if grid:
                 eng.set_option("grid_graph", grid)
