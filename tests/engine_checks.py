@@ -1132,7 +1132,7 @@ def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
         np.testing.assert_array_equal(a, b)
 
 
-def check_train_loop_prefetch_is_schedule_only(lib, tmp_path, B=8, T=60):
+def check_train_loop_prefetch_is_schedule_only(lib, tmp_path, B=8, T=60, steps=7):
     """train.train with the batches drawn on a worker thread from private RNG streams (prefetch_batches 2, the default)
     against prefetch_batches 0 (every draw on the launching thread, in the global generators, as the reference does):
     bit-identical weights ACROSS validation passes, whose shuffles (data.py:593-595) advance the global numpy stream the
@@ -1145,9 +1145,9 @@ def check_train_loop_prefetch_is_schedule_only(lib, tmp_path, B=8, T=60):
         cfg = learnable_config(T=T)
         cfg["features"][1]["truncation_strategy"] = "random"   # consumes numpy.random per drawn sample
         cfg = dict(cfg, train_dir=str(tmp_path / ("run%d" % depth)), summaries_dir=str(tmp_path / ("run%d" % depth) / "logs"),
-                   batch_size=B, spectrogram_length=T, training_steps=[7], learning_rates=[0.01], time_mask_max_size=[4],
+                   batch_size=B, spectrogram_length=T, training_steps=[steps], learning_rates=[0.01], time_mask_max_size=[4],
                    time_mask_count=[2], freq_mask_max_size=[4], freq_mask_count=[1], positive_class_weight=[1.0],
-                   negative_class_weight=[1.0], eval_step_interval=3, target_minimization=0.9, minimization_metric=None,
+                   negative_class_weight=[1.0], eval_step_interval=max(2, steps // 2), target_minimization=0.9, minimization_metric=None,
                    maximization_metric="accuracy", prefetch_batches=depth)
         random.seed(2)
         np.random.seed(2)
@@ -1259,7 +1259,7 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
             np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)
 
 
-def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194, 208, 212), steps=3, grid=0):
+def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194, 208, 212), steps=3, grid=0, combos=None):
     """The static-shape instantiations of the graph kernels (kernels_graph.hip.h GShape: the default Inception ops) against
     the run-time-shape kernels ("graph_static_shapes" 0): same arithmetic in the same order - the shapes only fold index
     computations - so parameters, moving statistics, probabilities and gradients are bit-identical over several steps;
@@ -1273,7 +1273,7 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
         outs = []
         # ... and so is the planar layout of the fused branch heads' tensors ("graph_planar": one plane per consumer slice)
-        for static, planar, graphs in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1)):
+        for static, planar, graphs in (combos or ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1))):
             lay, eng = make_inception_engine(lib, T, B, om, INC)
             eng.set_option("graph_static_shapes", static)
             eng.set_option("graph_planar", planar)
@@ -1518,12 +1518,12 @@ def check_inception_topology_fuzz(lib, cases=4, first=0, B=3, T=150):
 
 
 # ------------------------------------------------------------------------------------------ shape fuzz
-def check_first_conv_tail_rows(lib, B=5, grid=2, lengths=(194, 197, 200, 203, 204, 206, 207, 209)):
+def check_first_conv_tail_rows(lib, B=5, grid=2, lengths=(194, 197, 200, 203, 204, 206, 207, 209), topologies=None):
     """Strided first convolutions (the notebook's 5x1 stride 3): windows whose a0 length is TT + 1 ... TT + K - 1 rows run as ONE
     tile with the rows behind the 64 MFMA rows computed on the VALU (fwd_first_body.inc "tail rows"); lengths on both sides of
     that range (exactly one tile, two tiles) take the ordinary paths.  Forward taps and a train step each, two topologies."""
     for T in lengths:
-        for flags in (NOTEBOOK, CROSSED[3]):
+        for flags in (topologies or (NOTEBOOK, CROSSED[3])):
             check_forward_parity(lib, B=B, T=T, training=True, grid=grid, flags=flags)
             check_train_steps(lib, B=B, T=T, steps=1, grid=grid, flags=flags)
 

@@ -253,7 +253,7 @@ def test_prefetched_batches_train_like_the_synchronous_sampler(emu_lib):
 
 
 def test_train_loop_prefetch_is_schedule_only(emu_lib, tmp_path):
-    ec.check_train_loop_prefetch_is_schedule_only(emu_lib, tmp_path)
+    ec.check_train_loop_prefetch_is_schedule_only(emu_lib, tmp_path, B=6, steps=5)
 
 
 def test_train_loop_data_parallel_world1(emu_lib, tmp_path):
@@ -262,11 +262,11 @@ def test_train_loop_data_parallel_world1(emu_lib, tmp_path):
 
 
 def test_first_conv_tail_rows(emu_lib):
-    ec.check_first_conv_tail_rows(emu_lib, B=3, lengths=(203, 206, 209))
+    ec.check_first_conv_tail_rows(emu_lib, B=2, lengths=(203, 206), topologies=(ec.NOTEBOOK,))
 
 
 def test_inception_static_shapes_are_schedule_only(emu_lib):
-    ec.check_inception_static_shapes_are_schedule_only(emu_lib, B=5, lengths=(100, 208, 212, 236), steps=2, grid=2)
+    ec.check_inception_static_shapes_are_schedule_only(emu_lib, B=4, lengths=(100, 236), steps=2, grid=2, combos=((0, 0, 0), (1, 1, 0), (1, 1, 1)))
 
 
 def test_bn_inline_matches_finalize(emu_lib):
