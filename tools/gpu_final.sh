@@ -7,7 +7,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 600 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+# the library that travelled with the tree is the one measured (and the one whose sha256 the PMC summary is stamped with: a
+# rebuild on the box - copied sources may look newer than the copied library - would produce another binary than the one the
+# driver's own bench run loads)
+python -c "import hashlib; print('library sha256_16 =', hashlib.sha256(open('microwakeword_amd/libmww_hip.so','rb').read()).hexdigest()[:16])"
 echo "== pytest -m gpu"
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3
 echo "== smoke"
@@ -16,11 +19,14 @@ Q="--no-cpu-baseline --no-validation"
 echo "== bench default (as the driver runs it: 5 + 20 steps; then 20 + 200 steps)"
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench.err; tail -c 2600 $OUT/bench_driver_form.json; tail -2 $OUT/bench.err
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 300 $OUT/bench.json; echo
+echo "== the product loop (train.train) at batch 1024"
+timeout 600 python tools/train_loop_throughput.py 2000 2>/dev/null | grep "train.train" | tee $OUT/train_loop_throughput.txt
 echo "== synchronous sampler"
 timeout 600 python bench.py $Q --no-prefetch > $OUT/bench_sync_sampler.json 2>/dev/null; head -c 200 $OUT/bench_sync_sampler.json; echo
 echo "== bench inception / notebook / generic"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; head -c 300 $OUT/bench_inception.json; echo
-MWW_BENCH_OPTIONS=graph_static_shapes=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_runtime_shapes.json 2>/dev/null; head -c 200 $OUT/bench_inception_runtime_shapes.json; echo
+MWW_BENCH_OPTIONS=graph_static_shapes=0,graph_planar=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_runtime_shapes.json 2>/dev/null; head -c 200 $OUT/bench_inception_runtime_shapes.json; echo
+MWW_BENCH_OPTIONS=graph_planar=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_interleaved.json 2>/dev/null; head -c 200 $OUT/bench_inception_interleaved.json; echo
 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook.json 2> $OUT/bench_notebook.err; head -c 300 $OUT/bench_notebook.json; echo
 MWW_BENCH_T=194 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook_T194_one_full_tile.json 2>/dev/null; head -c 200 $OUT/bench_notebook_T194_one_full_tile.json; echo
 timeout 900 python bench.py --force-generic $Q --steps 100 --warmup 10 > $OUT/bench_mixednet_on_graph_kernels.json 2>/dev/null; head -c 200 $OUT/bench_mixednet_on_graph_kernels.json; echo
