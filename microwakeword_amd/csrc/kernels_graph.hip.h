@@ -686,6 +686,8 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
                                                      float* sSrcAcc) {
   if constexpr (I < SH::NSRC) {
     constexpr int C = SH::srcC(I), LD = SH::srcLD(I), c0 = SH::srcC0(I);
+    constexpr int kGES = 8;   // rows in flight per thread (the run-time epilogue keeps kGE = 4: a window's share of a 10- / 16-channel
+                              // slice is 8-12 rows per thread, i.e. two or three dependent round trips there)
     const GSrc& s = src[I];
     if (s.flags & GSRC_GRAD) {
       constexpr int nrg = kThreads / C;
@@ -699,16 +701,16 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
         const size_t woff = (size_t)b * s.T * LD + s.c0;
         const int wbytes = ((s.T - 1) * LD + C) * 4;
         const BufRsrc pr = tile_rsrc(s.p + woff, wbytes), gr = tile_rsrc(s.g + woff, wbytes), go = tile_rsrc(s.g + woff, accum ? wbytes : 0);
-        for (int tb = rg; tb < s.T; tb += kGE * nrg) {
-          float pv[kGE], gold[kGE];
+        for (int tb = rg; tb < s.T; tb += kGES * nrg) {
+          float pv[kGES], gold[kGES];
 #pragma unroll
-          for (int u = 0; u < kGE; ++u) {
+          for (int u = 0; u < kGES; ++u) {
             const int off = ((tb + u * nrg) * LD + c) * 4;
             pv[u] = tile_load1(pr, off);
             gold[u] = tile_load1<MWW_AUX_GR_LD_GOLD>(go, off);
           }
 #pragma unroll
-          for (int u = 0; u < kGE; ++u) {
+          for (int u = 0; u < kGES; ++u) {
             const int t = tb + u * nrg;
             if (t < s.T) {
               const float p = pv[u];
@@ -1130,6 +1132,7 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[u][nt] = zero4();
   // dp columns NC..PO-1 and rows Tout..Tout4-1 stay zero: staging only writes the window's own elements
+  if (ST && tid < 8) sA[a.Tin * PI + tid] = 0.f;   // (the gap in front of the dp tile: read - against zero dp rows - by the unclamped k-steps)
   for (int i = tid; i < Tout4 * PO; i += kThreads) sDP[i] = 0.f;
   // statistics hand-over: the op's backward coefficients folded from the accumulator rows; this role publishes them
   __shared__ float sFoldB[3 * kGFoldC];
@@ -1173,6 +1176,41 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
         if constexpr (PIPE_D) dpipe.issue(a.y, v + nb, a.Tout, tid);
       }
     }
+    if constexpr (ST) {
+      // Static shapes: the k-steps walk two base pointers with immediate offsets, four steps per trip (the run-time loop
+      // below spends ~12 instructions around every MFMA: clamp, two row addresses, loop control - 47 trips for a 186-frame
+      // window, the larger half of what a weight-gradient wave of a 10-filter op issues).  No clamp: the frames a short last
+      // k-step reads past the window lie in front of / inside the dp tile (finite: the gap was zeroed above) and their dp
+      // rows are zero.
+      const int nsteps = (Tout - kp * 4 + 4 * KS - 1) / (4 * KS);
+      const float* pa = sA + (kp * 4 + g) * PI;
+      const float* pb = sDP + (kp * 4 + g) * PO + r16;
+      auto kstep = [&](const float* qa, const float* qb) {
+        float bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = qb[nt * 16];
+#pragma unroll
+        for (int u = 0; u < kGWgTilesPerWave; ++u) {
+          if (slot + u * nslot < MT) {   // wave-uniform
+            const float av = qa[offA[u]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
+          }
+        }
+      };
+      int i = 0;
+      for (; i + 4 <= nsteps; i += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kstep(pa + q * 4 * KS * PI, pb + q * 4 * KS * PO);
+        pa += 16 * KS * PI;
+        pb += 16 * KS * PO;
+      }
+      for (; i < nsteps; ++i) {
+        kstep(pa, pb);
+        pa += 4 * KS * PI;
+        pb += 4 * KS * PO;
+      }
+    } else
     for (int t0 = kp * 4; t0 < Tout; t0 += 4 * KS) {
       // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
       const int tf = min(t0 + g, Tout - 1);
