@@ -146,8 +146,19 @@ def main(argv=None):
         model_module = inception
     else:
         raise ValueError("Unknown model type: {}".format(flags.model_name))
+    already = "torch.distributed" in sys.modules and sys.modules["torch.distributed"].is_initialized()
     rank, local_rank, world = init_process_group_from_env()
     logging.basicConfig(level=getattr(logging, flags.verbosity.upper(), logging.INFO) if rank == 0 else logging.WARNING)
+    try:
+        return _run(flags, model_module, rank, local_rank, world)
+    finally:
+        if world > 1 and not already:   # the group this call created (a caller's own group is the caller's to end)
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def _run(flags, model_module, rank, local_rank, world):
     if any((flags.test_tf_nonstreaming, flags.test_tflite_nonstreaming, flags.test_tflite_nonstreaming_quantized,
             flags.test_tflite_streaming, flags.test_tflite_streaming_quantized)):
         raise NotImplementedError("model export / TFLite evaluation stays with the reference (microwakeword.utils / .test); "
