@@ -34,6 +34,7 @@
 #pragma once
 #include <type_traits>
 #include "common.hip.h"
+#include "kernels_fwd.hip.h"   // XGather / XShared / XStage: the stem's input straight from the feature stores
 
 namespace mww {
 
@@ -462,6 +463,96 @@ struct GDpPipe {
   }
 };
 
+// ---- the stem's input straight from the feature stores (XG instantiations) ---------------------------------------------
+// The graph form of kernels_fwd.hip.h "fused_input": a static shape whose one source is the spectrogram (40 bins, no
+// affine) gathers its windows from the stores while it stages them - pad / truncate offsets, uint16 scaling and the
+// SpecAugment masks applied on the way into LDS, bit-identical to assemble_kernel - so the [B][T][40] float32 batch is
+// neither written (the assembly launch: 14 us of the Inception step) nor read (twice: forward and weight gradient).
+// The register stage is XStage (one window ahead, like GSrcPipe); the descriptors of the workgroup's windows (at most
+// kXMaxSamples: the host checks the grid) sit behind the launch's dynamic LDS tiles.
+constexpr int kGXRows = 200;   // frames of a gathered window at most: 8 float4 per thread in flight
+template <int AUX>
+using GXStage = XStage<kGXRows, FBINS + 1, AUX>;
+struct GXNone {};
+
+// xgather_setup for a role's workgroup: windows first, first + stride, ...  (ends with a barrier)
+__device__ __forceinline__ void gx_setup(const XGather& g, XShared& sh, int nsamp, int tid, int first, int stride) {
+  if (tid < nsamp) {
+    const mww_window w = g.win[first + tid * stride];
+    const void* base = g.store[0];
+    int dt = g.dtype[0];
+#pragma unroll
+    for (int i = 1; i < MWW_MAX_STORES; ++i)
+      if (w.store == i) {
+        base = g.store[i];
+        dt = g.dtype[i];
+      }
+    sh.base[tid] = base;
+    sh.dtype[tid] = dt;
+    sh.src_elem[tid] = w.src_elem;
+    sh.pad_rows[tid] = w.pad_rows;
+    sh.copy_rows[tid] = w.copy_rows;
+  }
+  constexpr int WPS = kXRowWords + 2;
+  if (tid < nsamp * WPS) {
+    const int s = tid / WPS, word = tid - s * WPS;
+    const int nm = g.ntm + g.nfm;
+    const int* mk = g.masks + (size_t)(first + s * stride) * nm * 2;
+    int mv[2 * kXMaxMasks];
+#pragma unroll
+    for (int m = 0; m < 2 * kXMaxMasks; ++m) mv[m] = (m < 2 * nm) ? mk[m] : 0;
+    const bool row = word < kXRowWords;
+    const int w = row ? word : word - kXRowWords;
+    unsigned bits = 0u;
+#pragma unroll
+    for (int m = 0; m < kXMaxMasks; ++m)
+      if (m < nm && (m < g.ntm) == row) bits |= bits_of_range(mv[2 * m], mv[2 * m + 1], w);
+    if (row) sh.rowbits[s][w] = bits;
+    else sh.colbits[s][w] = bits;
+  }
+  __syncthreads();
+}
+
+// XStage::commit for a window of `rows` <= kGXRows frames: nothing is written behind the window (the tiles that follow it
+// in LDS are live)
+template <int AUX>
+__device__ __forceinline__ void gx_commit(const GXStage<AUX>& xs, float* sX, const XGather& g, const XShared& sh, int s, int rows, int tid) {
+  typedef GXStage<AUX> X;
+  constexpr int PX = FBINS + 1;
+  asm volatile("" : "+v"(tid));
+  const int rq = tid / X::QX, q = tid - rq * X::QX;
+  if (tid >= X::ACT) return;
+  const bool u16 = uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+  const unsigned cm = (sh.colbits[s][(4 * q) >> 5] >> ((4 * q) & 31)) & 0xfu;
+  unsigned rb[X::NJ];
+#pragma unroll
+  for (int j = 0; j < X::NJ; ++j) {
+    const int t = min(rq + X::RPP * j, rows - 1);
+    rb[j] = sh.rowbits[s][t >> 5] >> (t & 31);
+  }
+  float* dst = sX + rq * PX + q * 4;
+#pragma unroll
+  for (int j = 0; j < X::NJ; ++j) {
+    if (rq + X::RPP * j < rows) {
+      float4 v = xs.pre[j];
+      if (u16) {
+        const unsigned lo = __float_as_uint(v.x), hi = __float_as_uint(v.y);
+        v.x = (float)(lo & 0xffffu) * 0.0390625f;   // data.py:268-269
+        v.y = (float)(lo >> 16) * 0.0390625f;
+        v.z = (float)(hi & 0xffffu) * 0.0390625f;
+        v.w = (float)(hi >> 16) * 0.0390625f;
+      }
+      const unsigned m4 = (rb[j] & 1u) ? 0xfu : cm;
+      v.x = (m4 & 1u) ? 0.f : v.x;
+      v.y = (m4 & 2u) ? 0.f : v.y;
+      v.z = (m4 & 4u) ? 0.f : v.z;
+      v.w = (m4 & 8u) ? 0.f : v.w;
+      float* d = dst + X::RPP * j * PX;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+}
+
 // the sources of a static shape: the loop over them is unrolled, every source with its own compile-time width / row length
 template <class SH, int I = 0>
 __device__ __forceinline__ void stage_sources_static(const GSrc* src, int b, int rows, float* sIn, int PI, int tid, const GFoldFwd* fold,
@@ -736,11 +827,13 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
 }
 
 // SH: the op's shape where the instantiation knows it (GShape; static shapes have dilation = stride = 1 and whole windows)
-template <int NC, int MODE, int CDP = 0, bool CH = false, class SH = GShapeDyn>
-__device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb) {
+// XG (+ xgp): the op's one source is the spectrogram, gathered from the feature stores (see "the stem's input" above)
+template <int NC, int MODE, int CDP = 0, bool CH = false, class SH = GShapeDyn, bool XG = false>
+__device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, const int nb, const XGather* xgp = nullptr) {
   constexpr bool ST = SH::NSRC > 0;
   static_assert(!ST || !CH, "static shapes run whole windows");
   static_assert(!ST || MODE == 0 || CDP > 0, "the data gradient of a static shape knows its filter count");
+  static_assert(!XG || (ST && MODE == 0 && SH::NSRC == 1 && SH::CIN == FBINS), "gathered input: the forward convolution of a static shape over the 40 bins");
   // kernel length, dilation, stride, channels reduced over, number of sources: constants of a static shape
   const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride;
   const int kCin = ST ? (MODE == 0 ? SH::CIN : CDP) : a.cin;
@@ -749,10 +842,12 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   typedef typename std::conditional<ST, SH, GShape<1, 1, 4, 4> >::type SHX;
   typedef GSrcPipe<SHX> SrcPipe;
   typedef GDpPipe<(CDP > 0 ? CDP : 4)> DpPipe;
-  constexpr bool PIPE = ST && (MODE == 0 ? SrcPipe::REGS <= kGPipeRegs : DpPipe::REGS <= kGPipeRegs);
+  constexpr bool PIPE = ST && (XG || (MODE == 0 ? SrcPipe::REGS <= kGPipeRegs : DpPipe::REGS <= kGPipeRegs));
   SrcPipe spipe;
   DpPipe dpipe;
-  if constexpr (PIPE) {
+  typename std::conditional<XG, GXStage<MWW_AUX_LD_XF>, GXNone>::type xs;
+  (void)xs;
+  if constexpr (PIPE && !XG) {
     if (bid < a.B) {
       if constexpr (MODE == 0) spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
       else dpipe.issue(a.y, bid, a.Tin, (int)threadIdx.x);
@@ -799,6 +894,15 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   } else if (a.y.fold.acc) {
     gfold_backward_load(a.y.fold, kCin, a.y.rstd, tid, fr);
   }
+  // gathered input: the descriptors of this workgroup's windows, then the first window's rows (in flight while the weights
+  // are staged)
+  XShared* sXg = nullptr;
+  if constexpr (XG) {
+    sXg = reinterpret_cast<XShared*>(g_smem + ((max(kK * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads) + 1) & ~1));
+    const int nsamp = bid < a.B ? (a.B - bid + nb - 1) / nb : 0;
+    gx_setup(*xgp, *sXg, nsamp, tid, bid, nb);
+    if (bid < a.B) xs.issue(nullptr, *xgp, *sXg, 0, bid, a.Tin, 0, a.Tin, tid);
+  }
   {
     // (four elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
     // them in a row for the 5 x 40 x 24 stem; most ops have two elements per thread, and every predicated-off slot of a
@@ -840,11 +944,12 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       sIn[(pad + a.Tin) * PI + i] = 0.f;
     }
   }
-  if constexpr (PIPE) {
+  if constexpr (PIPE && !XG) {
     __syncthreads();   // the folded table is complete
     if constexpr (MODE == 0) spipe.load_affine(a.src, a.fold, sFold, tid);
     else dpipe.load_coeffs(a.y, sFold, tid);
   }
+  int xsamp = 0;   // (XG) the window's slot in sXg
   for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
     // work item v = window b, frames [f0, f0 + Tout) of its Ttot (whole-window kernels: f0 = 0, Tout = Ttot)
     int b = v, f0 = 0, chunk = 0;
@@ -857,7 +962,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       Tin = MODE == 0 ? (Tout - 1) * kStride + (kK - 1) * kDil + 1 : Tout;
     }
     __syncthreads();   // the previous window's epilogue is done with sOut / the conv with sIn
-    if constexpr (PIPE) {
+    if constexpr (XG) {
+      gx_commit(xs, sIn, *xgp, *sXg, xsamp, a.Tin, tid);
+    } else if constexpr (PIPE) {
       if constexpr (MODE == 0) spipe.commit(sIn, PI, a.Tin, tid);
       else dpipe.commit(sIn + pad * PI, PI, a.Tin, tid);
     } else {
@@ -866,7 +973,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       else stage_dp<CDP>(a.y, kCin, b, a.Tin, sIn + pad * PI, PI, tid, sFold);
     }
     __syncthreads();
-    if constexpr (PIPE) {
+    if constexpr (XG) {
+      ++xsamp;
+      if (v + nb < a.B) xs.issue(nullptr, *xgp, *sXg, xsamp, v + nb, a.Tin, 0, a.Tin, tid);
+    } else if constexpr (PIPE) {
       if (v + nb < a.B) {   // the next window's rows travel while this one is contracted and written out
         if constexpr (MODE == 0) spipe.issue(a.src, v + nb, a.Tin, tid);
         else dpipe.issue(a.y, v + nb, a.Tin, tid);
@@ -1041,6 +1151,10 @@ template <int NC, int MODE, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
   gconv_body<NC, MODE, 0, false, SH>(a, blockIdx.x, gridDim.x);
 }
+template <int NC, class SH>
+__global__ __launch_bounds__(kThreads) void gconv_xg_kernel(GConvArgs a, XGather xg) {
+  gconv_body<NC, 0, 0, false, SH, true>(a, blockIdx.x, gridDim.x, &xg);
+}
 template <int NC, int MODE>
 __global__ __launch_bounds__(kThreads) void gconv_chunk_kernel(GConvArgs a) {
   gconv_body<NC, MODE, 0, true>(a, blockIdx.x, gridDim.x);
@@ -1083,21 +1197,24 @@ __host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (
 // columns that are never stored - puts the stem's weight gradient at three per CU too, but measured 0.891 against 0.887.)
 __host__ __device__ inline int gwg_dp_pitch(int nc) { return (nc + 15) / 16 * 16; }
 
-template <int NC, bool CH = false, class SH = GShapeDyn>
-__device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb) {
+template <int NC, bool CH = false, class SH = GShapeDyn, bool XG = false>
+__device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int bid, const int nb, const XGather* xgp = nullptr) {
   constexpr bool ST = SH::NSRC > 0;
   static_assert(!ST || !CH, "static shapes run whole windows");
+  static_assert(!XG || (ST && SH::NSRC == 1 && SH::CIN == FBINS), "gathered input: a static shape over the 40 bins");
   const int kK = ST ? SH::K : a.k, kDil = ST ? 1 : a.dil, kStride = ST ? 1 : a.stride, kCin = ST ? SH::CIN : a.cin;
   const int kNsrc = ST ? SH::NSRC : a.n_src;
   // static shapes: the window's rows travel in registers, one window ahead (see gconv_body)
   typedef typename std::conditional<ST, SH, GShape<1, 1, 4, 4> >::type SHX;
   typedef GSrcPipe<SHX> SrcPipe;
   typedef GDpPipe<NC> DpPipe;
-  constexpr bool PIPE_S = ST && SrcPipe::REGS <= kGPipeRegs;
-  constexpr bool PIPE_D = PIPE_S && SrcPipe::REGS + DpPipe::REGS <= 32;   // (the 16-filter backward kernels passed 128 registers with it: three workgroups per CU instead of four)
+  constexpr bool PIPE_S = ST && (XG || SrcPipe::REGS <= kGPipeRegs);
+  constexpr bool PIPE_D = PIPE_S && !XG && SrcPipe::REGS + DpPipe::REGS <= 32;   // (the 16-filter backward kernels passed 128 registers with it: three workgroups per CU instead of four)
   SrcPipe spipe;
   DpPipe dpipe;
-  if constexpr (PIPE_S) {
+  typename std::conditional<XG, GXStage<MWW_AUX_LD_XB>, GXNone>::type xs;
+  (void)xs;
+  if constexpr (PIPE_S && !XG) {
     if (bid < a.B) {
       spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
       if constexpr (PIPE_D) dpipe.issue(a.y, bid, a.Tout, (int)threadIdx.x);
@@ -1136,12 +1253,20 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   for (int i = tid; i < Tout4 * PO; i += kThreads) sDP[i] = 0.f;
   // statistics hand-over: the op's backward coefficients folded from the accumulator rows; this role publishes them
   __shared__ float sFoldB[3 * kGFoldC];
+  XShared* sXg = nullptr;
+  if constexpr (XG) {   // the descriptors of this workgroup's windows, the first window's rows (see gconv_body)
+    sXg = reinterpret_cast<XShared*>(sDP + ((Tout4 * PO + 1) & ~1));
+    const int nsamp = bid < a.B ? (a.B - bid + nb - 1) / nb : 0;
+    gx_setup(*xgp, *sXg, nsamp, tid, bid, nb);
+    if (bid < a.B) xs.issue(nullptr, *xgp, *sXg, 0, bid, a.Tin, 0, a.Tin, tid);
+  }
   if (a.y.fold.acc) {
     GFoldRegs fr;
     gfold_backward_load(a.y.fold, NC, a.y.rstd, tid, fr);
     gfold_backward_finish(a.y.fold, NC, sFoldB, bid, tid, fr);
   }
-  if constexpr (PIPE_S) {
+  int xsamp = 0;
+  if constexpr (PIPE_S && !XG) {
     spipe.load_affine(a.src, nullptr, nullptr, tid);
     if constexpr (PIPE_D) {
       __syncthreads();   // the folded coefficients are complete
@@ -1158,7 +1283,8 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       Tin = (Tout - 1) * kStride + (kK - 1) * kDil + 1;
     }
     __syncthreads();
-    if constexpr (PIPE_S) spipe.commit(sA, PI, a.Tin, tid);
+    if constexpr (XG) gx_commit(xs, sA, *xgp, *sXg, xsamp, a.Tin, tid);
+    else if constexpr (PIPE_S) spipe.commit(sA, PI, a.Tin, tid);
     else stage_sources<SH>(a.src, kNsrc, b, Tin, sA, PI, tid, nullptr, nullptr, CH ? f0 * kStride : 0);
     if constexpr (PIPE_D) {
       dpipe.commit(sDP, PO, a.Tout, tid);
@@ -1170,7 +1296,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       stage_dp<NC>(a.y, NC, b, a.Tout, sDP, PO, tid, sFoldB);
     }
     __syncthreads();
-    if constexpr (PIPE_S) {
+    if constexpr (XG) {
+      ++xsamp;
+      if (v + nb < a.B) xs.issue(nullptr, *xgp, *sXg, xsamp, v + nb, a.Tin, 0, a.Tin, tid);
+    } else if constexpr (PIPE_S) {
       if (v + nb < a.B) {
         spipe.issue(a.src, v + nb, a.Tin, tid);
         if constexpr (PIPE_D) dpipe.issue(a.y, v + nb, a.Tout, tid);
@@ -1274,6 +1403,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 template <int NC, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
   gconv_wgrad_body<NC, false, SH>(a, blockIdx.x, gridDim.x);
+}
+template <int NC, class SH>
+__global__ __launch_bounds__(kThreads) void gconv_wgrad_xg_kernel(GWgradArgs a, XGather xg) {
+  gconv_wgrad_body<NC, false, SH, true>(a, blockIdx.x, gridDim.x, &xg);
 }
 template <int NC>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_chunk_kernel(GWgradArgs a) {

@@ -1031,12 +1031,14 @@ MWW_G_SHAPES(X)
 #define MWW_G_SHAPE_FWD(X)
 #define MWW_G_SHAPE_FWD2(X)
 #define MWW_G_SHAPE_WG(X)
+#define MWW_G_SHAPE_XG(X)
 #define MWW_G_SHAPE_BWD(X)
 #define MWW_G_SHAPE_BWD2(X)
 #else
 #define MWW_G_SHAPE_FWD(X) X(1, 24) X(2, 30) X(3, 10) X(4, 10) X(5, 10) X(6, 30) X(6, 48) X(7, 16) X(8, 16) X(9, 16) X(10, 10) X(11, 16)
 #define MWW_G_SHAPE_FWD2(X) X(3, 10) X(7, 16) X(4, 10) X(8, 16)
 #define MWW_G_SHAPE_WG(X) X(1, 24)
+#define MWW_G_SHAPE_XG(X) X(1, 24)   // forward + weight gradient with the input gathered from the feature stores (gconv_xg_kernel)
 #define MWW_G_SHAPE_BWD(X) X(2, 30, 24) X(3, 10, 10) X(4, 10, 10) X(5, 10, 30) X(6, 30, 10) X(6, 48, 10) X(7, 16, 16) X(8, 16, 16) X(9, 16, 48) X(10, 10, 30) X(11, 16, 48)
 #define MWW_G_SHAPE_BWD2(X) X(3, 10) X(7, 16) X(4, 10) X(8, 16)
 #endif
@@ -1072,9 +1074,58 @@ int g_shape_id(const mww_ctx* c, const GOp& o) {
   return 0;
 }
 
+// The stem of a conv/BN graph can read a descriptor-only batch in place ("fused_input", kernels_graph.hip.h XG): exactly one
+// op reads the spectrogram, as its only source, and its shape has a gathering instantiation.
+bool g_stem_gathers(const mww_ctx* c) {
+  if (!c->generic || !c->fused_input || c->d.frames > kGXRows) return false;
+  int readers = 0, stem = -1;
+  for (size_t i = 0; i < c->G.size(); ++i)
+    for (int s = 0; s < c->G[i].n_src; ++s)
+      if (c->G[i].src[s] < 0) {
+        ++readers;
+        stem = (int)i;
+      }
+  if (readers != 1) return false;
+  const GOp& o = c->G[stem];
+  if (o.n_src != 1 || o.toff[0] != 0 || o.tin != c->d.frames) return false;
+  const int shape = g_shape_id(c, o);
+#define XS(ID, N) if (shape == ID && o.cout == N) return true;
+  MWW_G_SHAPE_XG(XS)
+#undef XS
+  return false;
+}
+bool g_reads_lazy_x(const mww_ctx* c, const GSrc* src, int n) {
+  if (!c->x_lazy) return false;
+  for (int i = 0; i < n; ++i)
+    if (src[i].p == c->x) return true;
+  return false;
+}
+
 // (CH: the frame-chunk instantiations, a.S > 1)
 template <int MODE, bool CH = false>
 int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, size_t lds, int shape = 0) {
+  if (MODE == 0 && g_reads_lazy_x(c, a.src, a.n_src)) {
+    // descriptor-only batch: the gathering instantiation if there is one and the grid leaves every workgroup at most
+    // kXMaxSamples windows; else x is written out first
+    if constexpr (MODE == 0 && !CH) {
+#define XS(ID, N)                                                                                              \
+      if (shape == ID && nc == N && a.n_src == 1 && a.Tin <= kGXRows) {                                        \
+        auto k = &gconv_xg_kernel<N, GSh##ID>;                                                                 \
+        const void* f = reinterpret_cast<const void*>(k);                                                      \
+        const size_t ldx = lds + sizeof(XShared) + 16;                                                         \
+        if (ldx > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldx)); \
+        const int grid = g_role_grid(c, f, ldx, pk);                                                           \
+        if ((a.B + grid - 1) / grid <= kXMaxSamples) {                                                         \
+          hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), ldx, c->stream, a, x_gather(c));                   \
+          return MWW_OK;                                                                                       \
+        }                                                                                                      \
+      }
+      MWW_G_SHAPE_XG(XS)
+#undef XS
+    }
+    int rcx = materialise_x(c);
+    if (rcx) return rcx;
+  }
   if constexpr (MODE == 0 && !CH) {
 #define XS(ID, N)                                                                                              \
     if (shape == ID && nc == N) {                                                                              \
@@ -1104,6 +1155,26 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, siz
 
 template <bool CH = false>
 int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, size_t lds, int shape = 0) {
+  if (g_reads_lazy_x(c, a.src, a.n_src)) {   // (as in launch_gconv)
+    if constexpr (!CH) {
+#define XS(ID, N)                                                                                              \
+      if (shape == ID && nc == N && a.n_src == 1 && a.Tin <= kGXRows) {                                        \
+        auto k = &gconv_wgrad_xg_kernel<N, GSh##ID>;                                                           \
+        const void* f = reinterpret_cast<const void*>(k);                                                      \
+        const size_t ldx = lds + sizeof(XShared) + 16;                                                         \
+        if (ldx > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldx)); \
+        const int grid = g_role_grid(c, f, ldx, pk);                                                           \
+        if ((a.B + grid - 1) / grid <= kXMaxSamples) {                                                         \
+          hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), ldx, c->stream, a, x_gather(c));                   \
+          return MWW_OK;                                                                                       \
+        }                                                                                                      \
+      }
+      MWW_G_SHAPE_XG(XS)
+#undef XS
+    }
+    int rcx = materialise_x(c);
+    if (rcx) return rcx;
+  }
   if constexpr (!CH) {
 #define XS(ID, N)                                                                                              \
     if (shape == ID && nc == N) {                                                                              \
@@ -1322,6 +1393,10 @@ GDwArgs g_make_dw(mww_ctx* c, int oi, int B, bool backward, bool inl = false) {
 }
 
 int g_enqueue_forward(mww_ctx* c, int B, bool training, bool update_moving, bool loss, bool metrics) {
+  if (c->x_lazy && !g_stem_gathers(c)) {   // (an option changed since the batch was assembled)
+    int rcx = materialise_x(c);
+    if (rcx) return rcx;
+  }
   Launcher lp{c};
   const int n = (int)c->G.size();
   const int gg = std::min(B, c->grid_g);
@@ -2681,7 +2756,9 @@ int mww_assemble_batch(mww_ctx* c, const mww_window* win, const int32_t* masks, 
   {
     const int per_fwd = (B + std::min(B, c->grid_fwd) - 1) / std::min(B, c->grid_fwd);
     const int per_bwd = (B + std::min(B, c->grid_bwd) - 1) / std::min(B, c->grid_bwd);
-    if (c->fused_input && !c->generic && T <= 32 * kXRowWords && nm <= kXMaxMasks && per_fwd <= kXMaxSamples && per_bwd <= kXMaxSamples) {
+    // (conv/BN graphs: the stem's launches check their own grids and write x out themselves if a workgroup would own too many windows)
+    const bool lazy_ok = c->generic ? g_stem_gathers(c) : (per_fwd <= kXMaxSamples && per_bwd <= kXMaxSamples);
+    if (c->fused_input && lazy_ok && T <= 32 * kXRowWords && nm <= kXMaxMasks) {
       // descriptor-only batch: the first block's kernels gather from the stores (the labels / weights that
       // arrived in this mailbox are read in place)
       if (a.n_targets) {

@@ -1487,6 +1487,69 @@ def check_gather_fuzz(lib, cases=8, first=0, notebook=False):
             np.testing.assert_array_equal(a, b, err_msg="case %d" % case)
 
 
+def check_inception_gathered_stem(lib, cases=3, first=0, B=6, lengths=(194, 150, 200, 201), graphs=(0,), grid=0):
+    """The Inception stem reading a descriptor-only batch in place (kernels_graph.hip.h XG instantiations of the forward
+    convolution and the weight gradient: pad / truncate, uint16 scaling and SpecAugment masks applied while the window is
+    staged) against the materialised x ("fused_input" 0): the gathered values are the same floats, so evaluation outputs,
+    gradients, parameters after several steps and the batch read back afterwards are bit-identical.  Random feature sets /
+    policies / strategies (random_data_case: ragged lengths around T, uint16 and float32 stores, 0..3 masks per kind);
+    window lengths on both sides of the gather's limit (200 frames); a second step on the same batch (its mailbox slot has
+    moved on: x is written out); optionally through captured graphs and with a grid that leaves a workgroup more windows than
+    the gather keeps descriptors for (then x is written out by the launch itself)."""
+    for case in range(first, first + cases):
+        _, provs, policy, _, strategy = random_data_case(case)
+        T = lengths[case % len(lengths)]
+        for p in provs:   # (random_data_case's own rule, for this T: a cutoff larger than the spare frames raises in the reference)
+            if p["truncation_strategy"] == "fixed_right_cutoff":
+                p["store"] = [s if (s.shape[0] <= T or s.shape[0] - T >= max(p["fixed_right_cutoffs"])) else s[:T] for s in p["store"]]
+        cfg = {"stride": 1, "window_step_ms": 10, "features": [
+            dict(type="mmap", stores={"training": [p["store"]]}, truth=p["truth"], sampling_weight=p["sampling_weight"],
+                 penalty_weight=p["penalty_weight"], truncation_strategy=p["truncation_strategy"],
+                 fixed_right_cutoffs=p["fixed_right_cutoffs"]) for p in provs]}
+        om = perturbed_inception_oracle(T, INC)
+        outs = []
+        for fused, use_graphs in [(0, 0)] + [(1, g) for g in graphs]:
+            random.seed(case)
+            np.random.seed(case)
+            lay, eng = make_inception_engine(lib, T, B, om, INC)
+            eng.set_option("fused_input", fused)
+            eng.set_option("graphs", use_graphs)
+            if grid:
+                eng.set_option("grid_graph", grid)
+            fh = FeatureHandler(cfg, engine=eng)
+            got = []
+            for k in range(3):
+                fh.next_training_batch_on_device(B, T, strategy, policy)
+                eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+                eng.forward(B, training=False)
+                got.append(eng.read_outputs(B, want_loss=False)[0].copy())
+                fh.next_training_batch_on_device(B, T, strategy, policy)
+                eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+                eng.train_step(B, 1e-2)
+                got.append(eng.get_grads().copy())
+                got.append(eng.read_outputs(B)[0].copy())
+                if k == 0:   # same batch again
+                    eng.train_step(B, 1e-2)
+                    got.append(eng.get_grads().copy())
+                if k == 1:
+                    got.append(eng.get_batch(B).copy())
+            got += [eng.get_params().copy(), eng.get_bn_state().copy()]
+            outs.append(got)
+            if not use_graphs:   # the assembly launch runs exactly when the stem cannot gather
+                eng.set_option("profile", 1)
+                fh.next_training_batch_on_device(B, T, strategy, policy)
+                eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
+                eng.train_step(B, 1e-2, flags=native.STEP_NO_APPLY)
+                names = [nm for nm, _ in eng.profile_read()]
+                gathers = bool(fused) and T <= 200 and (not grid or -(-B // grid) <= 8)
+                assert any("assemble" in nm for nm in names) == (not gathers), (fused, T, names)
+            eng.close()
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                np.testing.assert_array_equal(a, b, err_msg="case %d T %d" % (case, T))
+
+
+
 # ------------------------------------------------------------------------------------------ inception topology fuzz
 def random_inception_flags(seed):
     """A random Inception flag set inside the widths the graph kernels instantiate: 1-2 stem layers, 1-3 blocks,

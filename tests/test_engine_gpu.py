@@ -518,3 +518,11 @@ def test_inception_topology_fuzz(lib):
 def test_shape_fuzz(lib):
     """12 of the random (frames, batch, grid) cases; tools/gpu_shape_fuzz.py ran 400 of them green."""
     ec.check_shape_fuzz(lib, cases=12, first=40)
+
+
+def test_inception_stem_gathers_descriptor_only_batches(lib):
+    ec.check_inception_gathered_stem(lib, cases=4, B=64, graphs=(0, 1))
+    ec.check_inception_gathered_stem(lib, cases=2, first=4, B=1024)                     # the bench shape: two windows per workgroup
+    ec.check_inception_gathered_stem(lib, cases=1, first=6, B=40, grid=4)               # ten windows per workgroup: x is written out
+    ec.check_inception_gathered_stem(lib, cases=1, first=7, B=40, grid=8, graphs=(1,))  # five per workgroup
+
