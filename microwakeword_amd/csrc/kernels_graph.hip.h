@@ -128,28 +128,47 @@ struct GFoldRegs {
   float p0, p1, m0, m1;   // forward: gamma, beta, old moving mean / variance;  backward: gamma, rstd
 };
 
+// lane `src`'s copy of v (all 64 lanes of the wave take part)
+__device__ __forceinline__ double gfold_lane(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __shfl(u.i[0], src);
+  u.i[1] = __shfl(u.i[1], src);
+  return u.d;
+}
+
+// The raw sums of channel ch's slot (lane ch of its wave; lanes >= C are idle but take part in the exchange).  Every lane
+// reads the kStatRows x 2 sums of its own channel - one round trip - and a SubSpectralNormalization slot's members are then
+// collected from their lanes in the order the former per-member loop added them (slot, slot + groups, ...: bit-identical
+// sums; as a loop of loads it was members - 1 = five more dependent round trips in front of the stem's consumers, and in a
+// kernel short of registers the compiler shared one temporary between an iteration's sixteen loads: eighty round trips).
 __device__ __forceinline__ void gfold_load_sums(const double* acc, int C, int groups, int ch, GFoldRegs& r) {
-  const int members = groups > 1 ? C / groups : 1, cstride = groups > 1 ? groups : 0;
-  const int slot = groups > 1 ? ch % groups : ch;
+  const bool active = ch < C;
 #pragma unroll
   for (int j = 0; j < kStatRows; ++j) {
-    r.v1[j] = acc[(size_t)j * 2 * C + slot];
-    r.v2[j] = acc[(size_t)j * 2 * C + C + slot];
+    r.v1[j] = active ? acc[(size_t)j * 2 * C + ch] : 0.0;
+    r.v2[j] = active ? acc[(size_t)j * 2 * C + C + ch] : 0.0;
   }
-  for (int m = 1; m < members; ++m) {   // SSN: the other channels of the slot
-    const int cc = slot + m * cstride;
+  if (groups > 1) {   // (uniform)
+    const int members = C / groups, slot = active ? ch % groups : 0;
 #pragma unroll
     for (int j = 0; j < kStatRows; ++j) {
-      r.v1[j] += acc[(size_t)j * 2 * C + cc];
-      r.v2[j] += acc[(size_t)j * 2 * C + C + cc];
+      double a1 = gfold_lane(r.v1[j], slot), a2 = gfold_lane(r.v2[j], slot);
+      for (int m = 1; m < members; ++m) {
+        a1 += gfold_lane(r.v1[j], slot + m * groups);
+        a2 += gfold_lane(r.v2[j], slot + m * groups);
+      }
+      r.v1[j] = a1;
+      r.v2[j] = a2;
     }
   }
 }
 
+// (called by whole waves: gfold_load_sums exchanges between lanes)
 __device__ __forceinline__ void gfold_forward_load(const GFoldFwd& f, int bid, int tid, GFoldRegs& r) {
+  gfold_load_sums(f.acc, f.C, f.groups, tid, r);
   if (tid >= f.C) return;
   const int slot = f.groups > 1 ? tid % f.groups : tid, nslots = f.groups > 1 ? f.groups : f.C;
-  gfold_load_sums(f.acc, f.C, f.groups, tid, r);
   r.p0 = f.gamma[slot];
   r.p1 = f.beta[slot];
   r.m0 = r.m1 = 0.f;
@@ -193,8 +212,8 @@ __device__ __forceinline__ void gfold_forward_finish(const GFoldFwd& f, float* t
 
 // C = channels of the op; rstd = its forward statistic (already published)
 __device__ __forceinline__ void gfold_backward_load(const GFoldBwd& f, int C, const float* rstd, int tid, GFoldRegs& r) {
-  if (tid >= C) return;
   gfold_load_sums(f.acc, C, f.groups, tid, r);
+  if (tid >= C) return;
   r.p0 = f.gamma[f.groups > 1 ? tid % f.groups : tid];
   r.p1 = rstd[tid];
 }
@@ -475,20 +494,15 @@ template <int AUX>
 using GXStage = XStage<kGXRows, FBINS + 1, AUX>;
 struct GXNone {};
 
-// xgather_setup for a role's workgroup: windows first, first + stride, ...  (ends with a barrier)
+// xgather_setup for a role's workgroup: windows first, first + stride, ...  No barrier of its own: the window loop's first
+// one stands between these writes and their readers (gx_commit; gx_window_lds for the second window on).
 __device__ __forceinline__ void gx_setup(const XGather& g, XShared& sh, int nsamp, int tid, int first, int stride) {
   if (tid < nsamp) {
     const mww_window w = g.win[first + tid * stride];
-    const void* base = g.store[0];
-    int dt = g.dtype[0];
-#pragma unroll
-    for (int i = 1; i < MWW_MAX_STORES; ++i)
-      if (w.store == i) {
-        base = g.store[i];
-        dt = g.dtype[i];
-      }
-    sh.base[tid] = base;
-    sh.dtype[tid] = dt;
+    // (g lives in the kernel-argument segment: the store table is indexed in place)
+    const int si = (unsigned)w.store < (unsigned)MWW_MAX_STORES ? w.store : 0;
+    sh.base[tid] = g.store[si];
+    sh.dtype[tid] = g.dtype[si];
     sh.src_elem[tid] = w.src_elem;
     sh.pad_rows[tid] = w.pad_rows;
     sh.copy_rows[tid] = w.copy_rows;
@@ -510,7 +524,51 @@ __device__ __forceinline__ void gx_setup(const XGather& g, XShared& sh, int nsam
     if (row) sh.rowbits[s][w] = bits;
     else sh.colbits[s][w] = bits;
   }
-  __syncthreads();
+}
+
+// Where a window's frames come from: first byte of its first copied frame, zero frames in front, frames copied, element type.
+// The first window's descriptor is read straight from HBM through the scalar unit (the address is workgroup-uniform) so that
+// its rows are requested at kernel entry like a dense batch's; later windows take theirs from LDS.
+struct GXWindow {
+  const char* src;
+  int pad, copy;
+  bool u16;
+};
+__device__ __forceinline__ GXWindow gx_window_global(const XGather& g, int b) {
+  const mww_window w = g.win[b];
+  const int si = (unsigned)w.store < (unsigned)MWW_MAX_STORES ? w.store : 0;
+  const void* base = g.store[si];
+  const int dt = g.dtype[si];
+  GXWindow x;
+  x.u16 = uniform_int(dt) == MWW_DTYPE_U16;
+  x.src = reinterpret_cast<const char*>(uniform_ptr(base)) + uniform_i64(w.src_elem) * (x.u16 ? 2 : 4);
+  x.pad = uniform_int(w.pad_rows);
+  x.copy = uniform_int(w.copy_rows);
+  return x;
+}
+__device__ __forceinline__ GXWindow gx_window_lds(const XShared& sh, int s) {
+  GXWindow x;
+  x.u16 = uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+  x.src = reinterpret_cast<const char*>(uniform_ptr(sh.base[s])) + uniform_i64(sh.src_elem[s]) * (x.u16 ? 2 : 4);
+  x.pad = uniform_int(sh.pad_rows[s]);
+  x.copy = uniform_int(sh.copy_rows[s]);
+  return x;
+}
+// XStage::issue for a whole window of `rows` frames (row0 = 0) described by `w`: the same loads
+template <int AUX>
+__device__ __forceinline__ void gx_issue(GXStage<AUX>& xs, const GXWindow& w, int rows, int tid) {
+  typedef GXStage<AUX> X;
+  asm volatile("" : "+v"(tid));
+  const int gb = w.u16 ? 8 : 16;                       // bytes of one float4 group in the source
+  const int r_lo = w.pad, r_hi = min(w.pad + w.copy, rows);
+  const int nbytes = (r_hi - r_lo) * (X::QX * gb);
+  const BufRsrc lo = tile_rsrc(w.src, nbytes), hi = tile_rsrc(w.src + 8, w.u16 ? 0 : nbytes - 8);
+  const int off0 = tid < X::ACT ? (tid - r_lo * X::QX) * gb : kOobOffset;
+#pragma unroll
+  for (int j = 0; j < X::NJ; ++j) {
+    const uint2 a = tile_load2<AUX>(lo, off0 + X::ACT * j * gb), c = tile_load2<AUX>(hi, off0 + X::ACT * j * gb);
+    xs.pre[j] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(c.x), __uint_as_float(c.y));
+  }
 }
 
 // XStage::commit for a window of `rows` <= kGXRows frames: nothing is written behind the window (the tiles that follow it
@@ -847,7 +905,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   DpPipe dpipe;
   typename std::conditional<XG, GXStage<MWW_AUX_LD_XF>, GXNone>::type xs;
   (void)xs;
-  if constexpr (PIPE && !XG) {
+  if constexpr (XG) {
+    if (bid < a.B) gx_issue(xs, gx_window_global(*xgp, bid), a.Tin, (int)threadIdx.x);
+  } else if constexpr (PIPE) {
     if (bid < a.B) {
       if constexpr (MODE == 0) spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
       else dpipe.issue(a.y, bid, a.Tin, (int)threadIdx.x);
@@ -894,14 +954,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   } else if (a.y.fold.acc) {
     gfold_backward_load(a.y.fold, kCin, a.y.rstd, tid, fr);
   }
-  // gathered input: the descriptors of this workgroup's windows, then the first window's rows (in flight while the weights
-  // are staged)
+  // gathered input: the descriptors and mask bitmaps of this workgroup's windows (behind the launch's tiles)
   XShared* sXg = nullptr;
   if constexpr (XG) {
     sXg = reinterpret_cast<XShared*>(g_smem + ((max(kK * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads) + 1) & ~1));
-    const int nsamp = bid < a.B ? (a.B - bid + nb - 1) / nb : 0;
-    gx_setup(*xgp, *sXg, nsamp, tid, bid, nb);
-    if (bid < a.B) xs.issue(nullptr, *xgp, *sXg, 0, bid, a.Tin, 0, a.Tin, tid);
+    gx_setup(*xgp, *sXg, bid < a.B ? (a.B - bid + nb - 1) / nb : 0, tid, bid, nb);
   }
   {
     // (four elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
@@ -975,7 +1032,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     __syncthreads();
     if constexpr (XG) {
       ++xsamp;
-      if (v + nb < a.B) xs.issue(nullptr, *xgp, *sXg, xsamp, v + nb, a.Tin, 0, a.Tin, tid);
+      if (v + nb < a.B) gx_issue(xs, gx_window_lds(*sXg, xsamp), a.Tin, tid);
     } else if constexpr (PIPE) {
       if (v + nb < a.B) {   // the next window's rows travel while this one is contracted and written out
         if constexpr (MODE == 0) spipe.issue(a.src, v + nb, a.Tin, tid);
@@ -1209,12 +1266,19 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   typedef GSrcPipe<SHX> SrcPipe;
   typedef GDpPipe<NC> DpPipe;
   constexpr bool PIPE_S = ST && (XG || SrcPipe::REGS <= kGPipeRegs);
-  constexpr bool PIPE_D = PIPE_S && !XG && SrcPipe::REGS + DpPipe::REGS <= 32;   // (the 16-filter backward kernels passed 128 registers with it: three workgroups per CU instead of four)
+  // (the 16-filter backward kernels passed 128 registers with the dp pipeline: three workgroups per CU instead of four; the
+  // gathering stem is a launch of its own whose 56 KB of tiles allow two per CU whatever it keeps in registers)
+  constexpr bool PIPE_D = PIPE_S && (XG || SrcPipe::REGS + DpPipe::REGS <= 32);
   SrcPipe spipe;
   DpPipe dpipe;
   typename std::conditional<XG, GXStage<MWW_AUX_LD_XB>, GXNone>::type xs;
   (void)xs;
-  if constexpr (PIPE_S && !XG) {
+  if constexpr (XG) {
+    if (bid < a.B) {
+      gx_issue(xs, gx_window_global(*xgp, bid), a.Tin, (int)threadIdx.x);
+      dpipe.issue(a.y, bid, a.Tout, (int)threadIdx.x);
+    }
+  } else if constexpr (PIPE_S) {
     if (bid < a.B) {
       spipe.issue(a.src, bid, a.Tin, (int)threadIdx.x);
       if constexpr (PIPE_D) dpipe.issue(a.y, bid, a.Tout, (int)threadIdx.x);
@@ -1254,11 +1318,9 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   // statistics hand-over: the op's backward coefficients folded from the accumulator rows; this role publishes them
   __shared__ float sFoldB[3 * kGFoldC];
   XShared* sXg = nullptr;
-  if constexpr (XG) {   // the descriptors of this workgroup's windows, the first window's rows (see gconv_body)
+  if constexpr (XG) {   // the descriptors and mask bitmaps of this workgroup's windows (see gconv_body)
     sXg = reinterpret_cast<XShared*>(sDP + ((Tout4 * PO + 1) & ~1));
-    const int nsamp = bid < a.B ? (a.B - bid + nb - 1) / nb : 0;
-    gx_setup(*xgp, *sXg, nsamp, tid, bid, nb);
-    if (bid < a.B) xs.issue(nullptr, *xgp, *sXg, 0, bid, a.Tin, 0, a.Tin, tid);
+    gx_setup(*xgp, *sXg, bid < a.B ? (a.B - bid + nb - 1) / nb : 0, tid, bid, nb);
   }
   if (a.y.fold.acc) {
     GFoldRegs fr;
@@ -1266,8 +1328,8 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
     gfold_backward_finish(a.y.fold, NC, sFoldB, bid, tid, fr);
   }
   int xsamp = 0;
-  if constexpr (PIPE_S && !XG) {
-    spipe.load_affine(a.src, nullptr, nullptr, tid);
+  if constexpr (PIPE_S) {
+    if constexpr (!XG) spipe.load_affine(a.src, nullptr, nullptr, tid);
     if constexpr (PIPE_D) {
       __syncthreads();   // the folded coefficients are complete
       dpipe.load_coeffs(a.y, sFoldB, tid);
@@ -1298,7 +1360,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
     __syncthreads();
     if constexpr (XG) {
       ++xsamp;
-      if (v + nb < a.B) xs.issue(nullptr, *xgp, *sXg, xsamp, v + nb, a.Tin, 0, a.Tin, tid);
+      if (v + nb < a.B) {
+        gx_issue(xs, gx_window_lds(*sXg, xsamp), a.Tin, tid);
+        dpipe.issue(a.y, v + nb, a.Tout, tid);
+      }
     } else if constexpr (PIPE_S) {
       if (v + nb < a.B) {
         spipe.issue(a.src, v + nb, a.Tin, tid);

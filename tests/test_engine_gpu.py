@@ -522,7 +522,10 @@ def test_shape_fuzz(lib):
 
 def test_inception_stem_gathers_descriptor_only_batches(lib):
     ec.check_inception_gathered_stem(lib, cases=4, B=64, graphs=(0, 1))
-    ec.check_inception_gathered_stem(lib, cases=2, first=4, B=1024)                     # the bench shape: two windows per workgroup
+    # the bench shape, two and four windows per workgroup (a fixed grid: the gathering kernels' own occupancy may give them
+    # another number of partial rows than the dense ones - same gradient up to float32 summation order, not bit for bit)
+    ec.check_inception_gathered_stem(lib, cases=1, first=4, B=1024, grid=512)
+    ec.check_inception_gathered_stem(lib, cases=1, first=5, B=1024, grid=256)
     ec.check_inception_gathered_stem(lib, cases=1, first=6, B=40, grid=4)               # ten windows per workgroup: x is written out
     ec.check_inception_gathered_stem(lib, cases=1, first=7, B=40, grid=8, graphs=(1,))  # five per workgroup
 
