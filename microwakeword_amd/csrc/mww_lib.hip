@@ -228,9 +228,11 @@ struct Launcher {
   mww_ctx* c;
   hipEvent_t ea = nullptr;
   const char* name = nullptr;
+  size_t idx = 0;   // this bracket's entry (a launch that has to write x out first opens a bracket of its own inside the caller's)
   void begin(const char* n, int layer = -1) {
     if (!c->profile) return;
     name = n;
+    idx = c->prof.size();
     ProfileEntry e;
     e.name = n;
     if (layer >= 0) e.name += std::to_string(layer + 1);
@@ -240,8 +242,8 @@ struct Launcher {
     c->prof.push_back(e);
   }
   void end() {
-    if (!c->profile) return;
-    (void)hipEventRecord(c->prof.back().b, c->stream);
+    if (!c->profile || idx >= c->prof.size()) return;
+    (void)hipEventRecord(c->prof[idx].b, c->stream);
   }
 };
 
