@@ -965,7 +965,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     // them in a row for the 5 x 40 x 24 stem; most ops have two elements per thread, and every predicated-off slot of a
     // wider batch still pays its index arithmetic: 16 / 8 / 4 / 2 / 1 per batch = 1.090 / 1.074 / 1.064 / 1.068 / 1.065 ms
     // per Inception step in same-session A/B)
-    constexpr int kWB = 4;
+    // A static shape knows its element count: one batch holds them all (25 per thread for the stem - one round trip where
+    // batches of four were seven in a row, the longest chain of its prologue; 2-5 for the other ops, without idle slots).
+    constexpr int kWStatic = ST ? (SH::K * (((MODE == 0 ? SH::CIN : CDP) + 3) / 4 * 4) * NCW + kThreads - 1) / kThreads : 0;
+    constexpr int kWB = (ST && kWStatic <= 28) ? kWStatic : 4;
     const int nw = kK * cin4 * NCW, nreal = kK * kCin * NC;
     for (int i0 = tid; i0 < nw; i0 += kWB * kThreads) {
       float wv[kWB];
@@ -1999,6 +2002,13 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     const float* rb = a.rp ? a.rp + ((size_t)b * a.rT + a.rdrop) * C : nullptr;
     float* kgen = a.keep_gen ? a.keep_gen + (size_t)b * n : nullptr;
     float dot = 0.f;
+    // the window's label and weight travel with its rows (thread 0 needs them between the two barriers below: fetched
+    // there they were one more memory round trip per window on the workgroup's critical path)
+    float y_pre = 0.f, w_pre = 0.f;
+    if (tid == 0 && a.y != nullptr) {
+      y_pre = a.y[b];
+      if (a.training & kHeadTraining) w_pre = a.sw[b];
+    }
     // rows in batches of kHB per thread: every load of a batch is issued before the first use (one load, one wait per
     // row made this kernel a chain of ~2 T C / 256 memory round trips per window: 51 us per launch for 10 MB in round 2)
     constexpr int kHB = 8;
@@ -2068,11 +2078,11 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
       a.prob[b] = pr;
       float dzz = 0.f;
       if (a.y != nullptr) {
-        const float yy = a.y[b];
+        const float yy = y_pre;
         const bool clipped_form = (a.training & kHeadClippedLoss) != 0;
         const float bce = bce_value(zz, pr, yy, clipped_form);
         if (a.training & kHeadTraining) {
-          const float w = a.sw[b];
+          const float w = w_pre;
           a.loss_part[b] = w * bce * a.inv_b;
           dzz = w * bce_dz(pr, yy, clipped_form) * a.inv_b;
           a.dz[b] = dzz;
