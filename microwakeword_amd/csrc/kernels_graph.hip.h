@@ -1971,6 +1971,30 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const int C = a.C, nrg = kThreads / C, c = tid % C, rg = tid / C;
   const bool active = rg < nrg;
   const int n = a.T * C;
+  // Register-resident path (windows with at most kHR rows per thread and no residual branch: Inception's head): a window's
+  // rows are loaded once (buffer loads, no predicate) and stay in registers for the backward half; the dense kernel rows
+  // of the thread are loaded once per workgroup.  The first window's rows and the dense rows are requested before the
+  // statistics fold below (they do not depend on it: one round trip less in front of the first window).
+  constexpr int kHR = 12;
+  const bool fast = a.rp == nullptr && (a.T + nrg - 1) / nrg <= kHR;
+  const bool kgen_on = a.keep_gen != nullptr;
+  float wvf[kHR], pvf[kHR], kvf[kHR];
+  auto load_rows = [&](int b) {
+    const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
+    const BufRsrc prs = tile_rsrc(a.p + (size_t)b * n, active ? n * 4 : 0), krs = tile_rsrc(kb, (active && kb && !kgen_on) ? n * 4 : 0);
+#pragma unroll
+    for (int u = 0; u < kHR; ++u) {
+      const int off = ((rg + u * nrg) * C + c) * 4;
+      pvf[u] = tile_load1(prs, off);
+      kvf[u] = tile_load1(krs, off);
+    }
+  };
+  if (fast) {
+    const BufRsrc wrs = tile_rsrc(a.wd, active ? n * 4 : 0);
+#pragma unroll
+    for (int u = 0; u < kHR; ++u) wvf[u] = tile_load1(wrs, ((rg + u * nrg) * C + c) * 4);
+    if ((int)blockIdx.x < a.B) load_rows(blockIdx.x);
+  }
   __shared__ float sFold[4 * kGFoldC];
   const bool folded = a.fold.acc != nullptr;
   if (folded) {
@@ -1985,17 +2009,9 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
   const float rsc = (active && a.rp) ? a.rscale[c] : 0.f, rsh = (active && a.rp) ? a.rshift[c] : 0.f;
   const float bias = a.bd[0];
   float g1 = 0.f, g2 = 0.f;
-  // Register-resident path (windows with at most kHR rows per thread and no residual branch: Inception's head): a window's
-  // rows are loaded once (buffer loads, no predicate) and stay in registers for the backward half; the dense kernel rows
-  // of the thread are loaded once per workgroup.
-  constexpr int kHR = 12;
-  const bool fast = a.rp == nullptr && (a.T + nrg - 1) / nrg <= kHR;
-  float wvf[kHR];
-  if (fast) {
-    const BufRsrc wrs = tile_rsrc(a.wd, active ? n * 4 : 0);
-#pragma unroll
-    for (int u = 0; u < kHR; ++u) wvf[u] = tile_load1(wrs, ((rg + u * nrg) * C + c) * 4);
-  }
+  // this step's dropout counter, read once (inside the window loop it was a dependent round trip per window: the stores of
+  // the loop keep the compiler from hoisting it)
+  const unsigned long long step = kgen_on ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const float* pb = a.p + (size_t)b * n;
     const float* kb = a.keep ? a.keep + (size_t)b * n : nullptr;
@@ -2012,16 +2028,8 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
     // rows in batches of kHB per thread: every load of a batch is issued before the first use (one load, one wait per
     // row made this kernel a chain of ~2 T C / 256 memory round trips per window: 51 us per launch for 10 MB in round 2)
     constexpr int kHB = 8;
-    float pvf[kHR], kvf[kHR];
     if (fast) {
-      const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
-      const BufRsrc prs = tile_rsrc(pb, active ? n * 4 : 0), krs = tile_rsrc(kb, (active && kb && !kgen) ? n * 4 : 0);
-#pragma unroll
-      for (int u = 0; u < kHR; ++u) {
-        const int off = ((rg + u * nrg) * C + c) * 4;
-        pvf[u] = tile_load1(prs, off);
-        kvf[u] = tile_load1(krs, off);
-      }
+      if (b != (int)blockIdx.x) load_rows(b);   // (the first window's rows are on their way since the kernel's entry)
 #pragma unroll
       for (int u = 0; u < kHR; ++u) {
         const int t = rg + u * nrg;
@@ -2038,7 +2046,6 @@ __global__ __launch_bounds__(kThreads) void ghead_kernel(GHeadArgs a) {
         }
       }
     } else if (active) {
-      const unsigned long long step = kgen ? (((unsigned long long)a.counter[1] << 32) | a.counter[0]) : 0ull;
       for (int t0 = rg; t0 < a.T; t0 += kHB * nrg) {
         float pv[kHB], wv[kHB], rv[kHB], kv[kHB];
 #pragma unroll
