@@ -167,9 +167,11 @@ typedef struct {
   int64_t src_elem;   /* element offset of the first copied frame inside the store */
 } mww_window;
 /* masks: [B][n_time_masks + n_freq_masks][2] = (start, width); time masks first.
- * Defines x[B][T][40] float32 of the context's batch buffer.  With the "fused_input" option (default for the
- * specialised MixedNet kernels) only the descriptors are uploaded and the first block's kernels read the stores;
- * the buffer itself is filled when a reader outside those kernels needs it (mww_get_batch, mww_debug_read "x"). */
+ * Defines x[B][T][40] float32 of the context's batch buffer.  With the "fused_input" option (the default) only the
+ * descriptors are uploaded and the kernels that read the spectrogram gather from the stores (the specialised MixedNet
+ * first-block kernels; the stem of a conv/BN graph when it is the static 5 x 40 shape of the default Inception and the
+ * window has at most 200 frames); the buffer itself is filled when any other reader needs it (other graphs,
+ * mww_get_batch, mww_debug_read "x", a batch reused after its mailbox slot has moved on). */
 int mww_assemble_batch(mww_ctx* ctx, const mww_window* windows, const int32_t* masks, int B, int n_time_masks,
                        int n_freq_masks);
 /* ready-made batch: the `x` argument of Keras train_on_batch / evaluate (train.py:295-299,50-58) */
@@ -274,8 +276,9 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * their two backward contractions take bf16-rounded operands with fp32 accumulation — BASELINE configs[4]),
  * "storage_bf16" (1 = additionally the block outputs p_k and the stashed gradients g_k live in HBM as bf16, every sum
  * stays fp32 and is taken from the unrounded values; implies pointwise_bf16, cleared by pointwise_bf16 = 0),
- * "fused_input" (default 1, specialised MixedNet kernels: mww_assemble_batch uploads descriptors only and the first
- * block's kernels gather / scale / mask their rows from the stores; x is materialised on demand — same values),
+ * "fused_input" (default 1: mww_assemble_batch uploads descriptors only and the kernels that read the spectrogram - the
+ * specialised MixedNet first-block kernels, the gathering stem of the default Inception graph - gather / scale / mask their
+ * rows from the stores; x is materialised on demand — same values),
  * "bn_inline" (default 1: BN sums travel in fp64 accumulator rows and are folded by their first consumer instead of
  * by finalize launches, in the MixedNet block kernels and in conv/BN graphs whose ops are convolutions with a BatchNorm (or
  * nothing) and depthwise ops with a bias (or nothing), without residual branches and attention / pooled heads; forced off by

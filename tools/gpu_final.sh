@@ -27,6 +27,7 @@ echo "== bench inception / notebook / generic"
 timeout 900 python bench.py --model inception --steps 100 --warmup 10 > $OUT/bench_inception.json 2> $OUT/bench_inception.err; head -c 300 $OUT/bench_inception.json; echo
 MWW_BENCH_OPTIONS=graph_static_shapes=0,graph_planar=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_runtime_shapes.json 2>/dev/null; head -c 200 $OUT/bench_inception_runtime_shapes.json; echo
 MWW_BENCH_OPTIONS=graph_planar=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_interleaved.json 2>/dev/null; head -c 200 $OUT/bench_inception_interleaved.json; echo
+MWW_BENCH_FUSED_INPUT=0 timeout 900 python bench.py --model inception --steps 100 --warmup 10 $Q > $OUT/bench_inception_materialised_input.json 2>/dev/null; head -c 200 $OUT/bench_inception_materialised_input.json; echo
 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook.json 2> $OUT/bench_notebook.err; head -c 300 $OUT/bench_notebook.json; echo
 MWW_BENCH_T=194 timeout 900 python bench.py --model notebook $Q > $OUT/bench_notebook_T194_one_full_tile.json 2>/dev/null; head -c 200 $OUT/bench_notebook_T194_one_full_tile.json; echo
 timeout 900 python bench.py --force-generic $Q --steps 100 --warmup 10 > $OUT/bench_mixednet_on_graph_kernels.json 2>/dev/null; head -c 200 $OUT/bench_mixednet_on_graph_kernels.json; echo
