@@ -60,6 +60,28 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = tid % Q, rg = tid / Q;
   const bool active = rg < NRG;
+  // The dense kernel rows of this thread are the same for every window: loaded once.  A window's rows are fetched while
+  // the previous window is reduced (its label / weight too: thread 0 used to load them after the reduction, a second
+  // round trip per window on the critical path).  Rows past T read as zeros through the buffer resource.  The dense rows
+  // and the first window are requested before BN_L's statistics are folded (they do not depend on them: one round trip
+  // less in front of the first window).
+  float4 wdv[JMAX];
+  {
+    const BufRsrc wr = tile_rsrc(a.wd, active ? a.T * C * 4 : 0);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) wdv[j] = tile_load4(wr, ((rg + NRG * j) * C + q * 4) * 4);
+  }
+  auto fetch = [&](int b, float4 (&dst)[JMAX], float& yy, float& ww) {
+    const bool ok = b < a.B;
+    const BufRsrc pr = tile_rsrc(elem_ptr<SB>(a.p, (size_t)(ok ? b : 0) * a.T * C), (ok && active) ? a.T * C * elem_bytes(SB) : 0);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) dst[j] = tile_load4s<SB, MWW_AUX_LD_HP>(pr, (rg + NRG * j) * Q + q);
+    yy = (ok && a.y != nullptr) ? a.y[b] : 0.f;
+    ww = (ok && a.y != nullptr && (a.training & kHeadTraining)) ? a.sw[b] : 0.f;
+  };
+  float4 raw[JMAX], nxt[JMAX];
+  float y_cur = 0.f, w_cur = 0.f, y_nxt = 0.f, w_nxt = 0.f;
+  fetch(blockIdx.x, raw, y_cur, w_cur);
   float4 sc = make_float4(0, 0, 0, 0), sh = sc, mu = sc, rs = sc;
   if (a.fold.acc) {
     float* sFold = sStat;   // [4][C], free until the first window's partials
@@ -83,26 +105,6 @@ __global__ __launch_bounds__(kThreads, 2) void head_kernel(HeadArgs a) {
   const float bias = a.bd[0];
   float4 g1 = make_float4(0, 0, 0, 0), g2 = g1;
 
-  // The dense kernel rows of this thread are the same for every window: loaded once.  A window's rows are fetched while
-  // the previous window is reduced (its label / weight too: thread 0 used to load them after the reduction, a second
-  // round trip per window on the critical path).  Rows past T read as zeros through the buffer resource.
-  float4 wdv[JMAX];
-  {
-    const BufRsrc wr = tile_rsrc(a.wd, active ? a.T * C * 4 : 0);
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) wdv[j] = tile_load4(wr, ((rg + NRG * j) * C + q * 4) * 4);
-  }
-  auto fetch = [&](int b, float4 (&dst)[JMAX], float& yy, float& ww) {
-    const bool ok = b < a.B;
-    const BufRsrc pr = tile_rsrc(elem_ptr<SB>(a.p, (size_t)(ok ? b : 0) * a.T * C), (ok && active) ? a.T * C * elem_bytes(SB) : 0);
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) dst[j] = tile_load4s<SB, MWW_AUX_LD_HP>(pr, (rg + NRG * j) * Q + q);
-    yy = (ok && a.y != nullptr) ? a.y[b] : 0.f;
-    ww = (ok && a.y != nullptr && (a.training & kHeadTraining)) ? a.sw[b] : 0.f;
-  };
-  float4 raw[JMAX], nxt[JMAX];
-  float y_cur = 0.f, w_cur = 0.f, y_nxt = 0.f, w_nxt = 0.f;
-  fetch(blockIdx.x, raw, y_cur, w_cur);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     float dot = 0.f;
     fetch(b + gridDim.x, nxt, y_nxt, w_nxt);
