@@ -101,7 +101,9 @@ def inception_kernel_elems(layout):
         n = 0
         for j, (s, d) in enumerate(zip(op["src"], op["drop"])):
             t = layout.frames if s < 0 else ops[s]["tout"]
-            n += (t if full else t - d) * width(op, j)
+            e = (t if full else t - d) * width(op, j)
+            # (the stem gathers the spectrogram from the uint16 stores: 2 bytes per element, as in the MixedNet first block)
+            n += e // 2 if (s < 0 and FUSED_INPUT and layout.frames <= 200) else e
         return n
 
     for i, op in enumerate(ops):
@@ -160,18 +162,23 @@ def pmc_traffic(kernel, model, path=None, library=LIBRARY):
     algorithmic bytes do not count).  The summary carries the sha256 of the library it was measured on; when that is not the
     library this process loaded, the figure is NOT reported (traffic null, the source says why)."""
     import re
-    path = path or os.path.join(ROOT, "profiles", PMC_FILE)
-    if model != "mixednet":
+    if model == "inception":   # the two stem launches have kernels of their own (every other symbol serves several ops)
+        path = path or os.path.join(ROOT, "profiles", PMC_FILE.replace(".txt", "_inception.txt"))
+        names = {"conv_fwd1": "gconv_xg_kernel<24,", "conv_wgrad1": "gconv_wgrad_xg_kernel<24,"} if FUSED_INPUT else {}
+    elif model == "mixednet":
+        path = path or os.path.join(ROOT, "profiles", PMC_FILE)
+        names = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
+                 "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
+                 "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
+                 "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}
+    else:
         return None, None
     if not os.path.isfile(path):
         return None, "missing: no PMC summary of this round's library yet (%s)" % os.path.basename(path)
     prof_sha, lib_sha = pmc_profile_sha16(path), library_sha16(library)
     if prof_sha is None or prof_sha != lib_sha:
         return None, "stale: profile sha %s != library sha %s (%s)" % (prof_sha, lib_sha, os.path.basename(path))
-    want = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
-            "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
-            "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
-            "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}.get(kernel)
+    want = names.get(kernel)
     if not want:
         return None, None
     fetch = write = None
