@@ -830,9 +830,31 @@ struct GConvArgs {
 // Data-gradient epilogue of a static shape (whole windows, no residual branches): source I's slice of the gradient tile goes
 // to g (first consumer: stored, later ones: accumulated) through the ReLU mask of the source, with the slice's backward sums.
 // Same arithmetic and order as the run-time loop in gconv_body; the slice width / row length are constants here.
+// A thread's channel of every source is the same for all windows: the producers' folded scale / shift (ReLU mask) and
+// mean / rstd (x-hat of the backward sums) are read once per workgroup.  (Inside the epilogue - where the stores of the window
+// loop keep the compiler from hoisting them - they were a dependent round trip per source and window in front of the rows'
+// loads.)
+struct GDgradCoef {
+  float sc[kGMaxSrc], sh[kGMaxSrc], mu[kGMaxSrc], rs[kGMaxSrc];
+};
+template <class SH, int I = 0>
+__device__ __forceinline__ void dgrad_coefs_static(const GSrc* src, int tid, GDgradCoef& dc) {
+  if constexpr (I < SH::NSRC) {
+    constexpr int C = SH::srcC(I);
+    const GSrc& s = src[I];
+    const int rg = tid / C, c = tid - rg * C;
+    const bool on = (s.flags & GSRC_GRAD) && rg < kThreads / C, stats = on && (s.flags & GSRC_STATS);
+    dc.sc[I] = on ? s.scale[s.c0 + c] : 0.f;
+    dc.sh[I] = on ? s.shift[s.c0 + c] : 0.f;
+    dc.mu[I] = stats ? s.mean[s.c0 + c] : 0.f;
+    dc.rs[I] = stats ? s.rstd[s.c0 + c] : 0.f;
+    dgrad_coefs_static<SH, I + 1>(src, tid, dc);
+  }
+}
+
 template <class SH, int I = 0>
 __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, const float* sOut, int PO, int tid, float& s1o, float& s2o,
-                                                     float* sSrcAcc) {
+                                                     float* sSrcAcc, const GDgradCoef& dc) {
   if constexpr (I < SH::NSRC) {
     constexpr int C = SH::srcC(I), LD = SH::srcLD(I), c0 = SH::srcC0(I);
     constexpr int kGES = 8;   // rows in flight per thread (the run-time epilogue keeps kGE = 4: a window's share of a 10- / 16-channel
@@ -842,10 +864,9 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
       constexpr int nrg = kThreads / C;
       const int rg = tid / C, c = tid - rg * C;
       if (rg < nrg) {
-        const float sc = s.scale[s.c0 + c], sh = s.shift[s.c0 + c];
-        const bool accum = (s.flags & GSRC_ACCUM) != 0, stats = (s.flags & GSRC_STATS) != 0;
+        const float sc = dc.sc[I], sh = dc.sh[I], mu = dc.mu[I], rs = dc.rs[I];
+        const bool accum = (s.flags & GSRC_ACCUM) != 0;
         const bool linear = (s.flags & GSRC_LINEAR) != 0;
-        const float mu = stats ? s.mean[s.c0 + c] : 0.f, rs = stats ? s.rstd[s.c0 + c] : 0.f;
         float t1 = 0.f, t2 = 0.f;
         const size_t woff = (size_t)b * s.T * LD + s.c0;
         const int wbytes = ((s.T - 1) * LD + C) * 4;
@@ -880,7 +901,7 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
         }
       }
     }
-    dgrad_sources_static<SH, I + 1>(src, b, sOut, PO, tid, s1o, s2o, sSrcAcc);
+    dgrad_sources_static<SH, I + 1>(src, b, sOut, PO, tid, s1o, s2o, sSrcAcc, dc);
   }
 }
 
@@ -1010,6 +1031,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     else dpipe.load_coeffs(a.y, sFold, tid);
   }
   int xsamp = 0;   // (XG) the window's slot in sXg
+  GDgradCoef dcoef;
+  if constexpr (ST && MODE == 1) dgrad_coefs_static<SHX>(a.src, tid, dcoef);
+  (void)dcoef;
   for (int v = bid; v < (CH ? a.B * a.S : a.B); v += nb) {
     // work item v = window b, frames [f0, f0 + Tout) of its Ttot (whole-window kernels: f0 = 0, Tout = Ttot)
     int b = v, f0 = 0, chunk = 0;
@@ -1103,7 +1127,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         }
       }
     } else if constexpr (ST) {
-      dgrad_sources_static<SH>(a.src, b, sOut, PO, tid, s1o, s2o, sSrcAcc);
+      dgrad_sources_static<SH>(a.src, b, sOut, PO, tid, s1o, s2o, sSrcAcc, dcoef);
     } else {
       int c0 = 0;
       for (int i = 0; i < kNsrc; ++i) {
