@@ -1070,7 +1070,13 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
       const int ntile = (Tout + 15) >> 4;
       const bool kfull = (kCin & 3) == 0;
-      for (int rt = wave; rt < ntile; rt += kThreads / 64) {
+      // (static forward convolutions: at most kGTmax / 16 = 13 tiles, i.e. four per wave, written as four guarded bodies - as
+      // a loop the compiler put an s_waitcnt vmcnt(0) in front of it, which made every wave wait for the NEXT window's rows,
+      // requested a few instructions earlier, before it contracted the current one: -0.5 .. -1.3 us per forward launch.  The
+      // data-gradient role keeps the loop: the bodies cost its launches 12-16 VGPRs, and the 16-filter twin backward launch,
+      // which sits at the 128-register line of four workgroups per CU, went 40 -> 47 us with them.)
+      constexpr int kRtMax = (ST && MODE == 0) ? (kGTmax / 16 + kThreads / 64 - 1) / (kThreads / 64) : 0;
+      auto row_tile = [&](const int rt) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = zero4();
@@ -1110,6 +1116,13 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
             const int row = rt * 16 + g * 4 + r, col = nt * 16 + r16;
             if (row < Tout && col < NC) sOut[row * PO + col] = acc[nt][r];
           }
+      };
+      if constexpr (kRtMax > 0) {
+#pragma unroll
+        for (int i = 0; i < kRtMax; ++i)
+          if (wave + i * (kThreads / 64) < ntile) row_tile(wave + i * (kThreads / 64));
+      } else {
+        for (int rt = wave; rt < ntile; rt += kThreads / 64) row_tile(rt);
       }
     }
     __syncthreads();
