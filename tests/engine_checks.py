@@ -1487,7 +1487,7 @@ def check_gather_fuzz(lib, cases=8, first=0, notebook=False):
             np.testing.assert_array_equal(a, b, err_msg="case %d" % case)
 
 
-def check_inception_gathered_stem(lib, cases=3, first=0, B=6, lengths=(194, 150, 200, 201), graphs=(0,), grid=0):
+def check_inception_gathered_stem(lib, cases=3, first=0, B=6, lengths=(194, 150, 200, 201), graphs=(0,), grid=0, rounds=3):
     """The Inception stem reading a descriptor-only batch in place (kernels_graph.hip.h XG instantiations of the forward
     convolution and the weight gradient: pad / truncate, uint16 scaling and SpecAugment masks applied while the window is
     staged) against the materialised x ("fused_input" 0): the gathered values are the same floats, so evaluation outputs,
@@ -1518,7 +1518,7 @@ def check_inception_gathered_stem(lib, cases=3, first=0, B=6, lengths=(194, 150,
                 eng.set_option("grid_graph", grid)
             fh = FeatureHandler(cfg, engine=eng)
             got = []
-            for k in range(3):
+            for k in range(rounds):
                 fh.next_training_batch_on_device(B, T, strategy, policy)
                 eng.set_dropout_mask(np.ones((B, eng_dense_inputs(lay)), np.uint8))
                 eng.forward(B, training=False)
@@ -1531,7 +1531,7 @@ def check_inception_gathered_stem(lib, cases=3, first=0, B=6, lengths=(194, 150,
                 if k == 0:   # same batch again
                     eng.train_step(B, 1e-2)
                     got.append(eng.get_grads().copy())
-                if k == 1:
+                if k == rounds - 1:
                     got.append(eng.get_batch(B).copy())
             got += [eng.get_params().copy(), eng.get_bn_state().copy()]
             outs.append(got)

@@ -293,6 +293,6 @@ def test_inception_topology_fuzz(emu_lib):
 
 def test_inception_stem_gathers_descriptor_only_batches(emu_lib):
     # (more cases, window lengths, captured graphs and grids: tools/gpu_inc_fuzz.py / test_engine_gpu.py on the device)
-    ec.check_inception_gathered_stem(emu_lib, cases=1, B=5, lengths=(194,))
-    ec.check_inception_gathered_stem(emu_lib, cases=1, first=4, B=12, grid=2, graphs=(1,), lengths=(150,))
+    ec.check_inception_gathered_stem(emu_lib, cases=1, B=4, lengths=(194,), rounds=1)
+    ec.check_inception_gathered_stem(emu_lib, cases=1, first=4, B=6, grid=2, graphs=(1,), lengths=(150,), rounds=2)
 
