@@ -365,6 +365,16 @@ def test_bench_traffic_figure_is_tied_to_the_library_it_was_measured_on(tmp_path
     lib.write_bytes(b"library build B")                       # the library moved on, the profile did not
     nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(good), library=str(lib))
     assert nbytes is None and src.startswith("stale: profile sha %s != library sha" % sha)
+    # Inception: the two stem launches have kernels of their own; the other ops share symbols and report nothing
+    lib.write_bytes(b"library build A")
+    inc = tmp_path / "inc.txt"
+    inc.write_text("# library sha256_16=%s\n## counters pmc3\ngconv_wgrad_xg_kernel<24, GShape<5, 1, 40, 40, 0, 0, 0, 0> > n=8 us=50 FETCH_SIZE=2.6e+04\n"
+                   "## counters pmc4\ngconv_wgrad_xg_kernel<24, GShape<5, 1, 40, 40, 0, 0, 0, 0> > n=8 us=50 WRITE_SIZE=9600\n" % sha)
+    nbytes, src = bench.pmc_traffic("conv_wgrad1", "inception", path=str(inc), library=str(lib))
+    assert nbytes == int(2 * 2.6e4 * 1024 + 9600 * 1024) and sha in src
+    assert bench.pmc_traffic("conv_bwd5", "inception", path=str(inc), library=str(lib)) == (None, None)
+    assert bench.pmc_traffic("bwd_block4", "notebook", path=str(inc), library=str(lib)) == (None, None)
+    lib.write_bytes(b"library build B")
     unstamped = tmp_path / "old.txt"
     unstamped.write_text(body)                                 # a summary from before the stamp existed
     nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(unstamped), library=str(lib))
