@@ -129,7 +129,7 @@ def inception_kernel_elems(layout):
 
 
 PMC_FILE = "round4_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
-LIBRARY = os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")
+LIBRARY = os.environ.get("MWW_HIP_LIB") or os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")   # the file native.NativeLib.get() loads
 
 
 def library_sha16(path=LIBRARY):
@@ -138,6 +138,22 @@ def library_sha16(path=LIBRARY):
         with open(path, "rb") as fh:
             return hashlib.sha256(fh.read()).hexdigest()[:16]
     except OSError:
+        return None
+
+
+def _source_sha_of_loaded_library():
+    try:
+        from microwakeword_amd import build_native
+        return build_native.library_source_sha16(LIBRARY)
+    except Exception:   # noqa: BLE001 - a bench line must not die on its provenance fields
+        return None
+
+
+def _tree_source_sha():
+    try:
+        from microwakeword_amd import build_native
+        return build_native.source_sha16()
+    except Exception:   # noqa: BLE001
         return None
 
 
@@ -666,6 +682,10 @@ def main():
                      "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4), "final_loss": round(float(last_loss), 5),
         "pre_roll_s": round(pre_roll_s, 3),
+        # which binary was timed, and which source set it was built from (mww_version() carries the sha256 of csrc/* +
+        # include/mww.h; __graft_entry__.build() rebuilds when it differs from the tree's): library_sha16 ties the line to a
+        # file, source_sha16 == tree_source_sha16 ties that file to this tree
+        "library_sha16": library_sha16(), "source_sha16": _source_sha_of_loaded_library(), "tree_source_sha16": _tree_source_sha(),
         "pre_roll_note": "GPU work of this process BEFORE the W warm-up steps, outside the timed region: validation leg (3 x both sets), ~80 ms of "
                          "inference forwards (device settle) and the per-kernel HIP-event pass (%d train steps).  It brings the device to its steady "
                          "clocks; without it (--no-validation --profile-steps 0) a 5 + 20-step run reads ~0.36 ms/step instead" % args.profile_steps,

@@ -68,6 +68,17 @@ __device__ __forceinline__ f32x4 zero4() {
 
 // LDS row pitch: +4 floats keeps 16-byte alignment of float4 rows and breaks 2^n strides.
 __host__ __device__ constexpr int pitch(int c) { return c + 4; }
+// Forward kernels, per array (tools/lds_banks.py; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 34 % with c + 4 everywhere):
+//   input tile (float4 commits, (channel, chunk) window reads): at c = 48 the 64 lanes of a wave straddle two chunks L = 13
+//   rows apart - a pitch of 48 (= 16 mod 32, L odd) puts the second chunk's 16 lanes on the banks the first leaves free;
+//   u tile (written per (channel, chunk), read as the MFMA A operand: lane (r16, g) reads row r16, column 4 kk + g):
+//   c + 2 = 2 or 18 mod 32 spreads the 16 rows x 2 columns of a 32-lane group over 32 banks (c + 4: two-way).  The bf16
+//   mode reads that operand as float4 and keeps 16-byte rows.
+#ifndef MWW_FWD_PITCH
+#define MWW_FWD_PITCH 1
+#endif
+__host__ __device__ constexpr int pitch_fa(int c) { return (MWW_FWD_PITCH && c == 48) ? 48 : c + 4; }
+__host__ __device__ constexpr int pitch_fu(int c, bool bf) { return (MWW_FWD_PITCH && !bf) ? c + 2 : c + 4; }
 
 // number of time chunks / chunk length of the (channel, chunk) VALU mapping
 __host__ __device__ constexpr int nchunks(int c) { return kThreads / c; }

@@ -389,11 +389,13 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinalizeArgs& a,
   }
 }
 
+#ifndef MWW_BLOCK_TU   // defined once, in mww_lib.hip (the block-kernel translation units skip it)
 __global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ double sOut[2];
   bn_bwd_finalize_body(a, blockIdx.x, sAcc, sOut, threadIdx.x);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Gradient assembly: the per-workgroup partial rows of every segment are summed in a fixed order by
@@ -422,6 +424,7 @@ struct AdamArgs {
   float beta1, beta2, eps;
 };
 
+#ifndef MWW_BLOCK_TU   // defined once, in mww_lib.hip (the block-kernel translation units skip it)
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs a) {
   const int p = blockIdx.x * kThreads + threadIdx.x;
   if (p >= a.P) return;
@@ -434,5 +437,6 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamArgs a) {
   a.v[p] = v;
   a.param[p] -= alpha * m / (sqrtf(v) + a.eps);
 }
+#endif
 
 }  // namespace mww

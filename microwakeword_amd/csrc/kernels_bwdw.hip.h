@@ -1,0 +1,588 @@
+// Wide-workgroup form of the block backward kernel (round 5).  Same arithmetic, same inputs / outputs / partial-row
+// layout as bwd_block_kernel (kernels_bwd.hip.h, reference: TF autodiff of microwakeword/mixednet.py:334-360), but a
+// 64-row time tile is shared by NTH = 384 or 512 threads instead of 256, with register budgets that let a CU hold
+// three or four waves per SIMD instead of two:
+//
+//   * VALU phases: thread -> (channel, chunk) with NTH / C chunks of L = 7 or 8 rows (256 threads: 13): the register
+//     windows of the depthwise phases shrink from L + K - 1 = 33 to 27 values at K = 21, and the one-pass depthwise
+//     backward is split into an input-gradient pass and a weight-gradient pass that reuse the same registers;
+//   * MFMA phase: waves own OUTPUT tiles instead of row slices.  A wave of the 256-thread kernel accumulates the whole
+//     C x C weight gradient over its 16 rows (36 accumulator registers at C = 48); here a wave owns at most three
+//     16 x 16 tiles of dW_pw over 32 or 64 rows (12 registers) and one to three 16 x 16 tiles of du (WideRoles below);
+//   * LDS pitches chosen per access pattern against the bank model of tools/lds_banks.py (WidePitch below): the
+//     (channel, chunk) windows, the row-pattern MFMA operands and the column-pattern operand are conflict-free or at
+//     the conflict-free rate (C = 48 / 512 threads: pitch 48 = no padding, the du A operand read as one float4 per lane).
+//
+// The weight-gradient partials keep a fixed summation order (per-wave tiles, then row halves, then the grid's partial
+// rows in grad_final_kernel): gradients stay bit-reproducible from run to run.  The k-order of the contractions differs
+// from the 256-thread kernel's (other rows meet in one MFMA k-step), so the two forms agree to rounding, not bitwise.
+#pragma once
+#include "kernels_bwd.hip.h"
+
+namespace mww {
+
+// P: row pitch of the activation / gradient tiles; D: row distance between the four k-values of one dW k-step
+// (rows s + D g of a block of 4 D rows, g = lane >> 4: a 32-lane LDS group holds two of them and D * P = 16 mod 32 keeps
+// their banks disjoint); C128: the du A operand (lanes across rows, fixed column) is read as one float4 per lane =
+// the lane's k of four k-steps (k = 16 kb + 4 g + s), else as one dword per k-step (k = 4 kk + g); PW: pitch of W^T,
+// whose rows are read 4 apart (C128) or 1 apart.
+template <int C, int NTH>
+struct WidePitch;
+template <>
+struct WidePitch<48, 512> {
+  static constexpr int P = 48, D = 1, PW = 52;
+  static constexpr bool C128 = true;
+};
+template <>
+struct WidePitch<48, 384> {
+  static constexpr int P = 50, D = 8, PW = 48;
+  static constexpr bool C128 = false;
+};
+template <>
+struct WidePitch<64, 512> {
+  static constexpr int P = 72, D = 2, PW = 68;
+  static constexpr bool C128 = true;
+};
+
+// four floats to LDS at a row whose pitch may be 8-byte aligned only
+template <int P>
+__device__ __forceinline__ void lds_store4(float* dst, const float4& v) {
+  if constexpr (P % 4 == 0) {
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+    *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+  }
+}
+
+// dp tile of the wide kernel (DpStage with the thread count and the pitch as parameters)
+template <int C, bool LAST, bool SB, int NTH, int P>
+struct DpStageW {
+  static constexpr int Q = C / 4, N = (TT * Q + NTH - 1) / NTH;
+  float4 pk[N], gg[N];
+
+  __device__ __forceinline__ void issue(const float* pk_base, const float* g_base, int nvalid, int tid) {
+    constexpr bool SG = SB && !LAST;
+    const BufRsrc rp = tile_rsrc(pk_base, nvalid * 4 * elem_bytes(SB)), rg = tile_rsrc(g_base, nvalid * 4 * elem_bytes(SG));
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      pk[j] = tile_load4s<SB, MWW_AUX_LD_PK>(rp, tid + j * NTH);
+      gg[j] = tile_load4s<SG, MWW_AUX_LD_GK>(rg, tid + j * NTH);
+    }
+  }
+
+  // sKp rows: 0 = c1, 1 = kA, 2 = kB (dp = c1 g + kA p + kB), 5 / 6 = BN_k scale / shift (LAST: ReLU mask of the head input)
+  __device__ __forceinline__ void commit(float* sDP, const float* sKp, float dzb, int nvalid, int tid) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int i = tid + j * NTH;
+      if (i < TT * Q) {
+        const int r = i / Q, q = i - r * Q;
+        float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvalid) {
+          const float4 p = pk[j];
+          const float4 c1 = *reinterpret_cast<const float4*>(sKp + 0 * C + q * 4);
+          const float4 kA = *reinterpret_cast<const float4*>(sKp + 1 * C + q * 4);
+          const float4 kB = *reinterpret_cast<const float4*>(sKp + 2 * C + q * 4);
+          float4 g = gg[j];
+          if (LAST) {
+            const float4 sc = *reinterpret_cast<const float4*>(sKp + 5 * C + q * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(sKp + 6 * C + q * 4);
+            g.x = fmaf(p.x, sc.x, sh.x) > 0.f ? dzb * g.x : 0.f;
+            g.y = fmaf(p.y, sc.y, sh.y) > 0.f ? dzb * g.y : 0.f;
+            g.z = fmaf(p.z, sc.z, sh.z) > 0.f ? dzb * g.z : 0.f;
+            g.w = fmaf(p.w, sc.w, sh.w) > 0.f ? dzb * g.w : 0.f;
+          }
+          dp.x = fmaf(g.x, c1.x, fmaf(p.x, kA.x, kB.x));
+          dp.y = fmaf(g.y, c1.y, fmaf(p.y, kA.y, kB.y));
+          dp.z = fmaf(g.z, c1.z, fmaf(p.z, kA.z, kB.z));
+          dp.w = fmaf(g.w, c1.w, fmaf(p.w, kA.w, kB.w));
+        }
+        lds_store4<P>(sDP + r * P + q * 4, dp);
+      }
+    }
+  }
+};
+
+// dW tiles of one wave: acc[nt] += U[rows, mcol..]^T DP[rows, ncol0 + 16 nt ..] over NBLK blocks of BLK rows from row0;
+// blocks that start past the sample's last output row are skipped (u and dp are zero there).  The operands of k-step
+// kk + 1 are read before the MFMAs of k-step kk.
+template <int NTW, int NBLK, int BLK, int D, int P>
+__device__ __forceinline__ void wide_dw_rows(const float* sU, const float* sDP, int row0, int nrows, int mcol, int ncol0,
+                                             int r16, int g, f32x4 (&acc)[NTW]) {
+  constexpr int KSB = BLK / 4;
+  static_assert(BLK % (4 * D) == 0, "a block holds whole groups of 4 D rows");
+  const float* pu = sU + (row0 + D * g) * P + mcol + r16;
+  const float* pd = sDP + (row0 + D * g) * P + ncol0 + r16;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (row0 + blk * BLK < nrows) {   // wave-uniform
+      float av[2], bv[2][NTW];
+      auto ld = [&](int kk, int s) {
+        const int ro = (blk * BLK + (kk / D) * 4 * D + (kk % D)) * P;
+        av[s] = pu[ro];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[s][nt] = pd[ro + nt * 16];
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KSB; ++kk) {
+        if (kk + 1 < KSB) ld(kk + 1, (kk + 1) & 1);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = mfma4(av[kk & 1], bv[kk & 1][nt], acc[nt]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + NTW, 0);
+      sched_read_mfma_groups<KSB - 1, 1 + NTW, NTW>();
+      sched_read_mfma_groups<1, 0, NTW>();
+    }
+  }
+}
+
+// du tiles of one wave: du[mu] = DP[16 rows of tile rt, :] W^T[:, mcol0 + 16 mu ..], stored to the ring rows
+// [K-1 + 16 rt, +16).  A tile past the sample's last output row only writes its zeros.
+template <int C, int NMU, int K, int P, int PW, bool C128>
+__device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt, float* sDU, int rt, int nrows, int mcol0,
+                                              int r16, int g) {
+  f32x4 du[NMU];
+#pragma unroll
+  for (int mu = 0; mu < NMU; ++mu) du[mu] = zero4();
+  if (rt * 16 < nrows) {   // wave-uniform
+    if constexpr (C128) {
+      const float* pa = sDP + (rt * 16 + r16) * P + 4 * g;
+      const float* pb = sWt + (4 * g) * PW + mcol0 + r16;
+      float4 a4[2];
+      a4[0] = *reinterpret_cast<const float4*>(pa);
+#pragma unroll
+      for (int kb = 0; kb < C / 16; ++kb) {
+        if (kb + 1 < C / 16) a4[(kb + 1) & 1] = *reinterpret_cast<const float4*>(pa + (kb + 1) * 16);
+        float bv[4][NMU];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mu = 0; mu < NMU; ++mu) bv[s][mu] = pb[(kb * 16 + s) * PW + mu * 16];
+        const float4 av = a4[kb & 1];
+        const float as[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(as[s], bv[s][mu], du[mu]);
+      }
+    } else {
+      const float* pa = sDP + (rt * 16 + r16) * P + g;
+      const float* pb = sWt + g * PW + mcol0 + r16;
+      float av[2], bv[2][NMU];
+      auto ld = [&](int kk, int s) {
+        av[s] = pa[kk * 4];
+#pragma unroll
+        for (int mu = 0; mu < NMU; ++mu) bv[s][mu] = pb[kk * 4 * PW + mu * 16];
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < C / 4; ++kk) {
+        if (kk + 1 < C / 4) ld(kk + 1, (kk + 1) & 1);
+#pragma unroll
+        for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(av[kk & 1], bv[kk & 1][mu], du[mu]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMU, 0);
+      sched_read_mfma_groups<C / 4 - 1, 1 + NMU, NMU>();
+      sched_read_mfma_groups<1, 0, NMU>();
+    }
+  }
+  float* pd = sDU + (K - 1 + rt * 16 + g * 4) * P + mcol0 + r16;
+#pragma unroll
+  for (int mu = 0; mu < NMU; ++mu)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pd[r * P + mu * 16] = du[mu][r];
+}
+
+// one du tile per (row tile, column tile) with a shared B operand: du[rt] = DP[16 rt .., :] W^T[:, mcol ..] for NRT row tiles
+template <int C, int NRT, int K, int P, int PW>
+__device__ __forceinline__ void wide_du_column(const float* sDP, const float* sWt, float* sDU, int nrows, int mcol, int r16, int g) {
+  f32x4 du[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) du[rt] = zero4();
+  const float* pa = sDP + r16 * P + g;
+  const float* pb = sWt + g * PW + mcol + r16;
+  float av[2][NRT], bv[2];
+  auto ld = [&](int kk, int s) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) av[s][rt] = pa[rt * 16 * P + kk * 4];
+    bv[s] = pb[kk * 4 * PW];
+  };
+  ld(0, 0);
+#pragma unroll
+  for (int kk = 0; kk < C / 4; ++kk) {
+    if (kk + 1 < C / 4) ld(kk + 1, (kk + 1) & 1);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) du[rt] = mfma4(av[kk & 1][rt], bv[kk & 1], du[rt]);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 1 + NRT, 0);
+  sched_read_mfma_groups<C / 4 - 1, 1 + NRT, NRT>();
+  sched_read_mfma_groups<1, 0, NRT>();
+  (void)nrows;   // rows past the sample hold dp = 0: their du is an exact zero
+  float* pd = sDU + (K - 1 + g * 4) * P + mcol + r16;
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pd[(rt * 16 + r) * P] = du[rt][r];
+}
+
+
+// Depthwise sums over a sub-range [I0, I1) of the K taps, for one (channel, chunk): the register window of a phase is
+// L + (I1 - I0) - 1 rows instead of L + K - 1, so long kernels run their phases in two or three tap groups.
+//   dw_tap_group     : acc[t] += sum_i w(i) * src[t + i]      (w(i) = taps[i], or taps[K-1-i] when REV: the input gradient)
+//   dw_wgrad_group   : accw[i] += sum_t du[t] * src[t + i]    (the depthwise weight gradient)
+// src_c / taps_c point at the thread's channel (row 0 of its window, tap 0).
+template <int K, int L, int I0, int I1, bool REV>
+__device__ __forceinline__ void dw_tap_group(const float* src_c, int pitch, const float* taps_c, int tap_pitch, float (&acc)[L]) {
+  constexpr int N = I1 - I0;
+  float win[L + N - 1], w[N];
+#pragma unroll
+  for (int j = 0; j < L + N - 1; ++j) win[j] = src_c[(I0 + j) * pitch];
+#pragma unroll
+  for (int i = 0; i < N; ++i) w[i] = taps_c[(REV ? K - 1 - (I0 + i) : I0 + i) * tap_pitch];
+  lds_reads_first();
+#pragma unroll
+  for (int t = 0; t < L; ++t)
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[t] = fmaf(w[i], win[t + i], acc[t]);
+}
+template <int K, int L, int I0, int I1>
+__device__ __forceinline__ void dw_wgrad_group(const float* src_c, int pitch, const float (&du)[L], float (&accw)[K]) {
+  constexpr int N = I1 - I0;
+  float win[L + N - 1];
+#pragma unroll
+  for (int j = 0; j < L + N - 1; ++j) win[j] = src_c[(I0 + j) * pitch];
+  lds_reads_first();
+#pragma unroll
+  for (int t = 0; t < L; ++t)
+#pragma unroll
+    for (int i = 0; i < N; ++i) accw[I0 + i] = fmaf(du[t], win[t + i], accw[I0 + i]);
+}
+// tap groups of a K-tap kernel: one up to 11 taps, two up to 19, three beyond
+template <int K>
+struct TapGroups {
+  static constexpr int N = K <= 11 ? 1 : (K <= 19 ? 2 : 3);
+  static constexpr int lo(int gidx) { return gidx * K / N; }
+};
+template <int K, int L, bool REV, int G = 0>
+__device__ __forceinline__ void dw_all_groups(const float* src_c, int pitch, const float* taps_c, int tap_pitch, float (&acc)[L]) {
+  if constexpr (G < TapGroups<K>::N) {
+    dw_tap_group<K, L, TapGroups<K>::lo(G), TapGroups<K>::lo(G + 1), REV>(src_c, pitch, taps_c, tap_pitch, acc);
+    if constexpr (G + 1 < TapGroups<K>::N) __builtin_amdgcn_sched_barrier(0);
+    dw_all_groups<K, L, REV, G + 1>(src_c, pitch, taps_c, tap_pitch, acc);
+  }
+}
+template <int K, int L, int G = 0>
+__device__ __forceinline__ void dw_wgrad_all_groups(const float* src_c, int pitch, const float (&du)[L], float (&accw)[K]) {
+  if constexpr (G < TapGroups<K>::N) {
+    dw_wgrad_group<K, L, TapGroups<K>::lo(G), TapGroups<K>::lo(G + 1)>(src_c, pitch, du, accw);
+    if constexpr (G + 1 < TapGroups<K>::N) __builtin_amdgcn_sched_barrier(0);
+    dw_wgrad_all_groups<K, L, G + 1>(src_c, pitch, du, accw);
+  }
+}
+
+// MFMA work of the waves of one workgroup (288 MFMAs per tile at C = 48, 512 at C = 64, dealt evenly):
+//   C = 48, 8 waves: waves 0-5 own the dW tiles (mt = w % 3, nt = 0..2) over the row half w / 3 (24 MFMAs) and the du
+//                    tile (rt = 2 + w / 3, mt = w % 3) (12); waves 6, 7 own the du tiles (rt = w - 6, mt = 0..2) (36)
+//   C = 48, 6 waves: waves 0-2 own the dW tiles (mt = w, nt = 0..2) over all 64 rows (48); waves 3-5 the du column
+//                    mt = w - 3 of all four row tiles (48)
+//   C = 64, 8 waves: every wave owns the dW tiles (mt = w / 2, nt = 2 (w % 2) + {0, 1}) over all rows (32) and the du
+//                    tiles (rt = w / 2, mt = 2 (w % 2) + {0, 1}) (32)
+template <int C, int NW>
+struct WideRoles;
+template <>
+struct WideRoles<48, 8> {
+  static constexpr int NTW = 3, NPART = 2;
+  static __device__ __forceinline__ bool has_dw(int w) { return w < 6; }
+  static __device__ __forceinline__ int part(int w) { return w / 3; }
+  static __device__ __forceinline__ int mt(int w) { return w % 3; }
+  static __device__ __forceinline__ int nt0(int) { return 0; }
+};
+template <>
+struct WideRoles<48, 6> {
+  static constexpr int NTW = 3, NPART = 1;
+  static __device__ __forceinline__ bool has_dw(int w) { return w < 3; }
+  static __device__ __forceinline__ int part(int) { return 0; }
+  static __device__ __forceinline__ int mt(int w) { return w; }
+  static __device__ __forceinline__ int nt0(int) { return 0; }
+};
+template <>
+struct WideRoles<64, 8> {
+  static constexpr int NTW = 2, NPART = 1;
+  static __device__ __forceinline__ bool has_dw(int) { return true; }
+  static __device__ __forceinline__ int part(int) { return 0; }
+  static __device__ __forceinline__ int mt(int w) { return w / 2; }
+  static __device__ __forceinline__ int nt0(int w) { return 2 * (w % 2); }
+};
+
+template <int C, int K, int NTH>
+struct BwdWideLds {
+  typedef WidePitch<C, NTH> WP;
+  static constexpr int NCH = NTH / C, L = (TT + NCH - 1) / NCH, TTP = NCH * L, RAP = TTP + K - 1;
+  static constexpr int OFF_P = 0, OFF_DP = OFF_P + RAP * WP::P, OFF_U = OFF_DP + TT * WP::P, OFF_DU = OFF_U + TTP * WP::P;
+  static constexpr int OFF_END = OFF_DU + RAP * WP::P;
+  static constexpr int BYTES = (OFF_END + 7 * C + C * WP::PW + K * C + 2 * C) * 4;
+};
+
+// waves per SIMD the kernel is compiled for: two workgroups per CU where their LDS allows it
+template <int C, int K, int NTH>
+constexpr int wide_waves_per_simd() {
+  return (BwdWideLds<C, K, NTH>::BYTES <= 80 * 1024 ? 2 : 1) * (NTH / 64) / 4;
+}
+
+template <int CIN, int COUT, int K, bool LAST, int NTH>
+__global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd_blockw_kernel(BwdBlockArgs a) {
+  static_assert(CIN == COUT, "the wide form is instantiated for square blocks");
+  constexpr int C = CIN;
+  constexpr bool SB = false;
+  typedef WidePitch<C, NTH> WP;
+  typedef BwdWideLds<C, K, NTH> Lds;
+  constexpr int NW = NTH / 64;
+  typedef WideRoles<C, NW> Roles;
+  constexpr int P = WP::P, PW = WP::PW, D = WP::D;
+  constexpr int NCH = Lds::NCH, L = Lds::L, TTP = Lds::TTP, RA = TT + K - 1, RAP = Lds::RAP;
+  constexpr int Q = C / 4, MT = C / 16;
+  static_assert(NCH * L >= TT && TT >= K - 1, "tile geometry");
+  static_assert(Lds::OFF_END >= Roles::NPART * C * C && Lds::OFF_END >= NCH * (K + 1) * C, "scratch aliasing");
+
+  __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
+  __shared__ __attribute__((aligned(16))) float sKp[7 * C];
+  __shared__ __attribute__((aligned(16))) float sWt[C * PW];   // W_pw^T
+  __shared__ __attribute__((aligned(16))) float sDW[K * C];    // depthwise taps
+  __shared__ __attribute__((aligned(16))) float sAct[2 * C];   // BN_{k-1} folded scale / shift
+  float* sP = smem + Lds::OFF_P;
+  float* sDP = smem + Lds::OFF_DP;
+  float* sU = smem + Lds::OFF_U;
+  float* sDU = smem + Lds::OFF_DU;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+  const int c = tid % C, chunk = tid / C;
+  const bool dw_active = chunk < NCH;
+
+  const int ntiles = (a.Tin + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  constexpr int NP = (RA * Q + NTH - 1) / NTH;
+  float4 pre_p[NP];
+  DpStageW<C, LAST, SB, NTH, P> dps;
+  float pre_dz = 0.f;
+  auto issue = [&](int it) {
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nvp = min(RA, a.Tin - t0) * Q;
+    const BufRsrc src = tile_rsrc(elem_ptr<SB>(a.in, ((size_t)b * a.Tin + t0) * C), nvp * 4 * elem_bytes(SB));
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pre_p[j] = tile_load4s<SB, MWW_AUX_LD_BP>(src, tid + j * NTH);
+    const int nvk = max(0, min(TT, a.Tout - t0)) * Q;
+    const size_t koff = ((size_t)b * a.Tout + t0) * C;
+    dps.issue(elem_ptr<SB>(a.pk, koff), LAST ? a.wd + (size_t)t0 * C : elem_ptr<SB>(a.gk, koff), nvk, tid);
+    if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
+  };
+  if (nitems > 0) issue(0);
+
+  // ---- prologue: every global load first (one memory round trip), then the LDS copies
+  constexpr int NWL = (C * C + NTH - 1) / NTH, NDL = (K * C + NTH - 1) / NTH;
+  float wl[NWL], dl[NDL];
+#pragma unroll
+  for (int j = 0; j < NWL; ++j) wl[j] = (tid + j * NTH < C * C) ? a.pw_w[tid + j * NTH] : 0.f;
+#pragma unroll
+  for (int j = 0; j < NDL; ++j) dl[j] = (tid + j * NTH < K * C) ? a.dw_w[tid + j * NTH] : 0.f;
+  float accw[K];
+  float accb = 0.f, gs1 = 0.f, gs2 = 0.f, dwb = 0.f;
+  float sc_c = 0.f, sh_c = 0.f, mu_c = 0.f, rs_c = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) accw[i] = 0.f;
+  if (dw_active) {
+    dwb = a.dw_b[c];
+    sc_c = a.in_scale[c];
+    sh_c = a.in_shift[c];
+    mu_c = a.in_mean[c];
+    rs_c = a.in_rstd[c];
+  }
+  for (int i = tid; i < C; i += NTH) {
+    const float krs = a.k_rstd[i];
+    const float kmean = a.k_mean[i];
+    const float ksc = LAST ? a.k_scale[i] : 0.f, ksh = LAST ? a.k_shift[i] : 0.f;
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, C, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
+    const float kA = -c1 * krs * mgx;
+    sKp[0 * C + i] = c1;
+    sKp[1 * C + i] = kA;
+    sKp[2 * C + i] = -c1 * mg - kA * kmean;
+    sKp[5 * C + i] = ksc;
+    sKp[6 * C + i] = ksh;
+  }
+#pragma unroll
+  for (int j = 0; j < NWL; ++j) {
+    const int i = tid + j * NTH;
+    if (i < C * C) sWt[(i % C) * PW + i / C] = wl[j];   // W[ci][co] -> W^T[co][ci]
+  }
+#pragma unroll
+  for (int j = 0; j < NDL; ++j)
+    if (tid + j * NTH < K * C) sDW[tid + j * NTH] = dl[j];
+  for (int i = RA * P + tid; i < RAP * P; i += NTH) {   // rows only the padded windows touch
+    sP[i] = 0.f;
+    sDU[i] = 0.f;
+  }
+  f32x4 dwacc[Roles::NTW];
+#pragma unroll
+  for (int nt = 0; nt < Roles::NTW; ++nt) dwacc[nt] = zero4();
+  if (chunk == 0) {
+    sAct[c] = sc_c;
+    sAct[C + c] = sh_c;
+  }
+  // sP holds a = relu(BN_{k-1}(p_{k-1})); the ReLU decision of a unit is a > 0 and its x-hat = a * xk1 + xk0 (see bwd_block_body.inc)
+  float xk1 = sc_c != 0.f ? rs_c / sc_c : 0.f;
+  float xk0 = -(sh_c + mu_c * sc_c) * xk1;
+  pin(dwb); pin(xk1); pin(xk0);
+  __syncthreads();
+
+  for (int it = 0; it < nitems; ++it) {
+    rotate_priority(it, 2);
+    const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
+    const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
+    // ---- P0: commit the activated input rows [t0, t0 + RA) (zero past the sample), the dp rows; roll the du ring
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = tid + j * NTH;
+      if (i < RA * Q) {
+        const int r = i / Q, q = i - r * Q;
+        const float4 s4 = *reinterpret_cast<const float4*>(sAct + q * 4), h4 = *reinterpret_cast<const float4*>(sAct + C + q * 4);
+        float4 v = pre_p[j];
+        v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+        lds_store4<P>(sP + r * P + q * 4, v);
+      }
+    }
+    dps.commit(sDP, sKp, pre_dz, nrows_new * Q, tid);
+    for (int i = tid; i < (K - 1) * P; i += NTH) sDU[i] = (t0 == 0) ? 0.f : sDU[TT * P + i];
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    // ---- P1: recompute u = depthwise(a) + bias for the tile's output rows
+    if (dw_active) {
+      if (chunk * L < nrows_new) {
+        float o[L];
+#pragma unroll
+        for (int t = 0; t < L; ++t) o[t] = dwb;
+        dw_all_groups<K, L, false>(sP + chunk * L * P + c, P, sDW + c, C, o);
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int tl = chunk * L + t;
+          sU[tl * P + c] = (tl < nrows_new) ? o[t] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < L; ++t) sU[(chunk * L + t) * P + c] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
+    if constexpr (C == 48 && NW == 8) {
+      if (wave < 6) {
+        wide_dw_rows<3, 32 / (D > 4 ? 32 : 16), (D > 4 ? 32 : 16), D, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
+        wide_du_tiles<C, 1, K, P, PW, WP::C128>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
+      } else {
+        wide_du_tiles<C, 3, K, P, PW, WP::C128>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
+      }
+    } else if constexpr (C == 48 && NW == 6) {
+      if (wave < 3) wide_dw_rows<3, 64 / (D > 4 ? 32 : 16), (D > 4 ? 32 : 16), D, P>(sU, sDP, 0, nrows_new, 16 * wave, 0, r16, g, dwacc);
+      else wide_du_column<C, 4, K, P, PW>(sDP, sWt, sDU, nrows_new, 16 * (wave - 3), r16, g);
+    } else {
+      wide_dw_rows<2, 4, 16, D, P>(sU, sDP, 0, nrows_new, 16 * (wave / 2), 32 * (wave % 2), r16, g, dwacc);
+      wide_du_tiles<C, 2, K, P, PW, WP::C128>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
+    }
+    __syncthreads();
+    // ---- P4: depthwise backward in two passes over the same registers.  No divergent branch around the global stores:
+    // the lanes past the last chunk shadow it, their stores are out of range and their sums are dropped by the epilogue.
+    {
+      const int cch = dw_active ? chunk : NCH - 1;
+      const BufRsrc gtile = tile_rsrc(elem_ptr<SB>(a.g_out, ((size_t)b * a.Tin + t0) * C), rows_da * C * elem_bytes(SB));
+      const int goff = (dw_active ? 0 : kOobOffset / 4) + cch * L * C + c;
+      const float* wdu_p = sDU + cch * L * P + c;
+      const float* wa_p = sP + cch * L * P + c;
+      {
+        // pass A: da[sl] = sum_j w[K-1-j] * du_ring[sl + j] (in tap groups), ReLU mask, store g_{k-1}, its BN sums
+        float da[L], am[L];
+#pragma unroll
+        for (int t = 0; t < L; ++t) da[t] = 0.f;
+        if (cch * L < rows_da) dw_all_groups<K, L, true>(wdu_p, P, sDW + c, C, da);   // ring rows past the tile are allocated and zero
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < L; ++t) am[t] = wa_p[t * P];
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const int sl = cch * L + t;
+          // (rows past TT of the last chunk belong to the next tile: their da is still partial, rows_da <= TT drops them)
+          const float gg = (sl < rows_da && am[t] > 0.f) ? da[t] : 0.f;
+          tile_store1s<SB, MWW_AUX_ST_G>(gtile, goff + t * C, gg);
+          gs1 += gg;
+          gs2 = fmaf(gg, fmaf(am[t], xk1, xk0), gs2);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (cch * L < nrows_new) {
+        // pass B: dW_dw[i] += sum_t du[t] * a[t + i] ; db += sum_t du[t]   (du[t] = ring row K-1 + chunk L + t)
+        float duk[L];
+#pragma unroll
+        for (int t = 0; t < L; ++t) duk[t] = wdu_p[(K - 1 + t) * P];
+#pragma unroll
+        for (int t = 0; t < L; ++t) accb += duk[t];
+        dw_wgrad_all_groups<K, L>(wa_p, P, duk, accw);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: per-workgroup partial rows [K*C (dW_dw) | C (db) | C*C (dW_pw)] and the BN sums of g_{k-1}
+  float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * C + C * C);
+  float* scratch = smem;
+  if (Roles::has_dw(wave)) {
+    float* sp = scratch + Roles::part(wave) * C * C + (Roles::mt(wave) * 16 + g * 4) * C + Roles::nt0(wave) * 16 + r16;
+#pragma unroll
+    for (int nt = 0; nt < Roles::NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sp[r * C + nt * 16] = dwacc[nt][r];
+  }
+  __syncthreads();
+  for (int e = tid; e < C * C; e += NTH) {
+    float v = scratch[e];
+    if constexpr (Roles::NPART == 2) v += scratch[C * C + e];
+    store_stream<MWW_AUX_ST_GP>(gdst + (K + 1) * C + e, v);
+  }
+  __syncthreads();
+  if (dw_active) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) scratch[(chunk * (K + 1) + i) * C + c] = accw[i];
+    scratch[(chunk * (K + 1) + K) * C + c] = accb;
+  }
+  __syncthreads();
+  for (int e = tid; e < (K + 1) * C; e += NTH) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v += scratch[j * (K + 1) * C + e];
+    store_stream<MWW_AUX_ST_GP>(gdst + e, v);
+  }
+  __syncthreads();
+  if (dw_active) {
+    scratch[(chunk * 2 + 0) * C + c] = gs1;
+    scratch[(chunk * 2 + 1) * C + c] = gs2;
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v += scratch[j * 2 * C + tid];
+    publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * C, 2 * C, tid, v);
+  }
+}
+
+}  // namespace mww

@@ -354,27 +354,24 @@ __device__ __forceinline__ void write_stat_partials(float (&s1)[NT], float (&s2)
 // HBM for bwd_first_kernel.  The depthwise / pointwise part of the tile then produces the output rows
 // [64 i - (K-1), 64 i + 64 - (K-1)) that those ring rows complete.
 // LDS of the first-block / block stages as float offsets into a fused launch's LDS array
-template <int K1, int C1, int COUT, int K, int S>
+template <int K1, int C1, int COUT, int K, int S, bool BF = false>
 struct FwdFirstLds {
-  static constexpr int CP1 = pitch(C1), RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
+  static constexpr int CP1 = pitch(C1), CPU = pitch_fu(C1, BF), RAP = halo_rows_padded(C1, K), TTP = tile_rows_padded(C1);
   static constexpr int TAIL = S > 1 ? K - 1 : 0;   // extra a0 rows of a single-tile window (fwd_first_body.inc "tail rows")
   static constexpr int XR = (TT + TAIL - 1) * S + K1, PX = FBINS + 1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
-  static constexpr int X = 0, A = X + up4(XR * PX), U = A + RAP * CP1, RED = U + TTP * CP1, XG = RED + 4 * 2 * COUT;
-  static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);
 };
-template <int CIN, int COUT, int K>
+template <int CIN, int COUT, int K, bool BF = false>
 struct FwdBlockLds {
-  static constexpr int CPI = pitch(CIN), RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
-  static constexpr int A = 0, U = A + RAP * CPI, RED = U + TTP * CPI, SCALE = RED + 4 * 2 * COUT, SHIFT = SCALE + CIN, END = SHIFT + CIN;
+  static constexpr int CPA = pitch_fa(CIN), CPU = pitch_fu(CIN, BF), RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
 };
 
 template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
-  typedef FwdFirstLds<K1, C1, COUT, K, S> Lds;
+  typedef FwdFirstLds<K1, C1, COUT, K, S, BF> Lds;
   __shared__ __attribute__((aligned(16))) float sX[Lds::XR * Lds::PX];
   __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CP1];
-  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CP1];
+  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPU];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ XShared sXg;
 #include "fwd_first_body.inc"
@@ -383,9 +380,9 @@ __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4))
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int K, bool BF, bool SB = false>
 __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void fwd_block_kernel(FwdBlockArgs a) {
-  typedef FwdBlockLds<CIN, COUT, K> Lds;
-  __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CPI];
-  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPI];
+  typedef FwdBlockLds<CIN, COUT, K, BF> Lds;
+  __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CPA];
+  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPU];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ __attribute__((aligned(16))) float sScale[CIN];
   __shared__ __attribute__((aligned(16))) float sShift[CIN];
@@ -442,6 +439,7 @@ __device__ __forceinline__ double reduce_partials_256(const float* part, int G, 
   return r;
 }
 
+#ifndef MWW_BLOCK_TU   // defined once, in mww_lib.hip (the block-kernel translation units skip it)
 __global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalizeArgs a) {
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   __shared__ double sOut[2];
@@ -474,6 +472,7 @@ __global__ __launch_bounds__(kThreads) void bn_fwd_finalize_kernel(BnFwdFinalize
     }
   }
 }
+#endif
 
 // sync-BN: this rank's partials [G][2][C] -> sums [2][C] in a fixed order, ready to be all-reduced
 struct StatCollapseArgs {
@@ -481,12 +480,14 @@ struct StatCollapseArgs {
   int G, C;
   float* out;   // [2][C]
 };
+#ifndef MWW_BLOCK_TU   // defined once, in mww_lib.hip (the block-kernel translation units skip it)
 __global__ __launch_bounds__(kThreads) void stat_collapse_kernel(StatCollapseArgs a) {
   __shared__ __attribute__((aligned(16))) double sAcc[256 + 16];
   const int tid = threadIdx.x, c = blockIdx.x;
   const double r = reduce_partials_256(a.part, a.G, a.C, c, sAcc, tid);
   if ((tid & 127) == 0) a.out[(tid >> 7) * a.C + c] = (float)r;
 }
+#endif
 
 // inference: fold the moving statistics of every BN layer (state = [mean|var] per layer, packed)
 struct BnEvalPrepareArgs {
@@ -499,6 +500,7 @@ struct BnEvalPrepareArgs {
   int C;
 };
 
+#ifndef MWW_BLOCK_TU   // defined once, in mww_lib.hip (the block-kernel translation units skip it)
 __global__ void bn_eval_prepare_kernel(BnEvalPrepareArgs a) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < a.C) {
@@ -508,5 +510,6 @@ __global__ void bn_eval_prepare_kernel(BnEvalPrepareArgs a) {
     a.shift[c] = a.beta[c] - a.moving_mean[c] * sc;
   }
 }
+#endif
 
 }  // namespace mww

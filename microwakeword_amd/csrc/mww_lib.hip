@@ -13,12 +13,16 @@
 #include <vector>
 
 #include "../../include/mww.h"
-#include "kernels_bwd.hip.h"
+#include "block_launch.hip.h"
 #include "kernels_data.hip.h"
-#include "kernels_fwd.hip.h"
 #include "kernels_graph.hip.h"
 #include "kernels_head.hip.h"
 #include "kernels_tail.hip.h"
+
+// threads per workgroup of the fp32 block backward kernels (option "bwd_wide"; kernels_bwdw.hip.h)
+#ifndef MWW_BWD_WIDE_DEFAULT
+#define MWW_BWD_WIDE_DEFAULT 0
+#endif
 
 using namespace mww;
 
@@ -112,6 +116,7 @@ struct mww_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int grid_fwd = 0, grid_bwd = 0, grid_head = 0;
+  int bwd_wide = MWW_BWD_WIDE_DEFAULT;   // threads per workgroup of the block backward kernels: 0 = 256 (bwd_block_kernel), 384 / 512 = bwd_blockw_kernel
   int64_t P = 0, S = 0;
   int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
   int t_last = 0, c_last = 0, dwd_stride = 0;
@@ -248,88 +253,27 @@ struct Launcher {
 };
 
 // ---------------------------------------------------------------------------------- dispatch
-// (conv1 kernel, conv1 filters, block-1 pointwise filters, block-1 depthwise kernel, conv1 stride)
-// Shapes with specialised block kernels: the reference's argparse defaults (3x1 first conv, 48 filters, [5],[9],[13],[21]),
-// its training notebook (5x1 first conv stride 3, 64 filters, [5],[7,11],[9,15],[23] - multi-kernel groups are fused to
-// their longest kernel) and the crosses of the two (either width with either kernel set, either first conv); everything
-// else runs on the conv / depthwise graph kernels.
-#ifdef MWW_SLIM   // kernel-tuning builds (tools/build_variant.sh): the default topology only, compiles in a quarter of the time
-#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1)
-#define MWW_BLOCK_SHAPES(X) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21)
-#else
-#define MWW_FIRST_SHAPES(X) X(3, 32, 48, 5, 1) X(5, 32, 64, 5, 3) X(5, 32, 64, 5, 1) X(3, 32, 64, 5, 1) X(5, 32, 48, 5, 3) X(5, 32, 48, 5, 1)
-#define MWW_BLOCK_SHAPES(X)                                                                               \
-  X(48, 48, 5) X(48, 48, 9) X(48, 48, 13) X(48, 48, 21) X(48, 48, 11) X(48, 48, 15) X(48, 48, 23)         \
-  X(64, 64, 11) X(64, 64, 15) X(64, 64, 23) X(64, 64, 5) X(64, 64, 9) X(64, 64, 13) X(64, 64, 21)
-#endif
-
+// The block kernels are instantiated and launched in their own translation units (tu_fwd.hip, tu_bwd.hip, tu_bwdw.hip:
+// compiled in parallel by build()); block_launch.hip.h declares their launchers and the table of specialised shapes.
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
-#define X(K1, C1, CO, K, S)                                                                                    \
-  if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    if (c->st_bf16)                                                                                            \
-      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else if (c->pw_bf16)                                                                                       \
-      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else                                                                                                       \
-      hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    return MWW_OK;                                                                                             \
-  }
-  MWW_FIRST_SHAPES(X)
-#undef X
+  if (k_launch_fwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block kernel for this (conv1 kernel, filters, pointwise, depthwise) shape");
 }
 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
-#define X(K1, C1, CO, K, S)                                                                                    \
-  if (k1 == K1 && c1 == C1 && cout == CO && k == K && st == S) {                                               \
-    if (c->st_bf16)                                                                                            \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else if (c->pw_bf16)                                                                                       \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else                                                                                                       \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    return MWW_OK;                                                                                             \
-  }
-  MWW_FIRST_SHAPES(X)
-#undef X
+  if (k_launch_bwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block backward kernel for this shape");
 }
 
 int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a, int grid) {
-#define X(CI, CO, K)                                                                                           \
-  if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (c->st_bf16)                                                                                            \
-      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else if (c->pw_bf16)                                                                                       \
-      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);    \
-    else                                                                                                       \
-      hipLaunchKernelGGL((fwd_block_kernel<CI, CO, K, false>), dim3(grid), dim3(kThreads), 0, c->stream, a);   \
-    return MWW_OK;                                                                                             \
-  }
-  MWW_BLOCK_SHAPES(X)
-#undef X
+  if (k_launch_fwd_block(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), cin, cout, k, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no block kernel for this (cin, cout, depthwise) shape");
 }
 
 int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
-#define X(CI, CO, K)                                                                                           \
-  if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (last && c->st_bf16)                                                                                    \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
-    else if (c->st_bf16)                                                                                       \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else if (last && c->pw_bf16)                                                                               \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, c->stream, a);  \
-    else if (last)                                                                                             \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else if (c->pw_bf16)                                                                                       \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    else                                                                                                       \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, false>), dim3(grid), dim3(kThreads), 0, c->stream, a); \
-    return MWW_OK;                                                                                             \
-  }
-  MWW_BLOCK_SHAPES(X)
-#undef X
+  // wide-workgroup form: fp32 arithmetic and storage only
+  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_blockw(c->stream, c->bwd_wide, cin, cout, k, last, a, grid)) return MWW_OK;
+  if (k_launch_bwd_block(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), cin, cout, k, last, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no block backward kernel for this shape");
 }
 
@@ -2070,7 +2014,7 @@ int open_device(mww_ctx* c, int device, void* stream) {
 // ====================================================================================== C ABI
 extern "C" {
 
-const char* mww_version(void) { return "mww-hip 0.1 (gfx950)"; }
+// mww_version(): version.cpp (carries the sha256 of the source set the library was built from)
 const char* mww_last_error(void) { return g_err.c_str(); }
 
 int mww_device_count(void) {
@@ -3106,6 +3050,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
     c->st_bf16 = v != 0;
     if (v) c->pw_bf16 = true;
   }
+  else if (!strcmp(name, "bwd_wide")) { if (v != 0 && v != 384 && v != 512) return fail(MWW_ERR_INVALID, "bwd_wide must be 0, 384 or 512"); c->bwd_wide = (int)v; }
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_graph")) {   // 0: per-launch grids by occupancy (default); > 0: this many workgroups per launch

@@ -83,6 +83,10 @@ def claim_train_dir(config, restore_checkpoint):
 
 
 def train_model(config, model, data_processor, restore_checkpoint):
+    """model_train_eval.py:99-128: claims ``train_dir`` (a fresh directory, or an existing one only with
+    ``restore_checkpoint``: "model already exists" otherwise), writes the configuration and the model summary, trains.
+    Called once the model and the data processor exist - as in the reference - so a set-up failure leaves no directory."""
+    claim_train_dir(config, restore_checkpoint)
     if train_mod.process_group()[0] == 0:
         with open(os.path.join(config["train_dir"], "training_config.yaml"), "w") as outfile:
             yaml.dump({k: v for k, v in config.items() if k != "features" or all("stores" not in f for f in v)}, outfile,
@@ -165,7 +169,6 @@ def _run(flags, model_module, rank, local_rank, world):
                                   "train here, then load the saved weights there (INTEGRATION.md)")
     config = load_config(flags, model_module)
     if flags.train:
-        claim_train_dir(config, flags.restore_checkpoint)
         device = flags.device if local_rank is None else local_rank
         if world > 1 and config["batch_size"] % world:
             raise ValueError("batch_size %d (the global batch) is not divisible by the %d ranks" % (config["batch_size"], world))

@@ -29,18 +29,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build_emulator_lib():
     """TEST INFRASTRUCTURE: compiles the unchanged product HIP sources as host C++ against tests/hipemu
     (fibers + emulated wave ops) and returns the path of the resulting library, or None without clang++."""
-    import subprocess
-    csrc = os.path.join(ROOT, "microwakeword_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("mww_lib.hip", "sampler.cpp")] + [os.path.join(ROOT, "tests", "hipemu", "hipemu.cpp")]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc)]
-    deps += [os.path.join(ROOT, "include", "mww.h"), os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h")]
-    if not os.path.isfile(CLANG):
-        return None
-    if not os.path.isfile(EMU) or any(os.path.getmtime(d) > os.path.getmtime(EMU) for d in deps):
-        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "hipemu"),
-               "-I", os.path.join(ROOT, "include"), "-Wno-unused-value", "-pthread"] + srcs + ["-o", EMU, "-ldl"]
-        subprocess.run(cmd, check=True)
-    return EMU
+    from microwakeword_amd import build_native
+    return build_native.build_emulator(EMU)
 
 
 @pytest.fixture(scope="session")

@@ -41,6 +41,8 @@ def make_engine(lib, T, max_batch, om=None, flags=DEF):
         eng.set_option("pointwise_bf16", 1)
     if flags.get("st_bf16"):
         eng.set_option("storage_bf16", 1)
+    if flags.get("bwd_wide") is not None:   # threads per workgroup of the block backward kernels (kernels_bwdw.hip.h)
+        eng.set_option("bwd_wide", flags["bwd_wide"])
     if om is not None:
         p, s = lay.pack(om.get_weights())
         eng.set_params(p)

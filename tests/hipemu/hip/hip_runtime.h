@@ -176,6 +176,8 @@ static inline void hipemu_setprio(int) {}
 #define __builtin_amdgcn_s_setprio hipemu_setprio
 static inline void hipemu_sched_group_barrier(int, int, int) {}
 #define __builtin_amdgcn_sched_group_barrier hipemu_sched_group_barrier
+static inline void hipemu_sched_barrier(int) {}
+#define __builtin_amdgcn_sched_barrier hipemu_sched_barrier
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

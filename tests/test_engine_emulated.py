@@ -296,3 +296,19 @@ def test_inception_stem_gathers_descriptor_only_batches(emu_lib):
     ec.check_inception_gathered_stem(emu_lib, cases=1, B=4, lengths=(194,), rounds=1)
     ec.check_inception_gathered_stem(emu_lib, cases=1, first=4, B=6, grid=2, graphs=(1,), lengths=(150,), rounds=2)
 
+
+
+@pytest.mark.parametrize("threads", [384, 512])
+def test_wide_block_backward_kernels(emu_lib, threads):
+    """bwd_blockw_kernel (kernels_bwdw.hip.h): the block backward with 384 / 512 threads per 64-row tile."""
+    flags = dict(ec.DEF, bwd_wide=threads)
+    ec.check_train_steps(emu_lib, B=5, T=194, steps=2, grid=2, flags=flags)
+    ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4, flags=flags)
+    ec.check_gradients_unimposed(emu_lib, B=6, T=130, bound=1e-2, flags=flags)
+    ec.check_train_steps(emu_lib, B=2, T=60, steps=1, grid=1, graphs=True, flags=flags)
+
+
+def test_wide_block_backward_kernels_notebook_and_crosses(emu_lib):
+    ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=dict(ec.NOTEBOOK, bwd_wide=512))
+    for flags in ec.CROSSED[:3]:
+        ec.check_train_steps(emu_lib, B=3, T=204 if flags.get("stride", 1) == 3 else 150, steps=1, grid=2, flags=dict(flags, bwd_wide=512))

@@ -385,3 +385,53 @@ def test_bench_traffic_figure_is_tied_to_the_library_it_was_measured_on(tmp_path
     assert first.startswith("# library sha256_16=")
     if os.path.isfile(bench.LIBRARY):
         assert first.endswith(bench.library_sha16())
+
+
+def test_train_model_claims_the_directory_like_the_reference(tmp_path, monkeypatch):
+    """model_train_eval.py:99-128: a fresh train_dir is created, an existing one is an error unless restore_checkpoint."""
+    calls = []
+    monkeypatch.setattr(model_train_eval.train_mod, "train", lambda model, config, dp: calls.append("train") or "done")
+    monkeypatch.setattr(model_train_eval, "save_model_summary", lambda model, path, file_name="model_summary.txt": calls.append("summary"))
+    cfg = {"train_dir": str(tmp_path / "run"), "summaries_dir": str(tmp_path / "run" / "logs"), "features": []}
+    assert model_train_eval.train_model(cfg, object(), object(), 0) == "done"
+    assert os.path.isfile(os.path.join(cfg["train_dir"], "training_config.yaml")) and os.path.isdir(cfg["summaries_dir"])
+    with pytest.raises(ValueError, match="model already exists"):
+        model_train_eval.train_model(cfg, object(), object(), 0)
+    assert model_train_eval.train_model(cfg, object(), object(), 1) == "done"
+    assert calls == ["summary", "train", "summary", "train"]
+
+
+def test_source_stamp_of_the_library(tmp_path, monkeypatch):
+    """build_native: the stamp compiled into the library (mww_version()) is the sha256 of csrc/* + include/mww.h;
+    __graft_entry__.build() rebuilds exactly when the library's stamp differs from the tree's."""
+    import importlib
+    from microwakeword_amd import build_native as bn
+    tree = bn.source_sha16()
+    assert len(tree) == 16 and tree == bn.source_sha16()
+    fake = tmp_path / "lib.so"
+    fake.write_bytes(b"\x7fELF....mww-hip 0.1 (gfx950) src=%s\0...." % tree.encode())
+    assert bn.library_source_sha16(str(fake)) == tree
+    fake.write_bytes(b"\x7fELF....mww-hip 0.1 (gfx950)\0....")     # a library from before the stamp
+    assert bn.library_source_sha16(str(fake)) is None
+    assert bn.library_source_sha16(str(tmp_path / "missing.so")) is None
+    # both branches of build(): up to date -> nothing compiled; stamp differs -> build_library is called
+    ge = importlib.import_module("__graft_entry__")
+    built = []
+    monkeypatch.setattr(bn, "build_library", lambda out, **kw: built.append(out) or 1)
+    state = {"sha": tree}
+    monkeypatch.setattr(bn, "library_source_sha16", lambda path=bn.LIB: state["sha"])
+    monkeypatch.setattr(bn, "library_sha16", lambda path=bn.LIB: "0" * 16)
+    monkeypatch.setattr(ge.os.path, "getmtime", lambda p: 0.0)
+    import microwakeword_amd.native as native
+
+    class _NL:
+        def __init__(self, path): pass
+        def version(self): return "stub"
+    monkeypatch.setattr(native, "NativeLib", _NL)
+    monkeypatch.setattr("builtins.open", lambda *a, **k: (_ for _ in ()).throw(OSError("no build_info in this test")) if str(a[0]).endswith("build_info.json") else open.__wrapped__(*a, **k) if hasattr(open, "__wrapped__") else __import__("io").open(*a, **k))
+    ge.build()
+    assert built == []
+    state["sha"] = "f" * 16
+    with pytest.raises(RuntimeError, match="does not carry"):   # the stubbed build changes nothing, which build() must notice
+        ge.build()
+    assert built == [ge.LIB]
