@@ -17,6 +17,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernel
 print('$lab', d['ms_per_step'], 'host', d.get('host_enqueue_ms_per_step'), {n:round(v*1e3,1) for n,v in k.items()})" | tee -a $OUT/summary.txt
 }
 for rep in 1 2; do
+  MWW_HIP_LIB=$R/microwakeword_amd/libmww_r5base.so MWW_BENCH_OPTIONS=bwd_wide=0 line "B1024 c+4-pitches(r5base) wide=0" --steps 200 --warmup 20
   for w in 0 384 512; do
     MWW_BENCH_OPTIONS=bwd_wide=$w line "B1024 wide=$w" --steps 200 --warmup 20
   done
