@@ -1,9 +1,10 @@
 // Wide-workgroup form of the block backward kernel (round 5).  Same arithmetic, same inputs / outputs / partial-row
 // layout as bwd_block_kernel (kernels_bwd.hip.h, reference: TF autodiff of microwakeword/mixednet.py:334-360), but a
-// 64-row time tile is shared by NTH = 384 or 512 threads instead of 256, with register budgets that let a CU hold
-// three or four waves per SIMD instead of two:
+// 64-row time tile is shared by NTH = 512 threads instead of 256, with a register budget (128) that lets a CU hold four
+// waves per SIMD instead of two (a 384-thread form - six waves, three per SIMD - was built and lost: 56-63 us per launch
+// against 44-54, profiles/round5_bwd_forms_ab.txt; six waves leave two of the four SIMDs with twice the MFMA work):
 //
-//   * VALU phases: thread -> (channel, chunk) with NTH / C chunks of L = 7 or 8 rows (256 threads: 13): the register
+//   * VALU phases: thread -> (channel, chunk) with NTH / C chunks of L = 7 (C = 48) or 8 (C = 64) rows (256 threads: 13 / 16): the register
 //     windows of the depthwise phases shrink from L + K - 1 = 33 to 27 values at K = 21, and the one-pass depthwise
 //     backward is split into an input-gradient pass and a weight-gradient pass that reuse the same registers;
 //   * MFMA phase: waves own OUTPUT tiles instead of row slices.  A wave of the 256-thread kernel accumulates the whole
@@ -23,37 +24,19 @@ namespace mww {
 
 // P: row pitch of the activation / gradient tiles; D: row distance between the four k-values of one dW k-step
 // (rows s + D g of a block of 4 D rows, g = lane >> 4: a 32-lane LDS group holds two of them and D * P = 16 mod 32 keeps
-// their banks disjoint); C128: the du A operand (lanes across rows, fixed column) is read as one float4 per lane =
-// the lane's k of four k-steps (k = 16 kb + 4 g + s), else as one dword per k-step (k = 4 kk + g); PW: pitch of W^T,
-// whose rows are read 4 apart (C128) or 1 apart.
+// their banks disjoint).  The du A operand (lanes across rows, fixed column) is read as one float4 per lane = the lane's k of
+// four k-steps (k = 16 kb + 4 g + s: two-way conflicts at P = 48, i.e. the rate of four conflict-free dword reads; none at
+// 72); PW: pitch of W^T, whose rows are then read 4 apart (4 PW = 16 mod 32).
 template <int C, int NTH>
 struct WidePitch;
 template <>
 struct WidePitch<48, 512> {
   static constexpr int P = 48, D = 1, PW = 52;
-  static constexpr bool C128 = true;
-};
-template <>
-struct WidePitch<48, 384> {
-  static constexpr int P = 50, D = 8, PW = 48;
-  static constexpr bool C128 = false;
 };
 template <>
 struct WidePitch<64, 512> {
   static constexpr int P = 72, D = 2, PW = 68;
-  static constexpr bool C128 = true;
 };
-
-// four floats to LDS at a row whose pitch may be 8-byte aligned only
-template <int P>
-__device__ __forceinline__ void lds_store4(float* dst, const float4& v) {
-  if constexpr (P % 4 == 0) {
-    *reinterpret_cast<float4*>(dst) = v;
-  } else {
-    *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
-    *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
-  }
-}
 
 // dp tile of the wide kernel (DpStage with the thread count and the pitch as parameters)
 template <int C, bool LAST, bool SB, int NTH, int P>
@@ -98,7 +81,7 @@ struct DpStageW {
           dp.z = fmaf(g.z, c1.z, fmaf(p.z, kA.z, kB.z));
           dp.w = fmaf(g.w, c1.w, fmaf(p.w, kA.w, kB.w));
         }
-        lds_store4<P>(sDP + r * P + q * 4, dp);
+        *reinterpret_cast<float4*>(sDP + r * P + q * 4) = dp;
       }
     }
   }
@@ -140,52 +123,31 @@ __device__ __forceinline__ void wide_dw_rows(const float* sU, const float* sDP, 
 
 // du tiles of one wave: du[mu] = DP[16 rows of tile rt, :] W^T[:, mcol0 + 16 mu ..], stored to the ring rows
 // [K-1 + 16 rt, +16).  A tile past the sample's last output row only writes its zeros.
-template <int C, int NMU, int K, int P, int PW, bool C128>
+template <int C, int NMU, int K, int P, int PW>
 __device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt, float* sDU, int rt, int nrows, int mcol0,
                                               int r16, int g) {
   f32x4 du[NMU];
 #pragma unroll
   for (int mu = 0; mu < NMU; ++mu) du[mu] = zero4();
   if (rt * 16 < nrows) {   // wave-uniform
-    if constexpr (C128) {
-      const float* pa = sDP + (rt * 16 + r16) * P + 4 * g;
-      const float* pb = sWt + (4 * g) * PW + mcol0 + r16;
-      float4 a4[2];
-      a4[0] = *reinterpret_cast<const float4*>(pa);
+    const float* pa = sDP + (rt * 16 + r16) * P + 4 * g;
+    const float* pb = sWt + (4 * g) * PW + mcol0 + r16;
+    float4 a4[2];
+    a4[0] = *reinterpret_cast<const float4*>(pa);
 #pragma unroll
-      for (int kb = 0; kb < C / 16; ++kb) {
-        if (kb + 1 < C / 16) a4[(kb + 1) & 1] = *reinterpret_cast<const float4*>(pa + (kb + 1) * 16);
-        float bv[4][NMU];
+    for (int kb = 0; kb < C / 16; ++kb) {
+      if (kb + 1 < C / 16) a4[(kb + 1) & 1] = *reinterpret_cast<const float4*>(pa + (kb + 1) * 16);
+      float bv[4][NMU];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int mu = 0; mu < NMU; ++mu) bv[s][mu] = pb[(kb * 16 + s) * PW + mu * 16];
-        const float4 av = a4[kb & 1];
-        const float as[4] = {av.x, av.y, av.z, av.w};
+        for (int mu = 0; mu < NMU; ++mu) bv[s][mu] = pb[(kb * 16 + s) * PW + mu * 16];
+      const float4 av = a4[kb & 1];
+      const float as[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(as[s], bv[s][mu], du[mu]);
-      }
-    } else {
-      const float* pa = sDP + (rt * 16 + r16) * P + g;
-      const float* pb = sWt + g * PW + mcol0 + r16;
-      float av[2], bv[2][NMU];
-      auto ld = [&](int kk, int s) {
-        av[s] = pa[kk * 4];
-#pragma unroll
-        for (int mu = 0; mu < NMU; ++mu) bv[s][mu] = pb[kk * 4 * PW + mu * 16];
-      };
-      ld(0, 0);
-#pragma unroll
-      for (int kk = 0; kk < C / 4; ++kk) {
-        if (kk + 1 < C / 4) ld(kk + 1, (kk + 1) & 1);
-#pragma unroll
-        for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(av[kk & 1], bv[kk & 1][mu], du[mu]);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 1 + NMU, 0);
-      sched_read_mfma_groups<C / 4 - 1, 1 + NMU, NMU>();
-      sched_read_mfma_groups<1, 0, NMU>();
+        for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(as[s], bv[s][mu], du[mu]);
     }
   }
   float* pd = sDU + (K - 1 + rt * 16 + g * 4) * P + mcol0 + r16;
@@ -194,39 +156,6 @@ __device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt
 #pragma unroll
     for (int r = 0; r < 4; ++r) pd[r * P + mu * 16] = du[mu][r];
 }
-
-// one du tile per (row tile, column tile) with a shared B operand: du[rt] = DP[16 rt .., :] W^T[:, mcol ..] for NRT row tiles
-template <int C, int NRT, int K, int P, int PW>
-__device__ __forceinline__ void wide_du_column(const float* sDP, const float* sWt, float* sDU, int nrows, int mcol, int r16, int g) {
-  f32x4 du[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) du[rt] = zero4();
-  const float* pa = sDP + r16 * P + g;
-  const float* pb = sWt + g * PW + mcol + r16;
-  float av[2][NRT], bv[2];
-  auto ld = [&](int kk, int s) {
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) av[s][rt] = pa[rt * 16 * P + kk * 4];
-    bv[s] = pb[kk * 4 * PW];
-  };
-  ld(0, 0);
-#pragma unroll
-  for (int kk = 0; kk < C / 4; ++kk) {
-    if (kk + 1 < C / 4) ld(kk + 1, (kk + 1) & 1);
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) du[rt] = mfma4(av[kk & 1][rt], bv[kk & 1], du[rt]);
-  }
-  __builtin_amdgcn_sched_group_barrier(0x100, 1 + NRT, 0);
-  sched_read_mfma_groups<C / 4 - 1, 1 + NRT, NRT>();
-  sched_read_mfma_groups<1, 0, NRT>();
-  (void)nrows;   // rows past the sample hold dp = 0: their du is an exact zero
-  float* pd = sDU + (K - 1 + g * 4) * P + mcol + r16;
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pd[(rt * 16 + r) * P] = du[rt][r];
-}
-
 
 // Depthwise sums over a sub-range [I0, I1) of the K taps, for one (channel, chunk): the register window of a phase is
 // L + (I1 - I0) - 1 rows instead of L + K - 1, so long kernels run their phases in two or three tap groups.
@@ -285,8 +214,6 @@ __device__ __forceinline__ void dw_wgrad_all_groups(const float* src_c, int pitc
 // MFMA work of the waves of one workgroup (288 MFMAs per tile at C = 48, 512 at C = 64, dealt evenly):
 //   C = 48, 8 waves: waves 0-5 own the dW tiles (mt = w % 3, nt = 0..2) over the row half w / 3 (24 MFMAs) and the du
 //                    tile (rt = 2 + w / 3, mt = w % 3) (12); waves 6, 7 own the du tiles (rt = w - 6, mt = 0..2) (36)
-//   C = 48, 6 waves: waves 0-2 own the dW tiles (mt = w, nt = 0..2) over all 64 rows (48); waves 3-5 the du column
-//                    mt = w - 3 of all four row tiles (48)
 //   C = 64, 8 waves: every wave owns the dW tiles (mt = w / 2, nt = 2 (w % 2) + {0, 1}) over all rows (32) and the du
 //                    tiles (rt = w / 2, mt = 2 (w % 2) + {0, 1}) (32)
 template <int C, int NW>
@@ -297,14 +224,6 @@ struct WideRoles<48, 8> {
   static __device__ __forceinline__ bool has_dw(int w) { return w < 6; }
   static __device__ __forceinline__ int part(int w) { return w / 3; }
   static __device__ __forceinline__ int mt(int w) { return w % 3; }
-  static __device__ __forceinline__ int nt0(int) { return 0; }
-};
-template <>
-struct WideRoles<48, 6> {
-  static constexpr int NTW = 3, NPART = 1;
-  static __device__ __forceinline__ bool has_dw(int w) { return w < 3; }
-  static __device__ __forceinline__ int part(int) { return 0; }
-  static __device__ __forceinline__ int mt(int w) { return w; }
   static __device__ __forceinline__ int nt0(int) { return 0; }
 };
 template <>
@@ -460,7 +379,7 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
         v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
         v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f);
         v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
-        lds_store4<P>(sP + r * P + q * 4, v);
+        *reinterpret_cast<float4*>(sP + r * P + q * 4) = v;
       }
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * Q, tid);
@@ -488,17 +407,14 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
     if constexpr (C == 48 && NW == 8) {
       if (wave < 6) {
-        wide_dw_rows<3, 32 / (D > 4 ? 32 : 16), (D > 4 ? 32 : 16), D, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
-        wide_du_tiles<C, 1, K, P, PW, WP::C128>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
+        wide_dw_rows<3, 2, 16, D, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
+        wide_du_tiles<C, 1, K, P, PW>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
       } else {
-        wide_du_tiles<C, 3, K, P, PW, WP::C128>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
+        wide_du_tiles<C, 3, K, P, PW>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
       }
-    } else if constexpr (C == 48 && NW == 6) {
-      if (wave < 3) wide_dw_rows<3, 64 / (D > 4 ? 32 : 16), (D > 4 ? 32 : 16), D, P>(sU, sDP, 0, nrows_new, 16 * wave, 0, r16, g, dwacc);
-      else wide_du_column<C, 4, K, P, PW>(sDP, sWt, sDU, nrows_new, 16 * (wave - 3), r16, g);
     } else {
       wide_dw_rows<2, 4, 16, D, P>(sU, sDP, 0, nrows_new, 16 * (wave / 2), 32 * (wave % 2), r16, g, dwacc);
-      wide_du_tiles<C, 2, K, P, PW, WP::C128>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
+      wide_du_tiles<C, 2, K, P, PW>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
     }
     __syncthreads();
     // ---- P4: depthwise backward in two passes over the same registers.  No divergent branch around the global stores:

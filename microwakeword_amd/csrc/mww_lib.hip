@@ -19,9 +19,9 @@
 #include "kernels_head.hip.h"
 #include "kernels_tail.hip.h"
 
-// threads per workgroup of the fp32 block backward kernels (option "bwd_wide"; kernels_bwdw.hip.h)
+// the fp32 block backward runs as the wide-workgroup form (option "bwd_wide"; kernels_bwdw.hip.h) unless told otherwise
 #ifndef MWW_BWD_WIDE_DEFAULT
-#define MWW_BWD_WIDE_DEFAULT 0
+#define MWW_BWD_WIDE_DEFAULT 1
 #endif
 
 using namespace mww;
@@ -116,7 +116,7 @@ struct mww_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int grid_fwd = 0, grid_bwd = 0, grid_head = 0;
-  int bwd_wide = MWW_BWD_WIDE_DEFAULT;   // threads per workgroup of the block backward kernels: 0 = 256 (bwd_block_kernel), 384 / 512 = bwd_blockw_kernel
+  bool bwd_wide = MWW_BWD_WIDE_DEFAULT != 0;   // fp32 block backward kernels: 512 threads per workgroup (bwd_blockw_kernel) or 256 (bwd_block_kernel)
   int64_t P = 0, S = 0;
   int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
   int t_last = 0, c_last = 0, dwd_stride = 0;
@@ -272,7 +272,7 @@ int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a
 
 int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
   // wide-workgroup form: fp32 arithmetic and storage only
-  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_blockw(c->stream, c->bwd_wide, cin, cout, k, last, a, grid)) return MWW_OK;
+  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_blockw(c->stream, cin, cout, k, last, a, grid)) return MWW_OK;
   if (k_launch_bwd_block(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), cin, cout, k, last, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no block backward kernel for this shape");
 }
@@ -3050,7 +3050,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
     c->st_bf16 = v != 0;
     if (v) c->pw_bf16 = true;
   }
-  else if (!strcmp(name, "bwd_wide")) { if (v != 0 && v != 384 && v != 512) return fail(MWW_ERR_INVALID, "bwd_wide must be 0, 384 or 512"); c->bwd_wide = (int)v; }
+  else if (!strcmp(name, "bwd_wide")) c->bwd_wide = v != 0;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_graph")) {   // 0: per-launch grids by occupancy (default); > 0: this many workgroups per launch

@@ -11,16 +11,11 @@ static void launch_w(hipStream_t st, bool last, const BwdBlockArgs& a, int grid)
   else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH>), dim3(grid), dim3(NTH), 0, st, a);
 }
 
-// 48-wide blocks: 384 or 512 threads; 64-wide blocks: 512 threads whatever `threads` says
-bool k_launch_bwd_blockw(hipStream_t st, int threads, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
+bool k_launch_bwd_blockw(hipStream_t st, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
   if (cin != cout) return false;
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && k == K) {                                                                                   \
-    if constexpr (CI == CO && CI == 48) {                                                                      \
-      if (threads == 384) launch_w<CI, K, 384>(st, last, a, grid);                                             \
-      else launch_w<CI, K, 512>(st, last, a, grid);                                                            \
-      return true;                                                                                             \
-    } else if constexpr (CI == CO && CI == 64) {                                                               \
+    if constexpr (CI == CO && (CI == 48 || CI == 64)) {                                                        \
       launch_w<CI, K, 512>(st, last, a, grid);                                                                 \
       return true;                                                                                             \
     }                                                                                                          \

@@ -298,10 +298,10 @@ def test_inception_stem_gathers_descriptor_only_batches(emu_lib):
 
 
 
-@pytest.mark.parametrize("threads", [384, 512])
-def test_wide_block_backward_kernels(emu_lib, threads):
-    """bwd_blockw_kernel (kernels_bwdw.hip.h): the block backward with 384 / 512 threads per 64-row tile."""
-    flags = dict(ec.DEF, bwd_wide=threads)
+@pytest.mark.parametrize("wide", [0, 1])
+def test_both_forms_of_the_block_backward_kernels(emu_lib, wide):
+    """bwd_blockw_kernel (kernels_bwdw.hip.h, 512 threads per 64-row tile: the default) and bwd_block_kernel (256)."""
+    flags = dict(ec.DEF, bwd_wide=wide)
     ec.check_train_steps(emu_lib, B=5, T=194, steps=2, grid=2, flags=flags)
     ec.check_train_steps(emu_lib, B=3, T=130, steps=1, grid=4, flags=flags)
     ec.check_gradients_unimposed(emu_lib, B=6, T=130, bound=1e-2, flags=flags)
@@ -309,6 +309,6 @@ def test_wide_block_backward_kernels(emu_lib, threads):
 
 
 def test_wide_block_backward_kernels_notebook_and_crosses(emu_lib):
-    ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=dict(ec.NOTEBOOK, bwd_wide=512))
+    ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=dict(ec.NOTEBOOK, bwd_wide=1))
     for flags in ec.CROSSED[:3]:
-        ec.check_train_steps(emu_lib, B=3, T=204 if flags.get("stride", 1) == 3 else 150, steps=1, grid=2, flags=dict(flags, bwd_wide=512))
+        ec.check_train_steps(emu_lib, B=3, T=204 if flags.get("stride", 1) == 3 else 150, steps=1, grid=2, flags=dict(flags, bwd_wide=1))

@@ -120,12 +120,12 @@ def test_bf16_storage_mode_at_the_baseline_batch_4096(lib):
     ec.check_train_steps(lib, B=4096, T=194, steps=1, grid=0, flags=ec.BF16_STORED)
 
 
-@pytest.mark.parametrize("threads", [0, 384, 512])
-def test_block_backward_kernel_forms(lib, threads):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_block_backward_kernel_forms(lib, wide):
     """Every form of the block backward kernels, whichever is the library's default ("bwd_wide" 0 = 256 threads per 64-row
-    tile: bwd_block_kernel; 384 / 512: bwd_blockw_kernel, kernels_bwdw.hip.h): ragged tiles, several windows per workgroup,
+    tile: bwd_block_kernel; 1 = 512: bwd_blockw_kernel, kernels_bwdw.hip.h): ragged tiles, several windows per workgroup,
     graph replay, then the BASELINE configs[1] size against the float64 oracle with and without the engine's ReLU decisions."""
-    flags = dict(ec.DEF, bwd_wide=threads)
+    flags = dict(ec.DEF, bwd_wide=wide)
     ec.check_train_steps(lib, B=6, T=194, steps=2, grid=0, flags=flags)
     ec.check_train_steps(lib, B=5, T=130, steps=1, grid=3, flags=flags)
     ec.check_train_steps(lib, B=64, T=194, steps=1, grid=16, graphs=True, flags=flags)
@@ -134,21 +134,21 @@ def test_block_backward_kernel_forms(lib, threads):
     assert ec.check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, flags=flags) <= 1e-2
 
 
-@pytest.mark.parametrize("threads", [0, 512])
-def test_block_backward_kernel_forms_64_wide(lib, threads):
-    flags = dict(ec.NOTEBOOK, bwd_wide=threads)
+@pytest.mark.parametrize("wide", [0, 1])
+def test_block_backward_kernel_forms_64_wide(lib, wide):
+    flags = dict(ec.NOTEBOOK, bwd_wide=wide)
     ec.check_train_steps(lib, B=9, T=231, steps=1, grid=8, flags=flags)
     worst = ec.check_train_steps(lib, B=600, T=204, steps=1, grid=0, flags=flags)
     assert worst["l2_max"] <= 1e-4
-    assert ec.check_gradients_unimposed(lib, B=512, T=204, bound=2e-2, flags=dict(ec.CROSSED[4], bwd_wide=threads)) <= 2e-2
+    assert ec.check_gradients_unimposed(lib, B=512, T=204, bound=2e-2, flags=dict(ec.CROSSED[4], bwd_wide=wide)) <= 2e-2
 
 
-@pytest.mark.parametrize("threads", [0, 384, 512])
-def test_determinism_of_the_block_backward_forms(lib, threads):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_determinism_of_the_block_backward_forms(lib, wide):
     outs = []
     for _ in range(2):
         om = ec.perturbed_oracle(194)
-        lay, eng = ec.make_engine(lib, 194, 700, om, flags=dict(ec.DEF, bwd_wide=threads))
+        lay, eng = ec.make_engine(lib, 194, 700, om, flags=dict(ec.DEF, bwd_wide=wide))
         rng = np.random.default_rng(5)
         eng.set_batch(ec.synth_x(rng, 700, 194))
         eng.set_targets((rng.random(700) < 0.5).astype(np.float32), np.ones(700, np.float32))
