@@ -90,22 +90,22 @@ struct DpStageW {
 // dW tiles of one wave: acc[nt] += U[rows, mcol..]^T DP[rows, ncol0 + 16 nt ..] over NBLK blocks of BLK rows from row0;
 // blocks that start past the sample's last output row are skipped (u and dp are zero there).  The operands of k-step
 // kk + 1 are read before the MFMAs of k-step kk.
-template <int NTW, int NBLK, int BLK, int D, int P>
+template <int NTW, int NBLK, int BLK, int D, int PA, int PB = PA>
 __device__ __forceinline__ void wide_dw_rows(const float* sU, const float* sDP, int row0, int nrows, int mcol, int ncol0,
                                              int r16, int g, f32x4 (&acc)[NTW]) {
   constexpr int KSB = BLK / 4;
   static_assert(BLK % (4 * D) == 0, "a block holds whole groups of 4 D rows");
-  const float* pu = sU + (row0 + D * g) * P + mcol + r16;
-  const float* pd = sDP + (row0 + D * g) * P + ncol0 + r16;
+  const float* pu = sU + (row0 + D * g) * PA + mcol + r16;
+  const float* pd = sDP + (row0 + D * g) * PB + ncol0 + r16;
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) {
     if (row0 + blk * BLK < nrows) {   // wave-uniform
       float av[2], bv[2][NTW];
       auto ld = [&](int kk, int s) {
-        const int ro = (blk * BLK + (kk / D) * 4 * D + (kk % D)) * P;
-        av[s] = pu[ro];
+        const int ro = blk * BLK + (kk / D) * 4 * D + (kk % D);
+        av[s] = pu[ro * PA];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) bv[s][nt] = pd[ro + nt * 16];
+        for (int nt = 0; nt < NTW; ++nt) bv[s][nt] = pd[ro * PB + nt * 16];
       };
       ld(0, 0);
 #pragma unroll
@@ -121,9 +121,10 @@ __device__ __forceinline__ void wide_dw_rows(const float* sU, const float* sDP, 
   }
 }
 
-// du tiles of one wave: du[mu] = DP[16 rows of tile rt, :] W^T[:, mcol0 + 16 mu ..], stored to the ring rows
+// du tiles of one wave: du[mu] = DP[16 rows of tile rt, 0..C) W^T[0..C, mcol0 + 16 mu ..] (C = the block's output
+// channels = the contraction length; P / PW / PD = pitches of dp, W^T and the du ring), stored to the ring rows
 // [K-1 + 16 rt, +16).  A tile past the sample's last output row only writes its zeros.
-template <int C, int NMU, int K, int P, int PW>
+template <int C, int NMU, int K, int P, int PW, int PD = P>
 __device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt, float* sDU, int rt, int nrows, int mcol0,
                                               int r16, int g) {
   f32x4 du[NMU];
@@ -150,11 +151,11 @@ __device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt
         for (int mu = 0; mu < NMU; ++mu) du[mu] = mfma4(as[s], bv[s][mu], du[mu]);
     }
   }
-  float* pd = sDU + (K - 1 + rt * 16 + g * 4) * P + mcol0 + r16;
+  float* pd = sDU + (K - 1 + rt * 16 + g * 4) * PD + mcol0 + r16;
 #pragma unroll
   for (int mu = 0; mu < NMU; ++mu)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pd[r * P + mu * 16] = du[mu][r];
+    for (int r = 0; r < 4; ++r) pd[r * PD + mu * 16] = du[mu][r];
 }
 
 // Depthwise sums over a sub-range [I0, I1) of the K taps, for one (channel, chunk): the register window of a phase is
@@ -498,6 +499,305 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
 #pragma unroll
     for (int j = 0; j < NCH; ++j) v += scratch[j * 2 * C + tid];
     publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * C, 2 * C, tid, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide-workgroup form of the first block's backward kernel (bwd_first_kernel, kernels_bwd.hip.h: a0 = relu(conv1(x)) read
+// back, no input gradient; instead dW1 += im2col(x)^T g0 on MFMA).  512 threads per 64-row tile of a0:
+//   * VALU phases: C1 = 32 channels x 16 chunks of L = 4 rows;
+//   * pointwise phase: waves 0-3 own the du tiles of row tile w (both 16-channel halves), waves 4-7 the dW_pw tiles
+//     (mt = v % 2, nt = 0..NT-1) over the row half v / 2, v = w - 4;
+//   * dW1 phase: m-tile mi * 8 + w of W1 (both 16-column halves of C1) per wave, mi < ceil(MT1 / 8), rows met in the
+//     order s = kk + 16 g: the x rows of a k-step are 16 S rows apart (16 S * 41 = 16 mod 32 for S = 1, 3: conflict-free
+//     with the odd x pitch) and the g0 tile has an odd pitch of its own for the same reason.
+template <int K1, int C1, int COUT, int K, int S, int NTH>
+struct BwdFirstWideLds {
+  static constexpr int PI = C1 + 4;                        // a0 / du ring / u: row-pattern MFMA reads 4 rows apart (4 * 36 = 16 mod 32)
+  static constexpr int PO = COUT + 4;                      // dp: the same rows (4 * 52 = 4 * 68 = 16 mod 32), float4 column reads
+  static constexpr int PG = C1 + 5;                        // g0: rows 16 apart need an odd pitch
+  static constexpr int PW = C1 + 4;                        // W_pw^T [COUT][C1]: rows 4 apart
+  static constexpr int PX = FBINS + 1;
+  static constexpr int NCH = NTH / C1, L = (TT + NCH - 1) / NCH, TTP = NCH * L, RAP = TTP + K - 1;
+  static constexpr int TAIL = S > 1 ? K - 1 : 0;
+  static constexpr int XR = (TT + TAIL - 1) * S + K1;
+  static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
+  static constexpr int OFF_A = 0, OFF_DP = OFF_A + up4(RAP * PI), OFF_U = OFF_DP + TT * PO, OFF_DU = OFF_U + up4(TTP * PI);
+  static constexpr int OFF_G0 = OFF_DU + up4(RAP * PI), OFF_END = OFF_G0 + up4((TTP + TAIL + 3) * PG);
+  static constexpr int BYTES = (OFF_END + up4(XR * PX) + 7 * COUT + COUT * PW) * 4 + (int)sizeof(XShared);
+};
+
+template <int K1, int C1, int COUT, int K, int S, int NTH>
+constexpr int wide_first_waves_per_simd() {
+  return (BwdFirstWideLds<K1, C1, COUT, K, S, NTH>::BYTES <= 80 * 1024 ? 2 : 1) * (NTH / 64) / 4;
+}
+
+template <int K1, int C1, int COUT, int K, int S, int NTH>
+__global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S, NTH>())) void bwd_firstw_kernel(BwdFirstArgs a) {
+  typedef BwdFirstWideLds<K1, C1, COUT, K, S, NTH> Lds;
+  constexpr bool SB = false;
+  constexpr int CIN = C1;
+  constexpr int PI = Lds::PI, PO = Lds::PO, PG = Lds::PG, PW = Lds::PW, PX = Lds::PX;
+  constexpr int NW = NTH / 64, NCH = Lds::NCH, L = Lds::L, TTP = Lds::TTP, RA = TT + K - 1, RAP = Lds::RAP;
+  constexpr int TAIL = Lds::TAIL, XR = Lds::XR;
+  constexpr int NT1 = C1 / 16, M1 = K1 * FBINS, MT1 = (M1 + 15) / 16, MPW = (MT1 + NW - 1) / NW;
+  constexpr int MT = CIN / 16, NT = COUT / 16, QI = CIN / 4, QO = COUT / 4;
+  static_assert(NW == 8 && MT == 2 && NCH * L == TT && TT >= K - 1, "geometry of the wide first-block kernel");
+  static_assert(TAIL <= NCH && TTP + TAIL <= RAP, "tail rows");
+  static_assert(Lds::OFF_END >= 2 * CIN * COUT && Lds::OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
+
+  __shared__ __attribute__((aligned(16))) float sX[Lds::up4(XR * PX)];
+  __shared__ XShared sXg;
+  __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
+  __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * PW];   // W_pw^T
+  float* sA = smem + Lds::OFF_A;
+  float* sDP = smem + Lds::OFF_DP;
+  float* sU = smem + Lds::OFF_U;
+  float* sDU = smem + Lds::OFF_DU;
+  float* sG0 = smem + Lds::OFF_G0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+  const int c = tid % CIN, chunk = tid / CIN;
+  const int Ta = (a.T - K1) / S + 1;
+
+  const bool tailmode = TAIL > 0 && Ta > TT && Ta <= TT + TAIL;   // the window is one tile: rows [TT, Ta) ride behind the TT tile rows
+  const int ntiles = tailmode ? 1 : (Ta + TT - 1) / TT;
+  const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nitems = nsamp * ntiles;
+  XStage<XR, PX, MWW_AUX_LD_XB, NTH> xs;
+  DpStageW<COUT, false, SB, NTH, PO> dps;
+  constexpr int NA = (RA * QI + NTH - 1) / NTH;
+  float4 pre_a[NA];
+  auto issue = [&](int it) {
+    const int s = it / ntiles, b = blockIdx.x + s * gridDim.x, t0 = (it % ntiles) * TT;
+    const int nrx = ((tailmode ? Ta : min(TT, Ta - t0)) - 1) * S + K1;
+    xs.issue(a.x, a.xg, sXg, s, b, a.T, t0 * S, nrx, tid);
+    const BufRsrc ra = tile_rsrc(a.a0 + ((size_t)b * Ta + t0) * CIN, min(RA, Ta - t0) * QI * 16);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) pre_a[j] = tile_load4<MWW_AUX_LD_A0>(ra, (tid + j * NTH) * 16);
+    const int nvk = max(0, min(TT, a.Tout - t0)) * QO;
+    const size_t koff = ((size_t)b * a.Tout + t0) * COUT;
+    dps.issue(elem_ptr<SB>(a.pk, koff), elem_ptr<SB>(a.gk, koff), nvk, tid);
+  };
+  // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s*S+j][f]
+  int offm[MPW];
+  bool okm[MPW];
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi) {
+    const int m = (mi * NW + wave) * 16 + r16;
+    okm[mi] = m < M1;
+    offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
+  }
+  if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
+  if (nitems > 0) issue(0);
+
+  // every global load of the prologue first, then the LDS copies
+  constexpr int NWL = (CIN * COUT + NTH - 1) / NTH;
+  float wl[NWL];
+#pragma unroll
+  for (int j = 0; j < NWL; ++j) wl[j] = (tid + j * NTH < CIN * COUT) ? a.pw_w[tid + j * NTH] : 0.f;
+  float accw[K];
+  float accb = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) accw[i] = 0.f;
+  float dwb = a.dw_b[c];
+  // the depthwise taps stay in LDS (read per phase): scratch rows behind the g0 tile are not needed, sKp rows 3-4 are free
+  // (2 * COUT >= K * CIN / ... does not hold in general: the taps get their own rows of the x-stage array's padding) - kept
+  // simple: K * CIN floats at the end of sKp's unused rows 3..4 when they fit, else registers
+  float dww[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) dww[i] = a.dw_w[i * CIN + c];
+  for (int i = tid; i < COUT; i += NTH) {
+    const float krs = a.k_rstd[i];
+    const float kmean = a.k_mean[i];
+    float c1, mg, mgx;
+    if (a.gfold.acc) {
+      bn_grad_fold_channel(a.gfold, COUT, i, krs, c1, mg, mgx);
+    } else {
+      c1 = a.k_c1[i];
+      mg = a.k_mg[i];
+      mgx = a.k_mgx[i];
+    }
+    const float kA = -c1 * krs * mgx;
+    sKp[0 * COUT + i] = c1;
+    sKp[1 * COUT + i] = kA;
+    sKp[2 * COUT + i] = -c1 * mg - kA * kmean;
+    sKp[5 * COUT + i] = 0.f;
+    sKp[6 * COUT + i] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NWL; ++j) {
+    const int i = tid + j * NTH;
+    if (i < CIN * COUT) sWt[(i % COUT) * PW + i / COUT] = wl[j];   // W[ci][co] -> W^T[co][ci]
+  }
+  for (int i = RA * PI + tid; i < RAP * PI; i += NTH) {
+    sA[i] = 0.f;
+    sDU[i] = 0.f;
+  }
+  for (int i = TT * PG + tid; i < (TTP + TAIL + 3) * PG; i += NTH) sG0[i] = 0.f;   // rows the tail k-step may read
+#pragma unroll
+  for (int i = 0; i < K; ++i) pin(dww[i]);
+  pin(dwb);
+  f32x4 dwacc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) dwacc[nt] = zero4();
+  f32x4 w1acc[MPW][NT1];
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = zero4();
+  __syncthreads();
+
+  for (int it = 0; it < nitems; ++it) {
+    rotate_priority(it, 2);
+    const int t0 = (it % ntiles) * TT;
+    const int nrows_new = max(0, min(TT, a.Tout - t0));
+    const int rows_da = min(TT, Ta - t0);
+    // ---- P0: commit x (odd pitch), a0 rows [t0, t0+RA) (zero past the sample), dp; roll the du ring
+    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int i = tid + j * NTH;
+      if (i < RA * QI) {
+        const int r = i / QI, q = i - r * QI;
+        *reinterpret_cast<float4*>(sA + r * PI + q * 4) = pre_a[j];
+      }
+    }
+    dps.commit(sDP, sKp, 0.f, nrows_new * QO, tid);
+    for (int i = tid; i < (K - 1) * PI; i += NTH) sDU[i] = (t0 == 0) ? 0.f : sDU[TT * PI + i];
+    __syncthreads();
+    if (it + 1 < nitems) issue(it + 1);
+    // ---- P1: u = depthwise(a0) + bias
+    if (chunk * L < nrows_new) {
+      float o[L];
+      dw_chunk<K, L>(sA, PI, chunk * L, c, dww, dwb, o);
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int tl = chunk * L + t;
+        sU[tl * PI + c] = (tl < nrows_new) ? o[t] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < L; ++t) sU[(chunk * L + t) * PI + c] = 0.f;
+    }
+    __syncthreads();
+    // ---- P2/P3: waves 0-3: du tiles of row tile w; waves 4-7: dW_pw tiles (mt = v % 2, all nt) over the row half v / 2
+    if (wave < 4) {
+      wide_du_tiles<COUT, MT, K, PO, PW, PI>(sDP, sWt, sDU, wave, nrows_new, 0, r16, g);
+    } else {
+      const int v = wave - 4;
+      wide_dw_rows<NT, 2, 16, 4, PI, PO>(sU, sDP, 32 * (v / 2), nrows_new, 16 * (v % 2), 0, r16, g, dwacc);
+    }
+    __syncthreads();
+    // ---- P4: depthwise backward -> g0 = da * relu'(a0) kept in LDS; dW_dw, db
+    {
+      float wdu[L + K - 1], wa[L + K - 1];
+#pragma unroll
+      for (int j = 0; j < L + K - 1; ++j) wdu[j] = sDU[(chunk * L + j) * PI + c];
+#pragma unroll
+      for (int j = 0; j < L + K - 1; ++j) wa[j] = sA[(chunk * L + j) * PI + c];
+      lds_reads_first();
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int sl = chunk * L + t;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc = fmaf(dww[K - 1 - i], wdu[t + i], acc);
+        sG0[sl * PG + c] = (sl < rows_da && wa[t] > 0.f) ? acc : 0.f;
+      }
+      if (chunk * L < nrows_new) {
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+          const float dut = wdu[K - 1 + t];
+          accb += dut;
+#pragma unroll
+          for (int i = 0; i < K; ++i) accw[i] = fmaf(dut, wa[t + i], accw[i]);
+        }
+      }
+      if constexpr (TAIL > 0) {
+        if (tailmode && chunk < TAIL) {
+          // input-gradient rows [TT, Ta) of a single-tile window: one row per chunk (du rows past the tile are zero)
+          const int sl = TT + chunk;
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < K; ++j) acc = fmaf(dww[K - 1 - j], sl + j < RAP ? sDU[(sl + j) * PI + c] : 0.f, acc);
+          sG0[sl * PG + c] = (sl < Ta && sA[sl * PI + c] > 0.f) ? acc : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s*S + m/40][m%40], B[k=s][n] = g0[s][n]; k-step kk holds rows kk + 16 g
+    {
+      float av[2][MPW], bv[2][NT1];
+      auto load_w1 = [&](int srow, int sl) {   // srow = this lane's row of the k-step
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) bv[sl][nt] = sG0[srow * PG + nt * 16 + r16];
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi) {
+          const float v = sX[srow * S * PX + offm[mi]];   // (rows past M1 read offset 0 and are zeroed: no conditional load)
+          av[sl][mi] = okm[mi] ? v : 0.f;
+        }
+      };
+      load_w1(16 * g, 0);
+#pragma unroll
+      for (int kk = 0; kk < TT / 4; ++kk) {
+        if (kk + 1 < TT / 4) load_w1(kk + 1 + 16 * g, (kk + 1) & 1);
+#pragma unroll
+        for (int mi = 0; mi < MPW; ++mi)
+          if (mi * NW + wave < MT1) {   // wave-uniform
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[kk & 1][mi], bv[kk & 1][nt], w1acc[mi][nt]);
+          }
+      }
+      if constexpr (TAIL > 0) {
+        if (tailmode) {   // one more k-step: g0 / x rows [TT, TT + 4) (g0 rows past Ta are zero)
+          load_w1(TT + g, 0);
+#pragma unroll
+          for (int mi = 0; mi < MPW; ++mi)
+            if (mi * NW + wave < MT1) {
+#pragma unroll
+              for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[0][mi], bv[0][nt], w1acc[mi][nt]);
+            }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: partial row [M1*C1 (dW1) | K*CIN (dW_dw) | CIN (db) | CIN*COUT (dW_pw)]
+  float* gdst = a.grad_part + (size_t)blockIdx.x * (M1 * C1 + (K + 1) * CIN + CIN * COUT);
+#pragma unroll
+  for (int mi = 0; mi < MPW; ++mi)
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (mi * NW + wave) * 16 + g * 4 + r;
+        if (m < M1) store_stream<MWW_AUX_ST_GP>(gdst + m * C1 + nt * 16 + r16, w1acc[mi][nt][r]);
+      }
+  float* gblk = gdst + M1 * C1;
+  float* scratch = smem;
+  if (wave >= 4) {
+    const int v = wave - 4;
+    float* sp = scratch + (v / 2) * CIN * COUT + ((v % 2) * 16 + g * 4) * COUT + r16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sp[r * COUT + nt * 16] = dwacc[nt][r];
+  }
+  __syncthreads();
+  for (int e = tid; e < CIN * COUT; e += NTH) store_stream<MWW_AUX_ST_GP>(gblk + (K + 1) * CIN + e, scratch[e] + scratch[CIN * COUT + e]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < K; ++i) scratch[(chunk * (K + 1) + i) * CIN + c] = accw[i];
+  scratch[(chunk * (K + 1) + K) * CIN + c] = accb;
+  __syncthreads();
+  for (int e = tid; e < (K + 1) * CIN; e += NTH) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) v += scratch[j * (K + 1) * CIN + e];
+    store_stream<MWW_AUX_ST_GP>(gblk + e, v);
   }
 }
 

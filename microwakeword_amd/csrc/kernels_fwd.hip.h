@@ -91,13 +91,13 @@ __device__ __forceinline__ void xgather_setup(const XGather& g, XShared& sh, int
 }
 
 // register stage of the x rows of one (sample, tile) item.  Thread -> (row group rq = tid / 10, float4 column
-// q = tid % 10) for tid < 250; pass j handles row rq + 25 j: every per-pass address is a compile-time offset
+// q = tid % 10) for tid < 250 (NTH = 256 threads; 510 of 512); pass j handles row rq + 25 j (51 j): every per-pass address is a compile-time offset
 // from a per-thread base, in HBM (float4 index tid + 250 j of the tile) and in LDS (odd row pitch PX).
 // issue() fetches rows [row0, row0 + nrows) of the sample (dense) or gathers them (store rows row0 - pad_rows ...);
 // commit() writes them to LDS, converting / masking in gather mode.
-template <int XROWS, int PX, int AUX = 0>
+template <int XROWS, int PX, int AUX = 0, int NTH = kThreads>
 struct XStage {
-  static constexpr int QX = FBINS / 4, RPP = kThreads / QX, ACT = RPP * QX, NJ = (XROWS + RPP - 1) / RPP;
+  static constexpr int QX = FBINS / 4, RPP = NTH / QX, ACT = RPP * QX, NJ = (XROWS + RPP - 1) / RPP;
   float4 pre[NJ];
 
   // `tid` is laundered in both methods: the per-lane row / offset arithmetic is a handful of VALU ops per tile,

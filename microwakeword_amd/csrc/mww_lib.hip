@@ -261,6 +261,7 @@ int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 }
 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
+  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_firstw(c->stream, k1, c1, cout, k, st, a, grid)) return MWW_OK;
   if (k_launch_bwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block backward kernel for this shape");
 }

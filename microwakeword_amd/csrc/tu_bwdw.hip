@@ -25,4 +25,20 @@ bool k_launch_bwd_blockw(hipStream_t st, int cin, int cout, int k, bool last, co
   return false;
 }
 
+// first block: the shapes whose wide form holds more waves per CU than bwd_first_kernel does - the default first block
+// (two 512-thread workgroups per CU at 128 registers) and the stride-3 first convolutions (one per CU either way: LDS).
+// The stride-1 crosses would only trade two 256-thread workgroups for one of 512: they stay on bwd_first_kernel.
+bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid) {
+#define X(K1, C1, CO, K, S)                                                                                    \
+  if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
+    if constexpr (S > 1 || (K1 == 3 && CO == 48)) {                                                            \
+      hipLaunchKernelGGL((bwd_firstw_kernel<K1, C1, CO, K, S, 512>), dim3(grid), dim3(512), 0, st, a);         \
+      return true;                                                                                             \
+    }                                                                                                          \
+  }
+  MWW_FIRST_SHAPES(X)
+#undef X
+  return false;
+}
+
 }  // namespace mww
