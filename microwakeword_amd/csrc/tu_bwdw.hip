@@ -25,13 +25,15 @@ bool k_launch_bwd_blockw(hipStream_t st, int cin, int cout, int k, bool last, co
   return false;
 }
 
-// first block: the shapes whose wide form holds more waves per CU than bwd_first_kernel does - the default first block
-// (two 512-thread workgroups per CU at 128 registers) and the stride-3 first convolutions (one per CU either way: LDS).
-// The stride-1 crosses would only trade two 256-thread workgroups for one of 512: they stay on bwd_first_kernel.
+// first block: the stride-3 first convolutions only (194+ staged x rows: one workgroup per CU whatever its size, so 512
+// threads double the waves: 45.8 -> 37.5 us at the notebook topology).  The default first block was built and measured too
+// (two 512-thread workgroups per CU at 128 registers): 53.0-53.3 us against 51.2-51.8 for bwd_first_kernel in the same session
+// (profiles/round5_bwd_first_forms_ab.txt) - its launch is bound by the exact-fp32 MFMAs of the conv1 weight gradient, which
+// more waves do not make cheaper - and the stride-1 crosses would trade two 256-thread workgroups for one of 512.
 bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
-    if constexpr (S > 1 || (K1 == 3 && CO == 48)) {                                                            \
+    if constexpr (S > 1) {                                                                                     \
       hipLaunchKernelGGL((bwd_firstw_kernel<K1, C1, CO, K, S, 512>), dim3(grid), dim3(512), 0, st, a);         \
       return true;                                                                                             \
     }                                                                                                          \
