@@ -27,8 +27,8 @@ bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int 
 bool k_launch_fwd_block(hipStream_t st, int mode, int cin, int cout, int k, const FwdBlockArgs& a, int grid);
 bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid);
 bool k_launch_bwd_block(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
-// wide-workgroup form of the fp32 block backward (kernels_bwdw.hip.h: 512 threads per workgroup)
-bool k_launch_bwd_blockw(hipStream_t st, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
+// wide-workgroup form of the block backward (kernels_bwdw.hip.h: 512 threads per workgroup; every mode)
+bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
 bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid);
 
 }  // namespace mww

@@ -158,6 +158,59 @@ __device__ __forceinline__ void wide_du_tiles(const float* sDP, const float* sWt
     for (int r = 0; r < 4; ++r) pd[r * PD + mu * 16] = du[mu][r];
 }
 
+// bf16-operand forms of the two contractions (BASELINE configs[4], "pointwise_bf16": operands rounded to bf16, products
+// exact, fp32 accumulation; one v_mfma_f32_16x16x16_bf16 covers 16 rows / 16 channels of the contraction).  The lane's four
+// k-values of an MFMA are rows g + 4 j of the 16-row block (dW: one row per read instruction, the two g of a 32-lane
+// group one row apart - conflict-free at a pitch of 16 mod 32) or the channels 4 g + j of a float4 (du).
+template <int NTW, int NBLK, int PA, int PB = PA>
+__device__ __forceinline__ void wide_dw_rows_bf16(const float* sU, const float* sDP, int row0, int nrows, int mcol, int ncol0,
+                                                  int r16, int g, f32x4 (&acc)[NTW]) {
+  const float* pu = sU + (row0 + g) * PA + mcol + r16;
+  const float* pd = sDP + (row0 + g) * PB + ncol0 + r16;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    if (row0 + blk * 16 < nrows) {   // wave-uniform
+      const float* cu = pu + blk * 16 * PA;
+      const bf16x4 av = to_bf16x4(cu[0], cu[4 * PA], cu[8 * PA], cu[12 * PA]);
+      bf16x4 bv[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const float* cd = pd + blk * 16 * PB + nt * 16;
+        bv[nt] = to_bf16x4(cd[0], cd[4 * PB], cd[8 * PB], cd[12 * PB]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[nt] = mfma_bf16(av, bv[nt], acc[nt]);
+    }
+  }
+}
+
+template <int C, int NMU, int K, int P, int PW, int PD = P>
+__device__ __forceinline__ void wide_du_tiles_bf16(const float* sDP, const float* sWt, float* sDU, int rt, int nrows, int mcol0,
+                                                   int r16, int g) {
+  f32x4 du[NMU];
+#pragma unroll
+  for (int mu = 0; mu < NMU; ++mu) du[mu] = zero4();
+  if (rt * 16 < nrows) {   // wave-uniform
+    const float* pa = sDP + (rt * 16 + r16) * P + 4 * g;
+    const float* pb = sWt + (4 * g) * PW + mcol0 + r16;
+#pragma unroll
+    for (int kb = 0; kb < C / 16; ++kb) {
+      const float4 v = *reinterpret_cast<const float4*>(pa + kb * 16);
+      const bf16x4 a4 = to_bf16x4(v.x, v.y, v.z, v.w);
+#pragma unroll
+      for (int mu = 0; mu < NMU; ++mu) {
+        const float* col = pb + kb * 16 * PW + mu * 16;
+        du[mu] = mfma_bf16(a4, to_bf16x4(col[0], col[PW], col[2 * PW], col[3 * PW]), du[mu]);
+      }
+    }
+  }
+  float* pd = sDU + (K - 1 + rt * 16 + g * 4) * PD + mcol0 + r16;
+#pragma unroll
+  for (int mu = 0; mu < NMU; ++mu)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pd[r * PD + mu * 16] = du[mu][r];
+}
+
 // Depthwise sums over a sub-range [I0, I1) of the K taps, for one (channel, chunk): the register window of a phase is
 // L + (I1 - I0) - 1 rows instead of L + K - 1, so long kernels run their phases in two or three tap groups.
 //   dw_tap_group     : acc[t] += sum_i w(i) * src[t + i]      (w(i) = taps[i], or taps[K-1-i] when REV: the input gradient)
@@ -171,7 +224,9 @@ __device__ __forceinline__ void dw_tap_group(const float* src_c, int pitch, cons
   for (int j = 0; j < L + N - 1; ++j) win[j] = src_c[(I0 + j) * pitch];
 #pragma unroll
   for (int i = 0; i < N; ++i) w[i] = taps_c[(REV ? K - 1 - (I0 + i) : I0 + i) * tap_pitch];
+#ifndef MWW_WIDE_NOREADSFIRST
   lds_reads_first();
+#endif
 #pragma unroll
   for (int t = 0; t < L; ++t)
 #pragma unroll
@@ -183,7 +238,9 @@ __device__ __forceinline__ void dw_wgrad_group(const float* src_c, int pitch, co
   float win[L + N - 1];
 #pragma unroll
   for (int j = 0; j < L + N - 1; ++j) win[j] = src_c[(I0 + j) * pitch];
+#ifndef MWW_WIDE_NOREADSFIRST
   lds_reads_first();
+#endif
 #pragma unroll
   for (int t = 0; t < L; ++t)
 #pragma unroll
@@ -192,7 +249,11 @@ __device__ __forceinline__ void dw_wgrad_group(const float* src_c, int pitch, co
 // tap groups of a K-tap kernel: one up to 11 taps, two up to 19, three beyond
 template <int K>
 struct TapGroups {
+#ifdef MWW_WIDE_FEWGROUPS   // tuning builds: larger register windows, fewer scheduling fences
+  static constexpr int N = K <= 15 ? 1 : 2;
+#else
   static constexpr int N = K <= 11 ? 1 : (K <= 19 ? 2 : 3);
+#endif
   static constexpr int lo(int gidx) { return gidx * K / N; }
 };
 template <int K, int L, bool REV, int G = 0>
@@ -251,11 +312,10 @@ constexpr int wide_waves_per_simd() {
   return (BwdWideLds<C, K, NTH>::BYTES <= 80 * 1024 ? 2 : 1) * (NTH / 64) / 4;
 }
 
-template <int CIN, int COUT, int K, bool LAST, int NTH>
+template <int CIN, int COUT, int K, bool LAST, int NTH, bool BF = false, bool SB = false>
 __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd_blockw_kernel(BwdBlockArgs a) {
   static_assert(CIN == COUT, "the wide form is instantiated for square blocks");
   constexpr int C = CIN;
-  constexpr bool SB = false;
   typedef WidePitch<C, NTH> WP;
   typedef BwdWideLds<C, K, NTH> Lds;
   constexpr int NW = NTH / 64;
@@ -364,7 +424,9 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
   __syncthreads();
 
   for (int it = 0; it < nitems; ++it) {
+#ifndef MWW_WIDE_NOPRIO
     rotate_priority(it, 2);
+#endif
     const int b = blockIdx.x + (it / ntiles) * gridDim.x, t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));  // du rows produced by this tile
     const int rows_da = min(TT, a.Tin - t0);             // input-gradient rows finalised by this tile
@@ -408,11 +470,20 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
     if constexpr (C == 48 && NW == 8) {
       if (wave < 6) {
-        wide_dw_rows<3, 2, 16, D, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
-        wide_du_tiles<C, 1, K, P, PW>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
+        if constexpr (BF) {
+          wide_dw_rows_bf16<3, 2, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
+          wide_du_tiles_bf16<C, 1, K, P, PW>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
+        } else {
+          wide_dw_rows<3, 2, 16, D, P>(sU, sDP, 32 * (wave / 3), nrows_new, 16 * (wave % 3), 0, r16, g, dwacc);
+          wide_du_tiles<C, 1, K, P, PW>(sDP, sWt, sDU, 2 + wave / 3, nrows_new, 16 * (wave % 3), r16, g);
+        }
       } else {
-        wide_du_tiles<C, 3, K, P, PW>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
+        if constexpr (BF) wide_du_tiles_bf16<C, 3, K, P, PW>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
+        else wide_du_tiles<C, 3, K, P, PW>(sDP, sWt, sDU, wave - 6, nrows_new, 0, r16, g);
       }
+    } else if constexpr (BF) {
+      wide_dw_rows_bf16<2, 4, P>(sU, sDP, 0, nrows_new, 16 * (wave / 2), 32 * (wave % 2), r16, g, dwacc);
+      wide_du_tiles_bf16<C, 2, K, P, PW>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
     } else {
       wide_dw_rows<2, 4, 16, D, P>(sU, sDP, 0, nrows_new, 16 * (wave / 2), 32 * (wave % 2), r16, g, dwacc);
       wide_du_tiles<C, 2, K, P, PW>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
@@ -650,7 +721,9 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
   __syncthreads();
 
   for (int it = 0; it < nitems; ++it) {
+#ifndef MWW_WIDE_NOPRIO
     rotate_priority(it, 2);
+#endif
     const int t0 = (it % ntiles) * TT;
     const int nrows_new = max(0, min(TT, a.Tout - t0));
     const int rows_da = min(TT, Ta - t0);

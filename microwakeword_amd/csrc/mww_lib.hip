@@ -272,8 +272,8 @@ int launch_fwd_block(mww_ctx* c, int cin, int cout, int k, const FwdBlockArgs& a
 }
 
 int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
-  // wide-workgroup form: fp32 arithmetic and storage only
-  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_blockw(c->stream, cin, cout, k, last, a, grid)) return MWW_OK;
+  const int mode = c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0);
+  if (c->bwd_wide && k_launch_bwd_blockw(c->stream, mode, cin, cout, k, last, a, grid)) return MWW_OK;
   if (k_launch_bwd_block(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), cin, cout, k, last, a, grid)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no block backward kernel for this shape");
 }

@@ -6,17 +6,25 @@
 namespace mww {
 
 template <int C, int K, int NTH>
-static void launch_w(hipStream_t st, bool last, const BwdBlockArgs& a, int grid) {
-  if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH>), dim3(grid), dim3(NTH), 0, st, a);
-  else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH>), dim3(grid), dim3(NTH), 0, st, a);
+static void launch_w(hipStream_t st, int mode, bool last, const BwdBlockArgs& a, int grid) {
+  if (mode == 2) {
+    if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH, true, true>), dim3(grid), dim3(NTH), 0, st, a);
+    else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH, true, true>), dim3(grid), dim3(NTH), 0, st, a);
+  } else if (mode == 1) {
+    if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH, true>), dim3(grid), dim3(NTH), 0, st, a);
+    else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH, true>), dim3(grid), dim3(NTH), 0, st, a);
+  } else {
+    if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH>), dim3(grid), dim3(NTH), 0, st, a);
+    else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH>), dim3(grid), dim3(NTH), 0, st, a);
+  }
 }
 
-bool k_launch_bwd_blockw(hipStream_t st, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
+bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
   if (cin != cout) return false;
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && k == K) {                                                                                   \
     if constexpr (CI == CO && (CI == 48 || CI == 64)) {                                                        \
-      launch_w<CI, K, 512>(st, last, a, grid);                                                                 \
+      launch_w<CI, K, 512>(st, mode, last, a, grid);                                                               \
       return true;                                                                                             \
     }                                                                                                          \
   }
