@@ -128,7 +128,7 @@ def inception_kernel_elems(layout):
     return elems
 
 
-PMC_FILE = "round4_kernel_stats_and_pmc.txt"   # written by tools/gpu_final.sh for the kernel binary of this round
+PMC_FILE = "round5_kernel_stats_and_pmc.txt"   # written by tools/gpu_restamp.sh for the kernel binary of this round
 LIBRARY = os.environ.get("MWW_HIP_LIB") or os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")   # the file native.NativeLib.get() loads
 
 
@@ -185,8 +185,9 @@ def pmc_traffic(kernel, model, path=None, library=LIBRARY):
         path = path or os.path.join(ROOT, "profiles", PMC_FILE)
         names = {"bwd_block1": "bwd_first_kernel<", "fwd_block1": r"fwd_first_kernel<", "fwd_block2": r"fwd_block_kernel<48, 48, 9,",
                  "fwd_block3": r"fwd_block_kernel<48, 48, 13,", "fwd_block4": r"fwd_block_kernel<48, 48, 21,",
-                 "bwd_block2": r"bwd_block_kernel<48, 48, 9,", "bwd_block3": r"bwd_block_kernel<48, 48, 13,",
-                 "bwd_block4": r"bwd_block_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}
+                 # (the block backward is bwd_blockw_kernel by default, bwd_block_kernel with the option "bwd_wide" 0: one prefix serves both)
+                 "bwd_block2": r"bwd_block(w?)_kernel<48, 48, 9,", "bwd_block3": r"bwd_block(w?)_kernel<48, 48, 13,",
+                 "bwd_block4": r"bwd_block(w?)_kernel<48, 48, 21,", "assemble": r"assemble_kernel", "head": r"head_kernel<"}
     else:
         return None, None
     if not os.path.isfile(path):
@@ -199,7 +200,7 @@ def pmc_traffic(kernel, model, path=None, library=LIBRARY):
         return None, None
     fetch = write = None
     for line in open(path):
-        if line.startswith(want):
+        if re.match(want, line):
             m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
             fetch = float(m.group(1)) if m else fetch
             m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)

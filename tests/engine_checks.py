@@ -834,6 +834,8 @@ GRAPH_MIXEDNET_RESIDUAL = dict(mo.MIXEDNET_DEFAULTS, residual_connection="1,0,1"
 GRAPH_MIXEDNET_HEADS = [dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="24,32", repeat_in_block="1,1",
                              mixconv_kernel_sizes="[5],[7]", first_conv_filters=16, spatial_attention=sa, pooled=po, max_pool=mp)
                         for sa, po, mp in ((1, 0, 0), (0, 1, 0), (0, 1, 1), (1, 1, 0), (1, 1, 1))]
+# residual branches + the spatial-attention gate + the pooled head in one model (the default widths and kernels)
+GRAPH_MIXEDNET_FULL = dict(mo.MIXEDNET_DEFAULTS, residual_connection="1,0,1,0", spatial_attention=1, pooled=1)
 GRAPH_MIXEDNET_NOCONV1 = dict(mo.MIXEDNET_DEFAULTS, residual_connection="0,0", pointwise_filters="16,24", repeat_in_block="1,1",
                               mixconv_kernel_sizes="[5],[7,9]", first_conv_filters=0)
 

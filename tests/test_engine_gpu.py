@@ -113,6 +113,16 @@ def test_gradients_without_imposed_masks_on_the_other_paths(lib):
     ec.check_gradients_unimposed(lib, B=1024, T=194, bound=3e-2, flags=ec.BF16, noise_factor=3.0)
 
 
+def test_gradients_without_imposed_masks_on_the_remaining_paths(lib):
+    """... and for the three paths that still relied on mask-imposing checks alone (round-4 review): configs[4]'s full form
+    (bf16 operands AND bf16 storage, bounded by the mode's own float32-vs-float64 oracle noise like the operand mode), the
+    Inception variant with every flag away from its default (two stem layers, dilation 2, sub-spectral groups, dropout 0.3),
+    and a MixedNet with residual branches, the attention gate and the pooled head on the graph kernels."""
+    ec.check_gradients_unimposed(lib, B=1024, T=194, bound=3e-2, flags=ec.BF16_STORED, noise_factor=3.0)
+    assert ec.check_gradients_unimposed(lib, B=512, T=194, bound=2e-2, kind="inception", flags=ec.INC_VARIANT) <= 2e-2
+    assert ec.check_gradients_unimposed(lib, B=512, T=194, bound=3e-2, kind="graph_mixednet", flags=ec.GRAPH_MIXEDNET_FULL) <= 3e-2
+
+
 def test_bf16_storage_mode_at_the_baseline_batch_4096(lib):
     """BASELINE configs[4] names batch 4096: forward parity and one train step of the bf16-storage mode at that size
     (the oracle rounds the same stored tensors)."""
