@@ -64,6 +64,11 @@ const char* mww_version(void);
 const char* mww_last_error(void);
 int mww_device_count(void);
 
+/* 1 if every block of `desc` has a specialised MFMA block kernel (bf16 != 0: in the bf16 modes too), 0 if the model has to
+ * run on the conv / depthwise graph kernels of mww_create_convnet (mww_last_error() says which block is not covered).
+ * Needs no device: it answers from the build-time shape table (csrc/block_launch.hip.h). */
+int mww_block_kernels_cover(const mww_mixednet_desc* desc, int bf16);
+
 /* stream: a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a
  * private non-blocking stream. */
 int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx** out);

@@ -304,10 +304,10 @@ struct BwdFirstLds {
   static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);
 };
 
-// (64-wide blocks hold 93-107 KB of LDS per workgroup: one workgroup per CU whatever the register count, so they are compiled
-// for one - the bound of 2 they carried until round 3 could not be met and only produced "failed to meet occupancy target")
+// (64-wide blocks - and 48 -> 64 blocks with long kernels - hold 81-107 KB of LDS per workgroup: one workgroup per CU whatever
+// the register count, so they are compiled for one - the bound of 2 they carried until round 3 could not be met and only produced "failed to meet occupancy target")
 template <int CIN, int COUT, int K, bool LAST, bool BF, bool SB = false>
-__global__ __launch_bounds__(kThreads, (CIN > 48 ? 1 : 2)) void bwd_block_kernel(BwdBlockArgs a) {
+__global__ __launch_bounds__(kThreads, ((CIN > 48 || BwdBlockLds<CIN, COUT, K>::END * 4 > 80 * 1024) ? 1 : 2)) void bwd_block_kernel(BwdBlockArgs a) {
   typedef BwdBlockLds<CIN, COUT, K> Lds;
   __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];

@@ -287,26 +287,28 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
       hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                    \
     return MWW_OK;                                                                                             \
   }
-  X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
+  X(32, 2) X(32, 4) X(32, 8) X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
 }
 
-bool shape_supported(const mww_mixednet_desc& d, std::string* why) {
+// does every block of the model have a specialised kernel (bf16: in the bf16 modes too)?
+bool shape_supported(const mww_mixednet_desc& d, std::string* why, bool bf16 = false) {
+  if (d.n_blocks < 2 || d.n_blocks > MWW_MAX_BLOCKS) { *why = "the block kernels serve 2.." + std::to_string(MWW_MAX_BLOCKS) + " blocks"; return false; }
   bool ok = false;
 #define X(K1, C1, CO, K, S) ok = ok || (d.conv1_kernel == K1 && d.conv1_filters == C1 && d.block_filters[0] == CO && d.block_kernel[0] == K && d.conv1_stride == S);
-  MWW_FIRST_SHAPES(X)
+  if (bf16) { MWW_FIRST_SHAPES_BF16(X) } else { MWW_FIRST_SHAPES(X) }
 #undef X
-  if (!ok) { *why = "first block (conv1 kernel/filters, pointwise filters, depthwise kernel) not instantiated"; return false; }
+  if (!ok) { *why = "first block (conv1 kernel/filters/stride, pointwise filters, depthwise kernel) not instantiated"; return false; }
   for (int i = 1; i < d.n_blocks; ++i) {
     ok = false;
 #define X(CI, CO, K) ok = ok || (d.block_filters[i - 1] == CI && d.block_filters[i] == CO && d.block_kernel[i] == K);
-    MWW_BLOCK_SHAPES(X)
+    if (bf16) { MWW_BLOCK_SHAPES_BF16(X) } else { MWW_BLOCK_SHAPES(X) }
 #undef X
     if (!ok) { *why = "block " + std::to_string(i) + " (cin, cout, depthwise kernel) not instantiated"; return false; }
   }
   const int cl = d.block_filters[d.n_blocks - 1];
-  if (cl != 48 && cl != 64) { *why = "head kernel needs 48 or 64 channels"; return false; }
+  if (cl != 32 && cl != 48 && cl != 64) { *why = "head kernel needs 32, 48 or 64 channels"; return false; }
   return true;
 }
 
@@ -1999,7 +2001,9 @@ int open_device(mww_ctx* c, int device, void* stream) {
   }
   c->grid_fwd = c->n_cu * 4;
   c->grid_bwd = c->n_cu * 2;
-  if (!c->generic && c->d.n_blocks > 0 && c->d.block_filters[0] > 48) {
+  bool wide64 = false;
+  for (int i = 0; i < c->d.n_blocks; ++i) wide64 = wide64 || c->d.block_filters[i] > 48;
+  if (!c->generic && wide64) {
     // 64-wide blocks: the backward kernels fit once per CU (LDS), the forward kernels twice - grids of resident workgroups
     // only, no second dispatch round (tools/gpu_r3g.sh: notebook topology grid sweep)
     c->grid_fwd = c->n_cu * 2;
@@ -2022,6 +2026,14 @@ int mww_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int mww_block_kernels_cover(const mww_mixednet_desc* desc, int bf16) {
+  if (!desc) return fail(MWW_ERR_INVALID, "null descriptor");
+  std::string why;
+  if (shape_supported(*desc, &why, bf16 != 0)) return 1;
+  g_err = why;
+  return 0;
 }
 
 int mww_create(const mww_mixednet_desc* desc, int device, void* stream, mww_ctx** out) {
@@ -3043,11 +3055,13 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "profile_split")) c->profile_split = v != 0;
   else if (!strcmp(name, "pointwise_bf16")) {
     if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");
+    { std::string why; if (v && !shape_supported(c->d, &why, true)) return fail(MWW_ERR_UNSUPPORTED, "no bf16 mode for this topology: " + why); }
     c->pw_bf16 = v != 0;
     if (!v) c->st_bf16 = false;
   }
   else if (!strcmp(name, "storage_bf16")) {
     if (c->generic && v) return fail(MWW_ERR_UNSUPPORTED, "the conv/BN graph kernels have no bf16 mode");
+    { std::string why; if (v && !shape_supported(c->d, &why, true)) return fail(MWW_ERR_UNSUPPORTED, "no bf16 mode for this topology: " + why); }
     c->st_bf16 = v != 0;
     if (v) c->pw_bf16 = true;
   }

@@ -5,14 +5,22 @@
 namespace mww {
 
 bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid) {
+  if (mode != 0) {
+#define X(K1, C1, CO, K, S)                                                                                    \
+    if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                         \
+      if (mode == 2)                                                                                           \
+        hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
+      else                                                                                                     \
+        hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
+      return true;                                                                                             \
+    }
+    MWW_FIRST_SHAPES_BF16(X)
+#undef X
+    return false;
+  }
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
-    if (mode == 2)                                                                                             \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
-    else if (mode == 1)                                                                                        \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, st, a);    \
-    else                                                                                                       \
-      hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, st, a);   \
+    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, st, a);     \
     return true;                                                                                               \
   }
   MWW_FIRST_SHAPES(X)
@@ -21,18 +29,27 @@ bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int 
 }
 
 bool k_launch_bwd_block(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
+  if (mode != 0) {
+#define X(CI, CO, K)                                                                                           \
+    if (cin == CI && cout == CO && k == K) {                                                                   \
+      if (last && mode == 2)                                                                                   \
+        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
+      else if (mode == 2)                                                                                      \
+        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
+      else if (last)                                                                                           \
+        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, st, a);   \
+      else                                                                                                     \
+        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
+      return true;                                                                                             \
+    }
+    MWW_BLOCK_SHAPES_BF16(X)
+#undef X
+    return false;
+  }
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (last && mode == 2)                                                                                     \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
-    else if (mode == 2)                                                                                        \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
-    else if (last && mode == 1)                                                                                \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, st, a);     \
-    else if (last)                                                                                             \
+    if (last)                                                                                                  \
       hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, false>), dim3(grid), dim3(kThreads), 0, st, a);    \
-    else if (mode == 1)                                                                                        \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true>), dim3(grid), dim3(kThreads), 0, st, a);    \
     else                                                                                                       \
       hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, false>), dim3(grid), dim3(kThreads), 0, st, a);   \
     return true;                                                                                               \

@@ -6,25 +6,40 @@
 namespace mww {
 
 template <int C, int K, int NTH>
-static void launch_w(hipStream_t st, int mode, bool last, const BwdBlockArgs& a, int grid) {
+static void launch_w(hipStream_t st, bool last, const BwdBlockArgs& a, int grid) {
+  if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH>), dim3(grid), dim3(NTH), 0, st, a);
+  else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH>), dim3(grid), dim3(NTH), 0, st, a);
+}
+template <int C, int K, int NTH>
+static void launch_w_bf16(hipStream_t st, int mode, bool last, const BwdBlockArgs& a, int grid) {
   if (mode == 2) {
     if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH, true, true>), dim3(grid), dim3(NTH), 0, st, a);
     else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH, true, true>), dim3(grid), dim3(NTH), 0, st, a);
-  } else if (mode == 1) {
+  } else {
     if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH, true>), dim3(grid), dim3(NTH), 0, st, a);
     else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH, true>), dim3(grid), dim3(NTH), 0, st, a);
-  } else {
-    if (last) hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, true, NTH>), dim3(grid), dim3(NTH), 0, st, a);
-    else hipLaunchKernelGGL((bwd_blockw_kernel<C, C, K, false, NTH>), dim3(grid), dim3(NTH), 0, st, a);
   }
 }
 
+// square 48- and 64-wide blocks only (kernels_bwdw.hip.h: WidePitch / WideRoles); false = use the 256-thread kernel
 bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
   if (cin != cout) return false;
+  if (mode != 0) {
+#define X(CI, CO, K)                                                                                           \
+    if (cin == CI && k == K) {                                                                                 \
+      if constexpr (CI == CO && (CI == 48 || CI == 64)) {                                                      \
+        launch_w_bf16<CI, K, 512>(st, mode, last, a, grid);                                                    \
+        return true;                                                                                           \
+      }                                                                                                        \
+    }
+    MWW_BLOCK_SHAPES_BF16(X)
+#undef X
+    return false;
+  }
 #define X(CI, CO, K)                                                                                           \
   if (cin == CI && k == K) {                                                                                   \
     if constexpr (CI == CO && (CI == 48 || CI == 64)) {                                                        \
-      launch_w<CI, K, 512>(st, mode, last, a, grid);                                                               \
+      launch_w<CI, K, 512>(st, last, a, grid);                                                                 \
       return true;                                                                                             \
     }                                                                                                          \
   }

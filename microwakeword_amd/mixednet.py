@@ -44,7 +44,9 @@ def model(flags, shape, batch_size, **engine_kwargs):
     does (mixednet.py:298-305) — note the reference's own default ``--residual_connection`` has five
     entries against four blocks, so default flags need ``--residual_connection "0,0,0,0"``."""
     try:
-        return Model(flags, shape, batch_size, **engine_kwargs)   # specialised MFMA block kernels
+        m = Model(flags, shape, batch_size, **engine_kwargs)   # specialised MFMA block kernels
+        m.kernel_family = "specialised block kernels (MFMA pointwise, csrc/block_launch.hip.h)"
+        return m
     except (NotImplementedError, _native.NativeError) as e:
         if isinstance(e, _native.NativeError) and "error -3" not in str(e):   # anything but MWW_ERR_UNSUPPORTED
             raise
@@ -52,4 +54,18 @@ def model(flags, shape, batch_size, **engine_kwargs):
         # residual / attention / pooled heads still raise NotImplementedError from the layout below
         lay = _layout.GraphMixedNetLayout(flags, int(shape[0]))
         logging.getLogger("microwakeword_amd").warning("mixednet: %s -> generic graph kernels", e)
-        return Model(flags, shape, batch_size, layout=lay, name="mixednet (generic graph kernels)", **engine_kwargs)
+        m = Model(flags, shape, batch_size, layout=lay, name="mixednet (generic graph kernels)", **engine_kwargs)
+        m.kernel_family = "conv / depthwise graph kernels (%s)" % e
+        return m
+
+
+def kernel_family(flags, frames, lib=None, bf16=False):
+    """Which kernels a flag set gets, without building the model or touching a GPU: ("block", "") when every block has a
+    specialised MFMA kernel, ("graph", reason) when the model runs on the conv / depthwise graph kernels (about 2.5x the
+    step time of a covered shape: the reason names the first thing the shape table does not hold)."""
+    try:
+        lay = _layout.MixedNetLayout(flags, int(frames))
+    except NotImplementedError as e:
+        return "graph", str(e)
+    ok, why = (lib or _native.NativeLib.get()).block_kernels_cover(bf16=bf16, **lay.engine_args(1))
+    return ("block", "") if ok else ("graph", why)

@@ -323,6 +323,8 @@ class Model:
     def summary(self, print_fn=print):
         total, trainable = self.layout.keras_param_counts()
         print_fn("Model: %s on MI355X engine (%s)" % (self.name, self.engine.nl.version()))
+        if getattr(self, "kernel_family", None):
+            print_fn("Kernels: %s" % self.kernel_family)
         for line in self.layout.summary_lines():
             print_fn(line)
         print_fn("Total params: %d" % total)

@@ -86,7 +86,7 @@ class NativeError(RuntimeError):
 
 
 EXPORTS = [
-    "mww_version", "mww_last_error", "mww_device_count", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
+    "mww_version", "mww_last_error", "mww_device_count", "mww_block_kernels_cover", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
     "mww_set_allreduce_hook",
     "mww_destroy", "mww_synchronize",
     "mww_num_params", "mww_num_bn_state", "mww_set_params", "mww_get_params", "mww_set_bn_state", "mww_get_bn_state",
@@ -129,6 +129,7 @@ class NativeLib:
         L.mww_version.restype = C.c_char_p
         L.mww_last_error.restype = C.c_char_p
         L.mww_create.argtypes = [C.POINTER(MixedNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mww_block_kernels_cover.argtypes = [C.POINTER(MixedNetDesc), C.c_int]
         L.mww_create_convnet.argtypes = [C.POINTER(ConvNetDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mww_set_dropout_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mww_set_allreduce_hook.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -199,6 +200,23 @@ class NativeLib:
 
     def device_count(self) -> int:
         return int(self.lib.mww_device_count())
+
+    def block_kernels_cover(self, frames, conv1_filters, conv1_kernel, conv1_stride, block_filters, block_kernel, max_batch=1,
+                            bf16=False):
+        """``mww_block_kernels_cover``: (True, "") if every block of this MixedNet has a specialised MFMA block kernel, else
+        (False, reason) - the model then runs on the conv / depthwise graph kernels.  Needs no GPU (build-time shape table)."""
+        if len(block_filters) != len(block_kernel) or len(block_filters) > MWW_MAX_BLOCKS:
+            return False, "bad block lists"
+        d = MixedNetDesc()
+        d.frames, d.conv1_filters, d.conv1_kernel, d.conv1_stride = int(frames), int(conv1_filters), int(conv1_kernel), int(conv1_stride)
+        d.n_blocks = len(block_filters)
+        for i, (f, k) in enumerate(zip(block_filters, block_kernel)):
+            d.block_filters[i], d.block_kernel[i] = int(f), int(k)
+        d.max_batch = int(max_batch)
+        rc = int(self.lib.mww_block_kernels_cover(C.byref(d), 1 if bf16 else 0))
+        if rc < 0:
+            self.check(rc)
+        return (True, "") if rc == 1 else (False, self.lib.mww_last_error().decode())
 
     def allreduce_unique_id(self) -> np.ndarray:
         """ncclGetUniqueId through the library: 128 bytes rank 0 hands to every rank before ``Engine.allreduce_init``."""

@@ -312,3 +312,21 @@ def test_wide_block_backward_kernels_notebook_and_crosses(emu_lib):
     ec.check_train_steps(emu_lib, B=3, T=204, steps=1, grid=2, flags=dict(ec.NOTEBOOK, bwd_wide=1))
     for flags in ec.CROSSED[:3]:
         ec.check_train_steps(emu_lib, B=3, T=204 if flags.get("stride", 1) == 3 else 150, steps=1, grid=2, flags=dict(flags, bwd_wide=1))
+
+
+def test_block_kernels_of_the_wider_shape_table(emu_lib):
+    """Shapes the round-5 table added (csrc/block_launch.hip.h): 32-wide and mixed-width blocks, kernel lengths 3 / 7 / 17 / 19,
+    a stride-2 first convolution, five blocks - all on the specialised block kernels (the summary says which family)."""
+    from microwakeword_amd import mixednet
+    cases = [dict(ec.DEF, pointwise_filters="32,32,32,32", mixconv_kernel_sizes="[3],[7],[17],[19]"),
+             dict(ec.DEF, pointwise_filters="32,48,64,48", mixconv_kernel_sizes="[7],[5,9],[3],[11,15]", first_conv_kernel_size=5, stride=2),
+             dict(ec.DEF, pointwise_filters="64,32,32,48,48", mixconv_kernel_sizes="[3],[5],[7],[9],[11]", repeat_in_block="1,1,1,1,1",
+                  residual_connection="0,0,0,0,0")]
+    for flags in cases:
+        assert mixednet.kernel_family(flags, 150, lib=emu_lib)[0] == "block", flags
+        ec.check_forward_parity(emu_lib, B=2, T=150, training=True, grid=2, flags=flags)
+        ec.check_train_steps(emu_lib, B=3, T=150, steps=1, grid=2, flags=flags)
+    m = mixednet.model(cases[0], (150, 40), 2, lib=emu_lib, max_batch=2)
+    lines = []
+    m.summary(print_fn=lines.append)
+    assert any(l.startswith("Kernels: specialised block kernels") for l in lines)

@@ -435,3 +435,47 @@ def test_source_stamp_of_the_library(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="does not carry"):   # the stubbed build changes nothing, which build() must notice
         ge.build()
     assert built == [ge.LIB]
+
+
+def test_kernel_family_of_a_grid_of_flag_sets():
+    """Which MixedNet flag sets land on the specialised MFMA block kernels and which on the graph kernels (2.5x the step
+    time): answered from the build-time shape table through the C ABI, no GPU (mww_block_kernels_cover)."""
+    from microwakeword_amd import build_native, native
+    if not os.path.isfile(build_native.LIB):
+        pytest.skip("libmww_hip.so not built")
+    nl = native.NativeLib(build_native.LIB)
+    base = dict(mo_defaults(), residual_connection="0,0,0,0")
+
+    def fam(T=194, **kw):
+        return mixednet.kernel_family(dict(base, **kw), T, lib=nl)[0]
+
+    # the two documented topologies and everything between them
+    assert fam() == "block"
+    assert fam(T=204, first_conv_kernel_size=5, stride=3, pointwise_filters="64,64,64,64", mixconv_kernel_sizes="[5],[7,11],[9,15],[23]") == "block"
+    for widths in ("32,32,32,32", "48,48,48,48", "64,64,64,64", "32,48,64,64", "64,48,32,32", "48,64,48,64"):
+        for ks in ("[5],[9],[13],[21]", "[3],[7],[17],[19]", "[7],[11,15],[3,5,23],[9]", "[5],[5],[5],[5]"):
+            for k1, st in ((3, 1), (5, 1), (3, 2), (5, 3)):
+                assert fam(T=230, pointwise_filters=widths, mixconv_kernel_sizes=ks, first_conv_kernel_size=k1, stride=st) == "block", (widths, ks, k1, st)
+    # 2..6 blocks
+    for nb in (2, 3, 5, 6):
+        lists = dict(pointwise_filters=",".join(["48"] * nb), mixconv_kernel_sizes=",".join(["[5]"] + ["[9]"] * (nb - 1)),
+                     repeat_in_block=",".join(["1"] * nb), residual_connection=",".join(["0"] * nb))
+        assert fam(**lists) == "block", nb
+    one = dict(pointwise_filters="48", mixconv_kernel_sizes="[5]", repeat_in_block="1", residual_connection="0")
+    assert fam(**one) == "graph"
+    # off the table: other widths, even / long kernels, first-block kernels beyond 7, another first conv, the options
+    assert fam(pointwise_filters="40,40,40,40") == "graph"
+    assert fam(mixconv_kernel_sizes="[5],[10],[13],[21]") == "graph"
+    assert fam(T=260, mixconv_kernel_sizes="[5],[9],[13],[25]") == "graph"
+    assert fam(mixconv_kernel_sizes="[9],[9],[13],[21]") == "graph"
+    assert fam(first_conv_filters=16) == "graph" and fam(first_conv_kernel_size=7) == "graph" and fam(stride=4) == "graph"
+    assert fam(residual_connection="0,1,0,0") == "graph" and fam(repeat_in_block="1,2,1,1") == "graph"
+    assert fam(spatial_attention=1) == "graph" and fam(pooled=1) == "graph" and fam(first_conv_filters=0) == "graph"
+    # the bf16 modes exist for the documented topologies and their crosses only
+    assert mixednet.kernel_family(base, 194, lib=nl, bf16=True)[0] == "block"
+    assert mixednet.kernel_family(dict(base, pointwise_filters="32,32,32,32"), 194, lib=nl, bf16=True)[0] == "graph"
+
+
+def mo_defaults():
+    from oracle import model_oracle as mo
+    return dict(mo.MIXEDNET_DEFAULTS)
