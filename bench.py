@@ -625,6 +625,14 @@ def main():
             fh2._drop_prefetcher()
             m2.engine.close()
 
+        comm_ranks = None
+        if dp is not None:
+            try:
+                comm_ranks = eng.allreduce_world() if getattr(dp, "library_comm", False) else (dist.get_world_size() if dist.is_initialized() else 1)
+            except Exception as e:   # noqa: BLE001 - provenance only
+                comm_ranks = "unknown (%s)" % e
+            if isinstance(comm_ranks, int) and comm_ranks != world:
+                raise SystemExit("the step's communicator has %d ranks, the job %d" % (comm_ranks, world))
         if world > 1:
             dist.barrier()
 
@@ -675,7 +683,10 @@ def main():
                    "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch",
                    "sampler": "synchronous" if args.no_prefetch else "worker thread, 2 batches ahead",
                    "collectives": (("torch.distributed via callback" if args.torch_collectives else "RCCL called from the library")
-                                   + ", %d gradient bucket(s)" % args.grad_buckets) if (world > 1 or force_dp) else None},
+                                   + ", %d gradient bucket(s)" % args.grad_buckets) if (world > 1 or force_dp) else None,
+                   # ranks that took part in the step's collectives, as the communicator itself counts them (ncclCommCount of the
+                   # library-owned communicator; the process group's size for the callback form): must equal n_gpus
+                   "collective_ranks": comm_ranks},
         "roofline": {**roof, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,

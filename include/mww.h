@@ -235,6 +235,9 @@ int mww_set_allreduce_hook(mww_ctx* ctx, mww_allreduce_fn fn, void* user, int wo
 int mww_allreduce_unique_id(void* out_id, int capacity);
 int mww_allreduce_init(mww_ctx* ctx, int rank, int world_size, const void* unique_id, int sync_bn);
 int mww_allreduce_destroy(mww_ctx* ctx);
+/* ranks of the library-owned communicator as RCCL reports them (ncclCommCount); 0 without one: a bench line can state how
+ * many GPUs really took part in its collectives. */
+int mww_allreduce_world(mww_ctx* ctx);
 
 /* ---- inference forward on the current batch: replaces model(x, training=...) /
  * model.evaluate's per-batch forward (train.py:50-58). training=1 uses batch statistics without

@@ -101,6 +101,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;   // optional: mww_allreduce_world
   const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -2450,6 +2451,7 @@ int rccl_load(RcclApi* a) {
   a->AllReduce = reinterpret_cast<decltype(a->AllReduce)>(dlsym(a->so, "ncclAllReduce"));
   a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->so, "ncclCommDestroy"));
   a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->so, "ncclGetErrorString"));
+  a->CommCount = reinterpret_cast<decltype(a->CommCount)>(dlsym(a->so, "ncclCommCount"));
   if (!a->GetUniqueId || !a->CommInitRank || !a->AllReduce || !a->CommDestroy || !a->GetErrorString)
     return fail(MWW_ERR_UNSUPPORTED, "librccl.so lacks an entry point");
   return MWW_OK;
@@ -2517,6 +2519,16 @@ int mww_allreduce_destroy(mww_ctx* c) {
   delete r;
   c->rccl = nullptr;
   return MWW_OK;
+}
+
+int mww_allreduce_world(mww_ctx* c) {
+  if (!c) return fail(MWW_ERR_INVALID, "null context");
+  if (!c->rccl || !c->rccl->comm) return 0;
+  int n = 0;
+  if (!c->rccl->api.CommCount) return fail(MWW_ERR_UNSUPPORTED, "librccl.so lacks ncclCommCount");
+  const int e = c->rccl->api.CommCount(c->rccl->comm, &n);
+  if (e != 0) return fail(MWW_ERR_HIP, std::string("ncclCommCount: ") + c->rccl->api.GetErrorString(e));
+  return n;
 }
 
 int mww_allreduce_init(mww_ctx* c, int rank, int world, const void* unique_id, int sync_bn) {

@@ -184,7 +184,12 @@ class Model:
         from .parallel import DataParallel
         self.data_parallel = DataParallel.for_engine(self.engine, group=group, sync_bn=sync_bn, grad_buckets=grad_buckets,
                                                      library_comm=library_comm)
-        return self.data_parallel
+        dp = self.data_parallel
+        if dp.world > 1 and getattr(self.layout, "dropout", 0.0) > 0:
+            # every engine starts from the same dropout seed and counter: without this the W ranks would apply the SAME
+            # [B/W, features] mask at every step instead of B independent rows (Inception: dropout 0.2)
+            self.engine.set_option("dropout_seed", 0x5EED * dp.world + dp.rank + 1)
+        return dp
 
     def _metric_results(self, reduce=False):
         """``reduce``: the counters of every rank's context summed by ONE all-reduce of the raw state (collective; the

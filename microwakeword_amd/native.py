@@ -86,7 +86,7 @@ class NativeError(RuntimeError):
 
 
 EXPORTS = [
-    "mww_version", "mww_last_error", "mww_device_count", "mww_block_kernels_cover", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
+    "mww_version", "mww_last_error", "mww_device_count", "mww_block_kernels_cover", "mww_allreduce_world", "mww_create", "mww_create_convnet", "mww_set_dropout_mask",
     "mww_set_allreduce_hook",
     "mww_destroy", "mww_synchronize",
     "mww_num_params", "mww_num_bn_state", "mww_set_params", "mww_get_params", "mww_set_bn_state", "mww_get_bn_state",
@@ -454,6 +454,10 @@ class Engine:
 
     def allreduce_destroy(self):
         self.nl.check(self.nl.lib.mww_allreduce_destroy(self.h))
+
+    def allreduce_world(self) -> int:
+        """ranks of the library-owned RCCL communicator as RCCL counts them (``ncclCommCount``); 0 without one"""
+        return int(self.nl.check(self.nl.lib.mww_allreduce_world(self.h)))
 
     def set_dropout_mask(self, keep):
         """``keep`` [B, T_last*C_last] of 0/1 (None = built-in generator)."""

@@ -50,20 +50,31 @@ def host_floats(ptr: int, n: int) -> torch.Tensor:
     return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr)))
 
 
-def shard_feature_handler(handler, rank: int, world: int, seed: int, prefetch: int = 2):
+def shard_feature_handler(handler, rank: int, world: int, seed: Optional[int] = None, prefetch: int = 2, epoch: int = 0):
     """Per provider keep training samples ``rank, rank+W, ...`` of the provider's list in CANONICAL (store, sample) order -
     a partition whatever per-rank shuffle produced the list (``MmapFeatureProvider`` shuffles with the global ``random``
-    stream, which need not stand at the same point on every rank) - and give the rank its own RNG streams
-    (``seed * W + rank``).  Validation windows are sharded by index in ``FeatureHandler.evaluate_on_device``
-    (``handler.eval_shard``).  SURVEY 8(e)."""
-    for p in handler.feature_providers:
-        p.feature_sets["training"] = sorted(p.feature_sets["training"])[rank::world]
-        if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:
-            raise ValueError("provider has fewer training samples than ranks")
+    stream, which need not stand at the same point on every rank) - and give the rank its own RNG streams.  Validation
+    windows are sharded by index in ``FeatureHandler.evaluate_on_device`` (``handler.eval_shard``).  SURVEY 8(e).
+
+    The rank's streams are seeded from ``(base, rank, epoch)``: ``base`` is ``seed`` when the caller gives one, else 32 bits
+    drawn from the global ``random`` stream as it stands (a run the user seeded stays a function of that seed, an unseeded
+    run stays unseeded); ``epoch`` is the optimizer step the run resumes from, so a relaunch with ``--restore_checkpoint``
+    continues with fresh draws instead of replaying the batches of step 1.  Idempotent: a handler already sharded for this
+    (rank, world) keeps its lists (``train()`` called twice must not take a shard of a shard)."""
+    if getattr(handler, "_sharded_for", None) != (int(rank), int(world)):
+        if getattr(handler, "_sharded_for", None) is not None:
+            raise ValueError("feature handler already sharded for rank/world %r" % (handler._sharded_for,))
+        for p in handler.feature_providers:
+            p.feature_sets["training"] = sorted(p.feature_sets["training"])[rank::world]
+            if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:
+                raise ValueError("provider has fewer training samples than ranks")
+        handler._sharded_for = (int(rank), int(world))
     handler._sampler = None
     handler.eval_shard = (int(rank), int(world))
-    random.seed(seed * world + rank)
-    np.random.seed(seed * world + rank)
+    base = int(seed) if seed is not None else random.getrandbits(32)
+    mixed = (base * world + rank) * 1000003 + int(epoch)
+    random.seed(mixed)
+    np.random.seed(mixed % (2 ** 32))
     try:
         handler.use_private_rng(prefetch=prefetch)
     except TypeError:   # duck-typed handlers without the prefetch argument
@@ -99,6 +110,8 @@ class DataParallel:
         self._pending = []
         self.exchanges = []   # (n, flags) of the hook calls of the last step (tests / diagnostics)
         self._step_open = False
+        self._managed = False   # inside DataParallel.train_step (which opens and closes the record itself)
+        self._grads_base = int(engine.device_ptr(native.BUF_GRADS)) if hasattr(engine, "device_ptr") else 0
         self.library_comm = bool(library_comm)
         if self.sync_bn and wrap is None and not library_comm:
             raise ValueError("sync_bn needs a wrap(ptr, n) function")
@@ -221,6 +234,10 @@ class DataParallel:
             self.exchanges = []
             self._step_open = True
         self.exchanges.append((int(n), int(flags)))
+        if not self._managed and flags != native.EXCHANGE_DEFERRED and (flags == native.EXCHANGE_FLUSH or ptr == self._grads_base):
+            # the exchange that ends a step (the bucket that starts at the head of the flat gradient, or the flush behind the
+            # deferred one): the next hook call belongs to the next step and starts a new record
+            self._step_open = False
         with self._engine_stream():
             if flags == native.EXCHANGE_FLUSH:
                 for w in self._pending:
@@ -270,6 +287,7 @@ class DataParallel:
         callable, e.g. the draw of the next batch) runs after the step has been enqueued."""
         self.exchanges = []
         self._step_open = True
+        self._managed = True
         try:
             if self.engine_driven:
                 self.engine.train_step(B, lr, flags)   # statistics / gradient exchanges happen inside
@@ -287,3 +305,4 @@ class DataParallel:
             self.engine.apply_gradients(lr, 1.0 / self.world)
         finally:
             self._step_open = False
+            self._managed = False

@@ -205,8 +205,12 @@ def train(model, config, data_processor, verbose=True):
         from .parallel import shard_feature_handler
         dp = model.data_parallel or model.join_data_parallel(sync_bn=bool(config.get("sync_bn", False)),
                                                              grad_buckets=int(config.get("grad_buckets", 1)))
-        shard_feature_handler(data_processor, rank, world, seed=int(config.get("data_parallel_seed", 0)), prefetch=prefetch)
         dp.broadcast_parameters(0, optimizer_state=True)
+        # rank-distinct sampler streams, derived from the configured seed (or from the global stream as it stands) and from
+        # the optimizer step the run (re)starts at: a relaunch continues with fresh draws
+        resumed_step = int(model.engine.get_opt_state()[2]) if hasattr(model.engine, "get_opt_state") else 0
+        seed = config.get("data_parallel_seed")
+        shard_feature_handler(data_processor, rank, world, seed=None if seed is None else int(seed), prefetch=prefetch, epoch=resumed_step)
         log.info("data-parallel: rank %d of %d, %d windows per rank and step (global batch %d), %s BatchNorm", rank, world,
                  config["batch_size"] // world, config["batch_size"], "synchronised" if dp.sync_bn else "rank-local")
     elif fast and hasattr(data_processor, "use_private_rng") and prefetch > 0:

@@ -383,9 +383,9 @@ def test_local_bn_two_ranks_mixednet_graph_kernels(tmp_path):
 _LOOP_T, _LOOP_B, _LOOP_STEPS = 60, 8, 4
 
 
-def _loop_config(run_dir):
+def _loop_config(run_dir, n=24):
     import engine_checks as ec
-    return dict(ec.learnable_config(n=24, T=_LOOP_T), train_dir=str(run_dir), summaries_dir=os.path.join(str(run_dir), "logs"),
+    return dict(ec.learnable_config(n=n, T=_LOOP_T), train_dir=str(run_dir), summaries_dir=os.path.join(str(run_dir), "logs"),
                 batch_size=_LOOP_B, spectrogram_length=_LOOP_T, training_steps=[2, 2], learning_rates=[0.01, 0.003],
                 time_mask_max_size=[3], time_mask_count=[1], freq_mask_max_size=[3], freq_mask_count=[1],
                 positive_class_weight=[1.0], negative_class_weight=[1.0], eval_step_interval=2, target_minimization=0.9,
@@ -399,7 +399,7 @@ def _final_validation(tr, cfg, fh, model):
     return nm, counts
 
 
-def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn):
+def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn, n=24):
     import engine_checks as ec
     from microwakeword_amd import mixednet, native
     from microwakeword_amd import train as tr
@@ -408,7 +408,7 @@ def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     lib = native.NativeLib(emu_path)
-    cfg = dict(_loop_config(os.path.join(out_dir, "run")), sync_bn=sync_bn)
+    cfg = dict(_loop_config(os.path.join(out_dir, "run"), n=n), sync_bn=sync_bn)
     os.makedirs(cfg["train_dir"], exist_ok=True)
     # the ranks deliberately disagree on everything a single process would get from its seeds: initial weights and the
     # per-mode shuffles of the providers - the loop has to make them agree (broadcast, canonical shards)
@@ -419,7 +419,7 @@ def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn):
     n_train = [len(p.feature_sets["training"]) for p in fh.feature_providers]
     out = tr.train(model, cfg, fh, verbose=False)
     shard = [sorted(p.feature_sets["training"]) for p in fh.feature_providers]
-    assert all(len(s) * world >= n and len(s) <= -(-n // world) for s, n in zip(shard, n_train))
+    assert all(n // world <= len(s) <= -(-n // world) for s, n in zip(shard, n_train))
     nm, counts = _final_validation(tr, cfg, fh, model)
     m, v, step = model.engine.get_opt_state()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), params=model.engine.get_params(), state=model.engine.get_bn_state(), m=m, v=v,
@@ -471,6 +471,28 @@ def test_train_loop_two_ranks_end_to_end(tmp_path, sync_bn):
         np.testing.assert_array_equal(counts[k], r[0][k], err_msg=k)
     np.testing.assert_allclose(np.array([nm[k] for k in sorted(nm)], np.float64), r[0]["nm"], rtol=1e-6, atol=1e-9)
     model.engine.close()
+
+
+def test_train_loop_four_ranks_uneven_shards(tmp_path):
+    """The same loop on FOUR ranks with provider sizes that four does not divide (26 samples per provider: shards of 7, 7, 6, 6;
+    two windows per rank and step): identical model / optimizer state / decisions on every rank, the shards a partition, one
+    writer.  (Readiness for the first multi-GPU lease: nothing above two ranks had ever run.)"""
+    import conftest
+    emu = conftest.build_emulator_lib()
+    if emu is None:
+        pytest.skip("clang++ not available for the host-side emulator build")
+    W, n = 4, 26
+    mp.spawn(_train_loop_worker, args=(W, _free_port(), str(tmp_path), emu, False, n), nprocs=W, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(W)]
+    for k in ("params", "state", "m", "v", "step", "best", "nm", "tp", "fp", "tn", "fn"):
+        for j in range(1, W):
+            np.testing.assert_array_equal(r[0][k], r[j][k], err_msg="%s rank %d" % (k, j))
+    assert int(r[0]["step"]) == _LOOP_STEPS
+    shards = [set(map(tuple, r[k]["shard0"])) for k in range(W)]
+    assert sorted(len(s) for s in shards) == [6, 6, 7, 7]
+    assert len(set().union(*shards)) == sum(len(s) for s in shards)   # pairwise disjoint
+    run = tmp_path / "run"
+    assert len((run / "logs" / "validation" / "scalars.jsonl").read_text().splitlines()) == 2
 
 
 def _cli_worker(rank, world, port, emu_path, argv, expect_exists):
