@@ -679,6 +679,14 @@ def main():
         if mfma_flops / FP32_MFMA_PEAK > dom_bytes / HBM_PEAK:
             roof.update({"bound": "mfma", "achieved": round(tf / 1e12, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": round(tf / FP32_MFMA_PEAK, 4)})
+    if args.pointwise_bf16 or args.storage_bf16:
+        # the bf16 modes are governed by neither peak (halving the bytes with bf16 storage does not move the step, and
+        # the bf16 matrix time is nearly free): the per-tile chain of VALU depthwise phases, LDS windows and barriers at two
+        # workgroups per CU.  The HBM fraction stays in the line (hbm_frac); `bound` says what it is not.
+        roof["bound"] = "issue"
+        roof["bound_note"] = ("not HBM- and not MFMA-bound: the block backward launches take the same time with bf16 operands and with bf16 "
+                              "operands + bf16 storage (half the bytes); the depthwise VALU phases / LDS windows / barriers of a tile govern "
+                              "(DESIGN.md 4c, profiles/round5_bf16_modes_ab.txt)")
     out = {
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
