@@ -276,6 +276,24 @@ __device__ __forceinline__ void rotate_priority(int item, int levels) {
   }
 }
 
+// Staggered start (round 5 experiment, MWW_STAGGER_* = s_sleep units of 64 clocks; 0 = off): every workgroup of a launch
+// requests its first tile at once - 27 MB in ~5 us with nothing to compute - and the workgroups that share a CU then
+// stay in lockstep.  Delaying the workgroup dispatched `pos`-th into its CU (blockIdx >> 8 on the 256-CU part) lets the
+// earlier one compute its first tile while the later one loads.
+#ifndef MWW_STAGGER_BWD
+#define MWW_STAGGER_BWD 0
+#endif
+#ifndef MWW_STAGGER_FWD
+#define MWW_STAGGER_FWD 0
+#endif
+template <int UNITS>
+__device__ __forceinline__ void stagger_start() {
+  if constexpr (UNITS > 0) {
+    const int pos = (int)(blockIdx.x >> 8);
+    for (int i = 0; i < pos; ++i) __builtin_amdgcn_s_sleep(UNITS);
+  }
+}
+
 // keep a value (and the loads that produce it) from sinking below this point: used to retire the
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }

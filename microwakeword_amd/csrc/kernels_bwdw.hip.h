@@ -358,6 +358,7 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     dps.issue(elem_ptr<SB>(a.pk, koff), LAST ? a.wd + (size_t)t0 * C : elem_ptr<SB>(a.gk, koff), nvk, tid);
     if (LAST) pre_dz = tile_load1(tile_rsrc(a.dz, a.B * 4), b * 4);
   };
+  stagger_start<MWW_STAGGER_BWD>();
   if (nitems > 0) issue(0);
 
   // ---- prologue: every global load first (one memory round trip), then the LDS copies
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
     offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
   }
   if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
+  stagger_start<MWW_STAGGER_BWD>();
   if (nitems > 0) issue(0);
 
   // every global load of the prologue first, then the LDS copies
