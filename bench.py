@@ -504,6 +504,31 @@ def main():
                 next_batch()
                 eng.train_step(B, lr)
 
+        eng.synchronize()
+        t_pre_roll = time.perf_counter()
+        # ---- the train kernels' first launches happen here, FIRST in the pre-roll: the library is several code objects (one per
+        # translation unit, ~10 MB together) that the runtime loads at the first launch out of each - tens of milliseconds of an
+        # idle GPU.  Behind the validation leg / settle below (where the round-4 single-object library loaded everything at its
+        # very first launch) that idle time sat right in front of the W warm-up steps and a 5 + 20-step run read 0.33 ms
+        # against 0.303 over 200 steps; in front of them the device is back at its steady clocks when the warm-up starts.
+        def untimed_step(profiled_rank0_only=False):
+            fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
+            if dp is not None and world == 1:
+                dp.train_step(B, lr)          # forced-DP on one GPU: the exchanges are degenerate but present
+            elif dp is not None:
+                # no collective may be issued outside the timed loop's lockstep: forward + backward without the exchange /
+                # Adam (every rank still starts the timed loop from the broadcast weights)
+                eng.train_step(B, lr, flags=native.STEP_NO_APPLY)
+            else:
+                eng.train_step(B, lr)
+
+        if args.profile_steps > 0:
+            eng.set_option("graphs", 0)
+            for _ in range(2):
+                untimed_step()
+            if args.graphs and not args.no_graphs:
+                eng.set_option("graphs", 1)
+
         # ---- validation leg (N=1 only, not part of `value`): validate_nonstreaming's two
         # passes (validation set, truncate_start; ambient set, 100 ms-stride split) with the windows gathered and
         # scored in HBM, threshold counters accumulated on the device.  It runs BEFORE the timed train steps (as does the
@@ -512,8 +537,6 @@ def main():
         # 5 + 20-step run against 0.342 in a 20 + 200-step run (profiles/round3_*: the per-kernel event times are 2-3 %
         # longer, the rest is the pipeline fill of the first step).  K and W themselves are exactly what was asked for.
         validation = None
-        eng.synchronize()
-        t_pre_roll = time.perf_counter()
         if n_val and rank == 0:
             for mode, strat in (("validation", "truncate_start"), ("validation_ambient", "split")):   # warm-up: index build, caches
                 fh.evaluate_on_device(model, mode, T_FRAMES, strat, 1024)
@@ -547,26 +570,6 @@ def main():
             for _ in range(16):
                 eng.forward(B, training=False)
             eng.synchronize()
-
-        # ---- the train kernels' first launches (code object loads: 0.7-3 ms each) happen here, outside the timed region and outside
-        # the per-kernel pass: `profile_steps` plain train steps (every rank: same pre-roll everywhere)
-        def untimed_step(profiled_rank0_only=False):
-            fh.next_training_batch_on_device(B, T_FRAMES, "default", policy)
-            if dp is not None and world == 1:
-                dp.train_step(B, lr)          # forced-DP on one GPU: the exchanges are degenerate but present
-            elif dp is not None:
-                # no collective may be issued outside the timed loop's lockstep: forward + backward without the exchange /
-                # Adam (every rank still starts the timed loop from the broadcast weights)
-                eng.train_step(B, lr, flags=native.STEP_NO_APPLY)
-            else:
-                eng.train_step(B, lr)
-
-        if args.profile_steps > 0:
-            eng.set_option("graphs", 0)
-            for _ in range(2):
-                untimed_step()
-            if args.graphs and not args.no_graphs:
-                eng.set_option("graphs", 1)
 
         def fence():
             eng.synchronize()

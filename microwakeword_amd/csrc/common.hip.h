@@ -276,12 +276,14 @@ __device__ __forceinline__ void rotate_priority(int item, int levels) {
   }
 }
 
-// Staggered start (round 5 experiment, MWW_STAGGER_* = s_sleep units of 64 clocks; 0 = off): every workgroup of a launch
-// requests its first tile at once - 27 MB in ~5 us with nothing to compute - and the workgroups that share a CU then
-// stay in lockstep.  Delaying the workgroup dispatched `pos`-th into its CU (blockIdx >> 8 on the 256-CU part) lets the
-// earlier one compute its first tile while the later one loads.
+// Staggered start (round 5; MWW_STAGGER_* = s_sleep units of 64 clocks per position, 0 = off).  Every workgroup of a launch
+// requests its first tile at once - 27 MB in ~5 us with nothing to compute - and the workgroups that share a CU then run
+// their phases in lockstep.  Delaying the workgroup dispatched `pos`-th into its CU (blockIdx >> 8 on the 256-CU part) by a
+// fraction of that burst lets the earlier one start computing while the later one's rows arrive.  Backward kernels (two per
+// CU), same-session A/B (profiles/round5_stagger_ab.txt): 47 units (~1.3 us) 0.3030 -> 0.2983 ms per step, 94 units +-0; the
+// forward kernels (four per CU) gained nothing at 31 units per position.
 #ifndef MWW_STAGGER_BWD
-#define MWW_STAGGER_BWD 0
+#define MWW_STAGGER_BWD 47
 #endif
 #ifndef MWW_STAGGER_FWD
 #define MWW_STAGGER_FWD 0
