@@ -288,6 +288,9 @@ __device__ __forceinline__ void rotate_priority(int item, int levels) {
 #ifndef MWW_STAGGER_FWD
 #define MWW_STAGGER_FWD 0
 #endif
+#ifndef MWW_STAGGER_GRAPH   // the conv / BN graph kernels (3-4 workgroups per CU and launch)
+#define MWW_STAGGER_GRAPH 0
+#endif
 template <int UNITS>
 __device__ __forceinline__ void stagger_start() {
   if constexpr (UNITS > 0) {

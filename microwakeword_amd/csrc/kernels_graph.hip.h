@@ -1246,10 +1246,12 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
 
 template <int NC, int MODE, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_kernel(GConvArgs a) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   gconv_body<NC, MODE, 0, false, SH>(a, blockIdx.x, gridDim.x);
 }
 template <int NC, class SH>
 __global__ __launch_bounds__(kThreads) void gconv_xg_kernel(GConvArgs a, XGather xg) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   gconv_body<NC, 0, 0, false, SH, true>(a, blockIdx.x, gridDim.x, &xg);
 }
 template <int NC, int MODE>
@@ -1263,6 +1265,7 @@ __global__ __launch_bounds__(kThreads) void gconv_chunk_kernel(GConvArgs a) {
 struct GConv2Args { GConvArgs op[2]; };
 template <int NC, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_fwd2_kernel(GConv2Args a, int nb) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   const int op = (int)blockIdx.x >= nb ? 1 : 0;
   gconv_body<NC, 0, 0, false, SH>(a.op[op], blockIdx.x - op * nb, nb);
 }
@@ -1507,10 +1510,12 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 
 template <int NC, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   gconv_wgrad_body<NC, false, SH>(a, blockIdx.x, gridDim.x);
 }
 template <int NC, class SH>
 __global__ __launch_bounds__(kThreads) void gconv_wgrad_xg_kernel(GWgradArgs a, XGather xg) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   gconv_wgrad_body<NC, false, SH, true>(a, blockIdx.x, gridDim.x, &xg);
 }
 template <int NC>
@@ -1523,6 +1528,7 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_chunk_kernel(GWgradArgs 
 // own, so sharing the launch hides one of the two.
 template <int NCO, int NCI, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_bwd_kernel(GWgradArgs w, GConvArgs d, int nbw, int nbd) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   if ((int)blockIdx.x < nbw) gconv_wgrad_body<NCO, false, SH>(w, blockIdx.x, nbw);
   else gconv_body<NCI, 1, NCO, false, SH>(d, blockIdx.x - nbw, nbd);
 }
@@ -1536,6 +1542,7 @@ __global__ __launch_bounds__(kThreads, 3) void gconv_bwd_chunk_kernel(GWgradArgs
 struct GBwd2Args { GWgradArgs w[2]; GConvArgs d[2]; };
 template <int NCO, int NCI, class SH = GShapeDyn>
 __global__ __launch_bounds__(kThreads) void gconv_bwd2_kernel(GBwd2Args a, int nbw, int nbd) {
+  stagger_start<MWW_STAGGER_GRAPH>();
   const int pair = nbw + nbd, op = (int)blockIdx.x >= pair ? 1 : 0, bid = blockIdx.x - op * pair;
   if (bid < nbw) gconv_wgrad_body<NCO, false, SH>(a.w[op], bid, nbw);
   else gconv_body<NCI, 1, NCO, false, SH>(a.d[op], bid - nbw, nbd);
