@@ -74,11 +74,14 @@ __host__ __device__ constexpr int pitch(int c) { return c + 4; }
 //   u tile (written per (channel, chunk), read as the MFMA A operand: lane (r16, g) reads row r16, column 4 kk + g):
 //   c + 2 = 2 or 18 mod 32 spreads the 16 rows x 2 columns of a 32-lane group over 32 banks (c + 4: two-way).  The bf16
 //   mode reads that operand as float4 and keeps 16-byte rows.
-#ifndef MWW_FWD_PITCH
-#define MWW_FWD_PITCH 1
+#ifndef MWW_FWD_PITCH_A   // tuning builds: 0 = c + 4 on the input tile
+#define MWW_FWD_PITCH_A 1
 #endif
-__host__ __device__ constexpr int pitch_fa(int c) { return (MWW_FWD_PITCH && c == 48) ? 48 : c + 4; }
-__host__ __device__ constexpr int pitch_fu(int c, bool bf) { return (MWW_FWD_PITCH && !bf) ? c + 2 : c + 4; }
+#ifndef MWW_FWD_PITCH_U   // tuning builds: 0 = c + 4 on the u tile
+#define MWW_FWD_PITCH_U 1
+#endif
+__host__ __device__ constexpr int pitch_fa(int c) { return (MWW_FWD_PITCH_A && c == 48) ? 48 : c + 4; }
+__host__ __device__ constexpr int pitch_fu(int c, bool bf) { return (MWW_FWD_PITCH_U && !bf) ? c + 2 : c + 4; }
 
 // number of time chunks / chunk length of the (channel, chunk) VALU mapping
 __host__ __device__ constexpr int nchunks(int c) { return kThreads / c; }
