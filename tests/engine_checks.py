@@ -1190,7 +1190,7 @@ def check_train_loop_data_parallel_world1(lib, tmp_path, backend):
         model = mixednet.model(DEF, (T, 40), B, lib=lib, seed=3, max_batch=64)
         fh = FeatureHandler(cfg, engine=model.engine)
         if not extra:
-            # the plain loop on what rank 0 of a one-rank job draws from: canonical sample order, streams seeded seed * W + rank = 0
+            # the plain loop on what rank 0 of a one-rank job draws from: canonical sample order, streams seeded 0 (data_parallel_seed 0)
             for p in fh.feature_providers:
                 p.feature_sets["training"] = sorted(p.feature_sets["training"])
             random.seed(0)
@@ -1208,7 +1208,7 @@ def check_train_loop_data_parallel_world1(lib, tmp_path, backend):
     kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
     dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
     try:
-        p1, s1, o1, dp = run("dp", data_parallel=True)
+        p1, s1, o1, dp = run("dp", data_parallel=True, data_parallel_seed=0)   # streams seeded (0 * W + rank) * 1000003 + step 0 = 0
         assert dp is not None and dp.world == 1
     finally:
         dist.destroy_process_group()
