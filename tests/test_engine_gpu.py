@@ -168,6 +168,28 @@ def test_determinism_of_the_block_backward_forms(lib, wide):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+WIDER_TABLE = [dict(ec.DEF, pointwise_filters="32,32,32,32", mixconv_kernel_sizes="[3],[7],[17],[19]"),
+               dict(ec.DEF, pointwise_filters="32,48,64,48", mixconv_kernel_sizes="[7],[5,9],[3],[11,15]", first_conv_kernel_size=5, stride=2),
+               dict(ec.DEF, pointwise_filters="64,32,32,48,48", mixconv_kernel_sizes="[3],[5],[7],[9],[23]", repeat_in_block="1,1,1,1,1",
+                    residual_connection="0,0,0,0,0"),
+               dict(ec.DEF, pointwise_filters="48,64,64,32", mixconv_kernel_sizes="[5],[19],[21],[3]", stride=3, first_conv_kernel_size=3)]
+
+
+@pytest.mark.parametrize("which", range(len(WIDER_TABLE)))
+def test_block_kernels_of_the_wider_shape_table(lib, which):
+    """Shapes the round-5 table added (csrc/block_launch.hip.h): 32-wide and mixed-width blocks, kernel lengths 3 / 7 / 17 / 19 /
+    23, stride-2 / stride-3 first convolutions with a 3-tap depthwise behind them, five blocks - on the specialised block kernels
+    (asserted), forward parity, a train step with ragged tiles and several windows per workgroup, and at B = 256 without imposed
+    ReLU decisions."""
+    from microwakeword_amd import mixednet
+    flags = WIDER_TABLE[which]
+    T = 230
+    assert mixednet.kernel_family(flags, T, lib=lib)[0] == "block"
+    ec.check_forward_parity(lib, B=5, T=T, training=True, grid=3, flags=flags)
+    ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
+    assert ec.check_gradients_unimposed(lib, B=256, T=T, bound=2e-2, flags=flags) <= 2e-2
+
+
 def test_training_reduces_loss(lib):
     ec.check_training_reduces_loss(lib)
 
