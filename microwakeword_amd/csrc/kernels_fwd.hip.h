@@ -384,8 +384,12 @@ __global__ __launch_bounds__(kThreads, (CIN > 48 ? 2 : (K > 13 ? 3 : 4))) void f
   __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CPA];
   __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPU];
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
-  __shared__ __attribute__((aligned(16))) float sScale[CIN];
-  __shared__ __attribute__((aligned(16))) float sShift[CIN];
+  // BN_{k-1} folded scale | shift, typed float4: the commit reads them as ONE ds_read_b128 per lane (64 banks: the 12 or 16
+  // distinct float4 of a wave do not collide).  As float arrays the compiler could not prove the 16-byte alignment and split every
+  // read into three dword accesses, which at 48 channels wrap onto the 32 dword banks two-way (tools/ubench/lds_patterns "table4").
+  __shared__ float4 sAff4[2 * CIN / 4];
+  float* const sScale = reinterpret_cast<float*>(sAff4);
+  float* const sShift = sScale + CIN;
 #include "fwd_block_body.inc"
 }
 
