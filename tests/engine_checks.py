@@ -207,9 +207,10 @@ def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=Non
     mask-imposing checks cannot give (a wrong mask would be copied into the oracle there).  A float32-vs-float64 flip
     of a near-zero unit may move a tensor's gradient by ~1/sqrt(units), hence the loose per-tensor L2 bound; a mask
     bug moves it by O(1).  `kind` "inception" runs the conv/BN graph engine (dropout mask injected), "graph_mixednet" a
-    MixedNet flag set on the generic graph kernels, `flags` any topology.  `noise_factor` (the bf16 modes): the bound of a
-    tensor is that factor times the distance between the float32 and the float64 ORACLE on the same batch - the mode's own
-    rounding / decision-flip noise, measured here - but never below `bound`."""
+    MixedNet flag set on the generic graph kernels, `flags` any topology.  `noise_factor` (the bf16 modes; topologies whose
+    sub-spectral BN slots sum many channels into gradients that nearly cancel): the bound of a tensor is that factor times the
+    distance between the float32 and the float64 ORACLE on the same batch - the rounding / decision-flip noise of the
+    arithmetic itself, measured here - but never below `bound`.  (fp32 modes keep the tight loss / probability bounds.)"""
     rng = np.random.default_rng(seed)
     x = synth_x(rng, B, T)
     y = (rng.random(B) < 0.5).astype(np.float32)
@@ -241,6 +242,7 @@ def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=Non
     pr, z, loss = eng.read_outputs(B)
     lo, po, grads, _ = om.loss_and_grads(x, y, w, **kw)
     lowp = noise_factor is not None
+    lowp_fwd = lowp and _lowp(flags or {})   # only the bf16 modes loosen the forward bounds
 
     def flat(grads):
         if kind in ("inception", "graph_mixednet"):
@@ -251,9 +253,11 @@ def check_gradients_unimposed(lib, B=1024, T=194, bound=1e-2, seed=11, flags=Non
     gref = flat(grads)
     gnoise = None
     if lowp:
-        om32 = perturbed_oracle(T, flags=flags or DEF, dtype=torch.float32)
+        om32 = (perturbed_inception_oracle(T, flags, dtype=torch.float32) if kind == "inception"
+                else perturbed_oracle(T, flags=flags or DEF, dtype=torch.float32))
         lo32, po32, grads32, _ = om32.loss_and_grads(x, y, w, **kw)
         gnoise = flat(grads32)
+    if lowp_fwd:
         assert abs(loss - lo) <= max(1e-3, noise_factor * abs(lo32 - lo)) * max(1.0, abs(lo)), (loss, lo, lo32)
         assert np.abs(pr - po).max() <= max(5e-3, noise_factor * float(np.abs(po32 - po).max()))
     else:
@@ -534,8 +538,8 @@ INC_VARIANT = dict(cnn1_filters="16,24", cnn1_kernel_sizes="3,5", cnn1_subspectr
                    cnn2_filters2="10,16", cnn2_kernel_sizes="3,5", cnn2_subspectral_groups="2,1", cnn2_dilation="2,1", dropout=0.3)
 
 
-def perturbed_inception_oracle(T, flags, seed=42):
-    om = mo.OracleModel("inception", flags, T, seed=seed)
+def perturbed_inception_oracle(T, flags, seed=42, dtype=torch.float64):
+    om = mo.OracleModel("inception", flags, T, seed=seed, dtype=dtype)
     rng = np.random.default_rng(seed + 1)
     ws = []
     for v, w in zip(om.vars, om.get_weights()):
