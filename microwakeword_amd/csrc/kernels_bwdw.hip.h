@@ -339,6 +339,8 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
   const int c = tid % C, chunk = tid / C;
   const bool dw_active = chunk < NCH;
+  MWW_PC_DECL
+  MWW_PC_AT(0);   // kernel entry (profiling builds only: tools/phase_clocks.py)
 
   const int ntiles = (a.Tin + TT - 1) / TT;
   const int nsamp = (int)blockIdx.x < a.B ? (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -424,6 +426,8 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
   pin(dwb); pin(xk1); pin(xk0);
   __syncthreads();
 
+  MWW_PC_AT(1);   // prologue done
+  MWW_PC_START(MWW_ABLATE(a, 16) && tid == 0);
   for (int it = 0; it < nitems; ++it) {
 #ifndef MWW_WIDE_NOPRIO
     rotate_priority(it, 2);
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     }
     dps.commit(sDP, sKp, pre_dz, nrows_new * Q, tid);
     for (int i = tid; i < (K - 1) * P; i += NTH) sDU[i] = (t0 == 0) ? 0.f : sDU[TT * P + i];
+    MWW_PC_MARK(0);   // commit (incl. the wait for the prefetched rows)
     __syncthreads();
+    MWW_PC_MARK(1);   // barrier 1
     if (it + 1 < nitems) issue(it + 1);
     // ---- P1: recompute u = depthwise(a) + bias for the tile's output rows
     if (dw_active) {
@@ -467,7 +473,9 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
         for (int t = 0; t < L; ++t) sU[(chunk * L + t) * P + c] = 0.f;
       }
     }
+    MWW_PC_MARK(2);   // issue + P1 (u recompute)
     __syncthreads();
+    MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
     if constexpr (C == 48 && NW == 8) {
       if (wave < 6) {
@@ -489,7 +497,9 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
       wide_dw_rows<2, 4, 16, D, P>(sU, sDP, 0, nrows_new, 16 * (wave / 2), 32 * (wave % 2), r16, g, dwacc);
       wide_du_tiles<C, 2, K, P, PW>(sDP, sWt, sDU, wave / 2, nrows_new, 32 * (wave % 2), r16, g);
     }
+    MWW_PC_MARK(4);   // MFMA (dW_pw, du)
     __syncthreads();
+    MWW_PC_MARK(5);   // barrier 3
     // ---- P4: depthwise backward in two passes over the same registers.  No divergent branch around the global stores:
     // the lanes past the last chunk shadow it, their stores are out of range and their sums are dropped by the epilogue.
     {
@@ -528,8 +538,11 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
         dw_wgrad_all_groups<K, L>(wa_p, P, duk, accw);
       }
     }
+    MWW_PC_MARK(6);   // P4 (depthwise backward, stores)
     __syncthreads();
+    MWW_PC_MARK(7);   // barrier 4
   }
+  MWW_PC_AT(2);   // tile loop done
 
   // ---- epilogue: per-workgroup partial rows [K*C (dW_dw) | C (db) | C*C (dW_pw)] and the BN sums of g_{k-1}
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * C + C * C);
@@ -572,6 +585,8 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     for (int j = 0; j < NCH; ++j) v += scratch[j * 2 * C + tid];
     publish_stat(a.gacc, a.gstat_part + (size_t)blockIdx.x * 2 * C, 2 * C, tid, v);
   }
+  MWW_PC_AT(3);   // epilogue done
+  MWW_PC_DUMP(a.phase_clk ? a.phase_clk + (size_t)blockIdx.x * kClkSlots : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

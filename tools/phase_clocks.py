@@ -8,13 +8,10 @@ from microwakeword_amd import synthetic
 from microwakeword_amd.data import FeatureHandler
 from microwakeword_amd.model import Model
 
-import subprocess
-from microwakeword_amd import native
-LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_prof.so")   # FULL=1 bash tools/build_variant.sh prof -DMWW_PROFILE, built in the container
+from microwakeword_amd import build_native, native
+LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_prof.so")   # bash tools/build_variant.sh prof -DMWW_PROFILE, built in the container
 if not os.path.isfile(LIB):
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMWW_PROFILE",
-                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "microwakeword_amd", "csrc", "mww_lib.hip"),
-                    os.path.join(ROOT, "microwakeword_amd", "csrc", "sampler.cpp"), "-o", LIB], check=True)
+    build_native.build_library(LIB, defines=["-DMWW_PROFILE"], slim=True)
 B, T = int(os.environ.get("PC_B", "1024")), 194
 model = Model(synthetic.DEFAULT_MIXEDNET_FLAGS, (T, 40), B, seed=42, max_batch=B, lib=native.NativeLib(LIB))
 eng = model.engine
@@ -24,6 +21,9 @@ fh = FeatureHandler(cfg, engine=eng)
 fh.use_private_rng()
 extra = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 eng.set_option("ablate", 16 | extra)
+for opt in filter(None, os.environ.get("PC_OPTIONS", "").split(",")):   # e.g. PC_OPTIONS=pointwise_bf16=1 or storage_bf16=1,bwd_wide=0
+    eng.set_option(opt.split("=")[0], int(opt.split("=")[1]))
+print("== B = %d, options: %s" % (B, os.environ.get("PC_OPTIONS", "(fp32, wide backward)")))
 for _ in range(3):
     fh.next_training_batch_on_device(B, T, "default", synthetic.SPEC_AUGMENT_POLICY)
     eng.train_step(B, 1e-3)
