@@ -461,24 +461,12 @@ def main():
             eng.set_option("pointwise_bf16", 1)
         if args.storage_bf16:
             eng.set_option("storage_bf16", 1)
-        if os.environ.get("MWW_BENCH_SIDE_STREAM") is not None:
-            eng.set_option("side_stream", int(os.environ["MWW_BENCH_SIDE_STREAM"]))
-        if os.environ.get("MWW_BENCH_TAIL_ROLES") is not None:
-            eng.set_option("tail_roles", int(os.environ["MWW_BENCH_TAIL_ROLES"]))
-        if os.environ.get("MWW_BENCH_GRID_GRAPH") is not None:
-            eng.set_option("grid_graph", int(os.environ["MWW_BENCH_GRID_GRAPH"]))
-        for kv in filter(None, os.environ.get("MWW_BENCH_OPTIONS", "").split(",")):   # "name=value,..." (tools/: knob sweeps)
+        # engine options for A/B sweeps: MWW_BENCH_OPTIONS="name=value,..." (tools/: e.g. bwd_wide=0, bn_inline=0, grid_graph=768) - the one
+        # knob besides MWW_BENCH_FUSED_INPUT, which also changes the byte accounting above
+        for kv in filter(None, os.environ.get("MWW_BENCH_OPTIONS", "").split(",")):
             eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-        if os.environ.get("MWW_BENCH_DGRAD_SHARE") is not None:
-            eng.set_option("graph_dgrad_share", int(os.environ["MWW_BENCH_DGRAD_SHARE"]))
-        if os.environ.get("MWW_BENCH_ROLE_SPLIT") is not None:
-            eng.set_option("graph_role_split", int(os.environ["MWW_BENCH_ROLE_SPLIT"]))
-        if os.environ.get("MWW_BENCH_BN_INLINE") is not None:
-            eng.set_option("bn_inline", int(os.environ["MWW_BENCH_BN_INLINE"]))
         if os.environ.get("MWW_BENCH_FUSED_INPUT") is not None:
             eng.set_option("fused_input", int(os.environ["MWW_BENCH_FUSED_INPUT"]))
-        if os.environ.get("MWW_BENCH_ASM_SPLIT") is not None:
-            eng.set_option("assemble_split", int(os.environ["MWW_BENCH_ASM_SPLIT"]))
         if args.graphs and not args.no_graphs:
             eng.set_option("graphs", 1)
         policy = synthetic.SPEC_AUGMENT_POLICY

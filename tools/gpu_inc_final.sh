@@ -8,7 +8,7 @@ cd $R
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -k "inception or graph or residual or attention or train_loop" 2>&1 | tail -8 | tee $OUT/pytest.log
 timeout 600 python bench.py --model inception --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_inception.json 2> $OUT/bench_inception.err; tail -c 600 $OUT/bench_inception.json
 timeout 600 python bench.py --model inception --steps 100 --warmup 10 --no-cpu-baseline --no-validation --no-graphs > $OUT/bench_inception_eager.json 2> $OUT/bench_inception_eager.err
-MWW_BENCH_BN_INLINE=0 timeout 600 python bench.py --model inception --steps 100 --warmup 10 --no-cpu-baseline --no-validation > $OUT/bench_inception_finalize_launches.json 2> $OUT/bench_inception_fl.err
+MWW_BENCH_OPTIONS=bn_inline=0 timeout 600 python bench.py --model inception --steps 100 --warmup 10 --no-cpu-baseline --no-validation > $OUT/bench_inception_finalize_launches.json 2> $OUT/bench_inception_fl.err
 for b in 256 4096; do timeout 300 python bench.py --model inception --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-validation --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch $b', d['value'], d['ms_per_step'], d['roofline']['step_frac'])" | tee -a $OUT/batch_sweep_inception.txt; done
 python - $OUT <<'PY'
 import json,sys,os

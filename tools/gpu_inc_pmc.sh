@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp
-export TMPDIR=/tmp MWW_BENCH_GRID_GRAPH=${GRID:-0}
+export TMPDIR=/tmp MWW_BENCH_OPTIONS=grid_graph=${GRID:-0}
 B="python $R/bench.py --model inception --steps 6 --warmup 2 --no-graphs --no-cpu-baseline --no-validation --profile-steps 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $B > /dev/null 2> $OUT/trace.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1 -o p -- $B > /dev/null 2> $OUT/pmc1.err
