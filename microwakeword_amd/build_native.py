@@ -1,6 +1,6 @@
 """Builds ``libmww_hip.so`` (and, for the test-suite, the host-side emulator library) from ``csrc/``.
 
-The library is several translation units (``mww_lib.hip`` + one per block-kernel family, ``block_launch.hip.h``)
+The library is ten translation units (``mww_lib.hip`` + the block-kernel families of ``block_launch.hip.h``, the largest split by width)
 compiled in parallel and linked once.  Objects are cached under ``build/obj`` keyed by the sha256 of the flags and of
 every file the unit includes, so editing one kernel header recompiles only the units that see it.
 
@@ -22,7 +22,8 @@ CSRC = os.path.join(ROOT, "microwakeword_amd", "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")
 OBJDIR = os.path.join(ROOT, "build", "obj")
-UNITS = ("version.cpp", "mww_lib.hip", "tu_fwd.hip", "tu_bwd.hip", "tu_bwdw.hip", "sampler.cpp")   # version.cpp first: the one unit that carries the stamp
+UNITS = ("version.cpp", "mww_lib.hip", "tu_bwd_first.hip", "tu_bwd64.hip", "tu_bwd48.hip", "tu_bwd32.hip", "tu_fwd.hip", "tu_bwdw.hip", "tu_bwd.hip",
+         "sampler.cpp")   # version.cpp first: the one unit that carries the stamp
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-pthread")
 EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 EMU_CLANG = "/opt/rocm/lib/llvm/bin/clang++"

@@ -83,6 +83,11 @@ __host__ __device__ constexpr int pitch(int c) { return c + 4; }
 __host__ __device__ constexpr int pitch_fa(int c) { return (MWW_FWD_PITCH_A && c == 48) ? 48 : c + 4; }
 __host__ __device__ constexpr int pitch_fu(int c, bool bf) { return (MWW_FWD_PITCH_U && !bf) ? c + 2 : c + 4; }
 
+// pitch of W_pw^T in the 256-thread backward kernels: its rows are read one apart by the fp32 contraction (the two rows of a
+// 32-lane LDS group land on disjoint banks at 16 mod 32: 48 / 48 / 80 for 32 / 48 / 64 channels; c + 4 was two-way) and four
+// apart by the bf16 one (where c + 4 already is conflict-free)
+__host__ __device__ constexpr int pitch_wt(int c, bool bf) { return bf ? c + 4 : (c % 32 == 16 ? c : c + 16); }
+
 // number of time chunks / chunk length of the (channel, chunk) VALU mapping
 __host__ __device__ constexpr int nchunks(int c) { return kThreads / c; }
 __host__ __device__ constexpr int chunk_len(int c) { return (TT + nchunks(c) - 1) / nchunks(c); }

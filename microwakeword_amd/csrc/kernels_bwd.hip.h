@@ -110,9 +110,9 @@ struct DpStage {
 // follows issues its own, and store() writes LDS once everything has arrived.  (Rolled loops with a load and an LDS
 // write per iteration cost one L2 round trip per element - nine in a row for W_pw^T: the round-2 timeline showed a
 // 6 us prologue per backward kernel.)
-template <int CIN, int COUT, int KD>
+template <int CIN, int COUT, int KD, int PWT = pitch(CIN)>
 struct WeightStage {
-  static constexpr int CPI = pitch(CIN), NW = (CIN * COUT + kThreads - 1) / kThreads, ND = KD > 0 ? (KD * CIN + kThreads - 1) / kThreads : 1;
+  static constexpr int CPI = PWT, NW = (CIN * COUT + kThreads - 1) / kThreads, ND = KD > 0 ? (KD * CIN + kThreads - 1) / kThreads : 1;
   float w[NW], d[ND];
   __device__ __forceinline__ void load(const float* pw_w, const float* dw_w, int tid) {
 #pragma unroll
@@ -120,7 +120,7 @@ struct WeightStage {
 #pragma unroll
     for (int j = 0; j < ND; ++j) d[j] = (KD > 0 && tid + j * kThreads < KD * CIN) ? dw_w[tid + j * kThreads] : 0.f;
   }
-  // sWt [COUT][pitch(CIN)] = W_pw^T; sDW [KD][CIN] (KD = 0: the taps stay in registers, nothing to stage)
+  // sWt [COUT][PWT] = W_pw^T; sDW [KD][CIN] (KD = 0: the taps stay in registers, nothing to stage)
   __device__ __forceinline__ void store(float* sWt, float* sDW, int tid) const {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -159,6 +159,7 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
                                                         int g, const float* sWt,
                                                         f32x4 (&dwacc)[CIN / 16][COUT / 16], bool live) {
   constexpr int CPI = pitch(CIN), CPO = pitch(COUT), MT = CIN / 16, NT = COUT / 16, KSO = COUT / 4;
+  constexpr int PWT = pitch_wt(CIN, BF);
   f32x4 du[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) du[mt] = zero4();
@@ -172,7 +173,9 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
     {
       float av[2][MT], bv[2][NT];
       auto load_dw = [&](int kk, int s) {
-        const int row = wave * 16 + kk * 4 + g;
+        // k-step kk meets the rows kk, kk + 4, kk + 8, kk + 12 of the wave's 16: the two rows of a 32-lane LDS group are four
+        // apart, and 4 * (c + 4) = 16 (mod 32) for c = 32, 48, 64 puts them on disjoint banks (rows one apart: two-way on every read)
+        const int row = wave * 16 + kk + 4 * g;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) av[s][mt] = sU[row * CPI + mt * 16 + r16];
 #pragma unroll
@@ -182,7 +185,7 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
       auto load_du = [&](int kk, int s) {
         a2[s] = sDP[(wave * 16 + r16) * CPO + kk * 4 + g];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) b2[s][mt] = sWt[(kk * 4 + g) * CPI + mt * 16 + r16];
+        for (int mt = 0; mt < MT; ++mt) b2[s][mt] = sWt[(kk * 4 + g) * PWT + mt * 16 + r16];
       };
       load_dw(0, 0);
 #pragma unroll
@@ -231,8 +234,8 @@ __device__ __forceinline__ void pointwise_backward_tile(const float* sU, const f
       const bf16x4 a4 = to_bf16x4(v.x, v.y, v.z, v.w);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float* col = sWt + (kk * 16 + 4 * g) * CPI + mt * 16 + r16;
-        du[mt] = mfma_bf16(a4, to_bf16x4(col[0], col[CPI], col[2 * CPI], col[3 * CPI]), du[mt]);
+        const float* col = sWt + (kk * 16 + 4 * g) * PWT + mt * 16 + r16;
+        du[mt] = mfma_bf16(a4, to_bf16x4(col[0], col[PWT], col[2 * PWT], col[3 * PWT]), du[mt]);
       }
     }
   }
@@ -290,7 +293,7 @@ struct BwdBlockLds {
   static constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
   static constexpr int OFF_END = RAP * CPI + TT * CPO + TTP * CPI + RAP * CPI;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
-  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), DW = WT + COUT * CPI, ACT = DW + up4(K * CIN), END = ACT + 2 * CIN;
+  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), DW = WT + COUT * pitch_wt(CIN, false), ACT = DW + up4(K * CIN), END = ACT + 2 * CIN;
 };
 template <int K1, int C1, int COUT, int K, int S>
 struct BwdFirstLds {
@@ -300,7 +303,7 @@ struct BwdFirstLds {
   static constexpr int OFF_END = RAP * CPI + TT * CPO + TTP * CPI + RAP * CPI + (TTP + TAIL) * CPI;
   static constexpr int XR = (TT + TAIL - 1) * S + K1, PX = FBINS + 1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
-  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), X = WT + COUT * CPI, XG = X + up4(XR * PX);
+  static constexpr int KP = OFF_END, WT = KP + up4(7 * COUT), X = WT + COUT * pitch_wt(CIN, false), XG = X + up4(XR * PX);
   static constexpr int END = XG + up4((int)(sizeof(XShared) + 3) / 4);
 };
 
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kThreads, ((CIN > 48 || BwdBlockLds<CIN, COUT, K>::
   typedef BwdBlockLds<CIN, COUT, K> Lds;
   __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
-  __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * pitch_wt(CIN, BF)];   // W_pw^T
   __shared__ __attribute__((aligned(16))) float sDW[K * CIN];      // depthwise taps
   __shared__ __attribute__((aligned(16))) float sAct[2 * CIN];     // BN_{k-1} folded scale / shift (activation at commit)
 #include "bwd_block_body.inc"
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(kThreads, (S > 1 ? 1 : 2)) void bwd_first_kernel(Bw
   __shared__ XShared sXg;
   __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
-  __shared__ __attribute__((aligned(16))) float sWt[COUT * Lds::CPI];   // W_pw^T
+  __shared__ __attribute__((aligned(16))) float sWt[COUT * pitch_wt(C1, BF)];   // W_pw^T
 #include "bwd_first_body.inc"
 }
 

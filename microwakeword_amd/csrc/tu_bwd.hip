@@ -1,61 +1,17 @@
-// Translation unit of the 256-thread backward block kernels (see block_launch.hip.h).
+// Dispatch of the 256-thread backward block kernels to the translation unit of their input width (tu_bwd32 / 48 / 64.hip).
 #define MWW_BLOCK_TU 1
 #include "block_launch.hip.h"
 
 namespace mww {
 
-bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid) {
-  if (mode != 0) {
-#define X(K1, C1, CO, K, S)                                                                                    \
-    if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                         \
-      if (mode == 2)                                                                                           \
-        hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
-      else                                                                                                     \
-        hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
-      return true;                                                                                             \
-    }
-    MWW_FIRST_SHAPES_BF16(X)
-#undef X
-    return false;
-  }
-#define X(K1, C1, CO, K, S)                                                                                    \
-  if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
-    hipLaunchKernelGGL((bwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, st, a);     \
-    return true;                                                                                               \
-  }
-  MWW_FIRST_SHAPES(X)
-#undef X
-  return false;
-}
+bool k_launch_bwd_block_cin32(hipStream_t st, int mode, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
+bool k_launch_bwd_block_cin48(hipStream_t st, int mode, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
+bool k_launch_bwd_block_cin64(hipStream_t st, int mode, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
 
 bool k_launch_bwd_block(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid) {
-  if (mode != 0) {
-#define X(CI, CO, K)                                                                                           \
-    if (cin == CI && cout == CO && k == K) {                                                                   \
-      if (last && mode == 2)                                                                                   \
-        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
-      else if (mode == 2)                                                                                      \
-        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true, true>), dim3(grid), dim3(kThreads), 0, st, a); \
-      else if (last)                                                                                           \
-        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, true>), dim3(grid), dim3(kThreads), 0, st, a);   \
-      else                                                                                                     \
-        hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, true>), dim3(grid), dim3(kThreads), 0, st, a);  \
-      return true;                                                                                             \
-    }
-    MWW_BLOCK_SHAPES_BF16(X)
-#undef X
-    return false;
-  }
-#define X(CI, CO, K)                                                                                           \
-  if (cin == CI && cout == CO && k == K) {                                                                     \
-    if (last)                                                                                                  \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, true, false>), dim3(grid), dim3(kThreads), 0, st, a);    \
-    else                                                                                                       \
-      hipLaunchKernelGGL((bwd_block_kernel<CI, CO, K, false, false>), dim3(grid), dim3(kThreads), 0, st, a);   \
-    return true;                                                                                               \
-  }
-  MWW_BLOCK_SHAPES(X)
-#undef X
+  if (cin == 32) return k_launch_bwd_block_cin32(st, mode, cout, k, last, a, grid);
+  if (cin == 48) return k_launch_bwd_block_cin48(st, mode, cout, k, last, a, grid);
+  if (cin == 64) return k_launch_bwd_block_cin64(st, mode, cout, k, last, a, grid);
   return false;
 }
 
