@@ -157,12 +157,13 @@ def _tree_source_sha():
         return None
 
 
-def pmc_profile_sha16(path):
-    """tools/pmc_summary.py stamps the library it profiled into the first line of its summary (`# library sha256_16=...`)."""
+def pmc_profile_sha16(path, field="library sha256_16"):
+    """tools/pmc_summary.py stamps the library it profiled into the first line of its summary
+    (`# library sha256_16=... source_sha16=...`: the file's sha256 and the sha256 of the source set it was built from)."""
     import re
     try:
         with open(path) as fh:
-            m = re.match(r"#\s*library sha256_16=([0-9a-f]{16})", fh.readline())
+            m = re.search(re.escape(field) + r"=([0-9a-f]{16})", fh.readline())
         return m.group(1) if m else None
     except OSError:
         return None
@@ -193,8 +194,18 @@ def pmc_traffic(kernel, model, path=None, library=LIBRARY):
     if not os.path.isfile(path):
         return None, "missing: no PMC summary of this round's library yet (%s)" % os.path.basename(path)
     prof_sha, lib_sha = pmc_profile_sha16(path), library_sha16(library)
-    if prof_sha is None or prof_sha != lib_sha:
-        return None, "stale: profile sha %s != library sha %s (%s)" % (prof_sha, lib_sha, os.path.basename(path))
+    same_binary = prof_sha is not None and prof_sha == lib_sha
+    if not same_binary:
+        # a library rebuilt from the same source set holds the same kernels (hipcc builds are not bit-reproducible across
+        # paths): accepted, and the source says so
+        prof_src = pmc_profile_sha16(path, "source_sha16")
+        try:
+            from microwakeword_amd import build_native
+            lib_src = build_native.library_source_sha16(library)
+        except Exception:   # noqa: BLE001
+            lib_src = None
+        if prof_src is None or lib_src is None or prof_src != lib_src:
+            return None, "stale: profile sha %s != library sha %s (%s)" % (prof_sha, lib_sha, os.path.basename(path))
     want = names.get(kernel)
     if not want:
         return None, None
@@ -207,7 +218,8 @@ def pmc_traffic(kernel, model, path=None, library=LIBRARY):
             write = float(m.group(1)) if m else write
     if fetch is None or write is None:
         return None, None
-    return int(2 * fetch * 1024 + write * 1024), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB; library sha %s)" % (os.path.basename(path), lib_sha)
+    which = "library sha %s" % lib_sha if same_binary else "a library built from the same source set %s (binary sha %s, profiled %s)" % (prof_src, lib_sha, prof_sha)
+    return int(2 * fetch * 1024 + write * 1024), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB; %s)" % (os.path.basename(path), which)
 
 
 def parse_args():

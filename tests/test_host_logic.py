@@ -384,7 +384,18 @@ def test_bench_traffic_figure_is_tied_to_the_library_it_was_measured_on(tmp_path
     first = r.stdout.splitlines()[0]
     assert first.startswith("# library sha256_16=")
     if os.path.isfile(bench.LIBRARY):
-        assert first.endswith(bench.library_sha16())
+        from microwakeword_amd import build_native
+        assert first == "# library sha256_16=%s source_sha16=%s" % (bench.library_sha16(), build_native.library_source_sha16() or "unknown")
+    # a library REBUILT from the same source set (hipcc output is not bit-identical across build paths) is accepted by its
+    # source stamp, and the source string says that it was
+    rebuilt = tmp_path / "librebuilt.so"
+    rebuilt.write_bytes(b"other bytes, same kernels: mww-hip 0.1 (gfx950) src=0123456789abcdef\0")
+    stamped = tmp_path / "stamped.txt"
+    stamped.write_text("# library sha256_16=%s source_sha16=0123456789abcdef\n%s" % ("f" * 16, body))
+    nbytes, src = bench.pmc_traffic("bwd_block4", "mixednet", path=str(stamped), library=str(rebuilt))
+    assert nbytes == int(2 * 3.2e4 * 1024 + 4e4 * 1024) and "same source set 0123456789abcdef" in src
+    stamped.write_text("# library sha256_16=%s source_sha16=fedcba9876543210\n%s" % ("f" * 16, body))
+    assert bench.pmc_traffic("bwd_block4", "mixednet", path=str(stamped), library=str(rebuilt))[0] is None
 
 
 def test_train_model_claims_the_directory_like_the_reference(tmp_path, monkeypatch):

@@ -14,13 +14,17 @@ def short(name):
 
 
 def library_stamp():
-    """First line of every summary: the library the profile was measured on (bench.py refuses a summary whose stamp is not
-    the library it loaded)."""
+    """First line of every summary: the library the profile was measured on - the sha256 of the file and the sha256 of the
+    source set it was built from (mww_version()).  bench.py reports roofline.traffic only from a summary whose library is the
+    one it loaded, or was built from the same source set."""
     import hashlib
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microwakeword_amd", "libmww_hip.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "microwakeword_amd", "libmww_hip.so")
     try:
         with open(lib, "rb") as fh:
-            return "# library sha256_16=%s" % hashlib.sha256(fh.read()).hexdigest()[:16]
+            data = fh.read()
+        m = re.search(rb"mww-hip [0-9.]+ \(gfx950\) src=([0-9a-f]{16})", data)
+        return "# library sha256_16=%s source_sha16=%s" % (hashlib.sha256(data).hexdigest()[:16], m.group(1).decode() if m else "unknown")
     except OSError:
         return "# library sha256_16=unknown"
 
