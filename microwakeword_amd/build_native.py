@@ -169,13 +169,13 @@ def build_library(out: str = LIB, defines=(), slim: bool = False, jobs=None, ver
     return n_a + n_b
 
 
-def build_emulator(out: str = None, verbose=False):
+def build_emulator(out: str = None, verbose=False, defines=()):
     """TEST INFRASTRUCTURE: the unchanged product sources compiled as host C++ against tests/hipemu (fibers + emulated
     wave ops).  Returns the library path, or None without clang++."""
     out = out or os.path.join(EMU_DIR, "libmww_emu.so")
     if not os.path.isfile(EMU_CLANG):
         return None
-    flags = list(EMU_FLAGS) + ["-I", EMU_DIR, "-I", INCLUDE]
+    flags = list(EMU_FLAGS) + ["-I", EMU_DIR, "-I", INCLUDE] + list(defines)
     units = [os.path.join(CSRC, u) for u in UNITS] + [os.path.join(EMU_DIR, "hipemu.cpp")]
     extra = [os.path.join(EMU_DIR, "hip", "hip_runtime.h")]
     objs, n = _compile_units(EMU_CLANG, flags, units, "emu", extra_key_files=extra, verbose=verbose)
@@ -194,7 +194,7 @@ if __name__ == "__main__":
     ap.add_argument("defines", nargs="*", help="extra -D... flags")
     args = ap.parse_args()
     if args.emulator:
-        print(build_emulator(verbose=True))
+        print(build_emulator(args.out if args.out != LIB else None, verbose=True, defines=args.defines))
     else:
         n = build_library(args.out, defines=args.defines, slim=args.slim)
         print("[build] %s: %d unit(s) compiled, library sha256_16 %s, source sha16 %s" % (args.out, n, library_sha16(args.out), library_source_sha16(args.out)))

@@ -299,6 +299,19 @@ __device__ __forceinline__ void rotate_priority(int item, int levels) {
 #ifndef MWW_STAGGER_GRAPH   // the conv / BN graph kernels (3-4 workgroups per CU and launch)
 #define MWW_STAGGER_GRAPH 0
 #endif
+// Conv / BN graph kernels, static shapes (round 5, kernels_graph.hip.h):
+//   MWW_G_FWD_DIRECT  1 = the stem shape (5 x 40 input bins), 2 = every static forward convolution: output rows and BN sums
+//                     straight from the MFMA accumulators (no output tile in LDS, one barrier less per window);
+//   MWW_G_WGRAD_EVEN  the task tiles a weight gradient's four waves cannot share out evenly are cut into filter tiles.
+#ifndef MWW_G_FWD_DIRECT
+#define MWW_G_FWD_DIRECT 1
+#endif
+#ifndef MWW_G_WGRAD_EVEN
+#define MWW_G_WGRAD_EVEN 1
+#endif
+#ifndef MWW_G_WGRAD_XG_NARROW
+#define MWW_G_WGRAD_XG_NARROW 0
+#endif
 template <int UNITS>
 __device__ __forceinline__ void stagger_start() {
   if constexpr (UNITS > 0) {

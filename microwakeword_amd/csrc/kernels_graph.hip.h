@@ -905,6 +905,16 @@ __device__ __forceinline__ void dgrad_sources_static(const GSrc* src, int b, con
   }
 }
 
+// which forward instantiations store from the accumulators (see gconv_body "DIRECT"; the host sizes LDS with g_lds_fwd_direct)
+template <class SH, int MODE>
+__host__ __device__ constexpr bool g_fwd_direct() {
+  return SH::NSRC > 0 && MODE == 0 && (MWW_G_FWD_DIRECT >= 2 || (MWW_G_FWD_DIRECT == 1 && SH::NSRC == 1 && SH::CIN == FBINS));
+}
+// floats of the direct form's tiles: weights [k * cin4][NCW] + 8 (the wrap of the last row's last fragment) + the window
+__host__ __device__ constexpr int g_direct_tiles(int k, int cin, int nc, int rows_in) {
+  return k * ((cin + 3) / 4 * 4) * ((nc + 7) / 8 * 8) + 8 + rows_in * (cin | 1);
+}
+
 // SH: the op's shape where the instantiation knows it (GShape; static shapes have dilation = stride = 1 and whole windows)
 // XG (+ xgp): the op's one source is the spectrogram, gathered from the feature stores (see "the stem's input" above)
 template <int NC, int MODE, int CDP = 0, bool CH = false, class SH = GShapeDyn, bool XG = false>
@@ -939,9 +949,14 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // The convolution runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): per tap j a [16 frames] x [4 channels]
   // A tile of the window against a [4 channels] x [16 filters] B tile of the weights.  Weight rows are padded to whole
   // k-steps (cin4) and whole filter tiles (NCW) with zeros, so the inner loop carries no predicate on B.
-  constexpr int NT = (NC + 15) / 16, NCW = NT * 16;
+  // DIRECT (static forward convolutions, MWW_G_FWD_DIRECT): no output tile - a wave stores its accumulator tiles itself and keeps
+  // the BN sums of their columns; the weight rows shrink to whole 8-filter groups (a B fragment of the last filter tile then
+  // wraps into the next weight row: those products only reach columns that are neither stored nor summed).  For the stem
+  // (5 x 40 -> 24) that is 19 + 32 KB instead of 25 + 32 + 19: three workgroups per CU instead of two.
+  constexpr bool DIRECT = g_fwd_direct<SH, MODE>();
+  constexpr int NT = (NC + 15) / 16, NCW = DIRECT ? (NC + 7) / 8 * 8 : NT * 16;
   const int tid = threadIdx.x;
-  const int PI = kCin | 1, PO = NC | 1;
+  const int PI = kCin | 1, PO = DIRECT ? 0 : (NC | 1);
   const int cin4 = (kCin + 3) & ~3;
   const int pad = MODE == 1 ? (kK - 1) * kDil : 0;
   // rows of the input tile / of the output tile.  CH: a chunk of Tc output frames; the forward convolution stages the
@@ -949,8 +964,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   const int rows_in = CH ? (MODE == 0 ? (a.Tc - 1) * kStride + (kK - 1) * kDil + 1 : a.Tc) : a.Tin + 2 * pad;
   const int rows_o = CH ? a.Tc : a.Tout;
   float* sW = g_smem;                       // [k][cin4][NCW], loaded once per workgroup
-  float* sIn = sW + kK * cin4 * NCW;
+  float* sIn = sW + kK * cin4 * NCW + (DIRECT ? 8 : 0);
   float* sOut = sIn + rows_in * PI;
+  const int tiles_f = kK * cin4 * NCW + (DIRECT ? 8 : 0) + rows_in * PI + rows_o * PO;   // floats of the launch's tiles
   // running (sum, sum of squares) of this thread's channel: MODE 0 of the output, MODE 1 one pair per source - the first
   // source's in registers, the others' in LDS so that the sources can be walked by a real loop (their descriptors stay
   // in the kernel-argument segment instead of pinning ~100 SGPRs).  Static LDS is occupancy here: the windows of the
@@ -958,27 +974,30 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // live behind the tiles only for the sources that exist and the reduction scratch of the final publish reuses the
   // weight tile (the host sizes the dynamic segment to match: mww_lib.hip, lds_fwd / lds_dx).
   float s1o = 0.f, s2o = 0.f;
-  float* sSrcAcc = g_smem + max(kK * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
+  float* sSrcAcc = g_smem + max(tiles_f, 2 * kThreads);   // [(n_src - 1) * 2][kThreads]
   float* sRed = g_smem;   // [2 * kThreads], after the window loop
   if (MODE == 1)
     for (int i = 0; i < (kNsrc - 1) * 2; ++i) sSrcAcc[i * kThreads + tid] = 0.f;
 
   // statistics hand-over: fold what this launch is the first to consume.  The loads go out before the weights are staged,
   // the table is written after (visible to the other waves after the loop's first barrier).
-  __shared__ float sFold[MODE == 0 ? kGMaxSrc * 4 * kGFoldC : 3 * kGFoldC];
+  // (the direct form counts its LDS in single KB: one table per source it has, none for the gathered spectrogram)
+  constexpr int kFoldTabs = DIRECT ? (XG ? 0 : SH::NSRC) : kGMaxSrc;
+  __shared__ float sFold[MODE == 0 ? (kFoldTabs > 0 ? kFoldTabs * 4 * kGFoldC : 4) : 3 * kGFoldC];
   // (wave i folds source i: one set of fold registers per thread)
   GFoldRegs fr;
   const int fsrc = tid >> 6, ftid = tid & 63;
   static_assert(kGFoldC <= 64 && kGMaxSrc <= kThreads / 64, "one wave folds one source");
   if (MODE == 0) {
-    if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_load(a.fold[fsrc], bid, ftid, fr);
+    if constexpr (!XG)
+      if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_load(a.fold[fsrc], bid, ftid, fr);
   } else if (a.y.fold.acc) {
     gfold_backward_load(a.y.fold, kCin, a.y.rstd, tid, fr);
   }
   // gathered input: the descriptors and mask bitmaps of this workgroup's windows (behind the launch's tiles)
   XShared* sXg = nullptr;
   if constexpr (XG) {
-    sXg = reinterpret_cast<XShared*>(g_smem + ((max(kK * cin4 * NCW + rows_in * PI + rows_o * PO, 2 * kThreads) + 1) & ~1));
+    sXg = reinterpret_cast<XShared*>(g_smem + ((max(tiles_f, 2 * kThreads) + 1) & ~1));
     gx_setup(*xgp, *sXg, bid < a.B ? (a.B - bid + nb - 1) / nb : 0, tid, bid, nb);
   }
   {
@@ -1012,9 +1031,11 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         if (i < nw) sW[i] = wv[u];
       }
     }
+    if (DIRECT && tid < 8) sW[nw + tid] = 0.f;
   }
   if (MODE == 0) {
-    if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_finish(a.fold[fsrc], sFold + fsrc * 4 * kGFoldC, bid, ftid, fr);
+    if constexpr (!XG)
+      if (fsrc < kNsrc && a.fold[fsrc].acc) gfold_forward_finish(a.fold[fsrc], sFold + fsrc * 4 * kGFoldC, bid, ftid, fr);
   } else if (a.y.fold.acc) {
     gfold_backward_finish(a.y.fold, kCin, sFold, bid, tid, fr);
   }
@@ -1031,6 +1052,21 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     else dpipe.load_coeffs(a.y, sFold, tid);
   }
   int xsamp = 0;   // (XG) the window's slot in sXg
+  // DIRECT: lane (r16, g) owns column nt * 16 + r16 of its waves' accumulator tiles: where that column starts in the output
+  // tensor (plane and offset inside the plane's rows), and its running sums
+  float* dcol[DIRECT ? NT : 1];
+  float s1w[DIRECT ? NT : 1], s2w[DIRECT ? NT : 1];
+  const int drowc = (DIRECT && a.out_planes > 1) ? a.out_pc : NC;
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = min(nt * 16 + (tid & 15), NC - 1);
+      const int pl = a.out_planes > 1 ? col / a.out_pc : 0;
+      dcol[nt] = a.out + (size_t)pl * a.out_pstride + (col - pl * drowc);
+      s1w[nt] = s2w[nt] = 0.f;
+    }
+  }
+  (void)dcol; (void)s1w; (void)s2w; (void)drowc;
   GDgradCoef dcoef;
   if constexpr (ST && MODE == 1) dgrad_coefs_static<SHX>(a.src, tid, dcoef);
   (void)dcoef;
@@ -1109,6 +1145,23 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
           }
         }
         }
+        if constexpr (DIRECT) {
+          // D: lane (r16, g) holds rows rt*16 + g*4 + r of column nt*16 + r16: four row segments of 16 floats per store
+          const size_t wrow = (size_t)b * Ttot + rt * 16 + g * 4;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bool colok = (NC % 16 == 0) || nt < NT - 1 || r16 < NC - (NT - 1) * 16;
+            float* d = dcol[nt] + wrow * drowc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = colok && rt * 16 + g * 4 + r < Tout;
+              const float v = ok ? acc[nt][r] : 0.f;
+              if (ok) store_stream<MWW_AUX_GR_ST_P>(d + r * drowc, v);
+              s1w[nt] += v;
+              s2w[nt] = fmaf(v, v, s2w[nt]);
+            }
+          }
+        } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1116,6 +1169,7 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
             const int row = rt * 16 + g * 4 + r, col = nt * 16 + r16;
             if (row < Tout && col < NC) sOut[row * PO + col] = acc[nt][r];
           }
+        }
       };
       if constexpr (kRtMax > 0) {
 #pragma unroll
@@ -1125,8 +1179,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
         for (int rt = wave; rt < ntile; rt += kThreads / 64) row_tile(rt);
       }
     }
-    __syncthreads();
-    if (MODE == 0) {
+    if constexpr (!DIRECT) __syncthreads();
+    if constexpr (DIRECT) {
+      // (nothing: the waves stored their tiles)
+    } else if (MODE == 0) {
       const int nrg = kThreads / NC, c = tid % NC, rg = tid / NC;
       if (rg < nrg) {
         const bool planar = a.out_planes > 1;
@@ -1232,6 +1288,29 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
       }
     }
   }
+  if constexpr (DIRECT) {
+    // the waves' column sums -> thread c < NC (the layout publish_channel_partials takes: channel tid % NC, row group tid / NC)
+    __shared__ float sWS[(kThreads / 64) * 2 * NT * 16];
+    if (a.stat_part) {   // (uniform)
+      const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float t1 = sum_over_groups(s1w[nt]), t2 = sum_over_groups(s2w[nt]);
+        if (lane < 16) {
+          sWS[(wave * 2 + 0) * NT * 16 + nt * 16 + lane] = t1;
+          sWS[(wave * 2 + 1) * NT * 16 + nt * 16 + lane] = t2;
+        }
+      }
+      __syncthreads();
+      if (tid < NC) {
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+          s1o += sWS[(w * 2 + 0) * NT * 16 + tid];
+          s2o += sWS[(w * 2 + 1) * NT * 16 + tid];
+        }
+      }
+    }
+  }
   if (MODE == 0) {
     if (a.stat_part) publish_channel_partials(s1o, s2o, NC, sRed, a.stat_part + (size_t)bid * 2 * NC, tid, NC, a.sacc, 0, bid, nb);
   } else {
@@ -1289,7 +1368,7 @@ struct GWgradArgs {
 // parts through LDS at the end.  One partial row [k*cin][NC] per workgroup.
 constexpr int kGWgTilesPerWave = 4;   // 16 task tiles (k * cin <= 256) over four waves
 
-__host__ __device__ inline int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (tasks > 16 ? 2 : 4); }
+__host__ __device__ constexpr int gwg_kparts(int tasks) { return tasks > 32 ? 1 : (tasks > 16 ? 2 : 4); }
 // row pitch of the staged dp: the filter tiles, unpadded.  (A pitch of 16 mod 32 keeps the four k-rows of a B fragment on
 // disjoint banks, but for 17-32 filters it costs 16 floats per frame = 12 KB of a 190-frame window - the difference between
 // two and three resident workgroups for the 24 -> 30 op; same-session A/B of the Inception step: 0.943 against 0.949 ms.
@@ -1330,7 +1409,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   HIP_DYNAMIC_SHARED(float4, g_smem4)
   float* g_smem = reinterpret_cast<float*>(g_smem4);
   constexpr int NT = (NC + 15) / 16;
-  const int PO = gwg_dp_pitch(NC);
+  // (MWW_G_WGRAD_XG_NARROW: the gathering stem's dp rows at 8-float granularity - a B fragment of the last filter tile wraps into
+  // the next row, its products only reach columns that are never stored - and the kernel held to 168 registers: 50 KB of
+  // tiles, three workgroups per CU)
+  const int PO = (XG && MWW_G_WGRAD_XG_NARROW) ? (NC + 7) / 8 * 8 : gwg_dp_pitch(NC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int PI = kCin | 1;
   const int cap = CH ? a.Tc : a.Tout;                   // frames of the dp tile (CH: a chunk; the A tile holds its input frames + halo)
@@ -1342,10 +1424,21 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   const int kp = wave % KS, slot = wave / KS;
   // this wave's task tiles: mt = slot, slot + nslot, ...;  lane r16 <-> task m of the tile (tasks past the end repeat the
   // last one: their rows are not written)
+  // EVEN (static shapes whose task tiles do not divide by the four waves, e.g. the stem's 13): the whole rounds are dealt as
+  // before, the tiles left over are cut into their filter tiles and those units go to the waves (unit + rot) % 4, rot = the
+  // workgroup's round of the dispatch (blockIdx / 256: workgroups i and i + 256 share a CU), so that on every SIMD the waves of
+  // the resident workgroups add up to the same number of MFMAs per k-step (the stem: 13 where wave 0 of both had 8 = 16).
+  constexpr int kTasksS = ST ? SH::K * SH::CIN : 0, kMTS = (kTasksS + 15) / 16;
+  constexpr int kFull = kMTS / 4, kRem = kMTS % 4;
+  constexpr bool EVEN = ST && MWW_G_WGRAD_EVEN != 0 && gwg_kparts(kTasksS) == 1 && kRem > 0 && kRem * NT <= 4 && kFull < kGWgTilesPerWave;
+  const int my_unit = EVEN ? ((wave - (bid >> 8)) & 3) : 0;       // this wave's left-over unit (if < kRem * NT)
+  const bool has_rem = EVEN && my_unit < kRem * NT;
+  const int rem_mt = kFull * 4 + my_unit / NT, rem_nt = my_unit % NT;
   int offA[kGWgTilesPerWave];
 #pragma unroll
   for (int u = 0; u < kGWgTilesPerWave; ++u) {
-    const int m = min((slot + u * nslot) * 16 + r16, tasks - 1);
+    const int mt_u = (EVEN && u == kFull) ? min(rem_mt, kMTS - 1) : slot + u * nslot;
+    const int m = min(mt_u * 16 + r16, tasks - 1);
     int mj, mc;
     fast_divmod(m, kCin, mj, mc);
     offA[u] = mj * kDil * PI + mc;
@@ -1422,31 +1515,54 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
       const int nsteps = (Tout - kp * 4 + 4 * KS - 1) / (4 * KS);
       const float* pa = sA + (kp * 4 + g) * PI;
       const float* pb = sDP + (kp * 4 + g) * PO + r16;
-      auto kstep = [&](const float* qa, const float* qb) {
-        float bv[NT];
+      // (REM: this wave owns a left-over unit - two copies of the loop instead of a branch in every k-step)
+      auto run = [&](auto remc) {
+        constexpr bool REM = decltype(remc)::value;
+        const float* qa0 = pa;
+        const float* qb0 = pb;
+        auto kstep = [&](const float* qa, const float* qb) {
+          float bv[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = qb[nt * 16];
+          for (int nt = 0; nt < NT; ++nt) bv[nt] = qb[nt * 16];
+          if constexpr (EVEN) {
 #pragma unroll
-        for (int u = 0; u < kGWgTilesPerWave; ++u) {
-          if (slot + u * nslot < MT) {   // wave-uniform
-            const float av = qa[offA[u]];
+            for (int u = 0; u < kFull; ++u) {
+              const float av = qa[offA[u]];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
+              for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
+            }
+            if constexpr (REM) {   // the unit's filter tile is picked by a (wave-uniform) select, its products go to acc[kFull][0]
+              float bsel = bv[0];
+#pragma unroll
+              for (int nt = 1; nt < NT; ++nt) bsel = rem_nt == nt ? bv[nt] : bsel;
+              acc[kFull][0] = mfma4(qa[offA[kFull]], bsel, acc[kFull][0]);
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < kGWgTilesPerWave; ++u) {
+              if (slot + u * nslot < MT) {   // wave-uniform
+                const float av = qa[offA[u]];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
+              }
+            }
           }
+        };
+        int i = 0;
+        for (; i + 4 <= nsteps; i += 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kstep(qa0 + q * 4 * KS * PI, qb0 + q * 4 * KS * PO);
+          qa0 += 16 * KS * PI;
+          qb0 += 16 * KS * PO;
+        }
+        for (; i < nsteps; ++i) {
+          kstep(qa0, qb0);
+          qa0 += 4 * KS * PI;
+          qb0 += 4 * KS * PO;
         }
       };
-      int i = 0;
-      for (; i + 4 <= nsteps; i += 4) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) kstep(pa + q * 4 * KS * PI, pb + q * 4 * KS * PO);
-        pa += 16 * KS * PI;
-        pb += 16 * KS * PO;
-      }
-      for (; i < nsteps; ++i) {
-        kstep(pa, pb);
-        pa += 4 * KS * PI;
-        pb += 4 * KS * PO;
-      }
+      if (EVEN && has_rem) run(std::true_type{});
+      else run(std::false_type{});
     } else
     for (int t0 = kp * 4; t0 < Tout; t0 += 4 * KS) {
       // A: lane (r16, g) = task r16 of the tile, frame t0 + g (clamped: the matching dp rows are zero);  B: dp[t0 + g][nt*16 + r16]
@@ -1467,7 +1583,25 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   }
   // D: lane (r16, g) holds dW[task g*4 + r of the tile][filter nt*16 + r16]
   float* dst = a.grad_part + (size_t)bid * ((size_t)tasks * NC);
-  if (KS == 1) {
+  if constexpr (EVEN) {
+#pragma unroll
+    for (int u = 0; u < kFull; ++u) {   // whole rounds: tile slot + 4 u is never the last one
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (slot + u * 4) * 16 + g * 4 + r, co = nt * 16 + r16;
+          if (co < NC) store_stream<MWW_AUX_GR_ST_GP>(dst + (size_t)m * NC + co, acc[u][nt][r]);
+        }
+    }
+    if (has_rem) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = rem_mt * 16 + g * 4 + r, co = rem_nt * 16 + r16;
+        if (m < tasks && co < NC) store_stream<MWW_AUX_GR_ST_GP>(dst + (size_t)m * NC + co, acc[kFull][0][r]);
+      }
+    }
+  } else if (KS == 1) {
 #pragma unroll
     for (int u = 0; u < kGWgTilesPerWave; ++u) {
       const int mt = slot + u * nslot;
@@ -1514,7 +1648,7 @@ __global__ __launch_bounds__(kThreads) void gconv_wgrad_kernel(GWgradArgs a) {
   gconv_wgrad_body<NC, false, SH>(a, blockIdx.x, gridDim.x);
 }
 template <int NC, class SH>
-__global__ __launch_bounds__(kThreads) void gconv_wgrad_xg_kernel(GWgradArgs a, XGather xg) {
+__global__ __launch_bounds__(kThreads, (MWW_G_WGRAD_XG_NARROW ? 3 : 1)) void gconv_wgrad_xg_kernel(GWgradArgs a, XGather xg) {
   stagger_start<MWW_STAGGER_GRAPH>();
   gconv_wgrad_body<NC, false, SH, true>(a, blockIdx.x, gridDim.x, &xg);
 }

@@ -976,6 +976,12 @@ void g_share_roles(mww_ctx* c, const GridPick& pk, int* nbw, int* nbd) {
 #define X(ID, K, N, C0, L0, C1, L1, C2, L2) typedef GShape<K, N, C0, L0, C1, L1, C2, L2> GSh##ID;
 MWW_G_SHAPES(X)
 #undef X
+// dynamic LDS of a static shape's forward launch: the direct form (gconv_body "DIRECT") has no output tile and narrower weight rows
+template <class SH, int NC>
+size_t g_lds_fwd_static(size_t lds, const GConvArgs& a) {
+  if constexpr (g_fwd_direct<SH, 0>()) return g_lds_body((size_t)g_direct_tiles(SH::K, SH::CIN, NC, a.Tin), 0);
+  else return lds;
+}
 // (shape id, filters) of the forward / weight-gradient instantiations, (id, filters, input channels) of the backward pairs
 #ifdef MWW_SLIM
 #define MWW_G_SHAPE_FWD(X)
@@ -1062,7 +1068,7 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, siz
       if (shape == ID && nc == N && a.n_src == 1 && a.Tin <= kGXRows) {                                        \
         auto k = &gconv_xg_kernel<N, GSh##ID>;                                                                 \
         const void* f = reinterpret_cast<const void*>(k);                                                      \
-        const size_t ldx = lds + sizeof(XShared) + 16;                                                         \
+        const size_t ldx = g_lds_fwd_static<GSh##ID, N>(lds, a) + sizeof(XShared) + 16;                        \
         if (ldx > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldx)); \
         const int grid = g_role_grid(c, f, ldx, pk);                                                           \
         if ((a.B + grid - 1) / grid <= kXMaxSamples) {                                                         \
@@ -1081,9 +1087,10 @@ int launch_gconv(mww_ctx* c, int nc, const GConvArgs& a, const GridPick& pk, siz
     if (shape == ID && nc == N) {                                                                              \
       auto k = &gconv_kernel<N, 0, GSh##ID>;                                                                   \
       const void* f = reinterpret_cast<const void*>(k);                                                        \
-      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      const int grid = g_role_grid(c, f, lds, pk);                                                             \
-      hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, c->stream, a);                                    \
+      const size_t lds_s = g_lds_fwd_static<GSh##ID, N>(lds, a);                                               \
+      if (lds_s > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s)); \
+      const int grid = g_role_grid(c, f, lds_s, pk);                                                           \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds_s, c->stream, a);                                  \
       return MWW_OK;                                                                                           \
     }
     MWW_G_SHAPE_FWD(XS)
@@ -1111,7 +1118,8 @@ int launch_gwgrad(mww_ctx* c, int nc, const GWgradArgs& a, const GridPick& pk, s
       if (shape == ID && nc == N && a.n_src == 1 && a.Tin <= kGXRows) {                                        \
         auto k = &gconv_wgrad_xg_kernel<N, GSh##ID>;                                                           \
         const void* f = reinterpret_cast<const void*>(k);                                                      \
-        const size_t ldx = lds + sizeof(XShared) + 16;                                                         \
+        const size_t narrow = MWW_G_WGRAD_XG_NARROW ? g_up4(a.Tout) * (size_t)(gwg_dp_pitch(N) - (N + 7) / 8 * 8) * sizeof(float) : 0; \
+        const size_t ldx = lds - narrow + sizeof(XShared) + 16;                                                \
         if (ldx > 64 * 1024) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldx)); \
         const int grid = g_role_grid(c, f, ldx, pk);                                                           \
         if ((a.B + grid - 1) / grid <= kXMaxSamples) {                                                         \
@@ -1199,9 +1207,10 @@ bool launch_gfwd2(mww_ctx* c, int nc, const GConvArgs& a0, const GConvArgs& a1, 
 #define XS(ID, N)                                                                                              \
   if (shape == ID && nc == N) {                                                                                \
     const void* f = reinterpret_cast<const void*>(&gconv_fwd2_kernel<N, GSh##ID>);                             \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    const int grid = g_role_grid(c, f, lds, pk);                                                               \
-    hipLaunchKernelGGL((gconv_fwd2_kernel<N, GSh##ID>), dim3(2 * grid), dim3(kThreads), lds, c->stream, GConv2Args{{a0, a1}}, grid); \
+    const size_t lds_s = std::max(g_lds_fwd_static<GSh##ID, N>(lds, a0), g_lds_fwd_static<GSh##ID, N>(lds, a1)); \
+    if (lds_s > 64 * 1024) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s); \
+    const int grid = g_role_grid(c, f, lds_s, pk);                                                             \
+    hipLaunchKernelGGL((gconv_fwd2_kernel<N, GSh##ID>), dim3(2 * grid), dim3(kThreads), lds_s, c->stream, GConv2Args{{a0, a1}}, grid); \
     return true;                                                                                               \
   }
   MWW_G_SHAPE_FWD2(XS)

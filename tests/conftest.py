@@ -30,6 +30,9 @@ def build_emulator_lib():
     """TEST INFRASTRUCTURE: compiles the unchanged product HIP sources as host C++ against tests/hipemu
     (fibers + emulated wave ops) and returns the path of the resulting library, or None without clang++."""
     from microwakeword_amd import build_native
+    defines = os.environ.get("MWW_EMU_DEFINES", "").split()   # kernel-variant builds (-DMWW_...=..), into a file of their own
+    if defines:
+        return build_native.build_emulator(EMU.replace(".so", "_variant.so"), defines=defines)
     return build_native.build_emulator(EMU)
 
 

@@ -1269,9 +1269,12 @@ def check_bn_inline_matches_finalize(lib, B=12, T=194, steps=3, flags=DEF):
 
 def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194, 208, 212), steps=3, grid=0, combos=None):
     """The static-shape instantiations of the graph kernels (kernels_graph.hip.h GShape: the default Inception ops) against
-    the run-time-shape kernels ("graph_static_shapes" 0): same arithmetic in the same order - the shapes only fold index
-    computations - so parameters, moving statistics, probabilities and gradients are bit-identical over several steps;
-    window lengths on both sides of the static path's limit (208 frames), a batch smaller than the grid in between, eager
+    the run-time-shape kernels ("graph_static_shapes" 0): the same convolutions in the same order - the shapes fold index
+    computations - so parameters, moving statistics, probabilities and gradients agree over several steps; to float32
+    rounding, since the stem's static form sums its BN statistics per accumulator column instead of per row group
+    (gconv_body "DIRECT": pre-BN outputs identical, the batch statistics differ in the last bit).  Among the static
+    combinations (planar tensors, captured graphs) and among the run-time ones the results are bit-identical.
+    Window lengths on both sides of the static path's limit (208 frames), a batch smaller than the grid in between, eager
     and through captured graphs."""
     rng = np.random.default_rng(17)
     for T in lengths:
@@ -1279,9 +1282,10 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
         x = (rng.integers(0, 667, size=(steps, B, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
         y = (rng.random((steps, B)) < 0.4).astype(np.float32)
         w = rng.choice([0.5, 1.0, 2.0], size=B).astype(np.float32)
-        outs = []
+        outs, kinds = [], []
         # ... and so is the planar layout of the fused branch heads' tensors ("graph_planar": one plane per consumer slice)
         for static, planar, graphs in (combos or ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1))):
+            kinds.append(static)
             lay, eng = make_inception_engine(lib, T, B, om, INC)
             eng.set_option("graph_static_shapes", static)
             eng.set_option("graph_planar", planar)
@@ -1300,9 +1304,12 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
             got += [eng.get_params().copy(), eng.get_bn_state().copy()]
             outs.append(got)
             eng.close()
-        for other in outs[1:]:
-            for a, b in zip(outs[0], other):
+        for kind, other in zip(kinds[1:], outs[1:]):
+            same = outs[kinds.index(kind)]   # first run on the same kernel family
+            for a, b in zip(same, other):
                 np.testing.assert_array_equal(a, b)
+            for a, b in zip(outs[0], other):
+                assert np.linalg.norm(b.astype(np.float64) - a) <= 2e-4 * np.linalg.norm(a.astype(np.float64)) + 1e-7, (T, kind)
 
 
 def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=INC, fuse_heads=True):
