@@ -309,6 +309,9 @@ __device__ __forceinline__ void rotate_priority(int item, int levels) {
 #ifndef MWW_G_WGRAD_EVEN
 #define MWW_G_WGRAD_EVEN 1
 #endif
+#ifndef MWW_G_STEM_BREG
+#define MWW_G_STEM_BREG 0
+#endif
 #ifndef MWW_G_WGRAD_XG_NARROW
 #define MWW_G_WGRAD_XG_NARROW 0
 #endif

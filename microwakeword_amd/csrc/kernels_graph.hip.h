@@ -954,6 +954,9 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
   // wraps into the next weight row: those products only reach columns that are neither stored nor summed).  For the stem
   // (5 x 40 -> 24) that is 19 + 32 KB instead of 25 + 32 + 19: three workgroups per CU instead of two.
   constexpr bool DIRECT = g_fwd_direct<SH, MODE>();
+  // BREG (the gathering stem, MWW_G_STEM_BREG): the B fragments of every (tap, k-step, filter tile) stay in registers for the
+  // launch (100 for 5 x 40 x 24) - no weight tile in LDS, half the LDS reads of the contraction; two waves per SIMD.
+  constexpr bool BREG = DIRECT && XG && MWW_G_STEM_BREG != 0;
   constexpr int NT = (NC + 15) / 16, NCW = DIRECT ? (NC + 7) / 8 * 8 : NT * 16;
   const int tid = threadIdx.x;
   const int PI = kCin | 1, PO = DIRECT ? 0 : (NC | 1);
@@ -1000,6 +1003,23 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
     sXg = reinterpret_cast<XShared*>(g_smem + ((max(tiles_f, 2 * kThreads) + 1) & ~1));
     gx_setup(*xgp, *sXg, bid < a.B ? (a.B - bid + nb - 1) / nb : 0, tid, bid, nb);
   }
+  constexpr int kBK = BREG ? SH::K : 1, kBS = BREG ? (SH::CIN + 3) / 4 : 1, kBN = BREG ? (NC + 15) / 16 : 1;
+  float breg[kBK][kBS][kBN];
+  (void)breg;
+  if constexpr (BREG) {
+    const int lane_ = tid & 63, r16_ = lane_ & 15, g_ = lane_ >> 4;
+#pragma unroll
+    for (int j = 0; j < kBK; ++j)
+#pragma unroll
+      for (int ks = 0; ks < kBS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < kBN; ++nt) {
+          const int ci = ks * 4 + g_, co = nt * 16 + r16_;
+          const bool real = ci < SH::CIN && co < NC;
+          const float v = a.w[real ? (j * SH::CIN + ci) * NC + co : 0];
+          breg[j][ks][nt] = real ? v : 0.f;
+        }
+  } else
   {
     // (four elements per thread in flight: a rolled load -> LDS-write loop is one memory round trip per element, 25 of
     // them in a row for the 5 x 40 x 24 stem; most ops have two elements per thread, and every predicated-off slot of a
@@ -1130,7 +1150,10 @@ __device__ __forceinline__ void gconv_body(const GConvArgs& a, const int bid, co
               float av = arow[j * PI + ci0];
               if (!kfull && ci0 + 4 > kCin && ci0 + g >= kCin) av = 0.f;   // (only the last k-step carries the select)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(av, wrow[(j * cin4 + ci0) * NCW + nt * 16], acc[nt]);
+              for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (BREG) acc[nt] = mfma4(av, breg[j][ci0 / 4][nt], acc[nt]);
+                else acc[nt] = mfma4(av, wrow[(j * cin4 + ci0) * NCW + nt * 16], acc[nt]);
+              }
             }
           }
         } else {
@@ -1431,6 +1454,11 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
   constexpr int kTasksS = ST ? SH::K * SH::CIN : 0, kMTS = (kTasksS + 15) / 16;
   constexpr int kFull = kMTS / 4, kRem = kMTS % 4;
   constexpr bool EVEN = ST && MWW_G_WGRAD_EVEN != 0 && gwg_kparts(kTasksS) == 1 && kRem > 0 && kRem * NT <= 4 && kFull < kGWgTilesPerWave;
+  // UNI (static shapes whose task tiles do divide by the waves that share them, e.g. 50 tasks = 4 tiles, or the 1x1 ops' one or
+  // two tiles per frame part): every wave owns the same number of tiles - the k-step carries no wave-uniform branch either.
+  constexpr int kNslotS = 4 / gwg_kparts(kTasksS > 0 ? kTasksS : 64);
+  constexpr bool UNI = ST && MWW_G_WGRAD_EVEN != 0 && !EVEN && kMTS % kNslotS == 0 && kMTS / kNslotS <= kGWgTilesPerWave;
+  constexpr int kUniTiles = UNI ? kMTS / kNslotS : 0;
   const int my_unit = EVEN ? ((wave - (bid >> 8)) & 3) : 0;       // this wave's left-over unit (if < kRem * NT)
   const bool has_rem = EVEN && my_unit < kRem * NT;
   const int rem_mt = kFull * 4 + my_unit / NT, rem_nt = my_unit % NT;
@@ -1536,6 +1564,13 @@ __device__ __forceinline__ void gconv_wgrad_body(const GWgradArgs& a, const int 
 #pragma unroll
               for (int nt = 1; nt < NT; ++nt) bsel = rem_nt == nt ? bv[nt] : bsel;
               acc[kFull][0] = mfma4(qa[offA[kFull]], bsel, acc[kFull][0]);
+            }
+          } else if constexpr (UNI) {
+#pragma unroll
+            for (int u = 0; u < kUniTiles; ++u) {
+              const float av = qa[offA[u]];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[u][nt] = mfma4(av, bv[nt], acc[u][nt]);
             }
           } else {
 #pragma unroll

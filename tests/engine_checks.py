@@ -1308,8 +1308,14 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
             same = outs[kinds.index(kind)]   # first run on the same kernel family
             for a, b in zip(same, other):
                 np.testing.assert_array_equal(a, b)
-            for a, b in zip(outs[0], other):
-                assert np.linalg.norm(b.astype(np.float64) - a) <= 2e-4 * np.linalg.norm(a.astype(np.float64)) + 1e-7, (T, kind)
+            # across the families: the first step's probabilities to rounding; everything later within what one ReLU unit
+            # flipped by the last bit of a batch statistic moves (gradients ~1e-3..1e-2, then Adam's normalised update
+            # carries it into the parameters) - a wrong row count or a dropped tile is O(1)
+            for idx, (a, b) in enumerate(zip(outs[0], other)):
+                is_grad = idx < 2 * steps and idx % 2 == 1
+                tol = 1e-5 if idx == 0 else (3e-2 if is_grad else 1e-2)
+                err = np.linalg.norm(b.astype(np.float64) - a) / max(np.linalg.norm(a.astype(np.float64)), 1e-30)
+                assert err <= tol, (T, kind, idx, err)
 
 
 def check_inception_bn_inline_matches_finalize(lib, B=7, T=150, steps=3, flags=INC, fuse_heads=True):

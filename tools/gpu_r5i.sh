@@ -5,13 +5,13 @@
 #   libmww_hip.so     stem forward from the accumulators + even deal of the weight gradient's task tiles (the defaults)
 #   libmww_d2.so      ... every static forward convolution from the accumulators (-DMWW_G_FWD_DIRECT=2)
 #   libmww_narrow.so  ... the stem weight gradient at three workgroups per CU (-DMWW_G_WGRAD_XG_NARROW=1)
-# usage (repo root): bash tools/gpu_r5i.sh <tag>
+# usage (repo root): [LIBS="a b" VARIANTS="b" PMCLIBS="a" ALLK=1] bash tools/gpu_r5i.sh <tag>   (second sitting: LIBS="even hip breg", every gconv kernel listed)
 TAG=${1:-r5i}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT; cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
-LIBS="base hip d2 narrow"
+LIBS=${LIBS:-"base hip d2 narrow"}
 S=$OUT/summary.txt; : > $S
 for v in $LIBS; do python -c "
 import sys; sys.path.insert(0, '$R')
@@ -33,8 +33,8 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("== $v: kernel sum per step %.1f us" % (tot / 70 / 1000))
 for r in rows:
     n = r["Name"]
-    if "GShape<5, 1, 40" in n or "$v" == "d2" or "$v" == "base":
-        if "gconv" in n and ("bwd" not in n or "GShape<5, 1, 40" in n):
+    if "GShape<5, 1, 40" in n or "$v" in ("d2", "base") or "$ALLK" == "1":
+        if "gconv" in n and ("bwd" not in n or "GShape<5, 1, 40" in n or "$ALLK" == "1"):
             print("   %-70s calls %s avg %.2f us" % (n[:70], r["Calls"], float(r["AverageNs"]) / 1000))
 PY
 done
@@ -57,13 +57,13 @@ for rep in 1 2; do
   done
 done
 # 4. the variants' parity (cheap subset)
-for v in d2 narrow; do
+for v in ${VARIANTS:-d2 narrow}; do
   MWW_HIP_LIB=$R/microwakeword_amd/libmww_$v.so timeout 400 python -m pytest tests/test_engine_gpu.py -m gpu -q -x --timeout 300 -p no:cacheprovider -k "$K_FAST" > $OUT/pytest_$v.log 2>&1; echo "tests $v: $(grep -E 'passed|failed|error' $OUT/pytest_$v.log | tail -1)" >> $S
 done
 # 5. counters of the two stem kernels (new default and the narrow variant)
 B="python $R/bench.py --model inception --steps 6 --warmup 2 --no-cpu-baseline --no-validation --no-batch-sweep --profile-steps 0"
 cd /tmp
-for v in hip narrow; do
+for v in ${PMCLIBS:-hip narrow}; do
   MWW_HIP_LIB=$R/microwakeword_amd/libmww_$v.so timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc1_$v -o p -- $B > /dev/null 2> $OUT/pmc1_$v.err
   (cd $R; python tools/pmc_summary.py $OUT/pmc1_$v | grep "xg_kernel" | sed "s/^/$v: /" | cut -c1-400 >> $S)
 done
