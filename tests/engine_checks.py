@@ -1308,12 +1308,13 @@ def check_inception_static_shapes_are_schedule_only(lib, B=9, lengths=(100, 194,
             same = outs[kinds.index(kind)]   # first run on the same kernel family
             for a, b in zip(same, other):
                 np.testing.assert_array_equal(a, b)
-            # across the families: the first step's probabilities to rounding; everything later within what one ReLU unit
-            # flipped by the last bit of a batch statistic moves (gradients ~1e-3..1e-2, then Adam's normalised update
-            # carries it into the parameters) - a wrong row count or a dropped tile is O(1)
-            for idx, (a, b) in enumerate(zip(outs[0], other)):
-                is_grad = idx < 2 * steps and idx % 2 == 1
-                tol = 1e-5 if idx == 0 else (3e-2 if is_grad else 1e-2)
+            # across the families only the first step is comparable: probabilities to rounding, gradients within what one ReLU
+            # unit flipped by the last bit of a batch statistic moves (~1e-3).  Later steps are not: the same run-time-shape
+            # kernels on two grids (other partial sums) are 0.5 % apart in the second step's gradient and 26 % in the third's
+            # at T = 100 (tools/gpu_static_diag.py, profiles/round5_inception_stem_ab.txt) - the middle step's two-window
+            # batch amplifies rounding.  A wrong row count or a dropped tile is O(1) in the first step already.
+            for idx, tol in ((0, 1e-5), (1, 1e-2)):
+                a, b = outs[0][idx], other[idx]
                 err = np.linalg.norm(b.astype(np.float64) - a) / max(np.linalg.norm(a.astype(np.float64)), 1e-30)
                 assert err <= tol, (T, kind, idx, err)
 
