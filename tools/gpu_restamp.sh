@@ -10,6 +10,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 python -c "import hashlib; print('library sha256_16 =', hashlib.sha256(open('microwakeword_amd/libmww_hip.so','rb').read()).hexdigest()[:16])"
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
+# fuzzers on the shipped library (per-case reports; each one ends with a failure count)
+{ timeout 600 python tools/gpu_stem_fuzz.py 24 2>&1 | tail -2; timeout 600 python tools/gpu_inc_fuzz.py 0 40 2>&1 | tail -3; timeout 600 python tools/gpu_table_fuzz.py 300 60 2>&1 | tail -2; timeout 300 python tools/gpu_static_diag.py 2>&1 | grep "^T "; } > $OUT/fuzz.txt 2>&1; tail -4 $OUT/fuzz.txt
 B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-validation --no-batch-sweep --profile-steps 0"
 BS="python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-validation --no-batch-sweep --profile-steps 0"
 cd /tmp
