@@ -5,6 +5,11 @@
 #   libmww_hip.so     stem forward from the accumulators + even deal of the weight gradient's task tiles (the defaults)
 #   libmww_d2.so      ... every static forward convolution from the accumulators (-DMWW_G_FWD_DIRECT=2)
 #   libmww_narrow.so  ... the stem weight gradient at three workgroups per CU (-DMWW_G_WGRAD_XG_NARROW=1)
+# The variant libraries are built in the container before the call (they travel with the snapshot, *.so is git-ignored):
+#   cp microwakeword_amd/libmww_hip.so microwakeword_amd/libmww_base.so            (before the change)
+#   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_d2.so -- -DMWW_G_FWD_DIRECT=2
+#   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_narrow.so -- -DMWW_G_WGRAD_XG_NARROW=1
+#   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_breg.so -- -DMWW_G_STEM_BREG=1
 # usage (repo root): [LIBS="a b" VARIANTS="b" PMCLIBS="a" ALLK=1] bash tools/gpu_r5i.sh <tag>   (second sitting: LIBS="even hip breg", every gconv kernel listed)
 TAG=${1:-r5i}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
