@@ -607,10 +607,11 @@ struct BwdFirstWideLds {
   static constexpr int PX = FBINS + 1;
   static constexpr int NCH = NTH / C1, L = (TT + NCH - 1) / NCH, TTP = NCH * L, RAP = TTP + K - 1;
   static constexpr int TAIL = S > 1 ? K - 1 : 0;
-  static constexpr int XR = (TT + TAIL - 1) * S + K1;
+  static constexpr int TAILK = TAIL > 0 ? (TAIL > 4 ? TAIL : 4) : 0;   // the tail k-step of dW1 reads x / g0 rows [TT, TT + 4)
+  static constexpr int XR = (TT + TAILK - 1) * S + K1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
   static constexpr int OFF_A = 0, OFF_DP = OFF_A + up4(RAP * PI), OFF_U = OFF_DP + TT * PO, OFF_DU = OFF_U + up4(TTP * PI);
-  static constexpr int OFF_G0 = OFF_DU + up4(RAP * PI), OFF_END = OFF_G0 + up4((TTP + TAIL + 3) * PG);
+  static constexpr int OFF_G0 = OFF_DU + up4(RAP * PI), OFF_END = OFF_G0 + up4((TTP + TAILK) * PG);
   static constexpr int BYTES = (OFF_END + up4(XR * PX) + 7 * COUT + COUT * PW) * 4 + (int)sizeof(XShared);
 };
 
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
     sA[i] = 0.f;
     sDU[i] = 0.f;
   }
-  for (int i = TT * PG + tid; i < (TTP + TAIL + 3) * PG; i += NTH) sG0[i] = 0.f;   // rows the tail k-step may read
+  for (int i = TT * PG + tid; i < (TTP + Lds::TAILK) * PG; i += NTH) sG0[i] = 0.f;   // rows the tail k-step may read
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);

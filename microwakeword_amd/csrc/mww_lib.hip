@@ -288,7 +288,7 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
       hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                    \
     return MWW_OK;                                                                                             \
   }
-  X(32, 2) X(32, 4) X(32, 8) X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
+  X(32, 2) X(32, 4) X(32, 8) X(32, 12) X(32, 16) X(32, 24) X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
 }

@@ -265,6 +265,17 @@ def test_first_conv_tail_rows(emu_lib):
     ec.check_first_conv_tail_rows(emu_lib, B=2, lengths=(203, 206), topologies=(ec.NOTEBOOK,))
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+def test_first_block_tail_k_step_with_a_three_tap_depthwise(emu_lib, wide):
+    """A 3-tap first depthwise behind a strided first convolution has TAIL = 2 tail rows, but the tail k-step of the
+    dW1 contraction always reads four (round-5 advisor finding: g0 / x rows past the staged ones).  Lengths in tail mode
+    (Ta in {65, 66}), both forms of the first-block backward."""
+    for stride, lengths in ((3, (197, 200)), (2, (132, 134))):
+        flags = dict(ec.DEF, mixconv_kernel_sizes="[3],[9],[13],[21]", stride=stride, bwd_wide=wide)
+        for T in lengths:
+            ec.check_train_steps(emu_lib, B=3, T=T, steps=1, grid=2, flags=flags)
+
+
 def test_inception_static_shapes_are_schedule_only(emu_lib):
     ec.check_inception_static_shapes_are_schedule_only(emu_lib, B=4, lengths=(100, 236), steps=2, grid=2, combos=((0, 0, 0), (1, 1, 0), (1, 1, 1)))
 

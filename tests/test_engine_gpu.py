@@ -181,7 +181,8 @@ WIDER_TABLE = [dict(ec.DEF, pointwise_filters="32,32,32,32", mixconv_kernel_size
 @pytest.mark.parametrize("which", range(len(WIDER_TABLE)))
 def test_block_kernels_of_the_wider_shape_table(lib, which):
     """Shapes the round-5 table added (csrc/block_launch.hip.h): 32-wide and mixed-width blocks, kernel lengths 3 / 7 / 17 / 19 /
-    23, stride-2 / stride-3 first convolutions with a 3-tap depthwise behind them, five blocks - on the specialised block kernels
+    23, stride-2 / stride-3 first convolutions, five blocks (a strided first convolution WITH a 3-tap depthwise behind it, in
+    tail mode: test_first_block_tail_k_step_with_a_three_tap_depthwise) - on the specialised block kernels
     (asserted), forward parity, a train step with ragged tiles and several windows per workgroup, and at B = 256 without imposed
     ReLU decisions."""
     from microwakeword_amd import mixednet
@@ -191,6 +192,17 @@ def test_block_kernels_of_the_wider_shape_table(lib, which):
     ec.check_forward_parity(lib, B=5, T=T, training=True, grid=3, flags=flags)
     ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
     assert ec.check_gradients_unimposed(lib, B=256, T=T, bound=2e-2, flags=flags) <= 2e-2
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_first_block_tail_k_step_with_a_three_tap_depthwise(lib, wide):
+    """Tail-mode lengths (Ta in {65, 66}) of a strided first convolution with a 3-tap depthwise behind it (TAIL = 2 < the four
+    rows of the tail k-step), both forms of the first-block backward - the case the wider-table test above never reaches
+    (T = 230 is not in tail mode, and its [3] cases have stride 1)."""
+    for stride, lengths in ((3, (195, 197, 200)), (2, (131, 134))):
+        flags = dict(ec.DEF, mixconv_kernel_sizes="[3],[9],[13],[21]", stride=stride, bwd_wide=wide)
+        for T in lengths:
+            ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
 
 
 def test_training_reduces_loss(lib):
