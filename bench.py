@@ -73,10 +73,13 @@ BYTES_PER_WINDOW_STEP_BF16 = 427648   # bf16 p_k / g_k, fp32 input
 # flop counted here is a useful one)
 FP32_MFMA_PEAK = 157.3e12  # FLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CONV1_FLOPS, PW_FLOPS = 1474560, {1: 577536, 2: 829440, 3: 774144, 4: 681984}
+# (bwd_block1: since round 6 the conv1 weight gradient - CONV1_FLOPS of it - runs as six bf16 slice products per fp32 product
+# on v_mfma_f32_16x16x32_bf16 (option conv1_x6, csrc/common.hip.h): 6 x CONV1_FLOPS bf16 flops at 1/16 of the f32 cost each
+# = 0.375 of the exact-fp32 MFMA time, counted here as that many f32-equivalent flops)
 KERNEL_MFMA_FLOPS = {
     "fwd_block1": CONV1_FLOPS + PW_FLOPS[1], "fwd_block2": PW_FLOPS[2], "fwd_block3": PW_FLOPS[3], "fwd_block4": PW_FLOPS[4],
     "bwd_block4": 2 * PW_FLOPS[4], "bwd_block3": 2 * PW_FLOPS[3], "bwd_block2": 2 * PW_FLOPS[2],
-    "bwd_block1": CONV1_FLOPS + 2 * PW_FLOPS[1],
+    "bwd_block1": int(0.375 * CONV1_FLOPS) + 2 * PW_FLOPS[1],
 }
 
 
@@ -227,7 +230,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="windows per GPU per step (weak scaling: fixed as N grows)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling (BASELINE configs[4]'s sweep: 4096 windows per step whatever N): windows per step over ALL GPUs, "
+                         "--batch becomes global / N; refused when N does not divide it")
+    ap.add_argument("--range-repeats", type=int, default=5,
+                    help="N = 1: this many further K-step regions are timed AFTER the K steps `value` comes from (`value_range`, not part of `value`)")
     ap.add_argument("--model", choices=("mixednet", "inception", "notebook"), default="mixednet",
                     help="mixednet = BASELINE configs[1] (the headline workload); inception = configs[3] topology; notebook = the "
                          "MixedNet flags of the reference's training notebook (5x1 stride-3 first conv, 64 filters, MixConv groups, T=204)")
@@ -416,6 +424,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     stream = torch.cuda.Stream(device=device)
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not divisible by the %d GPUs of the job" % (args.global_batch, world))
+        args.batch = args.global_batch // world
     B = args.batch
 
     with torch.cuda.stream(stream):
@@ -500,9 +512,15 @@ def main():
                 next_batch()
                 dp.train_step(B, lr)
         else:
+            host_parts = [0.0, 0.0]   # launching thread, seconds inside the two native calls of a step
+
             def one_step():
+                h0 = time.perf_counter()
                 next_batch()
+                h1 = time.perf_counter()
                 eng.train_step(B, lr)
+                host_parts[0] += h1 - h0
+                host_parts[1] += time.perf_counter() - h1
 
         eng.synchronize()
         t_pre_roll = time.perf_counter()
@@ -586,10 +604,14 @@ def main():
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record(stream)
+        if dp is None:
+            host_parts[0] = host_parts[1] = 0.0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
         ev1.record(stream)
+        host_split = None if dp is not None else {"assemble_prefetched_ms": round(1e3 * host_parts[0] / args.steps, 4),
+                                                   "train_step_ms": round(1e3 * host_parts[1] / args.steps, 4)}
         host_enqueue = time.perf_counter() - t0   # the host's share: sampler + launches (+ exchange hooks); it must stay below the GPU's
         fence()
         elapsed = time.perf_counter() - t0
@@ -599,6 +621,23 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         _, _, last_loss = eng.read_outputs(B)
+
+        # ---- the spread of the figure: further K-step regions of the same loop, timed the same way AFTER the region `value` comes
+        # from (a 5 + 20-step run times 6 ms; fifteen of them on five boxes spanned 0.298-0.306 ms in round 5).  Not part of `value`.
+        value_range = None
+        if world == 1 and dp is None and args.range_repeats > 0:
+            reps = []
+            for _ in range(args.range_repeats):
+                fence()
+                tr0 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                fence()
+                reps.append((time.perf_counter() - tr0) / args.steps)
+            value_range = {"repeats": args.range_repeats, "steps_each": args.steps,
+                           "ms_per_step": {"min": round(1e3 * min(reps), 4), "median": round(1e3 * float(np.median(reps)), 4), "max": round(1e3 * max(reps), 4)},
+                           "value": {"min": round(B / max(reps), 1), "median": round(B / float(np.median(reps)), 1), "max": round(B / min(reps), 1)},
+                           "note": "further K-step regions timed like the one `value` comes from, after it; `value` itself is the first region only"}
 
         # ---- per-kernel durations with HIP events on the engine's stream (eager launches, a separate pass AFTER the timed region:
         # the device is at the clocks of the timed steps and no kernel is on its first launch; until round 4 this pass ran in
@@ -693,7 +732,7 @@ def main():
     out = {
         "metric": "spectrogram-windows/sec (train step) on default %s" % args.model,
         "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None, "dtype": ("bf16 storage of p_k/g_k, bf16-operand MFMA in the 1x1 contractions, f32 accumulate / BN sums / parameters" if args.storage_bf16 else
                                       "f32 storage/accumulate, bf16-operand MFMA in the 1x1 contractions" if args.pointwise_bf16 else "f32"),
         "data": "synthetic",
@@ -714,8 +753,16 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kern[dominant], 5),
                      "step_frac": round(value / world * step_bytes / HBM_PEAK, 4), "step_bytes_per_window": step_bytes,
                      "step_frac_note": "whole step, per GPU: windows/s x SURVEY 8(d) algorithmic bytes per window / 8.0 TB/s",
-                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4)},
-        "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4), "final_loss": round(float(last_loss), 5),
+                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern.items())}, "kernel_ms_sum": round(ksum, 4),
+                     "kernel_ms_note": "HIP-event pass of %d eager steps AFTER the timed region: every launch sits between two event records on the stream, "
+                                       "which adds what the back-to-back launches of the timed loop hide - the sum is %+.1f %% of ms_per_step; "
+                                       "kernel_ms_scaled = the same figures scaled to sum to ms_per_step"
+                                       % (args.profile_steps, 100.0 * (ksum / (1e3 * elapsed / args.steps) - 1.0)) if cands else None,
+                     "kernel_ms_scaled": {k: round(v * (1e3 * elapsed / args.steps) / ksum, 5) for k, v in sorted(kern.items())} if cands and ksum > 0 else None},
+        "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4),
+        # the launching thread's two native calls per step: mww_assemble_prefetched (wait for the worker's batch + descriptor / target
+        # upload) and mww_train_step (ten launches); in runs much longer than the mailbox ring both include back-pressure from the GPU
+        "host_enqueue_split": host_split, "final_loss": round(float(last_loss), 5),
         "pre_roll_s": round(pre_roll_s, 3),
         # which binary was timed, and which source set it was built from (mww_version() carries the sha256 of csrc/* +
         # include/mww.h; __graft_entry__.build() rebuilds when it differs from the tree's): library_sha16 ties the line to a
@@ -726,6 +773,8 @@ def main():
                          "clocks; without it (--no-validation --profile-steps 0) a 5 + 20-step run reads ~0.36 ms/step instead; the per-kernel HIP-event pass "
                          "(%d train steps) runs AFTER the timed region" % args.profile_steps,
     }
+    if value_range is not None:
+        out["value_range"] = value_range
     if batch_sweep is not None:
         out["batch_sweep"] = batch_sweep
     if validation is not None:

@@ -355,6 +355,16 @@ typedef struct mww_prefetcher mww_prefetcher;
 int mww_prefetch_create(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
                         const uint32_t* py_state, const uint32_t* np_state, int B, int T, int tmax, int tcount, int fmax,
                         int fcount, int32_t default_strategy, int depth, mww_prefetcher** out);
+/* The same with class and penalty weights kept apart: the reference multiplies penalty[B] by class_weight(y)[B,1]
+ * (microwakeword/train.py:288-293), a [B,B] matrix W[i,j] = penalty_j * cw(y_i) that Keras reduces against the [B] per-sample
+ * losses.  provider_weight = penalty weights; provider_class_weight = class weight of each provider's label;
+ * broadcast 0: w_j = penalty_j * cw_j (then identical to mww_prefetch_create with the products);
+ *           1: w_j = penalty_j * mean_i cw_i over the batch ("keras_last_axis": the reference's arithmetic, the default of
+ *              microwakeword_amd.train); 2: w_i = cw_i * mean_j penalty_j ("keras_first_axis").  Means in float64. */
+int mww_prefetch_create_weighted(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
+                                 const float* provider_class_weight, int broadcast, const uint32_t* py_state,
+                                 const uint32_t* np_state, int B, int T, int tmax, int tcount, int fmax, int fcount,
+                                 int32_t default_strategy, int depth, mww_prefetcher** out);
 /* waits for the next batch; the arrays ([B] windows, [B][tcount+fcount][2] masks, [B] labels / weights / provider /
  * index of the sample inside its provider's training set) stay valid until mww_prefetch_release.  Any pointer may be NULL. */
 int mww_prefetch_acquire(mww_prefetcher* p, const mww_window** windows, const int32_t** masks, const float** labels,

@@ -39,9 +39,10 @@
 namespace mww {
 
 // mode: 0 = fp32, 1 = bf16 operands of the 1x1 contractions, 2 = bf16 operands and bf16 storage of p_k / g_k
-bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const FwdFirstArgs& a, int grid);
+// x6: the first convolution (and, backward, its weight gradient) as bf16 slice products (common.hip.h; fp32 mode, stride 1)
+bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const FwdFirstArgs& a, int grid, bool x6);
 bool k_launch_fwd_block(hipStream_t st, int mode, int cin, int cout, int k, const FwdBlockArgs& a, int grid);
-bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid);
+bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid, bool x6);
 bool k_launch_bwd_block(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
 // wide-workgroup form of the block backward (kernels_bwdw.hip.h: 512 threads per workgroup; every mode)
 bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);

@@ -61,6 +61,60 @@ __device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) 
   return v;
 }
 
+// ---- fp32-grade products on the bf16 matrix pipe ("x6": the first convolution and its weight gradient, round 6) -----------
+// v = s0 + s1 + s2 exactly, the three 8-bit slices of the fp32 significand as bf16 values (by truncation: and / sub / and /
+// sub).  A product x * w is then the sum of nine slice products, each exact in fp32; the six with i + j <= 2 carry everything
+// above 2^-24 of it (tools/ubench/mfma_bf16x9: max error 1.08e-7 of sum |x w| against 1.19e-7 for the f32 MFMA's fma chain),
+// and six v_mfma_f32_16x16x32_bf16 (K = 32, ~17-19 cycles each) replace eight v_mfma_f32_16x16x4_f32 (K = 4, 32 cycles each).
+// Lane l of the 16x16x32 form supplies A[i = l&15][k = 8*(l>>4) + e] and B[k = 8*(l>>4) + e][n = l&15], e < 8, as one
+// 16-byte register quad; C/D as the f32 form.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma_bf16k32(u32x4v a, u32x4v b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the slices in the HIGH halves of three dwords (low halves zero)
+__device__ __forceinline__ void split3(float v, unsigned& h0, unsigned& h1, unsigned& h2) {
+  h0 = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(h1);   // at most 8 significant bits are left: a bf16 value
+  h2 = __float_as_uint(r2) & 0xffff0000u;
+}
+// two slices (high halves) -> one dword of two bf16: element 0 = a, element 1 = b
+__device__ __forceinline__ unsigned pack_hi2(unsigned a, unsigned b) { return (a >> 16) | b; }
+// slices of eight values as the three operand quads of the 16x16x32 form
+__device__ __forceinline__ void split3x8(const float (&v)[8], u32x4v (&q)[3]) {
+  unsigned h[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3(v[e], h[0][e], h[1][e], h[2][e]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) q[p][d] = pack_hi2(h[p][2 * d], h[p][2 * d + 1]);
+}
+// acc += x * w for operand slices xs[0..2], ws[0..2]: the six products with i + j <= 2, small terms first
+__device__ __forceinline__ f32x4 mfma_x6(const u32x4v (&xs)[3], const u32x4v (&ws)[3], f32x4 acc) {
+  acc = mfma_bf16k32(xs[2], ws[0], acc);
+  acc = mfma_bf16k32(xs[1], ws[1], acc);
+  acc = mfma_bf16k32(xs[0], ws[2], acc);
+  acc = mfma_bf16k32(xs[1], ws[0], acc);
+  acc = mfma_bf16k32(xs[0], ws[1], acc);
+  acc = mfma_bf16k32(xs[0], ws[0], acc);
+  return acc;
+}
+__device__ __forceinline__ void pin4(u32x4v& v) { asm volatile("" : "+v"(v)); }
+// ds_read_b64_tr_b16 (gfx950): within each group of 16 lanes, lane p supplies the 8-byte-aligned LDS address of four 16-bit
+// elements in[p][0..3] and lane i receives out[j] = in[4 j + (i >> 2)][i & 3], j < 4 (probed: tools/ubench/tr16_probe.hip).
+// With lane p pointing at row k0 + (p >> 2), columns c0 + 4 (p & 3) .. + 3 of a row-major bf16 tile, lane i gets column
+// c0 + i of rows k0 .. k0 + 3: a k-contiguous MFMA operand from a tile whose k runs over rows.  Returns two dwords.
+__device__ __forceinline__ u32x2v lds_read_tr16(const void* lds_ptr) {
+  typedef short s16x4t __attribute__((ext_vector_type(4)));
+  const s16x4t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(lds_ptr));
+  return __builtin_bit_cast(u32x2v, v);
+}
+
 __device__ __forceinline__ f32x4 zero4() {
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   return z;

@@ -347,12 +347,12 @@ struct BwdFirstArgs {
 };
 
 // (stride-3 first convolutions stage 194 x rows per tile: 92-99 KB of LDS, one workgroup per CU)
-template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false, bool X6 = false>
 __global__ __launch_bounds__(kThreads, (S > 1 ? 1 : 2)) void bwd_first_kernel(BwdFirstArgs a) {
   typedef BwdFirstLds<K1, C1, COUT, K, S> Lds;
-  __shared__ __attribute__((aligned(16))) float sX[Lds::XR * Lds::PX];
+  __shared__ __attribute__((aligned(16))) float sX[X6 ? 3 * Lds::XR * 96 / 4 : Lds::XR * Lds::PX];   // X6: three bf16 planes, 96-byte rows
   __shared__ XShared sXg;
-  __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
+  __shared__ __attribute__((aligned(16))) float smem[X6 ? Lds::OFF_END - (Lds::TTP + Lds::TAILK) * Lds::CPI : Lds::OFF_END];   // X6: g0 lives in the dp tile
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
   __shared__ __attribute__((aligned(16))) float sWt[COUT * pitch_wt(C1, BF)];   // W_pw^T
 #include "bwd_first_body.inc"

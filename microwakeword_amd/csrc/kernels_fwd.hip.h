@@ -171,6 +171,61 @@ struct XStage {
       }
     }
   }
+
+  // The "x6" kernels (common.hip.h "fp32-grade products on the bf16 matrix pipe") stage the rows as three bf16 slice planes
+  // instead: plane p holds slice p of every value, rows of PB bytes (FBINS bf16 + padding), planes PLB bytes apart; the same
+  // pad / truncate / scale / mask decisions as commit(), then and / sub / and / sub per value and one 8-byte store per plane.
+  template <int PB, int PLB>
+  __device__ __forceinline__ void commit_planes(unsigned* sXb, const XGather& g, const XShared& sh, int s, int row0, int tid) const {
+    asm volatile("" : "+v"(tid));
+    const int rq = tid / QX, q = tid - rq * QX;
+    if (tid >= ACT) return;
+    const bool gather = g.win != nullptr;
+    const bool u16 = gather && uniform_int(sh.dtype[s]) == MWW_DTYPE_U16;
+    unsigned cm = 0u, rb[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rb[j] = 0u;
+    if (gather) {
+      cm = (sh.colbits[s][(4 * q) >> 5] >> ((4 * q) & 31)) & 0xfu;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int t = min(row0 + rq + RPP * j, g.T - 1);   // rows past the window are zero already
+        rb[j] = sh.rowbits[s][t >> 5] >> (t & 31);
+      }
+    }
+    char* dst = reinterpret_cast<char*>(sXb) + rq * PB + q * 8;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int r = rq + RPP * j;
+      if (r < XROWS) {
+        float4 v = pre[j];
+        if (u16) {
+          const unsigned lo = __float_as_uint(v.x), hi = __float_as_uint(v.y);
+          v.x = (float)(lo & 0xffffu) * 0.0390625f;   // data.py:268-269
+          v.y = (float)(lo >> 16) * 0.0390625f;
+          v.z = (float)(hi & 0xffffu) * 0.0390625f;
+          v.w = (float)(hi >> 16) * 0.0390625f;
+        }
+        if (gather) {
+          const unsigned m4 = (rb[j] & 1u) ? 0xfu : cm;
+          v.x = (m4 & 1u) ? 0.f : v.x;
+          v.y = (m4 & 2u) ? 0.f : v.y;
+          v.z = (m4 & 4u) ? 0.f : v.z;
+          v.w = (m4 & 8u) ? 0.f : v.w;
+        }
+        unsigned h[3][4];
+        split3(v.x, h[0][0], h[1][0], h[2][0]);
+        split3(v.y, h[0][1], h[1][1], h[2][1]);
+        split3(v.z, h[0][2], h[1][2], h[2][2]);
+        split3(v.w, h[0][3], h[1][3], h[2][3]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          u32x2v w2 = {pack_hi2(h[p][0], h[p][1]), pack_hi2(h[p][2], h[p][3])};
+          *reinterpret_cast<u32x2v*>(dst + p * PLB + RPP * j * PB) = w2;
+        }
+      }
+    }
+  }
 };
 
 struct FwdFirstArgs {
@@ -366,12 +421,14 @@ struct FwdBlockLds {
   static constexpr int CPA = pitch_fa(CIN), CPU = pitch_fu(CIN, BF), RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
 };
 
-template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false>
+template <int K1, int C1, int COUT, int K, int S, bool BF, bool SB = false, bool X6 = false>
 __global__ __launch_bounds__(kThreads, ((S > 1 || COUT > 48 || K1 > 3) ? 2 : 4)) void fwd_first_kernel(FwdFirstArgs a) {
   typedef FwdFirstLds<K1, C1, COUT, K, S, BF> Lds;
-  __shared__ __attribute__((aligned(16))) float sX[Lds::XR * Lds::PX];
+  __shared__ __attribute__((aligned(16))) float sX[X6 ? 3 * Lds::XR * 96 / 4 : Lds::XR * Lds::PX];   // X6: three bf16 planes, 96-byte rows
+  static_assert(!X6 || 3 * Lds::XR * 96 / 4 >= Lds::TTP * Lds::CPU, "the u tile of the x6 form lives in the x planes");
   __shared__ __attribute__((aligned(16))) float sA[Lds::RAP * Lds::CP1];
-  __shared__ __attribute__((aligned(16))) float sU[Lds::TTP * Lds::CPU];
+  __shared__ __attribute__((aligned(16))) float sU[X6 ? 4 : Lds::TTP * Lds::CPU];
+  __shared__ __attribute__((aligned(16))) float sPw[X6 ? C1 * COUT : 4];   // X6: the 1x1 weights
   __shared__ __attribute__((aligned(16))) float sRed[4 * 2 * COUT];
   __shared__ XShared sXg;
 #include "fwd_first_body.inc"

@@ -20,6 +20,16 @@
 #include "kernels_tail.hip.h"
 
 // the fp32 block backward runs as the wide-workgroup form (option "bwd_wide"; kernels_bwdw.hip.h) unless told otherwise
+// options "conv1_x6" (the conv1 weight gradient in the first block's backward kernel) and "conv1_x6_fwd" (the first convolution
+// itself): see common.hip.h "fp32-grade products on the bf16 matrix pipe".  Same-session A/B at B = 1024 (profiles/round6_conv1_x6_ab.txt):
+// backward 49.7 -> 44.0 us; forward 33.5 -> 36-37 us (the matrix pipe's 6.5 us are paid back by the slicing of x and W1 in a
+// launch whose workgroups see three tiles each) - so the default is backward only.
+#ifndef MWW_CONV1_X6_DEFAULT
+#define MWW_CONV1_X6_DEFAULT 1
+#endif
+#ifndef MWW_CONV1_X6_FWD_DEFAULT
+#define MWW_CONV1_X6_FWD_DEFAULT 0
+#endif
 #ifndef MWW_BWD_WIDE_DEFAULT
 #define MWW_BWD_WIDE_DEFAULT 1
 #endif
@@ -117,6 +127,8 @@ struct mww_ctx {
   bool own_stream = false;
   int n_cu = 256;
   int grid_fwd = 0, grid_bwd = 0, grid_head = 0;
+  bool conv1_x6 = MWW_CONV1_X6_DEFAULT != 0;   // conv1 weight gradient as six bf16 slice products per fp32 product (stride-1 shapes, fp32 mode)
+  bool conv1_x6_fwd = MWW_CONV1_X6_FWD_DEFAULT != 0;   // ... and the first convolution of the forward kernel
   bool bwd_wide = MWW_BWD_WIDE_DEFAULT != 0;   // fp32 block backward kernels: 512 threads per workgroup (bwd_blockw_kernel) or 256 (bwd_block_kernel)
   int64_t P = 0, S = 0;
   int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
@@ -257,13 +269,13 @@ struct Launcher {
 // The block kernels are instantiated and launched in their own translation units (tu_fwd.hip, tu_bwd.hip, tu_bwdw.hip:
 // compiled in parallel by build()); block_launch.hip.h declares their launchers and the table of specialised shapes.
 int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const FwdFirstArgs& a, int grid) {
-  if (k_launch_fwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid)) return MWW_OK;
+  if (k_launch_fwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid, c->conv1_x6_fwd)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block kernel for this (conv1 kernel, filters, pointwise, depthwise) shape");
 }
 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
   if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_firstw(c->stream, k1, c1, cout, k, st, a, grid)) return MWW_OK;
-  if (k_launch_bwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid)) return MWW_OK;
+  if (k_launch_bwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid, c->conv1_x6)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block backward kernel for this shape");
 }
 
@@ -3087,6 +3099,8 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
     if (v) c->pw_bf16 = true;
   }
   else if (!strcmp(name, "bwd_wide")) c->bwd_wide = v != 0;
+  else if (!strcmp(name, "conv1_x6")) c->conv1_x6 = v != 0;
+  else if (!strcmp(name, "conv1_x6_fwd")) c->conv1_x6_fwd = v != 0;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_graph")) {   // 0: per-launch grids by occupancy (default); > 0: this many workgroups per launch

@@ -213,7 +213,9 @@ struct mww_prefetcher {
   std::vector<double> sampling_weight;
   std::vector<int32_t> strategy, set_store, set_len, cutoff_offsets, cutoffs;
   std::vector<int64_t> set_offsets, set_src_elem;
-  std::vector<float> label, weight;   // per provider
+  std::vector<float> label, weight;   // per provider (weight: penalty weight, or penalty x class weight when broadcast == 0)
+  std::vector<float> class_weight;     // per provider (broadcast 1 / 2)
+  int broadcast = 0;                   // how class and penalty weights combine: 0 per sample, 1 Keras' last-axis reading, 2 first-axis
   mww_sampler_desc d;
   int B = 0, T = 0, tmax = 0, tcount = 0, fmax = 0, fcount = 0, depth = 0;
   int32_t default_strategy = -1;
@@ -244,11 +246,26 @@ struct mww_prefetcher {
       Slot& s = slots[tail];
       s.rc = mww_sample_training_batch(&d, py, np_, B, T, tmax, tcount, fmax, fcount, default_strategy, 1, s.win.data(),
                                        s.masks.data(), s.prov.data(), s.samp.data(), s.order.data());
-      if (s.rc == MWW_OK)
+      if (s.rc == MWW_OK) {
+        // train.py:288-293 multiplies penalty[B] by class_weight(y)[B,1]: a [B,B] matrix W[i,j] = penalty_j cw(y_i) that Keras
+        // reduces against the [B] losses.  broadcast 1: column means, w_j = penalty_j mean_i cw(y_i) (float64 like numpy);
+        // 2: row means, w_i = cw(y_i) mean_j penalty_j; 0: the product per sample (already folded into `weight`)
+        double mean_cw = 0.0, mean_pen = 0.0;
+        if (broadcast != 0) {
+          for (int j = 0; j < B; ++j) {
+            mean_cw += (double)class_weight[s.prov[j]];
+            mean_pen += (double)weight[s.prov[j]];
+          }
+          mean_cw /= B;
+          mean_pen /= B;
+        }
         for (int j = 0; j < B; ++j) {
           s.y[j] = label[s.prov[j]];
-          s.w[j] = weight[s.prov[j]];
+          if (broadcast == 1) s.w[j] = (float)((double)weight[s.prov[j]] * mean_cw);
+          else if (broadcast == 2) s.w[j] = (float)((double)class_weight[s.prov[j]] * mean_pen);
+          else s.w[j] = weight[s.prov[j]];
         }
+      }
       memcpy(s.py, py, sizeof(py));
       memcpy(s.np_, np_, sizeof(np_));
       {
@@ -265,8 +282,17 @@ struct mww_prefetcher {
 extern "C" int mww_prefetch_create(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
                                    const uint32_t* py_state, const uint32_t* np_state, int B, int T, int tmax, int tcount,
                                    int fmax, int fcount, int32_t default_strategy, int depth, mww_prefetcher** out) {
+  return mww_prefetch_create_weighted(d, provider_label, provider_weight, nullptr, 0, py_state, np_state, B, T, tmax, tcount, fmax,
+                                      fcount, default_strategy, depth, out);
+}
+
+extern "C" int mww_prefetch_create_weighted(const mww_sampler_desc* d, const float* provider_label, const float* provider_weight,
+                                            const float* provider_class_weight, int broadcast, const uint32_t* py_state,
+                                            const uint32_t* np_state, int B, int T, int tmax, int tcount, int fmax, int fcount,
+                                            int32_t default_strategy, int depth, mww_prefetcher** out) {
   if (!d || !provider_label || !provider_weight || !py_state || !np_state || !out || B <= 0 || depth < 1 || depth > 16 ||
-      d->n_providers <= 0 || d->n_providers > 64 || tcount < 0 || fcount < 0)
+      d->n_providers <= 0 || d->n_providers > 64 || tcount < 0 || fcount < 0 || broadcast < 0 || broadcast > 2 ||
+      (broadcast != 0 && !provider_class_weight))
     return MWW_ERR_INVALID;
   mww_prefetcher* p = new mww_prefetcher();
   const int n = d->n_providers;
@@ -283,6 +309,8 @@ extern "C" int mww_prefetch_create(const mww_sampler_desc* d, const float* provi
   if (p->cutoffs.empty()) p->cutoffs.push_back(0);                  // data() stays non-null
   p->label.assign(provider_label, provider_label + n);
   p->weight.assign(provider_weight, provider_weight + n);
+  if (provider_class_weight) p->class_weight.assign(provider_class_weight, provider_class_weight + n);
+  p->broadcast = broadcast;
   p->d.n_providers = n;
   p->d.sampling_weight = p->sampling_weight.data();
   p->d.strategy = p->strategy.data();

@@ -4,7 +4,18 @@
 
 namespace mww {
 
-bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const FwdFirstArgs& a, int grid) {
+// the x6 form of the first convolution exists for the stride-1 shapes (in a template: the other branch is not instantiated)
+template <int K1, int C1, int CO, int K, int S>
+static bool launch_fwd_first_x6(hipStream_t st, const FwdFirstArgs& a, int grid) {
+  if constexpr (S == 1) {
+    hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, false, false, true>), dim3(grid), dim3(kThreads), 0, st, a);
+    return true;
+  } else {
+    return false;
+  }
+}
+
+bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int k, int stride, const FwdFirstArgs& a, int grid, bool x6) {
   if (mode != 0) {
 #define X(K1, C1, CO, K, S)                                                                                    \
     if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                         \
@@ -20,6 +31,7 @@ bool k_launch_fwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int 
   }
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
+    if (x6 && launch_fwd_first_x6<K1, C1, CO, K, S>(st, a, grid)) return true;                                 \
     hipLaunchKernelGGL((fwd_first_kernel<K1, C1, CO, K, S, false>), dim3(grid), dim3(kThreads), 0, st, a);     \
     return true;                                                                                               \
   }

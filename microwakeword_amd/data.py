@@ -64,14 +64,20 @@ class MmapFeatureProvider:
                     count += 1
             random.shuffle(self.feature_sets[mode])  # data.py:206 — consumes the global RNG like the reference
             self.stats[mode] = {"spectrogram_count": count, "total_duration": duration}
-        # flat HBM image: one store per dtype
+        self.store_id: Dict[str, int] = {}
+        self.build_flat()
+
+    def build_flat(self, keep=None):
+        """The flat HBM image: one store per dtype, every sample's [T_i, 40] frames concatenated.  ``keep`` (a set of
+        (store, sample) pairs): only those samples go in - a data-parallel rank keeps its shard of the training samples
+        (FeatureHandler.shard_stores, SURVEY 8e "each rank uploads its shard to its own HBM"); the others get no offset."""
         self.flat: Dict[str, np.ndarray] = {}
-        self.sample_start: List[List[int]] = []   # [loaded_feature][sub] -> element offset in its flat store
+        self.sample_start: List[List[int]] = []   # [loaded_feature][sub] -> element offset in its flat store (-1: not resident)
         self.sample_len: List[List[int]] = []
         self.feature_dtype: List[str] = []
         chunks: Dict[str, List[np.ndarray]] = {}
         cursor: Dict[str, int] = {}
-        for st in self.loaded_features:
+        for fi, st in enumerate(self.loaded_features):
             starts, lens = [], []
             dt = None
             for i in range(len(st)):
@@ -85,16 +91,18 @@ class MmapFeatureProvider:
                     dt = key
                 elif dt != key:
                     raise ValueError("mixed dtypes inside one ragged store")
+                lens.append(a.shape[0])
+                if keep is not None and (fi, i) not in keep:
+                    starts.append(-1)
+                    continue
                 chunks.setdefault(key, []).append(np.ascontiguousarray(a).reshape(-1))
                 starts.append(cursor.get(key, 0))
-                lens.append(a.shape[0])
                 cursor[key] = cursor.get(key, 0) + a.size
             self.sample_start.append(starts)
             self.sample_len.append(lens)
             self.feature_dtype.append(dt or "u16")
         for key, parts in chunks.items():
             self.flat[key] = np.concatenate(parts)
-        self.store_id: Dict[str, int] = {}
 
     def get_mode_duration(self, mode):
         return self.stats[mode]["total_duration"]
@@ -109,7 +117,10 @@ class MmapFeatureProvider:
 class FeatureHandler:
     """Drop-in for ``microwakeword.data.FeatureHandler`` (mmap providers)."""
 
-    def __init__(self, config: dict, engine: Optional[native.Engine] = None):
+    def __init__(self, config: dict, engine: Optional[native.Engine] = None, shard: Optional[Tuple[int, int]] = None):
+        """``shard`` = (rank, world) of a data-parallel job: the rank keeps (and uploads) training samples rank, rank + W, ...
+        of every provider (parallel.shard_feature_handler does the same to a handler built without it, at the price of
+        one full upload first)."""
         self.feature_providers: List[MmapFeatureProvider] = []
         for feature_set in config["features"]:
             if feature_set["type"] == "mmap":
@@ -129,6 +140,10 @@ class FeatureHandler:
         self._prefetch_depth = 0
         self._pf = None
         self.eval_shard = (0, 1)   # (rank, world): evaluate_on_device scores windows rank, rank + W, ... (parallel.shard_feature_handler)
+        self.uploaded_bytes = 0    # bytes of feature stores this handler sent to its engine's HBM (all uploads)
+        self.resident_bytes = 0    # ... and what is resident now
+        if shard is not None and int(shard[1]) > 1:
+            self.shard_training_lists(int(shard[0]), int(shard[1]))
         if engine is not None:
             self.attach(engine)
 
@@ -141,18 +156,45 @@ class FeatureHandler:
 
     # ---- device residency
     def attach(self, engine: native.Engine):
-        """Uploads every provider's flat store into the engine's HBM (once)."""
+        """Uploads every provider's flat store into the engine's HBM (once; again after shard_training_lists)."""
         self.engine = engine
         next_id = 0
+        self.resident_bytes = 0
         for p in self.feature_providers:
             for key, flat in p.flat.items():
                 if next_id >= native.MWW_MAX_STORES:
                     raise ValueError("too many feature stores")
                 engine.upload_store(next_id, flat)
+                self.uploaded_bytes += flat.nbytes
+                self.resident_bytes += flat.nbytes
                 p.store_id[key] = next_id
                 next_id += 1
         self._sampler = None
         self._eval_cache = {}
+
+    def shard_training_lists(self, rank: int, world: int):
+        """per provider, training sample i of the CANONICAL (store, sample) order goes to rank i mod W - a partition
+        whatever per-rank shuffle produced the list - and only those samples (plus every validation / testing sample: their
+        windows are sharded by index at evaluation time) stay in the provider's flat HBM image, which is uploaded again if
+        the handler is attached.  Idempotent for the same (rank, world)."""
+        if getattr(self, "_sharded_for", None) == (int(rank), int(world)):
+            return
+        if getattr(self, "_sharded_for", None) is not None:
+            raise ValueError("feature handler already sharded for rank/world %r" % (self._sharded_for,))
+        for p in self.feature_providers:
+            p.feature_sets["training"] = sorted(p.feature_sets["training"])[rank::world]
+            if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:
+                raise ValueError("provider has fewer training samples than ranks")
+            keep = set(p.feature_sets["training"])
+            for mode in MODES:
+                if mode != "training":
+                    keep.update(p.feature_sets[mode])
+            p.build_flat(keep)
+        self._sharded_for = (int(rank), int(world))
+        if getattr(self, "_pf", None) is not None:
+            self._drop_prefetcher(keep_streams=True)   # its sampler description points into the old image
+        if self.engine is not None:
+            self.attach(self.engine)
 
     def _need_engine(self):
         if self.engine is None:
@@ -301,7 +343,7 @@ class FeatureHandler:
                     draw_windows=buf["win"].copy(), draw_masks=buf["masks"].copy())
 
     def next_training_batch_on_device(self, batch_size, features_length, truncation_strategy="default",
-                                      augmentation_policy=None, class_weights=(1.0, 1.0), weight_broadcast="per_sample",
+                                      augmentation_policy=None, class_weights=(1.0, 1.0), weight_broadcast=None,
                                       want_targets=False):
         """Fast path of the train loop: leaves x in the engine's batch buffer (no host copy of the
         spectrograms) and the labels / per-sample weights (penalty x class weight, train.py:288-293) next
@@ -309,12 +351,15 @@ class FeatureHandler:
         enqueued.  ``class_weights`` = (negative, positive); ``weight_broadcast``: model.combine_weights.  Returns
         ``(labels, penalty_weights)``."""
         neg, pos = class_weights
-        if self._prefetch_depth > 0 and self._private_rng is not None and weight_broadcast == "per_sample":
+        if weight_broadcast is None:
+            from .model import DEFAULT_WEIGHT_BROADCAST
+            weight_broadcast = DEFAULT_WEIGHT_BROADCAST
+        if self._prefetch_depth > 0 and self._private_rng is not None:
             # batches drawn ahead by the worker thread: one native call per step on this thread
             self._need_engine()
             pol = dict(DEFAULT_POLICY)
             pol.update(augmentation_policy or {})
-            key = (int(batch_size), int(features_length), truncation_strategy, float(neg), float(pos),
+            key = (int(batch_size), int(features_length), truncation_strategy, float(neg), float(pos), weight_broadcast,
                    tuple(int(pol[k]) for k in ("time_mask_max_size", "time_mask_count", "freq_mask_max_size", "freq_mask_count")))
             if self._pf is None or self._pf[0] != key or self._sampler is None:
                 self._drop_prefetcher()
@@ -322,15 +367,18 @@ class FeatureHandler:
                     self._build_sampler()
                 d, arrs, live = self._sampler
                 tmax, tc, fmax, fc, dstrat = self._policy(augmentation_policy, truncation_strategy)
-                cw = np.where(arrs["labels"] != 0, float(pos), float(neg))   # train.py:288-293, per-sample form
+                cw = np.where(arrs["labels"] != 0, float(pos), float(neg))   # train.py:288-293: class weight of each provider's label
                 py, npst = self._private_rng
-                self._pf = (key, native.Prefetcher(self.engine.nl, d, arrs["labels"], arrs["penalty"] * cw, py, npst, int(batch_size),
-                                                   int(features_length), tmax, tc, fmax, fc, dstrat, self._prefetch_depth))
+                # penalty and class weights travel apart: the worker combines them per batch as `weight_broadcast` says
+                # (model.combine_weights; every reading is the per-sample product while the class weights are uniform)
+                self._pf = (key, native.Prefetcher(self.engine.nl, d, arrs["labels"], arrs["penalty"], py, npst, int(batch_size),
+                                                   int(features_length), tmax, tc, fmax, fc, dstrat, self._prefetch_depth,
+                                                   class_weights=cw, broadcast=weight_broadcast))
             return self.engine.assemble_prefetched(self._pf[1], want_targets)
         buf, tc, fc, arrs = self._sample(int(batch_size), features_length, truncation_strategy, augmentation_policy, 1)
         y = arrs["labels"][buf["prov"]]
         w = arrs["penalty"][buf["prov"]]
-        if neg == 1.0 and pos == 1.0 and weight_broadcast == "per_sample":
+        if neg == 1.0 and pos == 1.0:
             self.engine.set_targets(y, w)
         else:
             from .model import combine_weights

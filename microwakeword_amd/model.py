@@ -78,35 +78,42 @@ class _Counts:
 
 
 WEIGHT_BROADCAST_MODES = ("per_sample", "keras_last_axis", "keras_first_axis")
-# How the reference's [B,B] sample weight (train.py:288-293) is reduced to per-sample weights when nothing else is
-# configured.  "per_sample" is the evident intent; which reading Keras 3 really evaluates is settled by
-# tests/test_tf_golden.py as soon as tests/golden/tf_golden.npz exists (tools/make_tf_golden.py) - that test fails until
-# this constant names the reading the reference's numbers follow.  Equal for all readings while class weights (or penalty
-# weights) are uniform, which holds for every BASELINE configuration.
-DEFAULT_WEIGHT_BROADCAST = "per_sample"
-# ... and how a [B,B] MATRIX handed to the drop-in ``train_on_batch`` is reduced: the caller that builds such a matrix is the
-# reference's own train.py (:288-293) and wants the reference's arithmetic, which by our reading of Keras 3
-# (keras/src/losses/loss.py: ``Loss.__call__`` -> ``reduce_weighted_values``: ``squeeze_or_expand_to_same_rank`` leaves a [B]
-# loss vector and a [B,B] weight as they are, ``values * sample_weight`` broadcasts the losses along the LAST axis,
-# ``reduce_values`` divides the sum by ``prod(shape(values))`` = B*B) is w_j = penalty_j * mean_i cw(y_i).  The vector-form
-# fast path of this package's own loop (train.train, config key ``sample_weight_broadcast``) keeps the evident intent
-# ``per_sample`` and says so in its log.  tests/test_tf_golden.py is the arbiter of both once TensorFlow numbers exist.
-MATRIX_WEIGHT_BROADCAST = "keras_last_axis"
+# How the reference's [B,B] sample weight (train.py:288-293: penalty[B] * class_weight(y)[B,1]) is reduced to per-sample
+# weights - ONE default for both entry points (round 6): the package's own loop (train.train, config key
+# ``sample_weight_broadcast``) and a [B,B] matrix handed to the drop-in ``train_on_batch`` by the reference's loop.  The default
+# is the reference's ARITHMETIC as we read Keras 3 (keras/src/losses/loss.py: ``Loss.__call__`` -> ``reduce_weighted_values``:
+# ``squeeze_or_expand_to_same_rank`` leaves a [B] loss vector and a [B,B] weight as they are, ``values * sample_weight``
+# broadcasts the losses along the LAST axis, ``reduce_values`` divides the sum by ``prod(shape(values))`` = B*B):
+# w_j = penalty_j * mean_i cw(y_i) - a user who switches between ``microwakeword_amd.train.train`` and the reference's loop
+# gets the same loss curve.  ``per_sample`` (the evident intent, w_i = penalty_i * cw(y_i)) is the opt-in.  All readings are
+# equal while class weights (or penalty weights) are uniform, which holds for every BASELINE configuration; which one
+# TensorFlow really evaluates is settled by tests/test_tf_golden.py as soon as tests/golden/tf_golden.npz exists
+# (tools/make_tf_golden.py) - that test fails until these constants name the reading the reference's numbers follow.
+DEFAULT_WEIGHT_BROADCAST = "keras_last_axis"
+MATRIX_WEIGHT_BROADCAST = DEFAULT_WEIGHT_BROADCAST
 
 
-def combine_weights(penalty, labels, negative_class_weight, positive_class_weight, mode="per_sample"):
+def readings_differ(penalty, labels, negative_class_weight, positive_class_weight):
+    """Do the readings of the [B,B] weight matrix give different per-sample weights on THIS batch?  (Only if the class weights
+    and the penalty weights both vary over it.)"""
+    cw = np.where(np.asarray(labels).reshape(-1) > 0.5, positive_class_weight, negative_class_weight)
+    pen = np.asarray(penalty).reshape(-1)
+    return bool(cw.size and cw.min() != cw.max() and pen.min() != pen.max())
+
+
+def combine_weights(penalty, labels, negative_class_weight, positive_class_weight, mode=DEFAULT_WEIGHT_BROADCAST):
     """The per-sample loss weights of a training batch.  train.py:288-293 multiplies penalty[B] by class_weight(y)[B,1],
     which broadcasts to a [B,B] matrix W[i,j] = penalty_j * cw(y_i) that Keras then reduces against the [B] per-sample
-    losses.  ``per_sample`` (default) is what the code evidently means: w_i = penalty_i * cw(y_i).  The two
-    readings of what Keras 3 actually evaluates are available for parity runs against the reference's loss curves:
-    ``keras_last_axis`` - the losses broadcast along the last axis of W and everything is divided by B*B:
+    losses.  ``per_sample`` is what the code evidently means: w_i = penalty_i * cw(y_i).  The two readings of
+    what Keras 3 actually evaluates:
+    ``keras_last_axis`` (the default of both entry points, DEFAULT_WEIGHT_BROADCAST) - the losses broadcast along the last axis of W and everything is divided by B*B:
     w_j = penalty_j * mean_i cw(y_i) (what keras/src/losses/loss.py reduce_weighted_values does as we read it: a [B] loss
     vector against a [B,B] weight is left as is by squeeze_or_expand_to_same_rank, multiplied with ordinary broadcasting
     and divided by the element count B*B - not verifiable here, TensorFlow is not installable); ``keras_first_axis`` -
     w_i = cw(y_i) * mean_j penalty_j.  per_sample equals keras_last_axis when the class weights are uniform over the batch
     and keras_first_axis when the penalty weights are; with both non-uniform (e.g. negative_class_weight 20 and mixed
-    penalty_weight providers) the loss curves differ: set ``sample_weight_broadcast: keras_last_axis`` in the training
-    config to follow the reference's arithmetic rather than its intent."""
+    penalty_weight providers) the loss curves differ: set ``sample_weight_broadcast: per_sample`` in the training config to
+    follow the reference's intent rather than its arithmetic."""
     penalty = np.asarray(penalty, np.float64).reshape(-1)
     cw = np.where(np.asarray(labels).reshape(-1) > 0.5, positive_class_weight, negative_class_weight).astype(np.float64)
     if mode == "per_sample":

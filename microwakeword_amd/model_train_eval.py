@@ -174,7 +174,10 @@ def _run(flags, model_module, rank, local_rank, world):
             raise ValueError("batch_size %d (the global batch) is not divisible by the %d ranks" % (config["batch_size"], world))
         # every rank's engine holds batch_size / W windows per step
         model = model_module.model(flags, config["training_input_shape"], config["batch_size"] // world, device=device)
-        data_processor = FeatureHandler(config, engine=model.engine)
+        from .train import process_group
+        rank, world = process_group()
+        # a data-parallel rank uploads its shard of the training samples only (train() would shard an unsharded handler too)
+        data_processor = FeatureHandler(config, engine=model.engine, shard=(rank, world) if world > 1 else None)
         if rank == 0:
             model.summary(print_fn=logging.getLogger("microwakeword_amd").info)
         return train_model(config, model, data_processor, flags.restore_checkpoint)

@@ -94,7 +94,7 @@ EXPORTS = [
     "mww_assemble_batch", "mww_set_batch", "mww_get_batch", "mww_set_targets", "mww_train_step", "mww_apply_gradients",
     "mww_forward", "mww_read_outputs", "mww_metrics_read", "mww_metrics_reset", "mww_device_ptr", "mww_debug_read",
     "mww_set_option", "mww_profile_read", "mww_sample_training_batch", "mww_rng_selftest",
-    "mww_prefetch_create", "mww_prefetch_acquire", "mww_prefetch_release", "mww_prefetch_rng_state", "mww_prefetch_shape",
+    "mww_prefetch_create", "mww_prefetch_create_weighted", "mww_prefetch_acquire", "mww_prefetch_release", "mww_prefetch_rng_state", "mww_prefetch_shape",
     "mww_prefetch_destroy", "mww_assemble_prefetched",
     "mww_allreduce_unique_id", "mww_allreduce_init", "mww_allreduce_destroy", "mww_evaluate_windows",
 ]
@@ -170,6 +170,9 @@ class NativeLib:
         L.mww_rng_selftest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
         L.mww_prefetch_create.argtypes = [C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int, C.POINTER(C.c_void_p)]
+        L.mww_prefetch_create_weighted.argtypes = [C.POINTER(SamplerDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int,
+                                                   C.POINTER(C.c_void_p)]
         L.mww_prefetch_acquire.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 6
         L.mww_prefetch_release.argtypes = [C.c_void_p]
         L.mww_prefetch_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -230,8 +233,12 @@ class Prefetcher:
     private copies of the two MT19937 streams.  ``py_state`` / ``np_state``: uint32[625] as exported by
     ``FeatureHandler._export_global_rng``.  Host-only (usable without a GPU)."""
 
+    BROADCAST = {"per_sample": 0, "keras_last_axis": 1, "keras_first_axis": 2}
+
     def __init__(self, nl: NativeLib, desc: SamplerDesc, labels, weights, py_state, np_state, B, T, tmax, tcount, fmax, fcount,
-                 default_strategy=-1, depth=2):
+                 default_strategy=-1, depth=2, class_weights=None, broadcast="per_sample"):
+        """``weights``: per-provider sample weight (penalty x class weight), or - with ``class_weights`` (per provider) - the
+        penalty weights alone, combined per batch as ``broadcast`` says (model.combine_weights, train.py:288-293)."""
         self.nl = nl
         self.B, self.nm = int(B), int(tcount) + int(fcount)
         lab = np.ascontiguousarray(labels, np.float32)
@@ -241,9 +248,19 @@ class Prefetcher:
         if py.size != 625 or npst.size != 625 or lab.size != desc.n_providers or wts.size != desc.n_providers:
             raise ValueError("bad prefetcher arguments")
         h = C.c_void_p()
-        nl.check(nl.lib.mww_prefetch_create(C.byref(desc), lab.ctypes.data_as(C.c_void_p), wts.ctypes.data_as(C.c_void_p),
-                                            py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p), int(B), int(T), int(tmax),
-                                            int(tcount), int(fmax), int(fcount), int(default_strategy), int(depth), C.byref(h)))
+        if class_weights is None:
+            nl.check(nl.lib.mww_prefetch_create(C.byref(desc), lab.ctypes.data_as(C.c_void_p), wts.ctypes.data_as(C.c_void_p),
+                                                py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p), int(B), int(T), int(tmax),
+                                                int(tcount), int(fmax), int(fcount), int(default_strategy), int(depth), C.byref(h)))
+        else:
+            cws = np.ascontiguousarray(class_weights, np.float32)
+            if cws.size != desc.n_providers or broadcast not in self.BROADCAST:
+                raise ValueError("bad prefetcher arguments")
+            nl.check(nl.lib.mww_prefetch_create_weighted(C.byref(desc), lab.ctypes.data_as(C.c_void_p), wts.ctypes.data_as(C.c_void_p),
+                                                         cws.ctypes.data_as(C.c_void_p), self.BROADCAST[broadcast],
+                                                         py.ctypes.data_as(C.c_void_p), npst.ctypes.data_as(C.c_void_p), int(B), int(T),
+                                                         int(tmax), int(tcount), int(fmax), int(fcount), int(default_strategy), int(depth),
+                                                         C.byref(h)))
         self.h = h
 
     def acquire(self):

@@ -61,7 +61,10 @@ def shard_feature_handler(handler, rank: int, world: int, seed: Optional[int] = 
     run stays unseeded); ``epoch`` is the optimizer step the run resumes from, so a relaunch with ``--restore_checkpoint``
     continues with fresh draws instead of replaying the batches of step 1.  Idempotent: a handler already sharded for this
     (rank, world) keeps its lists (``train()`` called twice must not take a shard of a shard)."""
-    if getattr(handler, "_sharded_for", None) != (int(rank), int(world)):
+    if hasattr(handler, "shard_training_lists"):
+        # FeatureHandler: the lists AND the HBM image (only this rank's training samples stay resident: 1 / W of the stores)
+        handler.shard_training_lists(int(rank), int(world))
+    elif getattr(handler, "_sharded_for", None) != (int(rank), int(world)):
         if getattr(handler, "_sharded_for", None) is not None:
             raise ValueError("feature handler already sharded for rank/world %r" % (handler._sharded_for,))
         for p in handler.feature_providers:

@@ -5,7 +5,7 @@
     ``training_steps``                                             train.py:168-204,249-263
   * ``model.optimizer.learning_rate.assign(lr)`` every step        train.py:265
   * ``get_data("training", batch_size, spectrogram_length, "default", policy)``   train.py:276-286
-  * class weight x penalty weight                                   train.py:288-293 (per-sample form)
+  * class weight x penalty weight                                   train.py:288-293 (the reference's arithmetic: SURVEY §A.5, model.combine_weights)
   * ``train_on_batch``                                              train.py:295-299
   * every ``eval_step_interval`` steps: save last weights, ``validate_nonstreaming``, reset metrics,
     best-weights rule, checkpoint                                   train.py:315-451
@@ -148,6 +148,11 @@ def _phase_lists(config):
     return lists
 
 
+def _penalties_vary(data_processor):
+    pens = {float(getattr(p, "penalty_weight", 1.0)) for p in getattr(data_processor, "feature_providers", [])}
+    return len(pens) > 1
+
+
 def _is_better(cur_min, cur_max, best_min, best_max, target):
     return ((cur_min <= target and (cur_max > best_max or best_min > target))
             or (cur_min > target and cur_min < best_min)
@@ -259,18 +264,10 @@ def train(model, config, data_processor, verbose=True):
                   "time_mask_max_size": ph["time_mask_max_size"][i], "time_mask_count": ph["time_mask_count"][i],
                   "freq_mask_max_size": ph["freq_mask_max_size"][i], "freq_mask_count": ph["freq_mask_count"][i]}
         cw_neg, cw_pos = ph["negative_class_weight"][i], ph["positive_class_weight"][i]
-        if cw_neg != cw_pos and not warned_weights and config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST) == "per_sample":
-            warned_weights = True
-            log.warning("class weights %g / %g are not uniform.  THIS RUN optimises mean_i(penalty_i x class_weight(y_i) x bce_i) "
-                        "(sample_weight_broadcast: per_sample - every sample carries its own class weight).  The reference hands Keras a "
-                        "[B,B] matrix here (train.py:288-293), which Keras 3 reduces - by our reading of keras/src/losses/loss.py - to "
-                        "mean_j(penalty_j x bce_j) x mean_i(class_weight(y_i)): the class weights only rescale the whole batch loss.  Set "
-                        "sample_weight_broadcast: keras_last_axis in the training config to follow the reference's loss curve instead "
-                        "(INTEGRATION.md section 2).", cw_neg, cw_pos)
+        mode = config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST)
         if fast:
             data_processor.next_training_batch_on_device(local_batch, config["spectrogram_length"], "default", policy,
-                                                         class_weights=(cw_neg, cw_pos),
-                                                         weight_broadcast=config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
+                                                         class_weights=(cw_neg, cw_pos), weight_broadcast=mode)
             boundary = (step % config["eval_step_interval"]) == 0 or step == steps_max
             want = boundary or (verbose and chief and (step % progress == 0 or step == 1))
             result = model.train_on_device_batch(local_batch, want_results=want)
@@ -278,8 +275,16 @@ def train(model, config, data_processor, verbose=True):
             x, y, w = data_processor.get_data("training", batch_size=config["batch_size"],
                                               features_length=config["spectrogram_length"], truncation_strategy="default",
                                               augmentation_policy=policy)
-            combined = combine_weights(w, y, cw_neg, cw_pos, config.get("sample_weight_broadcast", DEFAULT_WEIGHT_BROADCAST))
+            combined = combine_weights(w, y, cw_neg, cw_pos, mode)
             result = model.train_on_batch(x, y.reshape(-1, 1), sample_weight=combined)
+        if cw_neg != cw_pos and not warned_weights and _penalties_vary(data_processor):
+            # the readings of train.py:288-293 only part ways when class AND penalty weights are non-uniform
+            warned_weights = True
+            log.warning("class weights %g / %g and the providers' penalty weights are both non-uniform: this run follows %s "
+                        "(sample_weight_broadcast: %s).  keras_last_axis = the reference's arithmetic as Keras 3 reduces its [B,B] weight "
+                        "matrix (train.py:288-293): mean_j(penalty_j x bce_j) x mean_i(class_weight(y_i)) - the class weights only rescale "
+                        "the batch loss; per_sample = the evident intent, mean_i(penalty_i x class_weight(y_i) x bce_i).  INTEGRATION.md "
+                        "section 2.", cw_neg, cw_pos, "the reference's arithmetic" if mode == "keras_last_axis" else "this reading", mode)
         if verbose and chief and result is not None:
             print("Validation Batch #{:d}: Accuracy = {:.3f}; Recall = {:.3f}; Precision = {:.3f}; Loss = {:.4f}; Mini-Batch #{:d}".format(
                 (step // config["eval_step_interval"] + 1), result[1], result[2], result[3], result[9],

@@ -43,11 +43,56 @@ def make_engine(lib, T, max_batch, om=None, flags=DEF):
         eng.set_option("storage_bf16", 1)
     if flags.get("bwd_wide") is not None:   # threads per workgroup of the block backward kernels (kernels_bwdw.hip.h)
         eng.set_option("bwd_wide", flags["bwd_wide"])
+    if flags.get("conv1_x6") is not None:   # conv1 weight gradient (backward kernel) as bf16 slice products (common.hip.h) or exact-fp32 MFMA
+        eng.set_option("conv1_x6", flags["conv1_x6"])
+    if flags.get("conv1_x6_fwd") is not None:   # ... the first convolution of the forward kernel (off by default: measured slower)
+        eng.set_option("conv1_x6_fwd", flags["conv1_x6_fwd"])
     if om is not None:
         p, s = lay.pack(om.get_weights())
         eng.set_params(p)
         eng.set_bn_state(s)
     return lay, eng
+
+
+def check_conv1_x6_against_the_f32_form(lib, B=6, T=194, flags=DEF, raw_u16_range=False, fwd_too=True):
+    """Options "conv1_x6" (the conv1 weight gradient; on by default) and "conv1_x6_fwd" (the first convolution; off by default,
+    ``fwd_too`` switches both): six bf16 slice products per fp32 product on v_mfma_f32_16x16x32_bf16 instead of the exact-fp32 MFMA.  Both forms on the same batch: probabilities within 2e-6 (the split
+    drops terms below 2^-24 of each product), each form's gradients against the float64 oracle with its own ReLU decisions
+    imposed (check_train_steps: L2 <= 1e-4 per tensor), and the two forms' gradients against each other: within 5e-6 of each
+    tensor unless a ReLU decision differs between them - last-bit differences of a pre-activation within rounding of zero flip
+    relu'(0+-), which moves the gradient by that ONE element's share, ~1 / sqrt(elements) = 1e-3 relative (seen at B = 48,
+    T = 194: every tensor upstream of the flipped element off by 2e-3, the dense kernel - whose gradient multiplies the
+    activation, ~0 there - by 1e-6) - then within 2e-2.  And NOT bit-identical everywhere (then the option is not wired)."""
+    rng = np.random.default_rng(11)
+    if raw_u16_range:   # every uint16 value the micro-frontend store could hold, not just 0..666
+        x = (rng.integers(0, 65536, size=(B, T, 40)).astype(np.float32) * SCALE).astype(np.float32)
+    else:
+        x = synth_x(rng, B, T)
+    y = (rng.random(B) < 0.5).astype(np.float32)
+    outs = {}
+    for form in (0, 1):
+        om = perturbed_oracle(T, flags=flags) if flags is not DEF else perturbed_oracle(T)
+        lay, eng = make_engine(lib, T, B, om, flags=dict(flags, conv1_x6=form, conv1_x6_fwd=form if fwd_too else 0))
+        eng.set_batch(x)
+        eng.set_targets(y, np.ones(B, np.float32))
+        eng.train_step(B, 1e-3)
+        outs[form] = (eng.read_outputs(B)[0].copy(), eng.get_grads().copy(), lay)
+        eng.close()
+    p0, g0, lay = outs[0]
+    p1, g1, _ = outs[1]
+    assert np.abs(p0 - p1).max() <= 2e-6, np.abs(p0 - p1).max()
+    worst, detail = 0.0, []
+    off = 0
+    floor = 2e-2 * float(np.linalg.norm(g0))   # tensors whose gradient is analytically zero (depthwise biases in front of a BN) hold the rounding noise of long cancelling sums
+    for name, n in lay.segments():
+        a, b = g0[off:off + n], g1[off:off + n]
+        off += n
+        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(a), floor))
+        worst = max(worst, e)
+        detail.append("%s %.2e" % (name, e))
+    assert worst <= 2e-2, (worst, detail)
+    assert not np.array_equal(g0, g1), "conv1_x6 0 and 1 gave bit-identical gradients: the option is not wired"
+    return worst
 
 
 def synth_x(rng, B, T):

@@ -129,6 +129,50 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x16bf16(hipemu_s16x4 a, hipemu_s16x4
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k hipemu_mfma_16x16x16bf16
+// D = A(16x32) * B(32x16) + C with bf16 operands: lane l holds A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][n=l&15], e < 8
+// (verified on the device by tools/ubench/mfma_bf16x9: the split products reproduce the float64 reference)
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x4 hipemu_mfma_16x16x32bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+  unsigned long long ua[2], ub[2];
+  std::memcpy(ua, &a, 16);
+  std::memcpy(ub, &b, 16);
+  unsigned long long A[64][2], B[64][2];
+  const unsigned long long* all = hipemu::wave_publish2(ua[0], ua[1]);
+  std::memcpy(A, all, sizeof(A));
+  all = hipemu::wave_publish2(ub[0], ub[1]);
+  std::memcpy(B, all, sizeof(B));
+  auto elem = [](const unsigned long long (*M)[2], int lane, int e) {
+    unsigned bits = (unsigned)((M[lane][e >> 2] >> (16 * (e & 3))) & 0xFFFFull) << 16;
+    float f; std::memcpy(&f, &bits, 4); return f;
+  };
+  const int l = hipemu::lane_id(), col = l & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int gg = 0; gg < 4; ++gg)
+      for (int e = 0; e < 8; ++e) acc += elem(A, gg * 16 + row, e) * elem(B, gg * 16 + col, e);
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32bf16
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read), semantics probed on the device with tools/ubench/tr16_probe: within each group
+// of 16 lanes, lane p supplies the 8-byte-aligned address of four 16-bit elements in[p][0..3]; lane i receives
+// out[j] = in[4 j + (i >> 2)][i & 3], j < 4
+typedef short hipemu_s16x4v __attribute__((ext_vector_type(4)));
+static inline hipemu_s16x4v hipemu_ds_read_tr16(const void* p) {
+  unsigned long long mine;
+  std::memcpy(&mine, p, 8);
+  if (((uintptr_t)p & 7) != 0) { std::fprintf(stderr, "hipemu: ds_read_b64_tr_b16 address not 8-byte aligned\n"); std::abort(); }
+  const unsigned long long* all = hipemu::wave_publish2(mine, 0ull);
+  const int l = hipemu::lane_id(), grp = l & ~15, i = l & 15;
+  hipemu_s16x4v out;
+  for (int j = 0; j < 4; ++j) out[j] = (short)((all[(grp + 4 * j + (i >> 2)) * 2] >> (16 * (i & 3))) & 0xFFFFull);
+  return out;
+}
+
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16((const void*)(p))
 static inline unsigned long long hipemu_memtime() { return 0ull; }
 #define __builtin_amdgcn_s_memtime hipemu_memtime
 

@@ -276,6 +276,14 @@ def test_first_block_tail_k_step_with_a_three_tap_depthwise(emu_lib, wide):
             ec.check_train_steps(emu_lib, B=3, T=T, steps=1, grid=2, flags=flags)
 
 
+def test_conv1_x6_against_the_exact_fp32_form(emu_lib):
+    """The first convolution and its weight gradient as bf16 slice products (the default for stride-1 first convolutions) against
+    the exact-fp32 MFMA form of the same kernels, incl. values over the whole uint16 range (three-slice x)."""
+    ec.check_conv1_x6_against_the_f32_form(emu_lib, B=5, T=150)
+    ec.check_conv1_x6_against_the_f32_form(emu_lib, B=3, T=111, raw_u16_range=True)
+    ec.check_conv1_x6_against_the_f32_form(emu_lib, B=3, T=150, flags=dict(ec.DEF, first_conv_kernel_size=5, pointwise_filters="32,48,64,48"))
+
+
 def test_inception_static_shapes_are_schedule_only(emu_lib):
     ec.check_inception_static_shapes_are_schedule_only(emu_lib, B=4, lengths=(100, 236), steps=2, grid=2, combos=((0, 0, 0), (1, 1, 0), (1, 1, 1)))
 

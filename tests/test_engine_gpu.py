@@ -205,6 +205,47 @@ def test_first_block_tail_k_step_with_a_three_tap_depthwise(lib, wide):
             ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
 
 
+def test_conv1_x6_against_the_exact_fp32_form(lib):
+    """Round 6: the first convolution and its weight gradient as six bf16 slice products per fp32 product (the default for
+    stride-1 first convolutions; ds_read_b64_tr_b16 operands in the backward kernel) against the exact-fp32 MFMA form of the
+    same kernels (option "conv1_x6" 0): probabilities within 2e-6, gradients within 5e-6 per tensor where no ReLU decision
+    differs (engine_checks says what a flip costs), not bit-identical (the option is wired); each form against the float64 oracle
+    with its own ReLU decisions imposed.  Values over the whole uint16 range too (three-slice x), and a 5-tap first conv."""
+    small = ec.check_conv1_x6_against_the_f32_form(lib, B=12, T=194)
+    assert small <= 5e-6, small          # (no flip in this batch on the device; the emulated kernels agree to 1.6e-6 here)
+    for form in (0, 1):
+        worst = ec.check_train_steps(lib, B=256, T=194, steps=1, grid=0, flags=dict(ec.DEF, conv1_x6=form, conv1_x6_fwd=form))
+        assert worst["l2_max"] <= 1e-4
+    ec.check_conv1_x6_against_the_f32_form(lib, B=256, T=194)
+    ec.check_conv1_x6_against_the_f32_form(lib, B=37, T=111, raw_u16_range=True)
+    ec.check_conv1_x6_against_the_f32_form(lib, B=64, T=150, flags=dict(ec.DEF, first_conv_kernel_size=5, pointwise_filters="32,48,64,48"))
+    ec.check_conv1_x6_against_the_f32_form(lib, B=64, T=150, flags=dict(ec.DEF, pointwise_filters="64,64,64,64", mixconv_kernel_sizes="[7],[9],[13],[21]"))
+
+
+def test_reference_train_loop_trace_replay(lib, tmp_path):
+    """what the reference's OWN train loop does with this package's objects.  In the build container
+    ``oracle/ref_train_shim.py`` executes /root/reference/microwakeword/train.py unmodified against ``Model`` + ``FeatureHandler`` on the
+    host-emulated library (tests/test_reference_train_loop.py) and records every call it makes on the two objects and what came
+    back (tests/golden/ref_train_trace.json: 24 steps, two schedule phases, non-uniform class and penalty weights through the
+    [B,B] matrix of train.py:288-293, three validation passes with the ambient split, weights + checkpoint writes).  Here the
+    recorded call sequence is replayed on the MI355X (tests/ref_train_replay.py; /root/reference does not exist on this box): the
+    five numbers train.py reads after every step and every ``evaluate`` result must come back as recorded, up to what float32
+    rounding differences between the emulated and the real kernels grow to over 24 optimizer steps."""
+    import ref_train_replay as rr
+    fx = rr.load_fixture()
+    worst, evals, cfg = rr.replay(fx, ec, lib, tmp_path)
+    print("reference-loop replay: worst |difference| of (accuracy, recall, precision, auc, loss) over %d steps: %s" % (len(fx["steps"]), worst))
+    assert worst[:3].max() <= 0.02 and worst[3] <= 0.01 and worst[4] <= 5e-3, worst
+    for got, want in zip(evals, fx["evals"]):
+        for k in ("accuracy", "recall", "precision", "auc"):
+            assert abs(got[k] - want[k]) <= 0.02, (k, got[k], want[k])
+        assert abs(got["loss"] - want["loss"]) <= 5e-3 * (1 + want["loss"]), (got["loss"], want["loss"])
+        for k in ("tp", "fp", "tn", "fn"):
+            assert np.abs(got[k] - np.array(want[k], np.float32)).max() <= 2, k
+    for f in ("last_weights.weights.h5.npz", "best_weights.weights.h5.npz", "restore/ckpt.weights.npz", "restore/ckpt.opt.npz"):
+        assert os.path.isfile(os.path.join(cfg["train_dir"], f)), f
+
+
 def test_training_reduces_loss(lib):
     ec.check_training_reduces_loss(lib)
 

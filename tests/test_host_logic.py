@@ -161,18 +161,25 @@ def test_train_loop_schedule_and_weights(tmp_path):
     assert m.lrs == [0.01, 0.01, 0.001, 0.001, 0.001]                       # piecewise constant by cumulative steps
     assert [p["time_mask_max_size"] for p in d.policies] == [5, 5, 0, 0, 0]
     assert [p["time_mask_count"] for p in d.policies] == [2] * 5             # padded with the last entry
-    np.testing.assert_array_equal(m.weights_seen[0], [1.0, 40.0, 3.0, 80.0])  # penalty * class weight per sample
-    np.testing.assert_array_equal(m.weights_seen[4], [2.0, 40.0, 6.0, 80.0])
+    # the default reading of train.py:288-293 is the reference's arithmetic (keras_last_axis): penalty_j * mean_i cw(y_i)
+    np.testing.assert_allclose(m.weights_seen[0], np.array([1.0, 2.0, 3.0, 4.0]) * np.mean([1.0, 20.0, 1.0, 20.0]))
+    np.testing.assert_allclose(m.weights_seen[4], np.array([1.0, 2.0, 3.0, 4.0]) * np.mean([2.0, 20.0, 2.0, 20.0]))
+    m2, d2 = _FakeModel(), _FakeData()
+    tr.train(m2, dict(config, train_dir=str(tmp_path / "run2"), summaries_dir=str(tmp_path / "run2" / "logs"), sample_weight_broadcast="per_sample"),
+             d2, verbose=False)
+    np.testing.assert_array_equal(m2.weights_seen[0], [1.0, 40.0, 3.0, 80.0])  # opt-in: penalty * class weight per sample
+    np.testing.assert_array_equal(m2.weights_seen[4], [2.0, 40.0, 6.0, 80.0])
     assert m.evals == 3 and "best_weights.weights.h5" in m.saved and m.saved.count("last_weights.weights.h5") == 4
     assert "100000000_weights_2.weights.h5" in m.saved                      # previous best (10000) embedded in the name
     assert out["best_maximization"] == 0.9
 
 
 def test_sample_weight_broadcast_modes():
-    """train.py:288-293's [B,B] weight matrix W[i,j] = penalty_j * cw(y_i): the default reduces it to its diagonal (the
-    intended per-sample weight); the two readings of Keras' reduction are its column / row means; the vector form
-    (combine_weights) agrees with the matrix form; per_sample equals keras_last_axis when the class weights are uniform
-    and keras_first_axis when the penalties are."""
+    """train.py:288-293's [B,B] weight matrix W[i,j] = penalty_j * cw(y_i): the two readings of Keras' reduction are its
+    column / row means, "per_sample" its diagonal (the intended per-sample weight); the vector form (combine_weights) agrees
+    with the matrix form; per_sample equals keras_last_axis when the class weights are uniform and keras_first_axis when the
+    penalties are.  ONE default for both entry points (round 6): the package loop's vector form and the drop-in
+    train_on_batch's matrix form reduce a non-uniform batch to the same weights - the reference's arithmetic."""
     from microwakeword_amd.model import Model, combine_weights
     rng = np.random.default_rng(0)
     B = 7
@@ -189,13 +196,16 @@ def test_sample_weight_broadcast_modes():
     np.testing.assert_allclose(combine_weights(np.ones(B), y, 0.25, 3.0, "keras_first_axis"), combine_weights(np.ones(B), y, 0.25, 3.0, "per_sample"))
     with pytest.raises(ValueError):
         combine_weights(pen, y, 1.0, 1.0, "diagonal")
-    # the two defaults: a [B,B] matrix through the drop-in train_on_batch (its caller is the reference's train.py) follows
-    # the reference's arithmetic as Keras 3 reduces it; the vector-form fast path keeps the per-sample product
+    # both entry points agree on a batch where class AND penalty weights vary: a [B,B] matrix through the drop-in
+    # train_on_batch (its caller is the reference's train.py) and the vector form of the package's own loop
     from microwakeword_amd import model as model_mod
-    assert model_mod.MATRIX_WEIGHT_BROADCAST == "keras_last_axis" and model_mod.DEFAULT_WEIGHT_BROADCAST == "per_sample"
-    m.sample_weight_broadcast = model_mod.MATRIX_WEIGHT_BROADCAST
-    np.testing.assert_allclose(m._per_sample_weights(W, B), pen * cw.mean(), rtol=1e-6)
-    np.testing.assert_allclose(m._per_sample_weights(pen * cw, B), pen * cw, rtol=1e-6)   # a plain vector is taken as it is
+    assert model_mod.MATRIX_WEIGHT_BROADCAST == model_mod.DEFAULT_WEIGHT_BROADCAST == "keras_last_axis"
+    assert model_mod.readings_differ(pen, y, 0.25, 3.0) and not model_mod.readings_differ(pen, y, 2.0, 2.0)
+    fresh = Model.__new__(Model)
+    fresh.sample_weight_broadcast = model_mod.MATRIX_WEIGHT_BROADCAST          # what Model.__init__ sets
+    np.testing.assert_allclose(fresh._per_sample_weights(W, B), combine_weights(pen, y, 0.25, 3.0), rtol=1e-6)   # default mode of the vector form
+    np.testing.assert_allclose(fresh._per_sample_weights(W, B), pen * cw.mean(), rtol=1e-6)
+    np.testing.assert_allclose(fresh._per_sample_weights(pen * cw, B), pen * cw, rtol=1e-6)   # a plain vector is taken as it is
 
 
 def test_best_model_rule():

@@ -417,9 +417,16 @@ def _train_loop_worker(rank, world, port, out_dir, emu_path, sync_bn, n=24):
     model = mixednet.model(ec.DEF, (_LOOP_T, 40), _LOOP_B // world, lib=lib, seed=7 + rank, max_batch=64)
     fh = FeatureHandler(cfg, engine=model.engine)
     n_train = [len(p.feature_sets["training"]) for p in fh.feature_providers]
+    full_bytes = fh.resident_bytes
+    train_bytes = sum(int(np.asarray(p.loaded_features[fi][sub]).nbytes) for p in fh.feature_providers for fi, sub in p.feature_sets["training"])
     out = tr.train(model, cfg, fh, verbose=False)
     shard = [sorted(p.feature_sets["training"]) for p in fh.feature_providers]
     assert all(n // world <= len(s) <= -(-n // world) for s, n in zip(shard, n_train))
+    # SURVEY 8(e) "each rank uploads its shard to its own HBM": what stays resident is this rank's training samples (1 / W of
+    # the training stores, to the raggedness of the sample lengths) plus the validation / ambient samples every rank scores
+    mine = sum(int(np.asarray(p.loaded_features[fi][sub]).nbytes) for p in fh.feature_providers for fi, sub in p.feature_sets["training"])
+    assert fh.resident_bytes == full_bytes - train_bytes + mine
+    assert abs(mine - train_bytes / world) <= 0.25 * train_bytes / world, (mine, train_bytes, world)
     nm, counts = _final_validation(tr, cfg, fh, model)
     m, v, step = model.engine.get_opt_state()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), params=model.engine.get_params(), state=model.engine.get_bn_state(), m=m, v=v,

@@ -5,6 +5,7 @@
 #include "../../microwakeword_amd/csrc/kernels_tail.hip.h"
 namespace mww {
 template __global__ void fwd_first_kernel<3, 32, 48, 5, 1, false>(FwdFirstArgs);
+template __global__ void fwd_first_kernel<3, 32, 48, 5, 1, false, false, true>(FwdFirstArgs);
 template __global__ void fwd_block_kernel<48, 48, 9, false>(FwdBlockArgs);
 template __global__ void fwd_block_kernel<48, 48, 13, false>(FwdBlockArgs);
 template __global__ void fwd_block_kernel<48, 48, 21, false>(FwdBlockArgs);
@@ -12,5 +13,6 @@ template __global__ void bwd_block_kernel<48, 48, 9, false, false>(BwdBlockArgs)
 template __global__ void bwd_block_kernel<48, 48, 13, false, false>(BwdBlockArgs);
 template __global__ void bwd_block_kernel<48, 48, 21, true, false>(BwdBlockArgs);
 template __global__ void bwd_first_kernel<3, 32, 48, 5, 1, false>(BwdFirstArgs);
+template __global__ void bwd_first_kernel<3, 32, 48, 5, 1, false, false, true>(BwdFirstArgs);
 template __global__ void head_kernel<48, 8>(HeadArgs);
 }

@@ -1,0 +1,7 @@
+// ISA inspection unit: the wide (512-thread) block backward kernels of the default topology (tools/isa/dump.sh wide).
+#include "../../microwakeword_amd/csrc/kernels_bwdw.hip.h"
+namespace mww {
+template __global__ void bwd_blockw_kernel<48, 48, 9, false, 512>(BwdBlockArgs);
+template __global__ void bwd_blockw_kernel<48, 48, 13, false, 512>(BwdBlockArgs);
+template __global__ void bwd_blockw_kernel<48, 48, 21, true, 512>(BwdBlockArgs);
+}
