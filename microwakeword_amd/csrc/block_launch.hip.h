@@ -46,6 +46,6 @@ bool k_launch_bwd_first(hipStream_t st, int mode, int k1, int c1, int cout, int 
 bool k_launch_bwd_block(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
 // wide-workgroup form of the block backward (kernels_bwdw.hip.h: 512 threads per workgroup; every mode)
 bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, bool last, const BwdBlockArgs& a, int grid);
-bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid);
+bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid, bool wide_x6);
 
 }  // namespace mww

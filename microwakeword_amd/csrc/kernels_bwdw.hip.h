@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
 //   * dW1 phase: m-tile mi * 8 + w of W1 (both 16-column halves of C1) per wave, mi < ceil(MT1 / 8), rows met in the
 //     order s = kk + 16 g: the x rows of a k-step are 16 S rows apart (16 S * 41 = 16 mod 32 for S = 1, 3: conflict-free
 //     with the odd x pitch) and the g0 tile has an odd pitch of its own for the same reason.
-template <int K1, int C1, int COUT, int K, int S, int NTH>
+template <int K1, int C1, int COUT, int K, int S, int NTH, bool X6 = false>
 struct BwdFirstWideLds {
   static constexpr int PI = C1 + 4;                        // a0 / du ring / u: row-pattern MFMA reads 4 rows apart (4 * 36 = 16 mod 32)
   static constexpr int PO = COUT + 4;                      // dp: the same rows (4 * 52 = 4 * 68 = 16 mod 32), float4 column reads
@@ -611,18 +611,22 @@ struct BwdFirstWideLds {
   static constexpr int XR = (TT + TAILK - 1) * S + K1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
   static constexpr int OFF_A = 0, OFF_DP = OFF_A + up4(RAP * PI), OFF_U = OFF_DP + TT * PO, OFF_DU = OFF_U + up4(TTP * PI);
-  static constexpr int OFF_G0 = OFF_DU + up4(RAP * PI), OFF_END = OFF_G0 + up4((TTP + TAILK) * PG);
-  static constexpr int BYTES = (OFF_END + up4(XR * PX) + 7 * COUT + COUT * PW) * 4 + (int)sizeof(XShared);
+  // X6 (common.hip.h; bwd_first_body.inc): x as three bf16 slice planes of 96-byte rows, g0 as three planes of 64-byte rows in the
+  // dp (+ u) tile's space - no g0 tile of its own
+  static constexpr int PB = 96, PLB = XR * PB, GPB = 2 * C1, GPL = TT * GPB;
+  static constexpr int XFLOATS = X6 ? 3 * PLB / 4 : up4(XR * PX);
+  static constexpr int OFF_G0 = OFF_DU + up4(RAP * PI), OFF_END = X6 ? OFF_G0 : OFF_G0 + up4((TTP + TAILK) * PG);
+  static constexpr int BYTES = (OFF_END + XFLOATS + 7 * COUT + COUT * PW) * 4 + (int)sizeof(XShared);
 };
 
-template <int K1, int C1, int COUT, int K, int S, int NTH>
+template <int K1, int C1, int COUT, int K, int S, int NTH, bool X6 = false>
 constexpr int wide_first_waves_per_simd() {
-  return (BwdFirstWideLds<K1, C1, COUT, K, S, NTH>::BYTES <= 80 * 1024 ? 2 : 1) * (NTH / 64) / 4;
+  return (BwdFirstWideLds<K1, C1, COUT, K, S, NTH, X6>::BYTES <= 80 * 1024 ? 2 : 1) * (NTH / 64) / 4;
 }
 
-template <int K1, int C1, int COUT, int K, int S, int NTH>
-__global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S, NTH>())) void bwd_firstw_kernel(BwdFirstArgs a) {
-  typedef BwdFirstWideLds<K1, C1, COUT, K, S, NTH> Lds;
+template <int K1, int C1, int COUT, int K, int S, int NTH, bool X6 = false>
+__global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S, NTH, X6>())) void bwd_firstw_kernel(BwdFirstArgs a) {
+  typedef BwdFirstWideLds<K1, C1, COUT, K, S, NTH, X6> Lds;
   constexpr bool SB = false;
   constexpr int CIN = C1;
   constexpr int PI = Lds::PI, PO = Lds::PO, PG = Lds::PG, PW = Lds::PW, PX = Lds::PX;
@@ -633,8 +637,10 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
   static_assert(NW == 8 && MT == 2 && NCH * L == TT && TT >= K - 1, "geometry of the wide first-block kernel");
   static_assert(TAIL <= NCH && TTP + TAIL <= RAP, "tail rows");
   static_assert(Lds::OFF_END >= 2 * CIN * COUT && Lds::OFF_END >= NCH * (K + 1) * CIN, "scratch aliasing");
+  constexpr int PB = Lds::PB, PLB = Lds::PLB, GPB = Lds::GPB, GPL = Lds::GPL;
+  static_assert(!X6 || (S == 1 && CIN == 32 && (K1 * FBINS) % 8 == 0 && 3 * GPL <= (TT * PO + TTP * PI) * 4 && TTP == TT), "the x6 form serves the stride-1 first convolutions");
 
-  __shared__ __attribute__((aligned(16))) float sX[Lds::up4(XR * PX)];
+  __shared__ __attribute__((aligned(16))) float sX[Lds::XFLOATS];
   __shared__ XShared sXg;
   __shared__ __attribute__((aligned(16))) float smem[Lds::OFF_END];
   __shared__ __attribute__((aligned(16))) float sKp[7 * COUT];
@@ -671,11 +677,23 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
   // per-lane offsets of the dW1 rows this wave owns: row m = j*40+f of W1 reads x[s*S+j][f]
   int offm[MPW];
   bool okm[MPW];
+  int xoff[MPW], goff[NT1];   // X6: this lane's share of the transpose reads (bwd_first_body.inc)
+  if constexpr (X6) {
+    const int rowl = 4 * g + (r16 >> 2), cg = 4 * (r16 & 3);
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+      const int m = min((mi * NW + wave) * 16 + cg, M1 - 4);
+      xoff[mi] = (rowl + m / FBINS) * PB + (m % FBINS) * 2;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) goff[nt] = rowl * GPB + ((nt * 16 + cg) ^ ((rowl & 4) ? 16 : 0)) * 2;
+  } else {
 #pragma unroll
   for (int mi = 0; mi < MPW; ++mi) {
     const int m = (mi * NW + wave) * 16 + r16;
     okm[mi] = m < M1;
     offm[mi] = okm[mi] ? (m / FBINS) * PX + (m % FBINS) : 0;
+  }
   }
   if (a.xg.win) xgather_setup(a.xg, sXg, nsamp, tid);
   stagger_start<MWW_STAGGER_BWD>();
@@ -724,7 +742,8 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
     sA[i] = 0.f;
     sDU[i] = 0.f;
   }
-  for (int i = TT * PG + tid; i < (TTP + Lds::TAILK) * PG; i += NTH) sG0[i] = 0.f;   // rows the tail k-step may read
+  if constexpr (!X6)
+    for (int i = TT * PG + tid; i < (TTP + Lds::TAILK) * PG; i += NTH) sG0[i] = 0.f;   // rows the tail k-step may read
 #pragma unroll
   for (int i = 0; i < K; ++i) pin(dww[i]);
   pin(dwb);
@@ -746,7 +765,8 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
     const int nrows_new = max(0, min(TT, a.Tout - t0));
     const int rows_da = min(TT, Ta - t0);
     // ---- P0: commit x (odd pitch), a0 rows [t0, t0+RA) (zero past the sample), dp; roll the du ring
-    xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
+    if constexpr (X6) xs.template commit_planes<PB, PLB>(reinterpret_cast<unsigned*>(sX), a.xg, sXg, it / ntiles, t0 * S, tid);
+    else xs.commit(sX, a.xg, sXg, it / ntiles, t0 * S, tid);
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int i = tid + j * NTH;
@@ -795,7 +815,17 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < K; ++i) acc = fmaf(dww[K - 1 - i], wdu[t + i], acc);
-        sG0[sl * PG + c] = (sl < rows_da && wa[t] > 0.f) ? acc : 0.f;
+        const float gv = (sl < rows_da && wa[t] > 0.f) ? acc : 0.f;
+        if constexpr (X6) {
+          unsigned h0, h1, h2;
+          split3(gv, h0, h1, h2);
+          unsigned short* gp = reinterpret_cast<unsigned short*>(sDP) + sl * CIN + (c ^ ((sl & 4) ? 16 : 0));
+          gp[0] = (unsigned short)(h0 >> 16);
+          gp[GPL / 2] = (unsigned short)(h1 >> 16);
+          gp[GPL] = (unsigned short)(h2 >> 16);
+        } else {
+          sG0[sl * PG + c] = gv;
+        }
       }
       if (chunk * L < nrows_new) {
 #pragma unroll
@@ -819,7 +849,33 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
     }
     __syncthreads();
     // ---- dW1 += im2col(x)^T g0 : A[m][k=s] = x[s*S + m/40][m%40], B[k=s][n] = g0[s][n]; k-step kk holds rows kk + 16 g
-    {
+    if constexpr (X6) {
+      // six bf16 slice products per fp32 product, operands through ds_read_b64_tr_b16 (bwd_first_body.inc)
+      const char* xb = reinterpret_cast<const char*>(sX);
+      const char* gb = reinterpret_cast<const char*>(sDP);
+#pragma unroll
+      for (int kb = 0; kb < TT / 32; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          u32x4v gq[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u32x2v lo = lds_read_tr16(gb + goff[nt] + p * GPL + (32 * kb) * GPB), hi = lds_read_tr16(gb + goff[nt] + p * GPL + (32 * kb + 16) * GPB);
+            gq[p] = u32x4v{lo.x, lo.y, hi.x, hi.y};
+          }
+#pragma unroll
+          for (int mi = 0; mi < MPW; ++mi)
+            if (mi * NW + wave < MT1) {   // wave-uniform
+              u32x4v xq[3];
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                const u32x2v lo = lds_read_tr16(xb + xoff[mi] + p * PLB + (32 * kb) * S * PB), hi = lds_read_tr16(xb + xoff[mi] + p * PLB + (32 * kb + 16) * S * PB);
+                xq[p] = u32x4v{lo.x, lo.y, hi.x, hi.y};
+              }
+              w1acc[mi][nt] = mfma_x6(xq, gq, w1acc[mi][nt]);
+            }
+        }
+    } else {
       float av[2][MPW], bv[2][NT1];
       auto load_w1 = [&](int srow, int sl) {   // srow = this lane's row of the k-step
 #pragma unroll

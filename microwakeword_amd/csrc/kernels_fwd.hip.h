@@ -228,6 +228,20 @@ struct XStage {
   }
 };
 
+// k-step map of the first convolution's im2col GEMM in the exact-fp32 form (fwd_first_body.inc): which (x row, first bin) k-step
+// kk meets, and whether it is a "wide" one (lane group g then adds (g >> 1) + 16 (g & 1) instead of g)
+#ifndef MWW_CONV1_KMAP   // tuning builds: 0 = the plain order k = 4 kk + g at every stride
+#define MWW_CONV1_KMAP 1
+#endif
+template <int S>
+struct Conv1KMap {
+  static constexpr bool permuted = MWW_CONV1_KMAP && (S % 2) == 1;
+  static constexpr int row(int kk) { return kk / (FBINS / 4); }
+  static constexpr int sub(int kk) { return kk % (FBINS / 4); }
+  static constexpr bool wide(int kk) { return permuted && sub(kk) < 8; }
+  static constexpr int col(int kk) { return !permuted ? sub(kk) * 4 : (sub(kk) < 8 ? 2 * sub(kk) : 32 + 4 * (sub(kk) - 8)); }
+};
+
 struct FwdFirstArgs {
   const float* x;        // [B][T][40]
   const float* w1;       // [K1*40][C1]   (Keras [K1,1,40,C1] flattened)

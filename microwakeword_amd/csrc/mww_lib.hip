@@ -30,6 +30,9 @@
 #ifndef MWW_CONV1_X6_FWD_DEFAULT
 #define MWW_CONV1_X6_FWD_DEFAULT 0
 #endif
+#ifndef MWW_BWD_FIRST_WIDE_DEFAULT   // option "bwd_first_wide"
+#define MWW_BWD_FIRST_WIDE_DEFAULT 0
+#endif
 #ifndef MWW_BWD_WIDE_DEFAULT
 #define MWW_BWD_WIDE_DEFAULT 1
 #endif
@@ -128,7 +131,8 @@ struct mww_ctx {
   int n_cu = 256;
   int grid_fwd = 0, grid_bwd = 0, grid_head = 0;
   bool conv1_x6 = MWW_CONV1_X6_DEFAULT != 0;   // conv1 weight gradient as six bf16 slice products per fp32 product (stride-1 shapes, fp32 mode)
-  bool conv1_x6_fwd = MWW_CONV1_X6_FWD_DEFAULT != 0;   // ... and the first convolution of the forward kernel
+  bool conv1_x6_fwd = MWW_CONV1_X6_FWD_DEFAULT != 0;
+  bool bwd_first_wide = MWW_BWD_FIRST_WIDE_DEFAULT != 0;   // stride-1 first block (3-tap conv1) with conv1_x6: the 512-thread form of its backward kernel   // ... and the first convolution of the forward kernel
   bool bwd_wide = MWW_BWD_WIDE_DEFAULT != 0;   // fp32 block backward kernels: 512 threads per workgroup (bwd_blockw_kernel) or 256 (bwd_block_kernel)
   int64_t P = 0, S = 0;
   int64_t o_conv1 = 0, o_dense_w = 0, o_dense_b = 0;
@@ -274,7 +278,7 @@ int launch_fwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const 
 }
 
 int launch_bwd_first(mww_ctx* c, int k1, int c1, int cout, int k, int st, const BwdFirstArgs& a, int grid) {
-  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_firstw(c->stream, k1, c1, cout, k, st, a, grid)) return MWW_OK;
+  if (c->bwd_wide && !c->pw_bf16 && !c->st_bf16 && k_launch_bwd_firstw(c->stream, k1, c1, cout, k, st, a, grid, c->conv1_x6 && c->bwd_first_wide)) return MWW_OK;
   if (k_launch_bwd_first(c->stream, c->st_bf16 ? 2 : (c->pw_bf16 ? 1 : 0), k1, c1, cout, k, st, a, grid, c->conv1_x6)) return MWW_OK;
   return fail(MWW_ERR_UNSUPPORTED, "no first-block backward kernel for this shape");
 }
@@ -3101,6 +3105,7 @@ int mww_set_option(mww_ctx* c, const char* name, int64_t v) {
   else if (!strcmp(name, "bwd_wide")) c->bwd_wide = v != 0;
   else if (!strcmp(name, "conv1_x6")) c->conv1_x6 = v != 0;
   else if (!strcmp(name, "conv1_x6_fwd")) c->conv1_x6_fwd = v != 0;
+  else if (!strcmp(name, "bwd_first_wide")) c->bwd_first_wide = v != 0;
   else if (!strcmp(name, "grid_fwd")) { if (v < 1 || v > c->n_cu * 4) return fail(MWW_ERR_INVALID, "grid_fwd out of range"); c->grid_fwd = (int)v; }
   else if (!strcmp(name, "grid_bwd")) { if (v < 1 || v > c->n_cu * 2) return fail(MWW_ERR_INVALID, "grid_bwd out of range"); c->grid_bwd = (int)v; }
   else if (!strcmp(name, "grid_graph")) {   // 0: per-launch grids by occupancy (default); > 0: this many workgroups per launch

@@ -53,9 +53,22 @@ bool k_launch_bwd_blockw(hipStream_t st, int mode, int cin, int cout, int k, boo
 // (two 512-thread workgroups per CU at 128 registers): 53.0-53.3 us against 51.2-51.8 for bwd_first_kernel in the same session
 // (profiles/round5_bwd_first_forms_ab.txt) - its launch is bound by the exact-fp32 MFMAs of the conv1 weight gradient, which
 // more waves do not make cheaper - and the stride-1 crosses would trade two 256-thread workgroups for one of 512.
-bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid) {
+// (round 6: with the conv1 weight gradient as bf16 slice products - x6 - the default first block is no longer bound by the
+// matrix pipe, and the wide form was measured again for stride 1: option "bwd_first_wide", profiles/round6_first_wide_and_kmap_ab.txt)
+template <int K1, int C1, int CO, int K, int S>
+static bool launch_bwd_firstw_x6(hipStream_t st, const BwdFirstArgs& a, int grid) {
+  if constexpr (S == 1 && K1 == 3 && CO <= 64) {
+    hipLaunchKernelGGL((bwd_firstw_kernel<K1, C1, CO, K, S, 512, true>), dim3(grid), dim3(512), 0, st, a);
+    return true;
+  } else {
+    return false;
+  }
+}
+
+bool k_launch_bwd_firstw(hipStream_t st, int k1, int c1, int cout, int k, int stride, const BwdFirstArgs& a, int grid, bool wide_x6) {
 #define X(K1, C1, CO, K, S)                                                                                    \
   if (k1 == K1 && c1 == C1 && cout == CO && k == K && stride == S) {                                           \
+    if (wide_x6 && launch_bwd_firstw_x6<K1, C1, CO, K, S>(st, a, grid)) return true;                           \
     if constexpr (S > 1) {                                                                                     \
       hipLaunchKernelGGL((bwd_firstw_kernel<K1, C1, CO, K, S, 512>), dim3(grid), dim3(512), 0, st, a);         \
       return true;                                                                                             \

@@ -42,9 +42,15 @@ def _run_reference_loop(emu_lib, tmp_path, steps=24):
     return ref, shim, cfg, model, data, trace
 
 
+@pytest.fixture(scope="module")
+def reference_run(emu_lib, tmp_path_factory):
+    """ONE 24-step run of the reference's loop for the tests below (it takes a minute on the emulated kernels)."""
+    return _run_reference_loop(emu_lib, tmp_path_factory.mktemp("refrun"))
+
+
 @pytest.mark.reference
-def test_reference_train_loop_drives_model_and_feature_handler(emu_lib, tmp_path):
-    ref, shim, cfg, model, data, trace = _run_reference_loop(emu_lib, tmp_path)
+def test_reference_train_loop_drives_model_and_feature_handler(emu_lib, tmp_path, reference_run):
+    ref, shim, cfg, model, data, trace = reference_run
     steps = int(np.sum(cfg["training_steps"]))
     run = cfg["train_dir"]
     # what train.py writes (the .weights.h5 names carry the documented .npz twin): last / best weights, the per-evaluation
@@ -86,7 +92,6 @@ def test_reference_train_loop_drives_model_and_feature_handler(emu_lib, tmp_path
     cfg2 = dict(cfg, training_steps=[2], learning_rates=[0.001], eval_step_interval=2)
     ref.train(tr2.model, cfg2, tr2.data)
     assert model2.engine.get_opt_state()[2] == steps + 2
-    model.engine.close()
     model2.engine.close()
 
 
@@ -101,12 +106,11 @@ def test_reference_loop_learns_the_task(emu_lib, tmp_path):
 
 
 @pytest.mark.reference
-def test_reference_trace_fixture_is_current(emu_lib, tmp_path):
+def test_reference_trace_fixture_is_current(reference_run):
     """The committed fixture is what the reference's loop does today on the emulated library (regenerate with
     ``MWW_WRITE_TRACE=1 python -m pytest tests/test_reference_train_loop.py -k fixture``)."""
-    ref, shim, cfg, model, data, trace = _run_reference_loop(emu_lib, tmp_path)
+    ref, shim, cfg, model, data, trace = reference_run
     fx = rr.trace_to_fixture(trace, dict(trace.config_before, train_dir=cfg["train_dir"]), _class_weights_per_step(cfg), None)
-    model.engine.close()
     if os.environ.get("MWW_WRITE_TRACE") == "1":
         with open(rr.FIXTURE, "w") as fh:
             json.dump(fx, fh, indent=0, separators=(",", ":"))

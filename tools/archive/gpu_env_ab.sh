@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-session A/B of runtime environment settings on the default bench line: bash tools/gpu_env_ab.sh tag "VAR=a" "VAR=b" ...  ("-" = unchanged environment)
+# same-session A/B of runtime environment settings on the default bench line: bash tools/archive/gpu_env_ab.sh tag "VAR=a" "VAR=b" ...  ("-" = unchanged environment)
 TAG=${1:-env}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

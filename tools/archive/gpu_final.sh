@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round GPU session: full GPU suite, smoke, the bench configurations, kernel trace and PMC passes.
-# usage (repo root): bash tools/gpu_final.sh <tag>   -> gpurun_out/<tag>/ ; copy what is to be judged into profiles/round<N>_*
+# usage (repo root): bash tools/archive/gpu_final.sh <tag>   -> gpurun_out/<tag>/ ; copy what is to be judged into profiles/round<N>_*
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The kernel trace + the four PMC passes of the headline configuration on the library that travelled with the tree (no rebuild):
-# usage (repo root): bash tools/gpu_pmc_only.sh <tag>  -> gpurun_out/<tag>/kernel_stats_and_pmc.txt (first line = the library's sha256)
+# usage (repo root): bash tools/archive/gpu_pmc_only.sh <tag>  -> gpurun_out/<tag>/kernel_stats_and_pmc.txt (first line = the library's sha256)
 TAG=${1:-pmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, session A: the block backward kernel forms (256 / 384 / 512 threads per 64-row tile, option "bwd_wide") on one box:
 # parity tests of all forms, alternating bench lines with per-kernel HIP-event times, kernel trace + the two SQ counter
-# passes per form.  usage (repo root): bash tools/gpu_r5a.sh <tag>
+# passes per form.  usage (repo root): bash tools/archive/gpu_r5a.sh <tag>
 TAG=${1:-r5a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

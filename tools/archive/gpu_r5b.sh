@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, session B: the wide first-block backward kernel (bwd_firstw_kernel) next to the 256-thread one, same box, same session:
 # parity tests, alternating bench lines ("bwd_wide" 0 / 1), kernel trace + SQ counter passes of the default form.
-# usage (repo root): bash tools/gpu_r5b.sh <tag>
+# usage (repo root): bash tools/archive/gpu_r5b.sh <tag>
 TAG=${1:-r5b}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

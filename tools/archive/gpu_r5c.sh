@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, session C: the bf16 modes (BASELINE configs[4]) on the wide block backward kernels next to the 256-thread ones
 # ("bwd_wide" 1 / 0), and kernel-tuning variants of the library given as extra arguments (libmww_<name>.so, slim builds).
-# usage (repo root): bash tools/gpu_r5c.sh <tag> [variant ...]
+# usage (repo root): bash tools/archive/gpu_r5c.sh <tag> [variant ...]
 TAG=${1:-r5c}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, session D: grad_final with one batch of partial-row loads per slice (shipped) vs four batches of 16 (variant final16),
-# and grid sweeps of the head / forward kernels.  usage (repo root): bash tools/gpu_r5d.sh <tag>
+# and grid sweeps of the head / forward kernels.  usage (repo root): bash tools/archive/gpu_r5d.sh <tag>
 TAG=${1:-r5d}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, session E: staggered start of the workgroups that share a CU (MWW_STAGGER_*: slim variant builds) against the
-# shipped library, and the driver's exact command three times.  usage (repo root): bash tools/gpu_r5e.sh <tag> [variant ...]
+# shipped library, and the driver's exact command three times.  usage (repo root): bash tools/archive/gpu_r5e.sh <tag> [variant ...]
 TAG=${1:-r5e}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

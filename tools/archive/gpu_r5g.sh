@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, session G: staggered start in the conv/BN graph kernels (Inception): variants libmww_<name>.so vs the shipped library.
-# usage (repo root): bash tools/gpu_r5g.sh <tag> [variant ...]
+# usage (repo root): bash tools/archive/gpu_r5g.sh <tag> [variant ...]
 TAG=${1:-r5g}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, session H: which LDS array of the forward block kernels carries the remaining bank conflicts - the SQ LDS counters of
 # variant builds with the old pitch (c + 4) on the input tile (fpa0), on the u tile (fpu0), on both (fp00) and the shipped pitches.
-# usage (repo root): bash tools/gpu_r5h.sh <tag> [variant ...]
+# usage (repo root): bash tools/archive/gpu_r5h.sh <tag> [variant ...]
 TAG=${1:-r5h}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

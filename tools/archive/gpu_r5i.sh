@@ -10,7 +10,7 @@
 #   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_d2.so -- -DMWW_G_FWD_DIRECT=2
 #   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_narrow.so -- -DMWW_G_WGRAD_XG_NARROW=1
 #   python -m microwakeword_amd.build_native --out microwakeword_amd/libmww_breg.so -- -DMWW_G_STEM_BREG=1
-# usage (repo root): [LIBS="a b" VARIANTS="b" PMCLIBS="a" ALLK=1] bash tools/gpu_r5i.sh <tag>   (second sitting: LIBS="even hip breg", every gconv kernel listed)
+# usage (repo root): [LIBS="a b" VARIANTS="b" PMCLIBS="a" ALLK=1] bash tools/archive/gpu_r5i.sh <tag>   (second sitting: LIBS="even hip breg", every gconv kernel listed)
 TAG=${1:-r5i}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -8,6 +8,8 @@
 #                              container first: tools/build_variant.sh <name> -DFLAG..., FULL=1 for every shape)
 #     tests[:<lib>[:<k-expr>]] pytest -m gpu on tests/test_engine_gpu.py with MWW_HIP_LIB=<lib> (default hip), optional -k (write '%' for a space)
 #     ab:<a>+<b>[+..][:<reps>[:<bench args, '%' for a space>]]   alternating bench.py runs (200 steps), per-kernel event times
+#     abopt:<lib>:<optsA>+<optsB>[+..][:<reps>[:<bench args>]]   the same with ONE library and engine options varied (MWW_BENCH_OPTIONS, e.g.
+#                              abopt:hip:bwd_first_wide=0+bwd_first_wide=1:3); several options of one arm are joined by ','
 #     driver[:<lib>[:<n>]]     the driver's command (python bench.py --steps 20 --warmup 5) n times (default 3)
 #     trace[:<lib>[:<bench args>]]   rocprofv3 --kernel-trace --stats, 60 steps: per-kernel averages -> trace_<lib>_kernel_stats.csv
 #     pmc[:<lib>[:<bench args>]]     trace + the four PMC passes (SQ x2, FETCH_SIZE, WRITE_SIZE) -> kernel_stats_and_pmc_<lib>.txt
@@ -44,6 +46,17 @@ p='$(lib $v)'; print('$v', 'sha256_16', b.library_sha16(p), 'source', b.library_
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline'].get('kernel_ms',{})
 print('$v', d['ms_per_step'], 'host', d.get('host_enqueue_ms_per_step'), {n:round(v*1e3,1) for n,v in k.items()})" >> $S
+        done
+      done ;;
+    abopt)
+      IFS=':' read -r what a1 a2 a3 a4 <<< "$step"
+      ARGS=$(sp "$a4")
+      for rep in $(seq 1 ${a3:-3}); do
+        for o in ${a2//+/ }; do
+          MWW_BENCH_OPTIONS="$o" MWW_HIP_LIB=$(lib $a1) timeout 300 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-validation --no-batch-sweep --range-repeats 0 $ARGS 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline'].get('kernel_ms',{})
+print('$a1 [$o]', d['ms_per_step'], 'host', d.get('host_enqueue_ms_per_step'), {n:round(v*1e3,1) for n,v in k.items()})" >> $S
         done
       done ;;
     driver)
