@@ -131,7 +131,7 @@ def inception_kernel_elems(layout):
     return elems
 
 
-PMC_FILE = "round5_kernel_stats_and_pmc.txt"   # written by tools/gpu_restamp.sh for the kernel binary of this round
+PMC_FILE = "round6_kernel_stats_and_pmc.txt"   # tools/gpu_session.sh pmc step (trace + four PMC passes) on the kernel binary of this round
 LIBRARY = os.environ.get("MWW_HIP_LIB") or os.path.join(ROOT, "microwakeword_amd", "libmww_hip.so")   # the file native.NativeLib.get() loads
 
 

@@ -181,6 +181,12 @@ class FeatureHandler:
             return
         if getattr(self, "_sharded_for", None) is not None:
             raise ValueError("feature handler already sharded for rank/world %r" % (self._sharded_for,))
+        if int(world) == 1:   # a world of one keeps everything (and the image it has): only the canonical order of the lists
+            for p in self.feature_providers:
+                p.feature_sets["training"] = sorted(p.feature_sets["training"])
+            self._sharded_for = (int(rank), 1)
+            self._sampler = None
+            return
         for p in self.feature_providers:
             p.feature_sets["training"] = sorted(p.feature_sets["training"])[rank::world]
             if p.stats["training"]["spectrogram_count"] and not p.feature_sets["training"]:

@@ -28,13 +28,13 @@ def _class_weights_per_step(cfg):
     return out
 
 
-def _run_reference_loop(emu_lib, tmp_path, steps=24):
+def _run_reference_loop(emu_lib, tmp_path, steps=24, B=16):
     import ref_train_shim as shim
     if not shim.available():
         pytest.skip("reference tree not present")
     ref = shim.load_reference_train_module()
     assert "tensorflow" not in sys.modules            # the stand-ins do not outlive the import
-    cfg = rr.run_config(ec, tmp_path, steps=steps)
+    cfg = rr.run_config(ec, tmp_path, steps=steps, B=B)
     model, data = rr.make_objects(ec, emu_lib, cfg)
     trace = shim.Trace(model, data)
     trace.config_before = {k: copy.deepcopy(v) for k, v in cfg.items() if k != "features"}   # train.py:191-204 pads the lists in place
@@ -99,7 +99,7 @@ def test_reference_train_loop_drives_model_and_feature_handler(emu_lib, tmp_path
 def test_reference_loop_learns_the_task(emu_lib, tmp_path):
     """Long enough for the BN moving averages (validation runs in inference mode): the reference's loop reaches >= 95 % validation
     accuracy on the separable task with this package's objects."""
-    ref, shim, cfg, model, data, trace = _run_reference_loop(emu_lib, tmp_path, steps=96)
+    ref, shim, cfg, model, data, trace = _run_reference_loop(emu_lib, tmp_path, steps=72, B=8)
     val = trace.evals[-2]          # the last pass over the validation set (the ambient pass accumulates behind it)
     assert val["accuracy"] >= 0.95, val["accuracy"]
     model.engine.close()
