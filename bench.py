@@ -270,6 +270,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def per_gpu_batch(batch, global_batch, world):
+    """Windows per GPU and step: --batch (weak scaling), or --global-batch / N (strong scaling: BASELINE configs[4]'s sweep keeps 4096
+    windows per step whatever N) - refused when N does not divide it."""
+    if global_batch:
+        if global_batch % world:
+            raise SystemExit("--global-batch %d is not divisible by the %d GPUs of the job" % (global_batch, world))
+        return global_batch // world
+    return batch
+
+
 def _reference_loader(batch, n_samples, policy):
     """the reference's UNMODIFIED FeatureHandler.get_data (microwakeword/data.py:497-597), imported
     through oracle/ref_data_shim over the same synthetic stores - only where /root/reference exists (the build
@@ -424,11 +434,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     stream = torch.cuda.Stream(device=device)
-    if args.global_batch:
-        if args.global_batch % world:
-            raise SystemExit("--global-batch %d is not divisible by the %d GPUs of the job" % (args.global_batch, world))
-        args.batch = args.global_batch // world
-    B = args.batch
+    B = args.batch = per_gpu_batch(args.batch, args.global_batch, world)
 
     with torch.cuda.stream(stream):
         if args.model == "inception":
@@ -622,6 +628,20 @@ def main():
             elapsed = float(tt.item())
         _, _, last_loss = eng.read_outputs(B)
 
+        # ---- the launching thread's own cost per step, free of back-pressure: the mailbox ring holds eight steps, so in any run
+        # longer than that the enqueue loop above is throttled to the GPU's pace (mail_begin waits for the slot's previous step)
+        # and host_enqueue_ms_per_step tends to ms_per_step.  Six steps from an idle device and an empty ring measure the host alone.
+        host_unblocked = None
+        if world == 1 and dp is None:
+            fence()
+            host_parts[0] = host_parts[1] = 0.0
+            tu0 = time.perf_counter()
+            for _ in range(6):
+                one_step()
+            host_unblocked = {"ms_per_step": round(1e3 * (time.perf_counter() - tu0) / 6, 4), "steps": 6,
+                              "assemble_prefetched_ms": round(1e3 * host_parts[0] / 6, 4), "train_step_ms": round(1e3 * host_parts[1] / 6, 4)}
+            fence()
+
         # ---- the spread of the figure: further K-step regions of the same loop, timed the same way AFTER the region `value` comes
         # from (a 5 + 20-step run times 6 ms; fifteen of them on five boxes spanned 0.298-0.306 ms in round 5).  Not part of `value`.
         value_range = None
@@ -762,7 +782,9 @@ def main():
         "gpu_stream_ms_per_step": round(gpu_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 4),
         # the launching thread's two native calls per step: mww_assemble_prefetched (wait for the worker's batch + descriptor / target
         # upload) and mww_train_step (ten launches); in runs much longer than the mailbox ring both include back-pressure from the GPU
-        "host_enqueue_split": host_split, "final_loss": round(float(last_loss), 5),
+        "host_enqueue_split": host_split,
+        # ... and without it: six steps enqueued from an idle device with an empty ring, after the timed region (not part of `value`)
+        "host_enqueue_unblocked": host_unblocked, "final_loss": round(float(last_loss), 5),
         "pre_roll_s": round(pre_roll_s, 3),
         # which binary was timed, and which source set it was built from (mww_version() carries the sha256 of csrc/* +
         # include/mww.h; __graft_entry__.build() rebuilds when it differs from the tree's): library_sha16 ties the line to a

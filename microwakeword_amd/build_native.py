@@ -27,7 +27,7 @@ UNITS = ("version.cpp", "mww_lib.hip", "tu_bwd_first.hip", "tu_bwd64.hip", "tu_b
 HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-pthread")
 EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 EMU_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-EMU_FLAGS = ("-x", "c++", "-std=c++17", "-O1", "-fPIC", "-Wno-unused-value", "-pthread")
+EMU_FLAGS = ("-x", "c++", "-std=c++17", "-O2", "-fPIC", "-Wno-unused-value", "-pthread")
 
 
 def source_files():

@@ -208,6 +208,15 @@ def test_sample_weight_broadcast_modes():
     np.testing.assert_allclose(fresh._per_sample_weights(pen * cw, B), pen * cw, rtol=1e-6)   # a plain vector is taken as it is
 
 
+def test_bench_global_batch_is_split_or_refused():
+    """bench.py --global-batch (strong scaling, BASELINE configs[4]): 4096 / N windows per GPU, refused when N does not divide it."""
+    import bench
+    assert bench.per_gpu_batch(1024, 0, 8) == 1024
+    assert [bench.per_gpu_batch(1024, 4096, n) for n in (1, 2, 4, 8)] == [4096, 2048, 1024, 512]
+    with pytest.raises(SystemExit, match="not divisible"):
+        bench.per_gpu_batch(1024, 4096, 3)
+
+
 def test_best_model_rule():
     f = tr._is_better
     assert f(0.5, 0.1, 10000, 0.0, 0.9)        # first time under target
