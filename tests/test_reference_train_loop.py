@@ -123,6 +123,10 @@ def test_reference_trace_fixture_is_current(reference_run):
 def test_reference_trace_replays_on_the_emulated_library(emu_lib, tmp_path):
     """The replayer used on the GPU box (tests/ref_train_replay.py) against the library the fixture was recorded on: the five
     numbers train.py reads after every step, and every evaluate result, come back as recorded."""
+    import ref_train_shim as shim
+    if shim.available() and os.environ.get("MWW_REPLAY_ALWAYS") != "1":
+        pytest.skip("the reference tree is here: test_reference_trace_fixture_is_current re-records the trace live and compares it with the "
+                    "fixture; the replayer itself runs in the -m gpu suite (MWW_REPLAY_ALWAYS=1 forces this test)")
     fx = rr.load_fixture()
     worst, evals, cfg = rr.replay(fx, ec, emu_lib, tmp_path)
     assert worst.max() <= 1e-6, worst
