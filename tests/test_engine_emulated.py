@@ -284,6 +284,16 @@ def test_conv1_x6_against_the_exact_fp32_form(emu_lib):
     ec.check_conv1_x6_against_the_f32_form(emu_lib, B=3, T=150, flags=dict(ec.DEF, first_conv_kernel_size=5, pointwise_filters="32,48,64,48"))
 
 
+def test_thirty_two_channel_head_beyond_256_frames(emu_lib):
+    """A 32-channel last block with more than 256 final frames (round-5 advisor finding: shape_supported accepted it, launch_head had
+    no instantiation: 'no head kernel for this (channels, frames) shape' at the first train step)."""
+    flags = dict(ec.DEF, pointwise_filters="48,48,48,32")
+    from microwakeword_amd import mixednet
+    assert mixednet.kernel_family(flags, 330, lib=emu_lib)[0] == "block"
+    ec.check_forward_parity(emu_lib, B=2, T=330, training=True, grid=2, flags=flags)
+    ec.check_train_steps(emu_lib, B=2, T=330, steps=1, grid=2, flags=flags)
+
+
 def test_wide_first_block_backward_with_x6(emu_lib):
     """Option "bwd_first_wide": the 512-thread form of the stride-1 first block's backward kernel with the conv1 weight gradient as
     bf16 slice products (kernels_bwdw.hip.h bwd_firstw_kernel<..., X6>), against the oracle: ragged tiles, several windows per
