@@ -204,6 +204,14 @@ class FeatureHandler:
 
     def _need_engine(self):
         if self.engine is None:
+            # the reference's CLI builds ``FeatureHandler(config)`` BEFORE the model (model_train_eval.py:402-407) and hands both to
+            # train.train: a handler built without an engine attaches, at its first use, to the engine created last in this process
+            ref = native.Engine.latest
+            eng = ref() if ref is not None else None
+            if eng is not None and getattr(eng, "h", None):
+                self.attach(eng)
+                return
+        if self.engine is None:
             raise RuntimeError("FeatureHandler is not attached to an MI355X engine (FeatureHandler.attach); "
                                "there is no CPU batch-assembly path")
 

@@ -9,6 +9,7 @@ sources.  Nothing in this package contains or selects a CPU implementation.)
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from typing import Optional
 
@@ -300,6 +301,8 @@ class Prefetcher:
 class Engine:
     """One device context (``mww_ctx``): model weights, HBM-resident feature stores, the train step."""
 
+    latest = None   # weakref to the engine created last: what a FeatureHandler built without one attaches to at first use
+
     def __init__(self, frames, conv1_filters=None, conv1_kernel=None, conv1_stride=1, block_filters=(), block_kernel=(),
                  max_batch=1024, device=0, stream=None, lib: Optional[NativeLib] = None, conv_ops=None, dropout=0.0,
                  head_attention=False, head_pool=0):
@@ -340,6 +343,7 @@ class Engine:
             self.h = h
             self.n_params = int(self.nl.lib.mww_num_params(h))
             self.n_state = int(self.nl.lib.mww_num_bn_state(h))
+            Engine.latest = weakref.ref(self)
             return
         d = MixedNetDesc()
         d.frames, d.conv1_filters, d.conv1_kernel, d.conv1_stride = frames, conv1_filters, conv1_kernel, conv1_stride
@@ -357,6 +361,7 @@ class Engine:
         self.h = h
         self.n_params = int(self.nl.lib.mww_num_params(h))
         self.n_state = int(self.nl.lib.mww_num_bn_state(h))
+        Engine.latest = weakref.ref(self)
 
     def close(self):
         if getattr(self, "h", None):

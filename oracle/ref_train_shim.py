@@ -175,6 +175,73 @@ def load_reference_train_module():
     return mod
 
 
+def run_reference_cli(argv):
+    """Executes the reference's ``microwakeword/model_train_eval.py`` AS ``__main__`` (its CLI: argparse, ``load_config``,
+    ``input_data.FeatureHandler(config)``, ``model_module.model(flags, shape, batch_size)``, ``train_model`` ->
+    ``train.train`` - reference ``model_train_eval.py:45-128,277-439``) with THIS package's modules bound to the names it imports:
+
+      microwakeword.data / .mixednet / .inception   -> microwakeword_amd.data / .mixednet / .inception  (the drop-in surface)
+      microwakeword.train                           -> the reference's own train.py (load_reference_train_module)
+      microwakeword.layers.modes                    -> the reference's own layers/modes.py (pure Python)
+      microwakeword.utils                           -> ``save_model_summary`` only (reference utils.py:131-145 restated: model.summary(print_fn=) into
+                                                       <path>/model_summary.txt; the rest of utils.py is TFLite conversion)
+      microwakeword.test                            -> empty (TFLite evaluation, not reached with the --test_* flags at 0)
+      tensorflow / absl                             -> the stand-ins above (+ absl.logging.set_verbosity and its level names)
+
+    Returns the module globals of the run."""
+    import runpy
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    train_mod = load_reference_train_module()
+    from microwakeword_amd import data as amd_data, inception as amd_inception, mixednet as amd_mixednet
+
+    spec = importlib.util.spec_from_file_location("mww_reference_modes", os.path.join(REFERENCE_ROOT, "microwakeword", "layers", "modes.py"))
+    modes = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(modes)
+
+    utils = types.ModuleType("microwakeword.utils")
+
+    def save_model_summary(model, path, file_name="model_summary.txt"):   # utils.py:131-145
+        lines = []
+        model.summary(print_fn=lambda x: lines.append(x))
+        with open(os.path.join(path, file_name), "w") as fd:
+            fd.write("\n".join(lines))
+
+    utils.save_model_summary = save_model_summary
+    stubs = _tensorflow_stub()
+    absl_logging = types.ModuleType("absl.logging")
+    absl_logging.info, absl_logging.warning = LogCapture.info, LogCapture.warning
+    absl_logging.DEBUG, absl_logging.INFO, absl_logging.WARN, absl_logging.ERROR, absl_logging.FATAL = 1, 0, -1, -2, -3
+    absl_logging.set_verbosity = lambda v: None
+    absl = types.ModuleType("absl")
+    absl.logging = absl_logging
+    pkg = types.ModuleType("microwakeword")
+    pkg.__path__ = []
+    layers = types.ModuleType("microwakeword.layers")
+    layers.__path__ = []
+    layers.modes = modes
+    pkg.data, pkg.train, pkg.test, pkg.utils, pkg.inception, pkg.mixednet, pkg.layers = (
+        amd_data, train_mod, types.ModuleType("microwakeword.test"), utils, amd_inception, amd_mixednet, layers)
+    stubs.update({"absl": absl, "absl.logging": absl_logging, "microwakeword": pkg, "microwakeword.data": amd_data,
+                  "microwakeword.train": train_mod, "microwakeword.test": pkg.test, "microwakeword.utils": utils,
+                  "microwakeword.inception": amd_inception, "microwakeword.mixednet": amd_mixednet, "microwakeword.layers": layers,
+                  "microwakeword.layers.modes": modes})
+    saved = {k: sys.modules.get(k) for k in stubs}
+    saved_argv = sys.argv
+    sys.modules.update(stubs)
+    sys.argv = ["model_train_eval.py"] + list(argv)
+    try:
+        return runpy.run_path(os.path.join(REFERENCE_ROOT, "microwakeword", "model_train_eval.py"), run_name="__main__")
+    finally:
+        sys.argv = saved_argv
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 # ------------------------------------------------------------------------------------------------- call / return trace
 class Trace:
     """Wraps a model and a data processor: every call the reference's loop makes on them is forwarded and recorded as

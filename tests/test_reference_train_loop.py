@@ -96,6 +96,63 @@ def test_reference_train_loop_drives_model_and_feature_handler(emu_lib, tmp_path
 
 
 @pytest.mark.reference
+def test_reference_cli_main_runs_on_the_package_modules(emu_lib, tmp_path, monkeypatch):
+    """The reference's OWN command line - ``model_train_eval.py`` executed as ``__main__`` (argparse, ``load_config``,
+    ``input_data.FeatureHandler(config)`` built BEFORE the model, ``mixednet.model(flags, shape, batch_size)``, ``train_model`` ->
+    its own ``train.train``; model_train_eval.py:45-128,277-439) - with this package's ``data`` / ``mixednet`` / ``inception`` modules
+    bound to the names it imports: stores read from ``<features_dir>/<mode>/*_mmap`` on disk, the handler attaches to the model's
+    engine at its first use, and the run leaves what the reference's run leaves."""
+    import yaml
+
+    import ref_train_shim as shim
+    from microwakeword_amd import ragged
+    if not shim.available():
+        pytest.skip("reference tree not present")
+    rng = np.random.default_rng(0)
+    for prov, positive in (("wake", True), ("background", False)):
+        for mode, n in (("training", 12), ("validation", 6), ("validation_ambient", 2)):
+            if mode == "validation_ambient" and positive:
+                continue
+            lo, hi = (200, 260) if mode == "validation_ambient" else (62, 90)
+            samples = []
+            for _ in range(n):
+                s_ = rng.integers(0, 200, size=(int(rng.integers(lo, hi)), 40)).astype(np.uint16)
+                if positive:
+                    s_[-30:-10, 8:24] += 400
+                samples.append(s_)
+            ragged.write_ragged_store(str(tmp_path / prov / mode / ("%s_mmap" % mode)), samples)
+    cfg = dict(window_step_ms=10, train_dir=str(tmp_path / "trained"), clip_duration_ms=160, batch_size=4, training_steps=[4],
+               learning_rates=[0.001], eval_step_interval=2, target_minimization=0.9, minimization_metric=None,
+               maximization_metric="average_viable_recall", time_mask_max_size=[3], time_mask_count=[1], freq_mask_max_size=[3],
+               freq_mask_count=[1], positive_class_weight=[1], negative_class_weight=[2],
+               features=[dict(features_dir=str(tmp_path / "wake"), sampling_weight=1.0, penalty_weight=1.0, truth=True,
+                              truncation_strategy="truncate_start", type="mmap"),
+                         dict(features_dir=str(tmp_path / "background"), sampling_weight=2.0, penalty_weight=1.0, truth=False,
+                              truncation_strategy="random", type="mmap")])
+    (tmp_path / "cfg.yaml").write_text(yaml.dump(cfg))
+    monkeypatch.setenv("MWW_HIP_LIB", emu_lib.path)       # the CLI builds its own engine: point it at the emulator build
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    random.seed(3)
+    np.random.seed(3)
+    # (--test_tflite_streaming_quantized defaults to 1: the TFLite export / evaluation stays with the reference and TensorFlow)
+    argv = ["--training_config", str(tmp_path / "cfg.yaml"), "--verbosity", "ERROR", "--test_tflite_streaming_quantized", "0",
+            "mixednet", "--residual_connection", "0,0,0,0"]
+    shim.run_reference_cli(argv)
+    run = tmp_path / "trained"
+    for f in ("training_config.yaml", "model_summary.txt", "best_weights.weights.h5.npz", "last_weights.weights.h5.npz",
+              "restore/ckpt.weights.npz", "restore/ckpt.opt.npz"):
+        assert (run / f).exists(), f
+    saved = yaml.load((run / "training_config.yaml").read_text(), yaml.Loader)
+    assert saved["spectrogram_length"] == 60 and saved["spectrogram_length_final_layer"] == 14 and saved["training_input_shape"] == (60, 40)
+    assert "Total params" in (run / "model_summary.txt").read_text()
+    assert int(np.load(run / "restore" / "ckpt.opt.npz")["step"]) == 4
+    with pytest.raises(ValueError, match="model already exists"):
+        shim.run_reference_cli(argv)                                   # model_train_eval.py:113-120
+    shim.run_reference_cli(argv[:2] + ["--restore_checkpoint", "1"] + argv[2:])
+    assert int(np.load(run / "restore" / "ckpt.opt.npz")["step"]) == 8   # restored (train.py:232-233) + 4 new optimizer steps
+
+
+@pytest.mark.reference
 def test_reference_loop_learns_the_task(emu_lib, tmp_path):
     """Long enough for the BN moving averages (validation runs in inference mode): the reference's loop reaches >= 95 % validation
     accuracy on the separable task with this package's objects."""
