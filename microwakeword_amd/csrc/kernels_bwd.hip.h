@@ -300,7 +300,7 @@ struct BwdFirstLds {
   static constexpr int CIN = C1, CPI = pitch(CIN), CPO = pitch(COUT);
   static constexpr int RAP = halo_rows_padded(CIN, K), TTP = tile_rows_padded(CIN);
   static constexpr int TAIL = S > 1 ? K - 1 : 0;   // extra a0 / g0 rows of a single-tile window (bwd_first_body.inc "tail rows")
-  static constexpr int TAILK = TAIL > 0 ? (TAIL > 4 ? TAIL : 4) : 0;   // the tail k-step of dW1 reads a whole k-step of four rows
+  static constexpr int TAILK = (TAIL + 3) / 4 * 4;   // the tail k-steps of dW1 read whole k-steps of four rows
   static constexpr int OFF_END = RAP * CPI + TT * CPO + TTP * CPI + RAP * CPI + (TTP + TAILK) * CPI;
   static constexpr int XR = (TT + TAILK - 1) * S + K1, PX = FBINS + 1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }

@@ -607,7 +607,7 @@ struct BwdFirstWideLds {
   static constexpr int PX = FBINS + 1;
   static constexpr int NCH = NTH / C1, L = (TT + NCH - 1) / NCH, TTP = NCH * L, RAP = TTP + K - 1;
   static constexpr int TAIL = S > 1 ? K - 1 : 0;
-  static constexpr int TAILK = TAIL > 0 ? (TAIL > 4 ? TAIL : 4) : 0;   // the tail k-step of dW1 reads x / g0 rows [TT, TT + 4)
+  static constexpr int TAILK = (TAIL + 3) / 4 * 4;   // the tail k-steps of dW1 read x / g0 rows [TT, TT + TAILK): whole k-steps of four
   static constexpr int XR = (TT + TAILK - 1) * S + K1;
   static constexpr int up4(int v) { return (v + 3) / 4 * 4; }
   static constexpr int OFF_A = 0, OFF_DP = OFF_A + up4(RAP * PI), OFF_U = OFF_DP + TT * PO, OFF_DU = OFF_U + up4(TTP * PI);
@@ -898,14 +898,17 @@ __global__ __launch_bounds__(NTH, (wide_first_waves_per_simd<K1, C1, COUT, K, S,
           }
       }
       if constexpr (TAIL > 0) {
-        if (tailmode) {   // one more k-step: g0 / x rows [TT, TT + 4) (g0 rows past Ta are zero)
-          load_w1(TT + g, 0);
+        if (tailmode) {   // the tail rows [TT, Ta): one or two more k-steps of four rows (g0 rows past Ta are zero)
 #pragma unroll
-          for (int mi = 0; mi < MPW; ++mi)
-            if (mi * NW + wave < MT1) {
+          for (int ks = 0; ks < Lds::TAILK / 4; ++ks) {
+            load_w1(TT + 4 * ks + g, 0);
 #pragma unroll
-              for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[0][mi], bv[0][nt], w1acc[mi][nt]);
-            }
+            for (int mi = 0; mi < MPW; ++mi)
+              if (mi * NW + wave < MT1) {
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) w1acc[mi][nt] = mfma4(av[0][mi], bv[0][nt], w1acc[mi][nt]);
+              }
+          }
         }
       }
     }

@@ -203,6 +203,11 @@ def test_first_block_tail_k_step_with_a_three_tap_depthwise(lib, wide):
         flags = dict(ec.DEF, mixconv_kernel_sizes="[3],[9],[13],[21]", stride=stride, bwd_wide=wide)
         for T in lengths:
             ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
+    # a 5- / 7-tap first depthwise: TAIL = 4 / 6 tail rows = one / TWO tail k-steps (round-6 fuzz finding: the second was missing)
+    for k, stride, lengths in ((7, 3, (207, 209, 212)), (7, 2, (139, 141)), (5, 3, (204, 206))):
+        flags = dict(ec.DEF, mixconv_kernel_sizes="[%d],[9],[13],[21]" % k, stride=stride, bwd_wide=wide)
+        for T in lengths:
+            ec.check_train_steps(lib, B=37, T=T, steps=1, grid=16, flags=flags)
 
 
 def test_conv1_x6_against_the_exact_fp32_form(lib):

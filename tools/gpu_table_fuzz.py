@@ -29,6 +29,13 @@ def random_table_flags(seed):
                  first_conv_filters=32, first_conv_kernel_size=int(rng.choice([3, 5])), stride=int(rng.choice([1, 1, 2, 3])))
     need = flags["first_conv_kernel_size"] + flags["stride"] * (sum(k[-1] - 1 for k in ks) + 1)
     T = int(rng.integers(need + 2, need + 260))
+    if flags["stride"] > 1 and rng.random() < 0.4:
+        # tail mode on purpose (fwd_first_body.inc "tail rows"): a window of 64 + 1 .. 64 + K - 1 first-conv rows is ONE tile whose
+        # rows behind the 64th ride along - the lengths the round-5 / round-6 tail k-step bugs needed
+        ta = 64 + int(rng.integers(1, ks[0][-1]))
+        t_tail = (ta - 1) * flags["stride"] + flags["first_conv_kernel_size"] + int(rng.integers(0, flags["stride"]))
+        if t_tail >= need + 2:
+            T = t_tail
     return flags, T, int(rng.integers(1, 40)), int(rng.choice([0, 1, 2, 3, 5, 8]))
 
 
