@@ -306,6 +306,12 @@ int64_t mww_debug_read(mww_ctx* ctx, const char* name, int B, float* host, int64
  * compile-time instantiation use it, the default; 0 = the run-time-shape kernels for every op),
  * "graph_planar" (conv/BN graph contexts: 1 = a 30- / 48-filter op whose consumers all read one of its equal channel slices keeps its
  * tensors one plane per slice, the default; 0 = interleaved),
+ * "bwd_wide" (default 1: the block backward kernels of square 48- / 64-wide blocks - and of stride-3 first blocks - as 512-thread
+ * workgroups; 0 = 256 threads),
+ * "conv1_x6" (default 1, stride-1 first convolutions: the conv1 weight gradient as six bf16 slice products per fp32 product on the
+ * bf16 matrix pipe, fp32-grade; 0 = exact-fp32 MFMA), "conv1_x6_fwd" (default 0: the same form for the first convolution of the
+ * forward kernel - measured slower), "bwd_first_wide" (default 0, with conv1_x6: the 512-thread form of the stride-1 first block's
+ * backward kernel - measured equal),
  * "grad_buckets" (data-parallel step: 1 = one exchange after the backward pass, the default; 2 =
  * overlapped two-bucket gradient exchange), "assemble_split" (workgroups per window of the
  * assembly kernel), "side_stream", "profile", "profile_split", "ablate" (profiling switches) */

@@ -276,7 +276,7 @@ def test_first_block_tail_k_step_with_a_three_tap_depthwise(emu_lib, wide):
             ec.check_train_steps(emu_lib, B=3, T=T, steps=1, grid=2, flags=flags)
     # ... and a 7-tap first depthwise has TAIL = 6 tail rows: TWO tail k-steps (round-6 fuzz finding, tools/gpu_table_fuzz.py case
     # 556: with one, rows TT + 4 and TT + 5 of a 69- / 70-row window never reached the conv1 weight gradient: error 1e-2)
-    for stride, T in ((3, 212), (3, 209), (2, 141)):
+    for stride, T in ((3, 212), (2, 141)):
         ec.check_train_steps(emu_lib, B=3, T=T, steps=1, grid=2, flags=dict(ec.DEF, mixconv_kernel_sizes="[7],[9],[13],[21]", stride=stride, bwd_wide=wide))
 
 
