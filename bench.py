@@ -756,6 +756,13 @@ def main():
         "vs_baseline": None, "dtype": ("bf16 storage of p_k/g_k, bf16-operand MFMA in the 1x1 contractions, f32 accumulate / BN sums / parameters" if args.storage_bf16 else
                                       "f32 storage/accumulate, bf16-operand MFMA in the 1x1 contractions" if args.pointwise_bf16 else "f32"),
         "data": "synthetic",
+        # every tensor, sum and update is fp32; ONE contraction - the conv1 weight gradient of stride-1 first blocks - is formed as six
+        # bf16 slice products per fp32 product (the three exact 8-bit slices of each operand's significand, fp32 accumulation:
+        # max error 1.08e-7 of sum|x w| against 1.19e-7 for the exact-fp32 MFMA's fma chain, tools/ubench/mfma_bf16x9).
+        # engine option conv1_x6 0 (MWW_BENCH_OPTIONS=conv1_x6=0) runs it on the exact-fp32 MFMA: +5.7 us per step
+        "precision_note": None if args.model == "inception" else
+                          "fp32 tensors / sums / updates; the conv1 weight gradient as six exact bf16 slice products per fp32 product with fp32 accumulation "
+                          "(fp32-grade: 1.08e-7 vs 1.19e-7 of sum|x w| for the exact-fp32 MFMA; option conv1_x6 0 = exact-fp32 MFMA, +5.7 us/step)",
         "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, %s, "
                                "SpecAugment 5/2/5/2, 2 providers x %d ragged uint16 samples resident in HBM"
                                % (args.model, " + residual_connection 0,0,0,0" if args.model == "mixednet" else ", dropout 0.2 from the built-in generator",
