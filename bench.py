@@ -760,7 +760,7 @@ def main():
         # bf16 slice products per fp32 product (the three exact 8-bit slices of each operand's significand, fp32 accumulation:
         # max error 1.08e-7 of sum|x w| against 1.19e-7 for the exact-fp32 MFMA's fma chain, tools/ubench/mfma_bf16x9).
         # engine option conv1_x6 0 (MWW_BENCH_OPTIONS=conv1_x6=0) runs it on the exact-fp32 MFMA: +5.7 us per step
-        "precision_note": None if args.model == "inception" else
+        "precision_note": None if (args.model != "mixednet" or args.force_generic) else
                           "fp32 tensors / sums / updates; the conv1 weight gradient as six exact bf16 slice products per fp32 product with fp32 accumulation "
                           "(fp32-grade: 1.08e-7 vs 1.19e-7 of sum|x w| for the exact-fp32 MFMA; option conv1_x6 0 = exact-fp32 MFMA, +5.7 us/step)",
         "config": {"workload": "default %s (argparse defaults%s), T=194, batch %d/GPU, %s, "
