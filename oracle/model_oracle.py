@@ -1,10 +1,19 @@
 """TEST INFRASTRUCTURE ONLY — CPU restatement (torch-CPU, fp64 or fp32) of the model half of the
-reference train step.  **Parity unpinned**: the reference has no tests/golden vectors for this
-path and its arithmetic lives in TensorFlow/Keras (``tensorflow>=2.16`` ⇒ Keras 3,
-reference ``setup.py:18``, un-vendored, not installable here), so this file restates the
-published Keras semantics and is pinned only by self-consistency tests
-(``tests/test_model_oracle.py``: finite differences, BN train/eval consistency, MixConv
-right-alignment, layer shapes/param counts from SURVEY §A.2/A.3).
+reference train step.
+
+Pinning.  **The graph is pinned to the reference's own code by execution** (round 6):
+``oracle/ref_model_shim.py`` runs ``/root/reference/microwakeword/mixednet.py`` / ``inception.py`` and the layer files
+they import, unmodified, and this module agrees with what they compute to 1e-11 (probabilities in both modes, loss,
+every gradient, BN moving statistics, variable order and shapes) on the hand-picked and random topologies of
+``tests/test_reference_graph.py``; the frozen outputs are ``tests/golden/ref_graph_golden.npz``
+(``tests/golden/make_golden_ref_graph.py``).  **The layer primitives stay unpinned against TensorFlow**: the
+reference's arithmetic lives in TensorFlow/Keras (``tensorflow>=2.16`` ⇒ Keras 3, reference ``setup.py:18``,
+un-vendored, not installable here) and the reference has no tests/golden vectors for this path, so that run uses
+stand-ins restating the published Keras semantics of Conv2D / DepthwiseConv2D / BatchNormalization / Dense / pooling
+(the shim's header lists them), as this file does; loss, optimizer and metrics are pinned only by self-consistency tests
+(``tests/test_model_oracle.py``: finite differences, BN train/eval consistency, layer shapes/param counts from SURVEY
+§A.2/A.3) and by the independent numpy twin (``oracle/model_oracle_np.py``).  "Parity unpinned" therefore still
+applies to: Keras' primitive arithmetic, BinaryCrossentropy / Adam / metric details, the ``[B,B]`` weight reduction.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
 this module; the product path never does.

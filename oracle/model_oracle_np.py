@@ -5,7 +5,9 @@ vectors or checkpoints for the model (``find /root/reference -name '*.h5' -o -na
 is empty) and TensorFlow cannot be installed here, so the torch oracle cannot be pinned against the
 reference itself; two restatements written separately from the reference source that agree to 1e-9 on loss,
 every gradient, the Adam step and the BN moving statistics are the strongest pin available
-(``tests/test_model_oracle_np.py``).  Parity of the model half therefore remains "unpinned against TF".
+(``tests/test_model_oracle_np.py``).  Since round 6 the GRAPH of both is also checked against the reference's own
+builders executed over stand-in Keras primitives (``oracle/ref_model_shim.py``, ``tests/test_reference_graph.py``, fixture
+``tests/golden/ref_graph_golden.npz``); the primitives' arithmetic, loss, optimizer and metrics remain "unpinned against TF".
 
 Written from (reference file:line):
   * microwakeword/mixednet.py:278-386  graph of ``model()``: expand_dims -> Stream(Conv2D(first_conv_filters,

@@ -3,6 +3,7 @@ debug run of the same kernel sources under tests/hipemu.  Every check compares t
 (through the C ABI) with oracle/ on identical seeded inputs."""
 import os
 import random
+import sys
 
 import numpy as np
 import torch
@@ -1143,6 +1144,62 @@ def check_against_frozen_oracle(lib, golden_dir):
         assert np.abs(pr - gold[name + "/p_train"]).max() <= FWD_TOL, name
         assert abs(loss - float(gold[name + "/loss"])) <= 1e-5 * max(1.0, abs(float(gold[name + "/loss"]))), name
         eng.close()
+
+
+def check_against_reference_graph_fixture(lib, golden_dir, names=None):
+    """The engine, through the package's drop-in builders (``mixednet.model`` / ``inception.model``), against
+    tests/golden/ref_graph_golden.npz: what the REFERENCE'S OWN ``mixednet.py`` / ``inception.py`` compute (executed by
+    oracle/ref_model_shim.py over float64 stand-ins of the Keras layer primitives, frozen by tests/golden/make_golden_ref_graph.py)
+    on the fixture's inputs - inference and training probabilities, loss, the gradient of every trainable variable, the BN
+    moving statistics after the step.  The reference's variable order is the order ``set_weights`` takes."""
+    import importlib.util
+    from microwakeword_amd import inception as amd_inception, mixednet as amd_mixednet
+    spec = importlib.util.spec_from_file_location("make_golden_ref_graph", os.path.join(golden_dir, "make_golden_ref_graph.py"))
+    sys.path.insert(0, golden_dir)
+    try:
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(golden_dir)
+    gold = np.load(os.path.join(golden_dir, "ref_graph_golden.npz"))
+    report = {}
+    for name in (names or mod.CASES):
+        kind, flags, T = mod.CASES[name]
+        x, y, w = gold[name + "/x"], gold[name + "/y"], gold[name + "/w"]
+        B = x.shape[0]
+        trainable = gold[name + "/trainable"]
+        values = [gold["%s/value/%03d" % (name, i)] for i in range(len(trainable))]
+        m = (amd_mixednet if kind == "mixednet" else amd_inception).model(flags, (T, 40), B, lib=lib, max_batch=B)
+        lay, eng = m.layout, m.engine
+        assert [tuple(sh) for _, sh, _ in lay.keras_vars] == [v.shape for v in values], name   # the reference's creation order and shapes
+        m.set_weights(values)
+        eng.set_batch(x)
+        eng.forward(B, training=False)
+        assert np.abs(eng.read_outputs(B, want_loss=False)[0] - gold[name + "/p_eval"]).max() <= FWD_TOL, name
+        if name + "/keep" in gold.files:
+            eng.set_dropout_mask(gold[name + "/keep"])
+        eng.set_targets(y, w)
+        eng.train_step(B, 1e-3, flags=native.STEP_NO_APPLY)
+        pr, z, loss = eng.read_outputs(B)
+        ref_loss = float(gold[name + "/loss"])
+        assert np.abs(pr - gold[name + "/p_train"]).max() <= FWD_TOL, name
+        assert np.abs(z - gold[name + "/z_train"]).max() <= 1e-4 * max(1.0, np.abs(gold[name + "/z_train"]).max()), name
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (name, loss, ref_loss)
+        arrs = [gold["%s/grad/%03d" % (name, i)].astype(np.float32) if t else np.zeros(v.shape, np.float32)
+                for i, (t, v) in enumerate(zip(trainable, values))]
+        gref = lay.pack(arrs)[0] * lay.grad_mask() if hasattr(lay, "grad_mask") and lay.grad_mask() is not None else lay.pack(arrs)[0]
+        g = eng.get_grads()
+        # float32 engine vs the float64 graph with these tiny batches: a unit within rounding of zero may sit on the other side of
+        # its ReLU (moves upstream gradients by ~1/sqrt(units)); the bound is the one the un-imposed oracle checks use
+        l2 = float(np.linalg.norm(g - gref) / max(np.linalg.norm(gref), 1e-30))
+        assert l2 <= 1e-2, (name, l2)
+        stats = lay.pack([gold["%s/moving/%03d" % (name, i)].astype(np.float32) if ("%s/moving/%03d" % (name, i)) in gold.files
+                          else np.zeros(v.shape, np.float32) for i, v in enumerate(values)])[1]
+        got = eng.get_bn_state()
+        assert np.abs(got - stats).max() <= 1e-5 * max(1.0, np.abs(stats).max()), (name, np.abs(got - stats).max())
+        report[name] = l2
+        eng.close()
+    return report
 
 
 def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):

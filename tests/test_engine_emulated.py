@@ -248,6 +248,12 @@ def test_against_frozen_oracle_outputs(emu_lib, golden_dir):
     ec.check_against_frozen_oracle(emu_lib, golden_dir)
 
 
+def test_against_the_reference_graph_fixture(emu_lib, golden_dir):
+    """tests/golden/ref_graph_golden.npz = the reference's own mixednet.py / inception.py executed over float64 stand-ins of the Keras
+    layer primitives (oracle/ref_model_shim.py): probabilities, loss, every gradient, BN moving statistics."""
+    print(ec.check_against_reference_graph_fixture(emu_lib, golden_dir))
+
+
 def test_prefetched_batches_train_like_the_synchronous_sampler(emu_lib):
     ec.check_prefetched_training_matches_synchronous(emu_lib)
 

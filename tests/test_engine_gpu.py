@@ -596,6 +596,12 @@ def test_against_frozen_oracle_outputs(lib, golden_dir):
     ec.check_against_frozen_oracle(lib, golden_dir)
 
 
+def test_against_the_reference_graph_fixture(lib, golden_dir):
+    """tests/golden/ref_graph_golden.npz = the reference's own mixednet.py / inception.py executed over float64 stand-ins of the Keras
+    layer primitives (oracle/ref_model_shim.py): probabilities, loss, every gradient, BN moving statistics."""
+    print(ec.check_against_reference_graph_fixture(lib, golden_dir))
+
+
 def test_frame_chunks_of_the_pointwise_graph_ops(lib):
     """"graph_frame_chunks" on the GPU (round 2 shipped these kernels emulator-tested only): the 1x1 ops of a conv/BN graph
     process a window as 2-4 frame chunks - Inception and MixedNet graphs, uneven last chunks, the automatic setting, a captured
