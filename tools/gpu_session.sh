@@ -14,6 +14,7 @@
 #     trace[:<lib>[:<bench args>]]   rocprofv3 --kernel-trace --stats, 60 steps: per-kernel averages -> trace_<lib>_kernel_stats.csv
 #     pmc[:<lib>[:<bench args>]]     trace + the four PMC passes (SQ x2, FETCH_SIZE, WRITE_SIZE) -> kernel_stats_and_pmc_<lib>.txt
 #     bin:<path>[:<args>]      run a prebuilt micro-benchmark binary (tools/ubench/...), output into the summary
+#     py:<script>[:<args>]     python <script> <args> (the fuzz sweeps under tools/), last lines of its output into the summary
 #     benchline:<name>[:<lib>[:<bench args>]]  one bench.py JSON line saved as bench_<name>.json
 TAG=${1:-session}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -92,6 +93,8 @@ PY
         head -3 $OUT/kernel_stats_and_pmc_$v.txt | cut -c1-200 >> $S
       fi
       cd $R ;;
+    py)
+      timeout 2400 python $R/$a1 $(sp "$a2") > $OUT/py_$(basename $a1 .py).log 2>&1; tail -6 $OUT/py_$(basename $a1 .py).log >> $S ;;
     bin)
       timeout 300 $R/$a1 $(sp "$a2") >> $S 2>&1 ;;
     benchline)
