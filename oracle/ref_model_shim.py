@@ -124,6 +124,7 @@ class Run:
         if trainable:
             val.requires_grad_(True)
         v = Variable("%s/%s" % (layer.name, name), val, trainable)
+        (layer._trainable_variables if trainable else layer._non_trainable_variables).append(v)
         self.variables.append(v)
         return v
 
@@ -162,6 +163,7 @@ class Layer:
         self.name = name or "%s_%d" % (base, Layer._count[base])
         self.trainable = trainable
         self.built = False
+        self._trainable_variables, self._non_trainable_variables = [], []      # what the layer owns itself (Keras 3's names)
         if Run.current is not None:
             Run.current.layers.append(self)
 

@@ -125,6 +125,30 @@ def test_reference_builders_raise_where_the_oracle_does():
 
 
 @pytest.mark.reference
+@pytest.mark.parametrize("kind,flags,T", [("inception", INC, 60), ("mixednet", dict(BASE, residual_connection="1,0,1,1", repeat_in_block="1,2,1,1"), 70)])
+def test_weight_conversion_tools_recover_the_creation_order(kind, flags, T):
+    """tools/keras_creation_order.py (used by keras_weights_to_npz.py / npz_to_keras_weights.py where Keras is installed): the log
+    of constructed layers gives back the order the reference's builder creates its variables in, whatever order the model lists
+    its weights in (a Keras functional model sorts layers by graph depth: not the creation order for residual blocks / Inception)."""
+    rm = _shim()
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    try:
+        import keras_creation_order as kco
+    finally:
+        sys.path.pop(0)
+    x = np.zeros((2, T, 40), np.float32)
+    with kco.layer_creation_log(rm.Layer) as created:
+        run = rm.run_reference_model(kind, flags, x, training=False)
+    listed = sorted(run.variables, key=lambda v: (v.name.split("/")[1], v.name))          # some other listing of the same variables
+    assert listed != run.variables
+    perm = kco.creation_permutation(listed, created)
+    assert [listed[i] for i in perm] == run.variables
+    with pytest.raises(RuntimeError, match="covers"):
+        kco.creation_permutation(listed, created[:-1])                                   # a weight no logged layer owns is an error
+    assert rm.Layer.__init__.__name__ == "__init__"                                      # the patch is undone
+
+
+@pytest.mark.reference
 def test_ref_graph_fixture_is_current():
     """tests/golden/ref_graph_golden.npz is what make_golden_ref_graph.py produces from the reference tree today
     (MWW_WRITE_REF_GRAPH=1 rewrites it)."""
