@@ -65,8 +65,10 @@ const char* mww_last_error(void);
 int mww_device_count(void);
 
 /* 1 if every block of `desc` has a specialised MFMA block kernel (bf16 != 0: in the bf16 modes too), 0 if the model has to
- * run on the conv / depthwise graph kernels of mww_create_convnet (mww_last_error() says which block is not covered).
- * Needs no device: it answers from the build-time shape table (csrc/block_launch.hip.h). */
+ * run on the conv / depthwise graph kernels of mww_create_convnet (mww_last_error() says which block is not covered, or that the
+ * classifier head holds fewer final frames than the model has: 768 / 504 / 384 at 32 / 48 / 64 channels).
+ * Needs no device: it answers from the build-time shape table (csrc/block_launch.hip.h).  mww_create refuses the same shapes
+ * with MWW_ERR_UNSUPPORTED. */
 int mww_block_kernels_cover(const mww_mixednet_desc* desc, int bf16);
 
 /* stream: a hipStream_t to run on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a

@@ -295,6 +295,10 @@ int launch_bwd_block(mww_ctx* c, int cin, int cout, int k, bool last, const BwdB
   return fail(MWW_ERR_UNSUPPORTED, "no block backward kernel for this shape");
 }
 
+constexpr int kHeadMaxRows = 24;   // frames per frame group of the widest head_kernel instantiation below
+// final frames one head workgroup covers at `ch` channels (a thread keeps one float4 of every frame of its group)
+int head_frame_limit(int ch) { return (kThreads / (ch / 4)) * kHeadMaxRows; }
+
 int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
 #define X(C, J)                                                                                                \
   if (ch == C && jmax <= J) {                                                                                  \
@@ -304,6 +308,7 @@ int launch_head(mww_ctx* c, int ch, int jmax, const HeadArgs& a, int grid) {
       hipLaunchKernelGGL((head_kernel<C, J>), dim3(grid), dim3(kThreads), 0, c->stream, a);                    \
     return MWW_OK;                                                                                             \
   }
+  static_assert(kHeadMaxRows == 24, "the widest instantiation below");
   X(32, 2) X(32, 4) X(32, 8) X(32, 12) X(32, 16) X(32, 24) X(48, 2) X(48, 4) X(48, 8) X(48, 12) X(48, 16) X(48, 24) X(64, 2) X(64, 4) X(64, 8) X(64, 12) X(64, 16) X(64, 24)
 #undef X
   return fail(MWW_ERR_UNSUPPORTED, "no head kernel for this (channels, frames) shape");
@@ -326,6 +331,14 @@ bool shape_supported(const mww_mixednet_desc& d, std::string* why, bool bf16 = f
   }
   const int cl = d.block_filters[d.n_blocks - 1];
   if (cl != 32 && cl != 48 && cl != 64) { *why = "head kernel needs 32, 48 or 64 channels"; return false; }
+  // the classifier head keeps a window's final frames in registers: more of them than its widest instantiation holds would only
+  // surface as MWW_ERR_UNSUPPORTED at the first forward (found by tools/gpu_x6_fuzz.py case 460: 64 channels x 390 frames)
+  int t = d.frames >= d.conv1_kernel && d.conv1_stride > 0 ? (d.frames - d.conv1_kernel) / d.conv1_stride + 1 : 0;
+  for (int i = 0; i < d.n_blocks; ++i) t -= d.block_kernel[i] - 1;
+  if (t > head_frame_limit(cl)) {
+    *why = "head kernel holds at most " + std::to_string(head_frame_limit(cl)) + " final frames at " + std::to_string(cl) + " channels (" + std::to_string(t) + " here)";
+    return false;
+  }
   return true;
 }
 

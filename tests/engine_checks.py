@@ -1202,6 +1202,34 @@ def check_against_reference_graph_fixture(lib, golden_dir, names=None):
     return report
 
 
+def check_head_frame_limit_is_refused_at_creation(lib, T=436, B=2):
+    """64 channels x 390 final frames (T = 436 on the default kernels): more than the classifier head kernel holds (24 frames per
+    frame group: 384 at 64 channels).  The block kernels must refuse the shape when the model is created, not at the first
+    forward (tools/gpu_x6_fuzz.py case 460); windows this long do not fit the graph kernels' LDS tiles either, so
+    ``mixednet.model`` ends in MWW_ERR_UNSUPPORTED - at creation, naming both reasons."""
+    import logging
+    from microwakeword_amd import mixednet
+    flags = dict(DEF, pointwise_filters="48,48,48,64")
+    assert mixednet.kernel_family(flags, T - 6, lib=lib)[0] == "block"        # 384 final frames: the widest head instantiation
+    fam, why = mixednet.kernel_family(flags, T, lib=lib)
+    assert fam == "graph" and "final frames" in why, (fam, why)
+    eng = None
+    try:
+        lay = MixedNetLayout(flags, T)
+        eng = native.Engine(lib=lib, **lay.engine_args(B))
+    except native.NativeError as e:
+        assert "error -3" in str(e) and "final frames" in str(e), e
+    assert eng is None, "the block kernels accepted a head they have no kernel for"
+    logging.disable(logging.WARNING)
+    try:
+        mixednet.model(flags, (T, 40), B, lib=lib, max_batch=B)
+        raise AssertionError("expected MWW_ERR_UNSUPPORTED at creation")
+    except native.NativeError as e:
+        assert "error -3" in str(e), e
+    finally:
+        logging.disable(logging.NOTSET)
+
+
 def check_prefetched_training_matches_synchronous(lib, B=8, T=60, steps=7):
     """Batches drawn ahead by the prefetcher's worker thread (native.Prefetcher, csrc/sampler.cpp) against the synchronous
     sampler on the launching thread: the same private streams give the same windows / masks / labels / weights in the same

@@ -304,6 +304,12 @@ def test_thirty_two_channel_head_beyond_256_frames(emu_lib):
     ec.check_train_steps(emu_lib, B=2, T=330, steps=1, grid=2, flags=flags)
 
 
+def test_head_frames_beyond_the_widest_instantiation_are_refused_at_creation(emu_lib):
+    """round-6 fuzz finding (tools/gpu_x6_fuzz.py case 460): 64 channels x 390 final frames passed shape_supported and failed in
+    launch_head at the first forward; now MWW_ERR_UNSUPPORTED when the model is created."""
+    ec.check_head_frame_limit_is_refused_at_creation(emu_lib)
+
+
 def test_wide_first_block_backward_with_x6(emu_lib):
     """Option "bwd_first_wide": the 512-thread form of the stride-1 first block's backward kernel with the conv1 weight gradient as
     bf16 slice products (kernels_bwdw.hip.h bwd_firstw_kernel<..., X6>), against the oracle: ragged tiles, several windows per

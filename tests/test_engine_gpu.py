@@ -591,6 +591,13 @@ def test_full_size_properties_batch1024(lib):
     assert np.linalg.norm(e["g"] - a["g"]) <= 1e-4 * np.linalg.norm(a["g"])
 
 
+def test_head_frames_beyond_the_widest_instantiation_are_refused_at_creation(lib):
+    """64 channels x 390 final frames: refused when the model is created (not at the first forward); 384 frames - the widest head
+    instantiation - train on the block kernels against the oracle."""
+    ec.check_head_frame_limit_is_refused_at_creation(lib, B=3)
+    ec.check_train_steps(lib, B=3, T=430, steps=1, grid=2, flags=dict(ec.DEF, pointwise_filters="48,48,48,64"))
+
+
 def test_against_frozen_oracle_outputs(lib, golden_dir):
     """Committed fixture route: tests/golden/model_oracle_golden.npz."""
     ec.check_against_frozen_oracle(lib, golden_dir)

@@ -501,6 +501,15 @@ def test_kernel_family_of_a_grid_of_flag_sets():
     assert fam(first_conv_filters=16) == "graph" and fam(first_conv_kernel_size=7) == "graph" and fam(stride=4) == "graph"
     assert fam(residual_connection="0,1,0,0") == "graph" and fam(repeat_in_block="1,2,1,1") == "graph"
     assert fam(spatial_attention=1) == "graph" and fam(pooled=1) == "graph" and fam(first_conv_filters=0) == "graph"
+    # the classifier head holds a window's final frames in registers: 24 frames per frame group = 768 / 504 / 384 frames at
+    # 32 / 48 / 64 channels; one more lands on the graph kernels at creation instead of failing at the first forward
+    # (tools/gpu_x6_fuzz.py case 460: 64 channels x 390 frames)
+    dropped = 2 + 4 + 8 + 12 + 20
+    for width, limit in ((32, 768), (48, 504), (64, 384)):
+        pf = "48,48,48,%d" % width
+        assert fam(T=limit + dropped, pointwise_filters=pf) == "block", width
+        fam_, why = mixednet.kernel_family(dict(base, pointwise_filters=pf), limit + 1 + dropped, lib=nl)
+        assert fam_ == "graph" and "final frames" in why, (width, why)
     # the bf16 modes exist for the documented topologies and their crosses only
     assert mixednet.kernel_family(base, 194, lib=nl, bf16=True)[0] == "block"
     assert mixednet.kernel_family(dict(base, pointwise_filters="32,32,32,32"), 194, lib=nl, bf16=True)[0] == "graph"
