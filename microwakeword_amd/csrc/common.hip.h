@@ -380,6 +380,8 @@ __device__ __forceinline__ void stagger_start() {
 // keep a value (and the loads that produce it) from sinking below this point: used to retire the
 // prologue's weight loads before the tile loop, so waits inside the loop never drain the prefetch
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+// the same for an index: what is derived from it afterwards cannot be hoisted above this point (kernels_bwdw.hip.h: MWW_WIDE_RELANE_K)
+__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
 
 // profiling only (build with -DMWW_PROFILE, see tools/phase_clocks.py): phase ablation by the "ablate" option bits
 // (results invalid) and per-phase shader-clock accounting of one thread ("ablate" bit 16).  Compiled out of the

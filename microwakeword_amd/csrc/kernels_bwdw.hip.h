@@ -20,6 +20,14 @@
 #pragma once
 #include "kernels_bwd.hip.h"
 
+// tuning switches of the wide block backward (see the tile loop of bwd_blockw_kernel and TapGroups)
+#ifndef MWW_WIDE_RELANE_K
+#define MWW_WIDE_RELANE_K 15
+#endif
+#ifndef MWW_WIDE_TWO_GROUPS_UPTO   // longest depthwise kernel whose phases run in two tap groups (three beyond)
+#define MWW_WIDE_TWO_GROUPS_UPTO 19
+#endif
+
 namespace mww {
 
 // P: row pitch of the activation / gradient tiles; D: row distance between the four k-values of one dW k-step
@@ -252,7 +260,7 @@ struct TapGroups {
 #ifdef MWW_WIDE_FEWGROUPS   // tuning builds: larger register windows, fewer scheduling fences
   static constexpr int N = K <= 15 ? 1 : 2;
 #else
-  static constexpr int N = K <= 11 ? 1 : (K <= 19 ? 2 : 3);
+  static constexpr int N = K <= 11 ? 1 : (K <= MWW_WIDE_TWO_GROUPS_UPTO ? 2 : 3);
 #endif
   static constexpr int lo(int gidx) { return gidx * K / N; }
 };
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
   float* sU = smem + Lds::OFF_U;
   float* sDU = smem + Lds::OFF_DU;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16_ = lane & 15, g_ = lane >> 4;
   const int c = tid % C, chunk = tid / C;
   const bool dw_active = chunk < NCH;
   MWW_PC_DECL
@@ -477,6 +485,18 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
     __syncthreads();
     MWW_PC_MARK(3);   // barrier 2
     // ---- P2/P3: dW_pw += u^T dp ; du = dp W^T -> ring rows [K-1, K-1+TT)
+    // Long depthwise kernels (K = 21: 21 tap-gradient accumulators + a 27-value window per lane) left no register for the
+    // loop-invariant fragment addresses of this phase: the compiler spilled two of them and reloaded them HERE, and a scratch
+    // reload waits with vmcnt(0) - i.e. for the rows of the next tile that were requested a phase ago.  Deriving the fragment
+    // coordinates from a lane id the compiler cannot hoist rebuilds the addresses per tile (a dozen integer instructions)
+    // instead (MWW_WIDE_RELANE_K: kernels at least this long; 0 = never).
+    int r16 = r16_, g = g_;
+    if constexpr (MWW_WIDE_RELANE_K > 0 && K >= MWW_WIDE_RELANE_K) {
+      int lm = lane;
+      pin(lm);
+      r16 = lm & 15;
+      g = lm >> 4;
+    }
     if constexpr (C == 48 && NW == 8) {
       if (wave < 6) {
         if constexpr (BF) {
@@ -548,7 +568,7 @@ __global__ __launch_bounds__(NTH, (wide_waves_per_simd<CIN, K, NTH>())) void bwd
   float* gdst = a.grad_part + (size_t)blockIdx.x * ((K + 1) * C + C * C);
   float* scratch = smem;
   if (Roles::has_dw(wave)) {
-    float* sp = scratch + Roles::part(wave) * C * C + (Roles::mt(wave) * 16 + g * 4) * C + Roles::nt0(wave) * 16 + r16;
+    float* sp = scratch + Roles::part(wave) * C * C + (Roles::mt(wave) * 16 + g_ * 4) * C + Roles::nt0(wave) * 16 + r16_;
 #pragma unroll
     for (int nt = 0; nt < Roles::NTW; ++nt)
 #pragma unroll

@@ -344,6 +344,7 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
     rng = np.random.default_rng(11)
     worst = {}
     engine_outputs = []   # (probabilities, logits, labels) of every step as the engine produced them
+    oracle_probs = []     # the float64 oracle's probabilities of every step
     # bf16-operand mode: the oracle rounds the same operands, but an fp32 value (engine) and its fp64 twin
     # (oracle) within 1e-7 of a bf16 rounding boundary round apart (a few per 1e5 operands, each a 0.4 %
     # operand error), so the bounds are those of that noise instead of fp32 rounding
@@ -394,6 +395,7 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         n_units = sum(B * b.tout * b.cout for b in lay.blocks)
         assert flips <= (2e-3 * n_units if lowp else max(8, 2e-5 * n_units)), flips
         lo, po, grads, _ = om.loss_and_grads(x, y, w, relu_masks=masks)
+        oracle_probs.append(np.asarray(po, np.float64).copy())
         g = eng.get_grads()
         gref = oracle_grads_native_order(lay, om, grads)
         scale = max(1e-6, float(np.abs(gref).max()))
@@ -465,6 +467,10 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         # 200 cutoffs x 2e-6): at most a handful, each moving a counter by one
         n_win = B * steps
         slack = 0 if n_win <= 64 else 1 + n_win // 256
+        # (a small batch is held to equality unless the oracle's own probability of a window lies within float32 rounding of
+        # one of the 101 cutoffs k / 100 - tools/gpu_table_fuzz.py case 1433, one window in ~3000 random cases)
+        pall = np.concatenate(oracle_probs) * 100.0
+        slack += int((np.abs(pall - np.round(pall)) < 2e-4).sum())
         for k in ("accuracy", "recall", "precision"):
             assert abs(m[k] - r[k]) <= (1e-6 if slack == 0 else (slack + 1.0) / n_win), (k, m[k], r[k])
         assert abs(m["auc"] - r["auc"]) <= (1e-6 if slack == 0 else 1e-3), (m["auc"], r["auc"])
