@@ -266,7 +266,7 @@ def parse_args():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: issue the exchange through the mww_set_allreduce_hook callback into torch.distributed instead of "
                          "RCCL called from the library (mww_allreduce_init, the default)")
-    ap.add_argument("--no-prefetch", action="store_true", help="draw every batch on the launching thread (default: a worker thread draws two batches ahead)")
+    ap.add_argument("--no-prefetch", action="store_true", help="draw every batch on the launching thread (default: a worker thread draws four batches ahead)")
     return ap.parse_args()
 
 
@@ -770,7 +770,7 @@ def main():
                                   args.store_samples),
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": bool(args.graphs and not args.no_graphs),
                    "bn": ("sync" if args.sync_bn else "local") if (world > 1 or force_dp) else "batch",
-                   "sampler": "synchronous" if args.no_prefetch else "worker thread, 2 batches ahead",
+                   "sampler": "synchronous" if args.no_prefetch else "worker thread, 4 batches ahead",
                    "collectives": (("torch.distributed via callback" if args.torch_collectives else "RCCL called from the library")
                                    + ", %d gradient bucket(s)" % args.grad_buckets) if (world > 1 or force_dp) else None,
                    # ranks that took part in the step's collectives, as the communicator itself counts them (ncclCommCount of the

@@ -262,7 +262,7 @@ class FeatureHandler:
         random.setstate((ps[0], tuple(int(v) for v in py), ps[2]))
         np.random.set_state((ns[0], npst[:624].copy(), int(npst[624]), ns[3], ns[4]))
 
-    def use_private_rng(self, prefetch: int = 2):
+    def use_private_rng(self, prefetch: int = 4):
         """Snapshot the global RNG states now and keep advancing private copies from here on
         (same streams, no per-batch get/setstate cost).  The global generators are left untouched.
         ``prefetch`` > 0 additionally lets ``next_training_batch_on_device`` take its batches from a worker thread that

@@ -50,7 +50,7 @@ def host_floats(ptr: int, n: int) -> torch.Tensor:
     return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr)))
 
 
-def shard_feature_handler(handler, rank: int, world: int, seed: Optional[int] = None, prefetch: int = 2, epoch: int = 0):
+def shard_feature_handler(handler, rank: int, world: int, seed: Optional[int] = None, prefetch: int = 4, epoch: int = 0):
     """Per provider keep training samples ``rank, rank+W, ...`` of the provider's list in CANONICAL (store, sample) order -
     a partition whatever per-rank shuffle produced the list (``MmapFeatureProvider`` shuffles with the global ``random``
     stream, which need not stand at the same point on every rank) - and give the rank its own RNG streams.  Validation

@@ -191,7 +191,7 @@ def train(model, config, data_processor, verbose=True):
     chief = rank == 0
     fast = hasattr(data_processor, "next_training_batch_on_device") and hasattr(model, "train_on_device_batch") \
         and getattr(data_processor, "engine", None) is getattr(model, "engine", object())
-    prefetch = int(config.get("prefetch_batches", 2))
+    prefetch = int(config.get("prefetch_batches", 4))
     ckpt_dir = os.path.join(config["train_dir"], "restore")
     ckpt = os.path.join(ckpt_dir, "ckpt")
     if chief and os.path.isfile(ckpt + ".weights.npz") and hasattr(model, "load_optimizer_state"):
