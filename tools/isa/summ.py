@@ -1,4 +1,6 @@
-"""Per-kernel resource use + the skeleton of the main loop's memory operations / waits / barriers."""
+"""Per-kernel resource use + the skeleton of the main loop's memory operations / waits / barriers.
+`reloads in loops`: scratch reloads that sit inside a loop - each waits with s_waitcnt vmcnt(0), i.e. for every load requested
+before it, the next tile's prefetch included (round 6: the K = 21 wide block backward lost 1-1.5 us per launch to two of them)."""
 import re, subprocess, sys
 txt = open(sys.argv[1]).read()
 verbose = len(sys.argv) > 2
@@ -6,8 +8,16 @@ for m in re.finditer(r'\n(_ZN3mww\S+):[^\n]*\n(.*?)\.amdhsa_kernel \1\n(.*?)\.en
     name, body, meta = m.group(1), m.group(2), m.group(3)
     dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
     g = lambda k: (re.search(r'\.amdhsa_' + k + r' (\S+)', meta) or [None, '?'])[1]
-    print('==', dem.replace('mww::', ''), '| vgpr', g('next_free_vgpr'), 'sgpr', g('next_free_sgpr'), 'lds', g('group_segment_fixed_size'), 'scratch', g('private_segment_fixed_size'))
     lines = body.split('\n')
+    # a block label carries "in Loop:" / "Loop Header" when it belongs to a loop: reloads between such a label and the next label
+    in_loop, reloads = False, 0
+    for l in lines:
+        if re.match(r'\.LBB\d+_\d+:', l):
+            in_loop = 'Loop' in l
+        elif in_loop and 'scratch_load' in l:
+            reloads += 1
+    print('==', dem.replace('mww::', ''), '| vgpr', g('next_free_vgpr'), 'sgpr', g('next_free_sgpr'), 'lds', g('group_segment_fixed_size'), 'scratch', g('private_segment_fixed_size'),
+          *(['reloads in loops', reloads] if g('private_segment_fixed_size') not in ('0', '?') else []))
     # main loop = from the first "Loop Header: Depth=1" that contains an s_barrier to the end
     sk = []
     for i, l in enumerate(lines):
