@@ -28,13 +28,14 @@ def _class_weights_per_step(cfg):
     return out
 
 
-def _run_reference_loop(emu_lib, tmp_path, steps=24, B=16):
+def _run_reference_loop(emu_lib, tmp_path, steps=24, B=16, evaluations=3):
     import ref_train_shim as shim
     if not shim.available():
         pytest.skip("reference tree not present")
     ref = shim.load_reference_train_module()
     assert "tensorflow" not in sys.modules            # the stand-ins do not outlive the import
     cfg = rr.run_config(ec, tmp_path, steps=steps, B=B)
+    cfg["eval_step_interval"] = steps // evaluations
     model, data = rr.make_objects(ec, emu_lib, cfg)
     trace = shim.Trace(model, data)
     trace.config_before = {k: copy.deepcopy(v) for k, v in cfg.items() if k != "features"}   # train.py:191-204 pads the lists in place
