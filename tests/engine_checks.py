@@ -473,7 +473,12 @@ def check_train_steps(lib, B=6, T=194, steps=2, grid=2, lr=1e-3, graphs=False, f
         slack += int((np.abs(pall - np.round(pall)) < 2e-4).sum())
         for k in ("accuracy", "recall", "precision"):
             assert abs(m[k] - r[k]) <= (1e-6 if slack == 0 else (slack + 1.0) / n_win), (k, m[k], r[k])
-        assert abs(m["auc"] - r["auc"]) <= (1e-6 if slack == 0 else 1e-3), (m["auc"], r["auc"])
+        # (the AUC has its own 200 cutoffs k / 199: a window whose oracle probability lies within float32 rounding of one of them
+        # moves one point of the ROC curve - tools/gpu_table_fuzz.py case 3183 on the emulator, 3e-7 away)
+        near_auc = int((np.abs(pall / 100.0 * 199.0 - np.round(pall / 100.0 * 199.0)) < 4e-4).sum())
+        labels = np.concatenate([ye for _, _, ye in engine_outputs])
+        fewer = max(1.0, min(float((labels > 0.5).sum()), float((labels <= 0.5).sum())))   # one window moves TPR or FPR at one cutoff by 1 / its class size
+        assert abs(m["auc"] - r["auc"]) <= (1e-6 if slack == 0 else 1e-3) + near_auc / fewer, (m["auc"], r["auc"])
         for k in ("tp", "fp", "tn", "fn"):
             assert np.abs(m[k] - r[k]).max() <= slack and np.count_nonzero(m[k] != r[k]) <= 2 * slack, (k, np.abs(m[k] - r[k]).max())
     assert abs(m["loss"] - r["loss"]) < (loss_tol if lowp else 1e-5)

@@ -337,6 +337,27 @@ def test_fused_input_through_captured_graphs(emu_lib):
     ec.check_fused_input(emu_lib, B=4, steps=9, graphs=True)   # more steps than mailbox slots (8): a slot's graph is replayed
 
 
+def test_shape_table_fuzz(emu_lib):
+    """Random flag sets out of the block kernels' shape table with random (frames, batch, grid) - tools/gpu_table_fuzz.py, which runs
+    thousands of them on the GPU - here on the emulator, whose LDS starts as NaN and whose allocations end at a guard page: an
+    uninitialised LDS read or an access past a buffer shows up here and not on the device."""
+    import sys
+    from microwakeword_amd import mixednet
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        from gpu_table_fuzz import random_table_flags
+    finally:
+        sys.path.remove(tools)
+    for case in range(5000, 5016):
+        flags, T, B, grid = random_table_flags(case)
+        assert mixednet.kernel_family(flags, T, lib=emu_lib)[0] == "block", (case, flags)
+        try:
+            ec.check_train_steps(emu_lib, B=min(B, 6), T=T, steps=1, grid=grid, flags=flags)   # (the float64 oracle is what takes the time)
+        except AssertionError as e:
+            raise AssertionError("case %d %s T %d B %d grid %d: %s" % (case, flags, T, B, grid, e))
+
+
 def test_gather_fuzz(emu_lib):
     ec.check_gather_fuzz(emu_lib, cases=1, first=11)   # the short-window cases of the fuzz (the GPU suite runs 46)
     ec.check_gather_fuzz(emu_lib, cases=1, first=5)
